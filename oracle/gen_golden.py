@@ -1,0 +1,331 @@
+#!/usr/bin/env python3
+"""gen_golden.py -- TEST INFRASTRUCTURE.  Generates tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Run only in the build container (needs /root/reference); the GPU box receives the .npz fixtures,
+never reference code.  Fixtures are pure data: inputs and the reference's outputs.
+
+What runs the reference, and with which third-party restatements:
+  * reader     : det3d/models/readers/pillar_encoder.py imported unmodified.  It imports
+                 `torch_scatter` (third-party CUDA/C++ package, un-vendored, version UNPINNED in
+                 docker/Dockerfile:16).  We restate its two published ops on torch primitives:
+                 scatter_max(src,index,dim=0)[0] = per-index maximum, scatter_mean = per-index
+                 sum / count.  Call sites: pillar_encoder.py:43,113,180.
+  * IoU        : det3d/core/iou3d_nms/src/iou3d_cpu.cpp compiled in place (oracle/_ref).
+  * NMS        : the reference has no CPU NMS; reference CPU IoU matrix + the greedy rule of
+                 iou3d_nms.cpp:144-155.
+  * decode     : det3d/models/heads/centerhead.py CenterHead.predict imported unmodified, with
+                 `det3d.core.iou3d_nms.iou3d_nms_cuda.nms_gpu` provided by the NMS above and
+                 `numba` (imported by det3d/core/__init__.py only for CPU augmentation code that is
+                 never called here) replaced by identity decorators.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from pillarnext_amd import synth  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+# --------------------------------------------------------------------------- third-party restatements
+def install_torch_scatter():
+    m = types.ModuleType("torch_scatter")
+
+    def scatter_max(src, index, dim=0):
+        n = int(index.max()) + 1
+        idx = index.view(-1, 1).expand_as(src)
+        out = torch.full((n, src.shape[1]), float("-inf"), dtype=src.dtype).scatter_reduce(0, idx, src, "amax", include_self=True)
+        return out, None
+
+    def scatter_mean(src, index, dim=0):
+        n = int(index.max()) + 1
+        idx = index.view(-1, 1).expand_as(src)
+        s = torch.zeros((n, src.shape[1]), dtype=src.dtype).scatter_reduce(0, idx, src, "sum", include_self=True)
+        cnt = torch.zeros((n,), dtype=src.dtype).scatter_reduce(0, index, torch.ones_like(index, dtype=src.dtype), "sum")
+        return s / cnt.clamp(min=1).view(-1, 1)
+
+    m.scatter_max, m.scatter_mean = scatter_max, scatter_mean
+    sys.modules["torch_scatter"] = m
+
+
+def install_numba_identity():
+    m = types.ModuleType("numba")
+
+    def _id(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+
+    m.njit = m.jit = _id
+    sys.modules["numba"] = m
+
+
+def install_iou3d_nms():
+    pkg = types.ModuleType("det3d.core.iou3d_nms")
+    pkg.__path__ = [os.path.join(REF, "det3d/core/iou3d_nms")]
+    ext = types.ModuleType("det3d.core.iou3d_nms.iou3d_nms_cuda")
+
+    def nms_gpu(boxes, keep, thresh):
+        k = O.ref_nms_rotated(boxes.detach().cpu().numpy(), float(thresh))
+        keep[: len(k)] = torch.from_numpy(k)
+        return len(k)
+
+    ext.nms_gpu = nms_gpu
+    pkg.iou3d_nms_cuda = ext
+    sys.modules["det3d.core.iou3d_nms"] = pkg
+    sys.modules["det3d.core.iou3d_nms.iou3d_nms_cuda"] = ext
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+# --------------------------------------------------------------------------- reader fixtures
+def edge_rows(pc_range, voxel_size, batch_idx):
+    """Boundary / NaN / -0.0 / out-of-range rows."""
+    x0, y0, x1, y1 = pc_range[0], pc_range[1], pc_range[3], pc_range[4]
+    vs = voxel_size[0]
+    f32 = np.float32
+    rows = [
+        [x0, y0, 0.0], [np.nextafter(f32(x0), f32(-1e9)), y0, 0.1], [x1, 0.0, 0.2], [np.nextafter(f32(x1), f32(-1e9)), 0.0, 0.3],
+        [0.0, y1, 0.0], [0.0, np.nextafter(f32(y1), f32(-1e9)), 0.0], [np.nan, 0.0, 0.0], [0.0, np.nan, 0.0],
+        [x0 + 3 * vs, y0 + 5 * vs, 0.5], [x0 + f32(3) * f32(vs), y0 + 5 * vs, 0.6], [x0 - 0.0, y0, 99.0], [1e9, 0.0, 0.0],
+        [-1e9, 0.0, 0.0], [x0 + 0.5 * vs, y0 + 0.5 * vs, -77.0], [x1 - 1e-4, y1 - 1e-4, 0.0], [0.0, 0.0, 0.0], [-0.0, -0.0, -0.0],
+    ]
+    # points sitting exactly on (computed) pillar edges all over the grid
+    for k in (1, 7, 100, 333, 671):
+        rows.append([x0 + k * vs, y0 + k * vs, 0.0])
+        rows.append([f32(x0) + f32(k) * f32(vs), f32(y0) + f32(k) * f32(vs), 0.0])
+    r = np.zeros((len(rows), 6), np.float32)
+    r[:, 0] = batch_idx
+    r[:, 1:4] = np.asarray(rows, np.float32)
+    r[:, 4] = 0.5
+    r[:, 5] = 0.1
+    return r
+
+
+def reader_case(name, pc_range, voxel_size, clouds, num_filters=(64, 64), seed=0, train=False):
+    from det3d.models.readers.pillar_encoder import PillarFeatureNet
+
+    pts = np.concatenate(clouds).astype(np.float32)
+    F = pts.shape[1] - 1
+    layers = synth.pfn_params(F, num_filters, seed)
+    net = PillarFeatureNet(F, list(num_filters), list(voxel_size), list(pc_range))
+    with torch.no_grad():
+        for L, pfn in zip(layers, net.pfn_layers):
+            pfn.linear.weight.copy_(torch.from_numpy(L["W"]))
+            pfn.norm.weight.copy_(torch.from_numpy(L["gamma"]))
+            pfn.norm.bias.copy_(torch.from_numpy(L["beta"]))
+            pfn.norm.running_mean.copy_(torch.from_numpy(L["mean"]))
+            pfn.norm.running_var.copy_(torch.from_numpy(L["var"]))
+    tp = torch.from_numpy(pts)
+    net.eval()
+    with torch.no_grad():
+        feats, coords_v, unq_inv, grid_v = net.voxelization(tp)
+        feat_max, coords, grid = net(tp)
+    assert torch.equal(coords, coords_v)
+    out = dict(points=pts, pc_range=np.asarray(pc_range, np.float64), voxel_size=np.asarray(voxel_size, np.float64),
+               num_filters=np.asarray(num_filters, np.int64), coords=coords.numpy().astype(np.int32),
+               unq_inv=unq_inv.numpy().astype(np.int64), features=feats.numpy(), feat_max=feat_max.numpy(),
+               grid=np.asarray(grid, np.int64), eps=np.float32(1e-3))
+    for i, L in enumerate(layers):
+        for k, v in L.items():
+            out[f"l{i}_{k}"] = v
+    if train:
+        # train mode: batch statistics, running-stat update, and gradients for a fixed upstream grad
+        net.train()
+        for p in net.parameters():
+            p.grad = None
+        fm_t, _, _ = net(tp)
+        g = torch.from_numpy(np.random.default_rng(seed + 7).standard_normal(tuple(fm_t.shape)).astype(np.float32))
+        fm_t.backward(g)
+        out["train_feat_max"] = fm_t.detach().numpy()
+        out["train_upstream_grad"] = g.numpy()
+        for i, pfn in enumerate(net.pfn_layers):
+            out[f"train_l{i}_dW"] = pfn.linear.weight.grad.numpy().copy()
+            out[f"train_l{i}_dgamma"] = pfn.norm.weight.grad.numpy().copy()
+            out[f"train_l{i}_dbeta"] = pfn.norm.bias.grad.numpy().copy()
+            out[f"train_l{i}_running_mean"] = pfn.norm.running_mean.numpy().copy()
+            out[f"train_l{i}_running_var"] = pfn.norm.running_var.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"[golden] {name}: N={len(pts)} N'={len(out['unq_inv'])} P={len(out['coords'])} grid={out['grid']}")
+
+
+def gen_reader():
+    rng = np.random.default_rng(42)
+    # (1) nuScenes reference-YAML geometry, B=2, uniform + clustered + edge rows, one fat pillar (>64 pts)
+    pr, vs = synth.CONFIGS["C2ref"]["pc_range"], synth.CONFIGS["C2ref"]["voxel_size"]
+    a = synth.uniform_cloud(1500, pr, 1000, 0)
+    b = synth.sweep_cloud(1500, pr, 1001, 1)
+    fat = np.zeros((150, 6), np.float32)
+    fat[:, 0] = 1
+    fat[:, 1] = 10.0 + rng.uniform(0, 0.07, 150)
+    fat[:, 2] = -7.0 + rng.uniform(0, 0.07, 150)
+    fat[:, 3] = rng.uniform(-3, 1, 150)
+    fat[:, 4] = rng.uniform(0, 1, 150)
+    clouds = [a, edge_rows(pr, vs, 0), b, fat, edge_rows(pr, vs, 1)]
+    perm = rng.permutation(sum(len(c) for c in clouds))
+    pts = np.concatenate(clouds)[perm]
+    reader_case("reader_nusc_b2", pr, vs, [pts], train=True)
+    # (2) BASELINE geometry (1440^2), single sample, dense little patch so pillars hold many points
+    pr, vs = synth.CONFIGS["C2"]["pc_range"], synth.CONFIGS["C2"]["voxel_size"]
+    c = synth.uniform_cloud(2500, pr, 1002, 0)
+    d = np.zeros((1200, 6), np.float32)
+    d[:, 1:3] = rng.uniform(-1.2, 1.2, (1200, 2)) + np.array([20.0, -13.0])
+    d[:, 3] = rng.uniform(-2, 1, 1200)
+    d[:, 4:6] = rng.uniform(0, 1, (1200, 2))
+    reader_case("reader_c2_b1", pr, vs, [c, d, edge_rows(pr, vs, 0)])
+    # (3) Tiny config C1 (0.2 m, 512^2): larger pillars, B=3 with an EMPTY middle sample (b=1 absent)
+    pr, vs = synth.CONFIGS["C1"]["pc_range"], synth.CONFIGS["C1"]["voxel_size"]
+    e = synth.sweep_cloud(3000, pr, 1003, 0)
+    f = synth.sweep_cloud(2000, pr, 1004, 2)
+    reader_case("reader_c1_b3_gap", pr, vs, [e, f, edge_rows(pr, vs, 2)])
+    # (4) Waymo reference-YAML geometry (2048^2), F=5
+    pr, vs = synth.CONFIGS["C5ref"]["pc_range"], synth.CONFIGS["C5ref"]["voxel_size"]
+    g = synth.sweep_cloud(4000, pr, 1005, 0, beams=64, sweeps=3)
+    reader_case("reader_waymo_b1", pr, vs, [g, edge_rows(pr, vs, 0)])
+    # (5) all points out of range -> P = 0 is NOT supported by the reference (index.max() of empty);
+    #     instead: a single point
+    pr, vs = synth.CONFIGS["C2ref"]["pc_range"], synth.CONFIGS["C2ref"]["voxel_size"]
+    one = np.array([[0, 1.0, 2.0, 0.5, 0.3, 0.0], [0, 1e6, 0.0, 0.0, 0.0, 0.0]], np.float32)
+    reader_case("reader_single_point", pr, vs, [one])
+
+
+# --------------------------------------------------------------------------- IoU / NMS fixtures
+def special_boxes():
+    b = [
+        [0, 0, 0, 4, 2, 1.5, 0.0], [0, 0, 0, 4, 2, 1.5, 0.0],  # identical
+        [0, 0, 0.2, 4, 2, 1.5, np.pi / 2], [0, 0, 0, 2, 1, 1.0, 0.3],  # 90 deg rotated / contained
+        [30, 30, 0, 4, 2, 1.5, 0.7], [4, 0, 0, 4, 2, 1.5, 0.0],  # disjoint / edge-touching
+        [2, 0, 0, 4, 2, 1.5, 0.0], [2, 1, 0, 4, 2, 1.5, 1e-3],  # half overlap / near-collinear edges
+        [0, 0, 0, 4, 2, 1.5, np.pi], [0, 0, 0, 4, 2, 1.5, -np.pi],  # same box, heading +-pi
+        [0.5, 0.5, 0, 3, 3, 1.0, np.pi / 4], [0.5, 0.5, 0, 3, 3, 1.0, 0.0],  # octagon intersection
+        [1, 1, 0, 1e-3, 1e-3, 1.0, 0.2], [0, 0, 0, 100, 100, 3, 2.0],  # tiny / huge
+        [0, 0, 0, 4, 2, 1.5, 7.5], [0, 0, 0, 4, 2, 1.5, -12.25],  # headings outside [-pi, pi]
+    ]
+    return np.asarray(b, np.float32)
+
+
+def min_margin(iou, thr):
+    n = iou.shape[0]
+    iu = np.triu_indices(n, 1)
+    return np.abs(iou[iu] - np.float32(thr)).min()
+
+
+def gen_iou_nms():
+    rng = np.random.default_rng(7)
+    sp = special_boxes()
+    rnd, _ = synth.clustered_boxes(48, 11, spread=6.0, n_clusters=5)
+    boxes = np.concatenate([sp, rnd])[:64]
+    iou = O.ref_boxes_iou_bev(boxes, boxes)
+    b2, _ = synth.clustered_boxes(40, 12, spread=6.0, n_clusters=4)
+    iou_ab = O.ref_boxes_iou_bev(boxes, b2)
+    al = O.ref_boxes_aligned_iou_bev(boxes[:40], b2)
+    np.savez_compressed(os.path.join(OUT, "iou_bev_64.npz"), boxes_a=boxes, boxes_b=b2, iou_aa=iou, iou_ab=iou_ab, iou_aligned=al)
+    print("[golden] iou_bev_64: nonzero frac", (iou > 0).mean())
+
+    cases = {}
+    for name, n, thr, seed in [("n256_t020", 256, 0.2, 21), ("n256_t070", 256, 0.7, 22), ("n1000_t020", 1000, 0.2, 23),
+                               ("n1000_t025", 1000, 0.25, 24), ("n130_t020", 130, 0.2, 25)]:
+        # re-draw until every pair IoU is >= 1e-4 away from the threshold
+        s = seed
+        while True:
+            boxes, scores = synth.clustered_boxes(n, s)
+            m = O.ref_boxes_iou_bev(boxes, boxes)
+            if min_margin(m, thr) >= 1e-4:
+                break
+            s += 1000
+        keep = O.ref_nms_rotated(boxes, thr)
+        cases[name + "_boxes"] = boxes
+        cases[name + "_scores"] = scores
+        cases[name + "_thr"] = np.float32(thr)
+        cases[name + "_keep"] = keep
+        print(f"[golden] nms {name}: kept {len(keep)} of {n} (seed {s}, margin {min_margin(m, thr):.2e})")
+    np.savez_compressed(os.path.join(OUT, "nms_rotated.npz"), **cases)
+
+
+# --------------------------------------------------------------------------- decode fixture
+def ns(**k):
+    return types.SimpleNamespace(**k)
+
+
+def gen_decode():
+    from det3d.models.heads.centerhead import CenterHead
+
+    torch.manual_seed(3)
+    tasks = [["car"], ["truck", "construction_vehicle"]]
+    common = {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2), "iou": (1, 2)}
+    pc_range = [-50.4, -50.4, -5.0, 50.4, 50.4, 3.0]
+    voxel = [0.075, 0.075, 8]
+    head = CenterHead(in_channels=16, tasks=tasks, weight=0.25, code_weights=[1.0] * 10, common_heads=common, strides=[2, 2],
+                      share_conv_channel=16, rectifier=[[0.5], [0.68, 0.2]])
+    B, H, W = 2, 24, 24
+    rng = np.random.default_rng(5)
+    preds = []
+    for t, names in enumerate(tasks):
+        d = {}
+        for k, c in [("reg", 2), ("height", 1), ("dim", 3), ("rot", 2), ("vel", 2), ("iou", 1), ("hm", len(names))]:
+            a = rng.standard_normal((B, c, H, W)).astype(np.float32)
+            if k == "hm":
+                a = a * 2.0 - 1.5
+            if k == "dim":
+                a = a * 0.3 + 0.8
+            if k == "reg":
+                a = rng.uniform(0, 1, (B, c, H, W)).astype(np.float32)
+            if k == "iou":
+                a = np.clip(a * 0.7, -1.3, 1.3)
+            d[k] = a
+        # make the grid spread over real-world metres: out_size_factor 56 -> 24*56*0.075 = 100.8 m
+        preds.append(d)
+    test_cfg = ns(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], score_threshold=0.1,
+                  nms=ns(nms_pre_max_size=1000, nms_post_max_size=83, nms_iou_threshold=[[0.2], [0.2, 0.25]]),
+                  out_size_factor=[56, 56], voxel_size=voxel, pc_range=pc_range)
+    tp = [{k: torch.from_numpy(v.copy()) for k, v in d.items()} for d in preds]
+    res = head.predict({"token": ["a", "b"]}, tp, test_cfg)
+    out = {}
+    for t, d in enumerate(preds):
+        for k, v in d.items():
+            out[f"t{t}_{k}"] = v
+    for i, r in enumerate(res):
+        out[f"s{i}_boxes"] = r["box3d_lidar"].numpy()
+        out[f"s{i}_scores"] = r["scores"].numpy()
+        out[f"s{i}_labels"] = r["label_preds"].numpy()
+        print(f"[golden] decode sample {i}: {len(r['scores'])} boxes")
+    out["rectifier"] = np.asarray([[0.5, 0.0], [0.68, 0.2]], np.float32)
+    out["num_classes"] = np.asarray([1, 2], np.int64)
+    out["nms_thr"] = np.asarray([[0.2, 0.0], [0.2, 0.25]], np.float32)
+    out["out_size_factor"] = np.asarray([56, 56], np.int64)
+    out["pc_range"] = np.asarray(pc_range, np.float64)
+    out["voxel_size"] = np.asarray(voxel, np.float64)
+    out["post_center_limit_range"] = np.asarray(test_cfg.post_center_limit_range, np.float64)
+    out["score_threshold"] = np.float32(0.1)
+    out["pre_max"] = np.int64(1000)
+    out["post_max"] = np.int64(83)
+    np.savez_compressed(os.path.join(OUT, "decode_2task.npz"), **out)
+
+
+def main():
+    assert os.path.isdir(REF), "gen_golden.py needs the reference tree"
+    os.makedirs(OUT, exist_ok=True)
+    O.build()
+    assert O.have_ref(), "oracle/_ref/libref_iou3d.so missing: run `make -C oracle ref`"
+    install_torch_scatter()
+    install_numba_identity()
+    install_iou3d_nms()
+    sys.path.insert(0, REF)
+    what = sys.argv[1:] or ["reader", "iou", "decode"]
+    if "reader" in what:
+        gen_reader()
+    if "iou" in what:
+        gen_iou_nms()
+    if "decode" in what:
+        gen_decode()
+
+
+if __name__ == "__main__":
+    main()
