@@ -1,0 +1,151 @@
+/* pnx.h -- C ABI of libpnx_hip.so: the MI355X (gfx950) PillarNeXt hot path.
+ *
+ * Drop-in boundary for two reference surfaces (paths relative to the reference tree):
+ *   B1  det3d/models/readers/pillar_encoder.py  PillarFeatureNet.forward  (:174-182)
+ *       = PillarNet.forward (:78-125) + 2 x PFNLayer.forward (:35-50) + scatter_max (:180),
+ *       plus the dense canvas of SparseConvTensor(...).dense() (det3d/models/backbones/sparse_resnet.py:63-68)
+ *   B2  det3d/core/iou3d_nms/src/iou3d_nms_api.cpp:11-19 (the 7 pybind exports of iou3d_nms_cuda)
+ *       and det3d/core/bbox/box_torch_ops.py:5-31 (rotate_nms_pcdet)
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer is a DEVICE pointer unless its name ends in _host
+ *   - the caller owns every output and the workspace; nothing is allocated on the hot path
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *   - return value: PNX_OK (0) or a negative pnx_status; pnx_last_error() gives a message.
+ *     Unlike the reference (iou3d_nms.cpp:14-38) nothing ever calls exit().
+ *   - not re-entrant on the same workspace; one workspace per stream.
+ */
+#ifndef PNX_H
+#define PNX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pnx_stream_t; /* hipStream_t */
+
+typedef enum pnx_status {
+  PNX_OK = 0,
+  PNX_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, misaligned buffer) */
+  PNX_ERR_UNSUPPORTED = -2, /* configuration outside what the kernels are built for */
+  PNX_ERR_WORKSPACE = -3,   /* workspace too small */
+  PNX_ERR_HIP = -4          /* a HIP runtime call failed */
+} pnx_status;
+
+typedef enum pnx_dtype { PNX_F32 = 0, PNX_BF16 = 1, PNX_F16 = 2 } pnx_dtype;
+typedef enum pnx_layout {
+  PNX_NHWC = 0, /* [B][gy][gx][C]  (torch channels_last memory of a (B,C,gy,gx) tensor) */
+  PNX_NCHW = 1  /* [B][C][gy][gx]  (what .dense() returns, sparse_resnet.py:68) */
+} pnx_layout;
+
+/* Voxel grid.  pc_min/voxel are the fp32 casts the reference applies (pillar_encoder.py:91-93);
+ * gx,gy = np.round((max-min)/voxel) evaluated in fp64, half-to-even (:87-89). */
+typedef struct pnx_geom {
+  float pc_min[3];
+  float voxel[3];
+  int32_t gx, gy;
+} pnx_geom;
+
+const char* pnx_last_error(void);
+const char* pnx_version(void);
+
+/* pillar_encoder.py:87-93 -- host helper, fills *geom from the YAML's fp64 lists. */
+int pnx_geom_init(const double* pc_range6_host, const double* voxel_size3_host, pnx_geom* geom_host);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reader, inference (BatchNorm in eval mode).
+ *
+ * PFN parameters are folded once per weight update into one device buffer of PNX_PFN_FOLDED_FLOATS(F)
+ * floats: [W0' (32 x (F+5)) | s0 (32) | W1' (64 x 64) | s1 (64)] with a = gamma / sqrt(running_var + eps),
+ * W'[c,:] = a[c] * W[c,:] and s = beta - running_mean * a   (BatchNorm1d eval folded into the Linear, :32-33,37-38;
+ * SURVEY.md H8 measured this fold at 1.4e-6 abs from the reference).
+ * Only num_filters = [64, 64] (every PillarNeXt config) and 3 <= F <= 6 are built.
+ */
+#define PNX_PFN_FOLDED_FLOATS(F) (32 * ((F) + 5) + 32 + 64 * 64 + 64)
+
+int pnx_pfn_fold_bn(int32_t num_point_features, /* F */
+                    const float* w0, const float* gamma0, const float* beta0, const float* mean0, const float* var0,
+                    const float* w1, const float* gamma1, const float* beta1, const float* mean1, const float* var1,
+                    float eps, float* folded_out, pnx_stream_t stream);
+
+/* Bytes of workspace pnx_reader_forward needs for at most n_points rows and `batch` samples. */
+size_t pnx_reader_workspace_bytes(int64_t n_points, int32_t batch, const pnx_geom* geom_host);
+
+/* PillarFeatureNet.forward (+ dense canvas).
+ *   points      (n_points, row_stride) fp32 rows [b, x, y, z, f4..]; row_stride = 1 + F
+ *   batch       number of samples B; rows with b outside [0,B) are dropped
+ * Outputs (each may be NULL):
+ *   canvas      B x 64 x gy x gx in canvas_dtype / canvas_layout; every element is written exactly once
+ *               (zeros where no pillar)  -- the dense input of the backbone
+ *   feat_max    (pillar_capacity, 64) fp32, row r = pillar of rank r            (:180-182)
+ *   coords      (pillar_capacity, 3) int32 [b, yi, xi], torch.unique order      (:110-111,125)
+ *   unq_inv     (n_points) int64: pillar rank of the j-th KEPT point, in input order (:110)
+ *   pillar_of_point (n_points) int32: pillar rank of input row i, -1 if the row was dropped
+ *   counts      int32[2] = {P (number of pillars), N' (number of kept points)}
+ * If P would exceed pillar_capacity the rows beyond it are not written (P is still reported).
+ */
+int pnx_reader_forward(const float* points, int64_t n_points, int32_t row_stride, int32_t batch, const pnx_geom* geom_host,
+                       const float* pfn_folded, void* canvas, int32_t canvas_dtype, int32_t canvas_layout, float* feat_max,
+                       int32_t* coords, int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, int32_t* counts,
+                       void* workspace, size_t workspace_bytes, pnx_stream_t stream);
+
+/* Voxelizer alone (PillarNet.forward :78-125): indices plus the decorated (N', F+5) features
+ * (rows in kept-point order; may be NULL).  Used by the training path, where Linear/BN stay in
+ * PyTorch so that SyncBatchNorm semantics are the reference's. */
+int pnx_voxelize(const float* points, int64_t n_points, int32_t row_stride, int32_t batch, const pnx_geom* geom_host,
+                 float* features, int32_t* coords, int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point,
+                 int32_t* counts, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
+
+/* torch_scatter.scatter_max(x, unq_inv, dim=0) over pillars (call sites :43,:180), fp32, values of
+ * any sign.  x (n, channels); index (n) int64 in [0,P); out (P, channels); argmax (P, channels) int64 =
+ * row of the maximum (lowest row index wins ties) or n for an empty pillar.  Deterministic. */
+size_t pnx_scatter_max_workspace_bytes(int64_t n, int64_t num_pillars);
+int pnx_scatter_max(const float* x, const int64_t* index, int64_t n, int32_t channels, int64_t num_pillars, float* out,
+                    int64_t* argmax, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
+/* its backward: grad_x[argmax[p,c], c] = grad_out[p,c], zero elsewhere (grad_x is fully written). */
+int pnx_scatter_max_backward(const float* grad_out, const int64_t* argmax, int64_t n, int32_t channels, int64_t num_pillars,
+                             float* grad_x, pnx_stream_t stream);
+
+/* Scatter an existing (P,64) fp32 pillar list to the dense canvas (sparse_resnet.py:63-68). */
+int pnx_scatter_canvas(const float* feat_max, const int32_t* coords, const int32_t* num_pillars_dev, int64_t pillar_capacity,
+                       int32_t batch, int32_t gy, int32_t gx, void* canvas, int32_t canvas_dtype, int32_t canvas_layout,
+                       pnx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rotated IoU / NMS.  Boxes are (n,7) fp32 [x, y, z, dx, dy, dz, heading].
+ * Arithmetic = iou3d_nms_kernel.cu:35-234 in fp32, with cos/sin/atan2 from pnx_detmath.h.
+ */
+/* boxes_overlap_bev_gpu (iou3d_nms.cpp:65-85): out (n,m) overlap areas */
+int pnx_boxes_overlap_bev(const float* boxes_a, int64_t n, const float* boxes_b, int64_t m, float* out, pnx_stream_t stream);
+/* boxes_iou_bev_gpu (:87-106): out (n,m) IoU */
+int pnx_boxes_iou_bev(const float* boxes_a, int64_t n, const float* boxes_b, int64_t m, float* out, pnx_stream_t stream);
+/* boxes_aligned_overlap_bev_gpu (:40-63): out (n) overlap area of pair i */
+int pnx_boxes_aligned_overlap_bev(const float* boxes_a, const float* boxes_b, int64_t n, float* out, pnx_stream_t stream);
+/* boxes_aligned_iou3d_gpu (iou3d_nms_utils.py:49-89): out (n) 3-D IoU of pair i, fused */
+int pnx_boxes_aligned_iou3d(const float* boxes_a, const float* boxes_b, int64_t n, float* out, pnx_stream_t stream);
+
+/* nms_gpu / nms_normal_gpu (iou3d_nms.cpp:113-159 / :162-211) for `num_segments` independent,
+ * already score-sorted box lists laid end to end:  segment s = boxes[seg_offsets[s] .. seg_offsets[s+1]).
+ * The bitmask AND the greedy scan run on the device (the reference copies the mask to the host).
+ *   seg_offsets   int32[num_segments+1] (device)
+ *   thresh        fp32[num_segments] (device) IoU threshold per segment
+ *   keep          int32, same length as boxes: keep[seg_offsets[s] + k] = index (within the segment) of the
+ *                 k-th kept box, ascending -- exactly what nms_gpu writes into `keep`
+ *   keep_count    int32[num_segments]: number kept (already min'ed with post_max if post_max > 0)
+ *   max_seg_len   an upper bound on any segment's length (host value; sizes the launch)
+ */
+size_t pnx_nms_workspace_bytes(int64_t total_boxes, int32_t num_segments, int32_t max_seg_len);
+int pnx_nms_rotated_batched(const float* boxes, const int32_t* seg_offsets, int32_t num_segments, int32_t max_seg_len,
+                            const float* thresh, int32_t post_max, int32_t* keep, int32_t* keep_count, void* workspace,
+                            size_t workspace_bytes, pnx_stream_t stream);
+int pnx_nms_normal_batched(const float* boxes, const int32_t* seg_offsets, int32_t num_segments, int32_t max_seg_len,
+                           const float* thresh, int32_t post_max, int32_t* keep, int32_t* keep_count, void* workspace,
+                           size_t workspace_bytes, pnx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNX_H */

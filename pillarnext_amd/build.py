@@ -1,0 +1,54 @@
+"""Builds libpnx_hip.so (the C-ABI library of include/pnx.h) in-tree with hipcc for gfx950."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpnx_hip.so")
+SOURCES = ["reader.hip", "pfn_mfma.hip", "scatter.hip", "iou3d.hip", "capi.cpp"]
+HEADERS = ["pnx_common.h", "pnx_scan.h", "pnx_detmath.h", os.path.join("..", "..", "include", "pnx.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        cmd = [_hipcc()] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError(f"hipcc failed on {src}")
+        if verbose and out:
+            print(out.decode())
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,659 @@
+// reader.hip -- point cloud -> pillars -> PFN -> dense BEV canvas, for gfx950 (MI355X).
+//
+// What it computes (reference: det3d/models/readers/pillar_encoder.py, "pe:" below):
+//   PillarNet.forward pe:78-125, PFNLayer.forward pe:35-50 (x2), PillarFeatureNet.forward pe:174-182,
+//   and the dense canvas of SparseConvTensor(...).dense() (det3d/models/backbones/sparse_resnet.py:63-68).
+//
+// How (nothing like the reference's torch.unique + torch_scatter sequence):
+//   1. k_keys        one coalesced pass over the raw point buffer: fp32 IEEE (x-min)/vs, range mask,
+//                    cell key = (b*gx + xi)*gyp + yi  (gyp = gy rounded up to 32), occupancy BITMAP
+//   2. scan          popcount prefix over the bitmap  -> pillar rank of every cell == torch.unique(dim=0)
+//                    order, without sorting a single point
+//   3. k_rank        per point: rank = prefix + popc(bits below); slot inside the pillar by an integer
+//                    atomic; the slot-0 point writes coords[rank]
+//   4. scan + k_fill counting sort -> CSR list of point ids per pillar
+//   5. k_pfn_*       Linear(10->32)+BN+ReLU, per-pillar max, concat, Linear(64->64)+BN+ReLU, per-pillar max
+//   6. k_canvas_*    32x32-cell tiles: the bitmap says which cells are empty (write zeros) and the rank
+//                    says which feat_max row to convert and write -- every canvas byte is written exactly
+//                    once, in 1 KiB contiguous wave-stores (NHWC), no memset pass.
+//
+// Determinism: pillar membership, rank, coords and the max-pool do not depend on thread timing.  The
+// per-pillar mean is summed in fp64 (exact for LiDAR-range coordinates), so the atomic slot order does
+// not show in the results either.
+#include "pnx_common.h"
+#include "pnx_scan.h"
+
+namespace {
+
+using GeomDev = PnxGeomDev;
+
+// ------------------------------------------------------------------------------------------ voxelize
+// pe:91-109.  fp32 subtract then IEEE divide (never a reciprocal multiply -- SURVEY H1), compares on the
+// float coordinate, truncation, key.  Rows whose batch index is outside [0,B) are dropped.
+__global__ __launch_bounds__(kBlock) void k_keys(const float* __restrict__ pts, int64_t n, int stride, GeomDev g,
+                                                 int32_t* __restrict__ key_out, uint32_t* __restrict__ bitmap) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float* p = pts + i * stride;
+  const float bf = p[0], x = p[1], y = p[2];
+  const float cx = __fdiv_rn(__fsub_rn(x, g.minx), g.vx);
+  const float cy = __fdiv_rn(__fsub_rn(y, g.miny), g.vy);
+  bool keep = (cx >= 0.f) && (cx < (float)g.gx) && (cy >= 0.f) && (cy < (float)g.gy);
+  keep = keep && (bf > -1.0f) && (bf < (float)g.B);  // (long)b in [0,B): truncation maps (-1,0) to 0
+  int32_t key = -1;
+  if (keep) {
+    const int xi = (int)cx, yi = (int)cy, bi = (int)bf;
+    key = (bi * g.gx + xi) * g.gyp + yi;
+    atomicOr(&bitmap[key >> 5], 1u << (key & 31));
+  }
+  key_out[i] = key;
+}
+
+__device__ __forceinline__ int32_t cell_rank(int32_t key, const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre,
+                                             const uint32_t* __restrict__ wblk) {
+  const int32_t w = key >> 5;
+  const uint32_t bits = bitmap[w];
+  return (int32_t)(wblk[w >> PNX_SCAN_SHIFT] + wpre[w] + __popc(bits & ((1u << (key & 31)) - 1u)));
+}
+
+// rank of every point (== unq_inv of the reference for kept points), slot inside the pillar, coords.
+__global__ __launch_bounds__(kBlock) void k_rank(const int32_t* __restrict__ key, int64_t n, GeomDev g,
+                                                 const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre,
+                                                 const uint32_t* __restrict__ wblk, int32_t* __restrict__ rank_out,
+                                                 int32_t* __restrict__ slot_out, uint32_t* __restrict__ count,
+                                                 int32_t* __restrict__ coords, int64_t pillar_capacity,
+                                                 int32_t* __restrict__ pillar_of_point) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int32_t k = key[i];
+  int32_t r = -1;
+  if (k >= 0) {
+    r = cell_rank(k, bitmap, wpre, wblk);
+    const uint32_t s = atomicAdd(&count[r], 1u);
+    slot_out[i] = (int32_t)s;
+    if (s == 0 && coords != nullptr && r < pillar_capacity) {
+      const int yi = k % g.gyp;
+      const int t = k / g.gyp;
+      const int xi = t % g.gx, bi = t / g.gx;
+      coords[(int64_t)r * 3 + 0] = bi;  // [b, yi, xi]  (pe:125 swaps x/y)
+      coords[(int64_t)r * 3 + 1] = yi;
+      coords[(int64_t)r * 3 + 2] = xi;
+    }
+  }
+  rank_out[i] = r;
+  if (pillar_of_point) pillar_of_point[i] = r;
+}
+
+__device__ __forceinline__ uint32_t pillar_start(int32_t r, const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk) {
+  return cblk[r >> PNX_SCAN_SHIFT] + cpre[r];
+}
+
+// CSR fill: plist[start(rank) + slot] = point id.
+__global__ __launch_bounds__(kBlock) void k_fill(const int32_t* __restrict__ rank, const int32_t* __restrict__ slot, int64_t n,
+                                                 const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
+                                                 int32_t* __restrict__ plist) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int32_t r = rank[i];
+  if (r >= 0) plist[pillar_start(r, cpre, cblk) + (uint32_t)slot[i]] = (int32_t)i;
+}
+
+// unq_inv (pe:110): pillar rank of the j-th kept point, j = exclusive count of kept rows before it.
+__global__ __launch_bounds__(kBlock) void k_write_inv(const int32_t* __restrict__ rank, int64_t n, const uint32_t* __restrict__ kpre,
+                                                      const uint32_t* __restrict__ kblk, int64_t* __restrict__ unq_inv) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int32_t r = rank[i];
+  if (r >= 0) unq_inv[kblk[i >> PNX_SCAN_SHIFT] + kpre[i]] = (int64_t)r;
+}
+
+// Per-pillar mean of xyz (scatter_mean, pe:113-114): fp64 sum over the CSR list, fp32 divide by count.
+__global__ __launch_bounds__(kBlock) void k_pillar_mean(const float* __restrict__ pts, int stride, const int32_t* __restrict__ plist,
+                                                        const uint32_t* __restrict__ count, const uint32_t* __restrict__ cpre,
+                                                        const uint32_t* __restrict__ cblk, const int32_t* __restrict__ counters,
+                                                        float* __restrict__ mean) {
+  const int32_t r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= counters[0]) return;
+  const uint32_t s = pillar_start(r, cpre, cblk), c = count[r];
+  double sx = 0, sy = 0, sz = 0;
+  for (uint32_t k = 0; k < c; k++) {
+    const float* p = pts + (int64_t)plist[s + k] * stride;
+    sx += (double)p[1];
+    sy += (double)p[2];
+    sz += (double)p[3];
+  }
+  const float fc = (float)c;
+  mean[(int64_t)r * 3 + 0] = __fdiv_rn((float)sx, fc);
+  mean[(int64_t)r * 3 + 1] = __fdiv_rn((float)sy, fc);
+  mean[(int64_t)r * 3 + 2] = __fdiv_rn((float)sz, fc);
+}
+
+// Decorated point features (pe:116-123): [raw F | xyz - mean | xy - pillar centre].
+template <int F>
+__device__ __forceinline__ void decorate(const float* __restrict__ p, const float mx, const float my, const float mz, const GeomDev& g,
+                                         float* f) {
+#pragma unroll
+  for (int k = 0; k < F; k++) f[k] = p[1 + k];
+  const float x = p[1], y = p[2], z = p[3];
+  f[F + 0] = __fsub_rn(x, mx);
+  f[F + 1] = __fsub_rn(y, my);
+  f[F + 2] = __fsub_rn(z, mz);
+  const float cx = __fdiv_rn(__fsub_rn(x, g.minx), g.vx);
+  const float cy = __fdiv_rn(__fsub_rn(y, g.miny), g.vy);
+  const float xi = (float)(int)cx, yi = (float)(int)cy;
+  // idx*vs + vs/2 + min, each step rounded (pe:119-120)
+  const float ctrx = __fadd_rn(__fadd_rn(__fmul_rn(xi, g.vx), __fdiv_rn(g.vx, 2.0f)), g.minx);
+  const float ctry = __fadd_rn(__fadd_rn(__fmul_rn(yi, g.vy), __fdiv_rn(g.vy, 2.0f)), g.miny);
+  f[F + 3] = __fsub_rn(x, ctrx);
+  f[F + 4] = __fsub_rn(y, ctry);
+}
+
+template <int F>
+__global__ __launch_bounds__(kBlock) void k_decorate(const float* __restrict__ pts, int64_t n, GeomDev g, const int32_t* __restrict__ rank,
+                                                     const uint32_t* __restrict__ kpre, const uint32_t* __restrict__ kblk,
+                                                     const float* __restrict__ mean, float* __restrict__ features) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int32_t r = rank[i];
+  if (r < 0) return;
+  float f[F + 5];
+  decorate<F>(pts + i * (F + 1), mean[(int64_t)r * 3], mean[(int64_t)r * 3 + 1], mean[(int64_t)r * 3 + 2], g, f);
+  float* o = features + (int64_t)(kblk[i >> PNX_SCAN_SHIFT] + kpre[i]) * (F + 5);
+#pragma unroll
+  for (int k = 0; k < F + 5; k++) o[k] = f[k];
+}
+
+// ------------------------------------------------------------------------------------------ PFN
+// folded layout (include/pnx.h): W0' (32 x C0) | s0 (32) | W1' (64 x 64) | s1 (64)
+template <int F>
+struct Folded {
+  static constexpr int C0 = F + 5;
+  static constexpr int W0 = 0, S0 = 32 * C0, W1 = S0 + 32, S1 = W1 + 64 * 64;
+};
+
+// BatchNorm1d(eval) folded into the bias-free Linear in front of it (pe:32-33,37-38).
+__global__ void k_fold_bn(int C0, const float* w0, const float* g0, const float* b0, const float* m0, const float* v0, const float* w1,
+                          const float* g1, const float* b1, const float* m1, const float* v1, float eps, float* out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int S0 = 32 * C0, W1 = S0 + 32, S1 = W1 + 4096;
+  if (t < 32 * C0) {
+    const int c = t / C0;
+    const float a = __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v0[c], eps))), g0[c]);
+    out[t] = __fmul_rn(w0[t], a);
+  }
+  if (t < 4096) {
+    const int c = t >> 6;
+    const float a = __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v1[c], eps))), g1[c]);
+    out[W1 + t] = __fmul_rn(w1[t], a);
+  }
+  if (t < 32) {
+    const float a = __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v0[t], eps))), g0[t]);
+    out[S0 + t] = __fsub_rn(b0[t], __fmul_rn(m0[t], a));
+  }
+  if (t < 64) {
+    const float a = __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v1[t], eps))), g1[t]);
+    out[S1 + t] = __fsub_rn(b1[t], __fmul_rn(m1[t], a));
+  }
+}
+
+// h0[c] = relu(W0'[c,:] . f + s0[c])
+template <int F>
+__device__ __forceinline__ void pfn_layer0(const float* f, const float* __restrict__ P, float* h0) {
+  using L = Folded<F>;
+#pragma unroll
+  for (int c = 0; c < 32; c++) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < L::C0; k++) acc = __builtin_fmaf(f[k], P[L::W0 + c * L::C0 + k], acc);
+    const float y = acc + P[L::S0 + c];
+    h0[c] = y > 0.f ? y : 0.f;
+  }
+}
+
+// Reference kernel ("v0"): one thread per pillar walks its CSR list three times (mean, layer-0 max,
+// layer-1 max).  Simple and obviously right; kept as the cross-check for the wave-tiled kernel below and
+// selected with PNX_PFN_IMPL=0.
+template <int F>
+__global__ __launch_bounds__(kBlock) void k_pfn_pillar(const float* __restrict__ pts, GeomDev g, const int32_t* __restrict__ plist,
+                                                       const uint32_t* __restrict__ count, const uint32_t* __restrict__ cpre,
+                                                       const uint32_t* __restrict__ cblk, const int32_t* __restrict__ counters,
+                                                       const float* __restrict__ P, float* __restrict__ g1, int64_t g1_rows) {
+  using L = Folded<F>;
+  const int32_t r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= counters[0] || r >= g1_rows) return;
+  const uint32_t s = pillar_start(r, cpre, cblk), c = count[r];
+  double sx = 0, sy = 0, sz = 0;
+  for (uint32_t k = 0; k < c; k++) {
+    const float* p = pts + (int64_t)plist[s + k] * (F + 1);
+    sx += (double)p[1];
+    sy += (double)p[2];
+    sz += (double)p[3];
+  }
+  const float fc = (float)c;
+  const float mx = __fdiv_rn((float)sx, fc), my = __fdiv_rn((float)sy, fc), mz = __fdiv_rn((float)sz, fc);
+  float g0[32];
+#pragma unroll
+  for (int q = 0; q < 32; q++) g0[q] = 0.f;
+  for (uint32_t k = 0; k < c; k++) {
+    float f[F + 5], h0[32];
+    decorate<F>(pts + (int64_t)plist[s + k] * (F + 1), mx, my, mz, g, f);
+    pfn_layer0<F>(f, P, h0);
+#pragma unroll
+    for (int q = 0; q < 32; q++) g0[q] = fmaxf(g0[q], h0[q]);
+  }
+  float out[64];
+#pragma unroll
+  for (int q = 0; q < 64; q++) out[q] = 0.f;
+  for (uint32_t k = 0; k < c; k++) {
+    float f[F + 5], h0[32];
+    decorate<F>(pts + (int64_t)plist[s + k] * (F + 1), mx, my, mz, g, f);
+    pfn_layer0<F>(f, P, h0);
+    for (int q = 0; q < 64; q++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; j++) acc = __builtin_fmaf(h0[j], P[L::W1 + q * 64 + j], acc);
+#pragma unroll
+      for (int j = 0; j < 32; j++) acc = __builtin_fmaf(g0[j], P[L::W1 + q * 64 + 32 + j], acc);
+      out[q] = fmaxf(out[q], acc + P[L::S1 + q]);  // relu folded into the 0 start value
+    }
+  }
+  float4* o = reinterpret_cast<float4*>(g1 + (int64_t)r * 64);
+#pragma unroll
+  for (int q = 0; q < 16; q++) o[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+}
+
+// ------------------------------------------------------------------------------------------ canvas
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ uint32_t f32_to_f16_rne(float f) {
+  const _Float16 hv = (_Float16)f;  // round-to-nearest-even
+  return (uint32_t)__builtin_bit_cast(unsigned short, hv);
+}
+template <int DT>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  if (DT == PNX_BF16) return f32_to_bf16_rne(a) | (f32_to_bf16_rne(b) << 16);
+  return f32_to_f16_rne(a) | (f32_to_f16_rne(b) << 16);
+}
+
+// NHWC canvas, 64 channels.  One block per 32x32-cell tile.  s_word[x] holds the 32 occupancy bits of
+// column x (rows y0..y0+31 -- one aligned bitmap word thanks to the gyp padding), s_pre[x] the rank of its
+// first pillar.  Each 16-byte store chunk is zero or 8 (4 for fp32) converted feat_max values.
+template <int DT>
+__global__ __launch_bounds__(kBlock) void k_canvas_nhwc(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre,
+                                                        const uint32_t* __restrict__ wblk, const float* __restrict__ g1, int64_t g1_rows,
+                                                        GeomDev g, void* __restrict__ canvas) {
+  constexpr int ESZ = (DT == PNX_F32) ? 4 : 2;
+  constexpr int CH = 64 * ESZ / 16;  // 16-byte chunks per cell
+  constexpr int VPC = 16 / ESZ;      // values per chunk
+  __shared__ uint32_t s_word[32], s_pre[32];
+  const int tiles_x = (g.gx + 31) >> 5, tiles_y = g.gyp >> 5;
+  int tile = blockIdx.x;
+  const int tx = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty = tile % tiles_y, b = tile / tiles_y;
+  const int x0 = tx << 5, y0 = ty << 5;
+  const int t = threadIdx.x;
+  if (t < 32) {
+    uint32_t word = 0, pre = 0;
+    const int xi = x0 + t;
+    if (xi < g.gx) {
+      const int32_t w = ((b * g.gx + xi) * g.gyp + y0) >> 5;
+      word = bitmap[w];
+      pre = wblk[w >> PNX_SCAN_SHIFT] + wpre[w];
+    }
+    s_word[t] = word;
+    s_pre[t] = pre;
+  }
+  __syncthreads();
+  uint4* out = reinterpret_cast<uint4*>(canvas);
+  const int rows = min(32, g.gy - y0);
+  for (int idx = t; idx < rows * 32 * CH; idx += kBlock) {
+    const int q = idx % CH;
+    const int xl = (idx / CH) & 31;
+    const int yl = idx / (CH * 32);
+    const int xi = x0 + xl;
+    if (xi >= g.gx) continue;
+    const uint32_t word = s_word[xl];
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if ((word >> yl) & 1u) {
+      const int64_t r = (int64_t)s_pre[xl] + __popc(word & ((1u << yl) - 1u));
+      if (r < g1_rows) {
+        const float4* src = reinterpret_cast<const float4*>(g1 + r * 64 + q * VPC);
+        if (DT == PNX_F32) {
+          const float4 a = src[0];
+          v = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w));
+        } else {
+          const float4 a = src[0], c = src[1];
+          v = make_uint4(pack2<DT>(a.x, a.y), pack2<DT>(a.z, a.w), pack2<DT>(c.x, c.y), pack2<DT>(c.z, c.w));
+        }
+      }
+    }
+    out[(((int64_t)b * g.gy + (y0 + yl)) * g.gx + xi) * CH + q] = v;
+  }
+}
+
+// NCHW canvas (what .dense() returns).  Not the performance layout; same tile scheme, one element per store.
+template <int DT>
+__global__ __launch_bounds__(kBlock) void k_canvas_nchw(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre,
+                                                        const uint32_t* __restrict__ wblk, const float* __restrict__ g1, int64_t g1_rows,
+                                                        GeomDev g, void* __restrict__ canvas) {
+  __shared__ uint32_t s_word[32], s_pre[32];
+  const int tiles_x = (g.gx + 31) >> 5, tiles_y = g.gyp >> 5;
+  int tile = blockIdx.x;
+  const int tx = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty = tile % tiles_y, b = tile / tiles_y;
+  const int x0 = tx << 5, y0 = ty << 5;
+  const int t = threadIdx.x;
+  if (t < 32) {
+    uint32_t word = 0, pre = 0;
+    const int xi = x0 + t;
+    if (xi < g.gx) {
+      const int32_t w = ((b * g.gx + xi) * g.gyp + y0) >> 5;
+      word = bitmap[w];
+      pre = wblk[w >> PNX_SCAN_SHIFT] + wpre[w];
+    }
+    s_word[t] = word;
+    s_pre[t] = pre;
+  }
+  __syncthreads();
+  const int rows = min(32, g.gy - y0);
+  const int xl = t & 31;
+  const int xi = x0 + xl;
+  if (xi >= g.gx) return;
+  const uint32_t word = s_word[xl];
+  for (int yl = t >> 5; yl < rows; yl += kBlock / 32) {
+    const bool occ = (word >> yl) & 1u;
+    const int64_t r = (int64_t)s_pre[xl] + __popc(word & ((1u << yl) - 1u));
+    const bool ok = occ && r < g1_rows;
+    for (int c = 0; c < 64; c++) {
+      const float v = ok ? g1[r * 64 + c] : 0.f;
+      const int64_t o = (((int64_t)b * 64 + c) * g.gy + (y0 + yl)) * g.gx + xi;
+      if (DT == PNX_F32)
+        reinterpret_cast<float*>(canvas)[o] = v;
+      else if (DT == PNX_BF16)
+        reinterpret_cast<uint16_t*>(canvas)[o] = (uint16_t)f32_to_bf16_rne(v);
+      else
+        reinterpret_cast<uint16_t*>(canvas)[o] = (uint16_t)f32_to_f16_rne(v);
+    }
+  }
+}
+
+// Zero-fill + scatter from an explicit (P,64) list and coords (pnx_scatter_canvas).
+__global__ __launch_bounds__(kBlock) void k_zero16(uint4* __restrict__ p, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (int64_t)gridDim.x * kBlock) p[i] = make_uint4(0, 0, 0, 0);
+}
+template <int DT>
+__global__ __launch_bounds__(kBlock) void k_scatter_list(const float* __restrict__ feat, const int32_t* __restrict__ coords,
+                                                         const int32_t* __restrict__ num_pillars, int64_t cap, int B, int gy, int gx,
+                                                         int layout, void* __restrict__ canvas) {
+  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t r = idx >> 6;
+  const int c = idx & 63;
+  const int64_t P = min((int64_t)num_pillars[0], cap);
+  if (r >= P) return;
+  const int b = coords[r * 3], yi = coords[r * 3 + 1], xi = coords[r * 3 + 2];
+  if (b < 0 || b >= B || yi < 0 || yi >= gy || xi < 0 || xi >= gx) return;
+  const float v = feat[r * 64 + c];
+  const int64_t o = layout == PNX_NHWC ? (((int64_t)b * gy + yi) * gx + xi) * 64 + c : (((int64_t)b * 64 + c) * gy + yi) * gx + xi;
+  if (DT == PNX_F32)
+    reinterpret_cast<float*>(canvas)[o] = v;
+  else if (DT == PNX_BF16)
+    reinterpret_cast<uint16_t*>(canvas)[o] = (uint16_t)f32_to_bf16_rne(v);
+  else
+    reinterpret_cast<uint16_t*>(canvas)[o] = (uint16_t)f32_to_f16_rne(v);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+struct ReaderWs {
+  int32_t* counters;  // [0]=P [1]=N'
+  uint32_t *bitmap, *wpre, *wblk;
+  int32_t *key, *rank, *slot;
+  uint32_t *count, *cpre, *cblk;
+  int32_t* plist;
+  uint32_t *kpre, *kblk;
+  float* mean;
+  float* g1;
+  int64_t nwords, pcap;
+  int nblk_w, nblk_c, nblk_k;
+  size_t bytes;
+};
+
+int64_t cells_padded(const pnx_geom* g, int32_t batch) {
+  const int64_t gyp = (g->gy + 31) / 32 * 32;
+  return (int64_t)batch * g->gx * gyp;
+}
+
+ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
+  ReaderWs w;
+  PnxCarver c(ws);
+  const int64_t cells = cells_padded(g, batch);
+  w.nwords = cells / 32;
+  w.pcap = n < (int64_t)batch * g->gx * g->gy ? n : (int64_t)batch * g->gx * g->gy;
+  if (w.pcap < 1) w.pcap = 1;
+  w.nblk_w = (int)((w.nwords + PNX_SCAN_ITEMS - 1) / PNX_SCAN_ITEMS);
+  w.nblk_c = (int)((w.pcap + PNX_SCAN_ITEMS - 1) / PNX_SCAN_ITEMS);
+  w.nblk_k = (int)((n + PNX_SCAN_ITEMS - 1) / PNX_SCAN_ITEMS);
+  if (w.nblk_k < 1) w.nblk_k = 1;
+  w.counters = c.take<int32_t>(64);
+  w.bitmap = c.take<uint32_t>(w.nwords + 8);
+  w.wpre = c.take<uint32_t>(w.nwords + 8);
+  w.wblk = c.take<uint32_t>(w.nblk_w + 8);
+  w.key = c.take<int32_t>(n + 8);
+  w.rank = c.take<int32_t>(n + 8);
+  w.slot = c.take<int32_t>(n + 8);
+  w.count = c.take<uint32_t>(w.pcap + 8);
+  w.cpre = c.take<uint32_t>(w.pcap + 8);
+  w.cblk = c.take<uint32_t>(w.nblk_c + 8);
+  w.plist = c.take<int32_t>(n + 8);
+  w.kpre = c.take<uint32_t>(n + 8);
+  w.kblk = c.take<uint32_t>(w.nblk_k + 8);
+  w.mean = c.take<float>(w.pcap * 3 + 8);
+  w.g1 = c.take<float>(w.pcap * 64 + 8);
+  w.bytes = c.used();
+  return w;
+}
+
+GeomDev make_geom(const pnx_geom* g, int32_t batch) {
+  GeomDev d;
+  d.minx = g->pc_min[0]; d.miny = g->pc_min[1]; d.minz = g->pc_min[2];
+  d.vx = g->voxel[0]; d.vy = g->voxel[1]; d.vz = g->voxel[2];
+  d.gx = g->gx; d.gy = g->gy; d.gyp = (g->gy + 31) / 32 * 32;
+  d.B = batch;
+  return d;
+}
+
+inline int nblocks(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
+
+int check_common(const float* points, int64_t n, int32_t stride, int32_t batch, const pnx_geom* g, void* ws, size_t ws_bytes) {
+  PNX_REQUIRE(g != nullptr, PNX_ERR_INVALID, "geom is NULL");
+  PNX_REQUIRE(n >= 0 && batch >= 1, PNX_ERR_INVALID, "n_points=%lld batch=%d", (long long)n, batch);
+  PNX_REQUIRE(n == 0 || points != nullptr, PNX_ERR_INVALID, "points is NULL");
+  PNX_REQUIRE(stride >= 4 && stride <= 7, PNX_ERR_UNSUPPORTED, "row_stride %d: kernels are built for 3..6 point features", stride);
+  PNX_REQUIRE(g->gx > 0 && g->gy > 0, PNX_ERR_INVALID, "empty grid");
+  PNX_REQUIRE(cells_padded(g, batch) < ((int64_t)1 << 31), PNX_ERR_UNSUPPORTED, "batch*gx*gy exceeds the int32 cell key");
+  PNX_REQUIRE(n < ((int64_t)1 << 31) - 64, PNX_ERR_UNSUPPORTED, "more than 2^31 points");
+  PNX_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0, PNX_ERR_INVALID, "workspace must be 256-byte aligned");
+  const size_t need = pnx_reader_workspace_bytes(n, batch, g);
+  PNX_REQUIRE(ws_bytes >= need, PNX_ERR_WORKSPACE, "workspace %zu bytes < %zu needed", ws_bytes, need);
+  return PNX_OK;
+}
+
+// Steps 1-4: keys, bitmap scan, rank/slots/coords, CSR.  Leaves counters = {P, N'}.
+int run_voxelize(const float* points, int64_t n, int32_t stride, const GeomDev& gd, const ReaderWs& w, int32_t* coords,
+                 int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, bool need_kept_scan, hipStream_t st) {
+  PNX_CHECK_HIP(hipMemsetAsync(w.counters, 0, 64 * sizeof(int32_t), st));
+  PNX_CHECK_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)w.nwords * 4, st));
+  PNX_CHECK_HIP(hipMemsetAsync(w.count, 0, (size_t)w.pcap * 4, st));
+  if (n > 0) {
+    k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bitmap);
+    PNX_LAUNCH_CHECK();
+  }
+  k_scan_local<SCAN_POPC><<<w.nblk_w, kBlock, 0, st>>>(w.bitmap, w.nwords, w.wpre, w.wblk);
+  k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
+  PNX_LAUNCH_CHECK();
+  if (n > 0) {
+    k_rank<<<nblocks(n), kBlock, 0, st>>>(w.key, n, gd, w.bitmap, w.wpre, w.wblk, w.rank, w.slot, w.count, coords, pillar_capacity,
+                                          pillar_of_point);
+    PNX_LAUNCH_CHECK();
+  }
+  k_scan_local<SCAN_IDENT><<<w.nblk_c, kBlock, 0, st>>>(w.count, w.pcap, w.cpre, w.cblk);
+  k_scan_blocks<<<1, kBlock, 0, st>>>(w.cblk, w.nblk_c, w.counters + 1);
+  PNX_LAUNCH_CHECK();
+  if (n > 0) {
+    k_fill<<<nblocks(n), kBlock, 0, st>>>(w.rank, w.slot, n, w.cpre, w.cblk, w.plist);
+    PNX_LAUNCH_CHECK();
+    if (need_kept_scan) {
+      k_scan_local<SCAN_KEPT><<<w.nblk_k, kBlock, 0, st>>>(reinterpret_cast<const uint32_t*>(w.key), n, w.kpre, w.kblk);
+      k_scan_blocks<<<1, kBlock, 0, st>>>(w.kblk, w.nblk_k, nullptr);
+      PNX_LAUNCH_CHECK();
+      if (unq_inv) {
+        k_write_inv<<<nblocks(n), kBlock, 0, st>>>(w.rank, n, w.kpre, w.kblk, unq_inv);
+        PNX_LAUNCH_CHECK();
+      }
+    }
+  }
+  return PNX_OK;
+}
+
+template <int DT>
+int launch_canvas(const ReaderWs& w, const float* g1, int64_t g1_rows, const GeomDev& gd, void* canvas, int layout, hipStream_t st) {
+  const int tiles = ((gd.gx + 31) / 32) * (gd.gyp / 32) * gd.B;
+  if (layout == PNX_NHWC)
+    k_canvas_nhwc<DT><<<tiles, kBlock, 0, st>>>(w.bitmap, w.wpre, w.wblk, g1, g1_rows, gd, canvas);
+  else
+    k_canvas_nchw<DT><<<tiles, kBlock, 0, st>>>(w.bitmap, w.wpre, w.wblk, g1, g1_rows, gd, canvas);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+}  // namespace
+
+// implemented in pfn_mfma.hip: the wave-tiled fp32-MFMA PFN kernel (PNX_PFN_IMPL=1, default)
+int pnx_launch_pfn_mfma(int F, const float* points, const PnxGeomDev& geom, const int32_t* plist, const int32_t* rank,
+                        const uint32_t* count, const uint32_t* cpre, const uint32_t* cblk, const int32_t* counters, const float* folded,
+                        float* g1, int64_t g1_rows, int64_t n_points, hipStream_t st);
+
+extern "C" {
+
+size_t pnx_reader_workspace_bytes(int64_t n_points, int32_t batch, const pnx_geom* g) {
+  if (!g || n_points < 0 || batch < 1) return 0;
+  return carve(nullptr, n_points, batch, g).bytes;
+}
+
+int pnx_pfn_fold_bn(int32_t F, const float* w0, const float* gamma0, const float* beta0, const float* mean0, const float* var0,
+                    const float* w1, const float* gamma1, const float* beta1, const float* mean1, const float* var1, float eps,
+                    float* folded_out, pnx_stream_t stream) {
+  PNX_REQUIRE(F >= 3 && F <= 6, PNX_ERR_UNSUPPORTED, "num_point_features %d not in 3..6", F);
+  PNX_REQUIRE(w0 && gamma0 && beta0 && mean0 && var0 && w1 && gamma1 && beta1 && mean1 && var1 && folded_out, PNX_ERR_INVALID,
+              "null parameter pointer");
+  k_fold_bn<<<16, 256, 0, (hipStream_t)stream>>>(F + 5, w0, gamma0, beta0, mean0, var0, w1, gamma1, beta1, mean1, var1, eps, folded_out);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t batch, const pnx_geom* g, const float* pfn_folded,
+                       void* canvas, int32_t canvas_dtype, int32_t canvas_layout, float* feat_max, int32_t* coords,
+                       int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, int32_t* counts, void* workspace,
+                       size_t workspace_bytes, pnx_stream_t stream) {
+  int rc = check_common(points, n, stride, batch, g, workspace, workspace_bytes);
+  if (rc != PNX_OK) return rc;
+  PNX_REQUIRE(pfn_folded != nullptr, PNX_ERR_INVALID, "pfn_folded is NULL");
+  PNX_REQUIRE(canvas_dtype >= PNX_F32 && canvas_dtype <= PNX_F16, PNX_ERR_INVALID, "bad canvas_dtype %d", canvas_dtype);
+  PNX_REQUIRE(canvas_layout == PNX_NHWC || canvas_layout == PNX_NCHW, PNX_ERR_INVALID, "bad canvas_layout %d", canvas_layout);
+  PNX_REQUIRE(canvas == nullptr || ((uintptr_t)canvas & 15) == 0, PNX_ERR_INVALID, "canvas must be 16-byte aligned");
+  PNX_REQUIRE(feat_max == nullptr || ((uintptr_t)feat_max & 15) == 0, PNX_ERR_INVALID, "feat_max must be 16-byte aligned");
+  PNX_REQUIRE((feat_max == nullptr && coords == nullptr) || pillar_capacity > 0, PNX_ERR_INVALID, "pillar_capacity must be > 0");
+  hipStream_t st = (hipStream_t)stream;
+  const ReaderWs w = carve(workspace, n, batch, g);
+  const GeomDev gd = make_geom(g, batch);
+
+  rc = run_voxelize(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, unq_inv != nullptr, st);
+  if (rc != PNX_OK) return rc;
+
+  // feat_max doubles as the PFN output buffer when it can hold every possible pillar
+  float* g1 = (feat_max && pillar_capacity >= w.pcap) ? feat_max : w.g1;
+  const int64_t g1_rows = (g1 == feat_max) ? pillar_capacity : w.pcap;
+  if (n > 0) {
+    const char* impl_env = getenv("PNX_PFN_IMPL");  // 0 = per-pillar cross-check kernel
+    const int impl = impl_env ? atoi(impl_env) : 1;
+    const int F = stride - 1;
+    if (impl == 0) {
+      const int nb = nblocks(w.pcap);
+      switch (F) {
+        case 3: k_pfn_pillar<3><<<nb, kBlock, 0, st>>>(points, gd, w.plist, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows); break;
+        case 4: k_pfn_pillar<4><<<nb, kBlock, 0, st>>>(points, gd, w.plist, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows); break;
+        case 5: k_pfn_pillar<5><<<nb, kBlock, 0, st>>>(points, gd, w.plist, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows); break;
+        default: k_pfn_pillar<6><<<nb, kBlock, 0, st>>>(points, gd, w.plist, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows); break;
+      }
+      PNX_LAUNCH_CHECK();
+    } else {
+      rc = pnx_launch_pfn_mfma(F, points, gd, w.plist, w.rank, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows, n, st);
+      if (rc != PNX_OK) return rc;
+    }
+  }
+  if (feat_max && g1 != feat_max) {
+    // caller's buffer is smaller than the worst case: copy what fits (P is unknown on the host)
+    PNX_CHECK_HIP(hipMemcpyAsync(feat_max, g1, (size_t)(pillar_capacity < w.pcap ? pillar_capacity : w.pcap) * 64 * sizeof(float),
+                                 hipMemcpyDeviceToDevice, st));
+  }
+  if (canvas) {
+    if (canvas_dtype == PNX_F32) rc = launch_canvas<PNX_F32>(w, g1, g1_rows, gd, canvas, canvas_layout, st);
+    else if (canvas_dtype == PNX_BF16) rc = launch_canvas<PNX_BF16>(w, g1, g1_rows, gd, canvas, canvas_layout, st);
+    else rc = launch_canvas<PNX_F16>(w, g1, g1_rows, gd, canvas, canvas_layout, st);
+    if (rc != PNX_OK) return rc;
+  }
+  if (counts) PNX_CHECK_HIP(hipMemcpyAsync(counts, w.counters, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return PNX_OK;
+}
+
+int pnx_voxelize(const float* points, int64_t n, int32_t stride, int32_t batch, const pnx_geom* g, float* features, int32_t* coords,
+                 int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, int32_t* counts, void* workspace,
+                 size_t workspace_bytes, pnx_stream_t stream) {
+  int rc = check_common(points, n, stride, batch, g, workspace, workspace_bytes);
+  if (rc != PNX_OK) return rc;
+  PNX_REQUIRE(coords == nullptr || pillar_capacity > 0, PNX_ERR_INVALID, "pillar_capacity must be > 0");
+  hipStream_t st = (hipStream_t)stream;
+  const ReaderWs w = carve(workspace, n, batch, g);
+  const GeomDev gd = make_geom(g, batch);
+  rc = run_voxelize(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, unq_inv != nullptr || features != nullptr, st);
+  if (rc != PNX_OK) return rc;
+  if (features && n > 0) {
+    k_pillar_mean<<<nblocks(w.pcap), kBlock, 0, st>>>(points, stride, w.plist, w.count, w.cpre, w.cblk, w.counters, w.mean);
+    switch (stride - 1) {
+      case 3: k_decorate<3><<<nblocks(n), kBlock, 0, st>>>(points, n, gd, w.rank, w.kpre, w.kblk, w.mean, features); break;
+      case 4: k_decorate<4><<<nblocks(n), kBlock, 0, st>>>(points, n, gd, w.rank, w.kpre, w.kblk, w.mean, features); break;
+      case 5: k_decorate<5><<<nblocks(n), kBlock, 0, st>>>(points, n, gd, w.rank, w.kpre, w.kblk, w.mean, features); break;
+      default: k_decorate<6><<<nblocks(n), kBlock, 0, st>>>(points, n, gd, w.rank, w.kpre, w.kblk, w.mean, features); break;
+    }
+    PNX_LAUNCH_CHECK();
+  }
+  if (counts) PNX_CHECK_HIP(hipMemcpyAsync(counts, w.counters, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return PNX_OK;
+}
+
+int pnx_scatter_canvas(const float* feat_max, const int32_t* coords, const int32_t* num_pillars_dev, int64_t pillar_capacity,
+                       int32_t batch, int32_t gy, int32_t gx, void* canvas, int32_t canvas_dtype, int32_t canvas_layout,
+                       pnx_stream_t stream) {
+  PNX_REQUIRE(feat_max && coords && num_pillars_dev && canvas, PNX_ERR_INVALID, "null pointer");
+  PNX_REQUIRE(batch >= 1 && gy > 0 && gx > 0 && pillar_capacity >= 0, PNX_ERR_INVALID, "bad sizes");
+  PNX_REQUIRE(canvas_dtype >= PNX_F32 && canvas_dtype <= PNX_F16, PNX_ERR_INVALID, "bad canvas_dtype %d", canvas_dtype);
+  PNX_REQUIRE(((uintptr_t)canvas & 15) == 0, PNX_ERR_INVALID, "canvas must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t bytes = (int64_t)batch * 64 * gy * gx * (canvas_dtype == PNX_F32 ? 4 : 2);
+  k_zero16<<<2048, kBlock, 0, st>>>(reinterpret_cast<uint4*>(canvas), bytes / 16);
+  if (pillar_capacity > 0) {
+    const int nb = nblocks(pillar_capacity * 64);
+    if (canvas_dtype == PNX_F32) k_scatter_list<PNX_F32><<<nb, kBlock, 0, st>>>(feat_max, coords, num_pillars_dev, pillar_capacity, batch, gy, gx, canvas_layout, canvas);
+    else if (canvas_dtype == PNX_BF16) k_scatter_list<PNX_BF16><<<nb, kBlock, 0, st>>>(feat_max, coords, num_pillars_dev, pillar_capacity, batch, gy, gx, canvas_layout, canvas);
+    else k_scatter_list<PNX_F16><<<nb, kBlock, 0, st>>>(feat_max, coords, num_pillars_dev, pillar_capacity, batch, gy, gx, canvas_layout, canvas);
+  }
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+"""Thin torch-tensor front-ends over the C ABI (include/pnx.h).  PyTorch is used for device memory and the
+current stream only; every computation below happens in libpnx_hip.so."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import PNX_BF16, PNX_F16, PNX_F32, PNX_NCHW, PNX_NHWC, PnxError, check, lib, ptr, stream_ptr
+
+_DT = {torch.float32: PNX_F32, torch.bfloat16: PNX_BF16, torch.float16: PNX_F16}
+
+
+def _need_cuda(t, name):
+    if not t.is_cuda:
+        raise PnxError(f"{name} must be a CUDA (ROCm) tensor; the PillarNeXt hot path has no CPU implementation")
+    if not t.is_contiguous():
+        raise PnxError(f"{name} must be contiguous")
+
+
+class Workspace:
+    """Grow-only device scratch buffer, one per (device, stream user)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+# --------------------------------------------------------------------------------------------- reader
+def fold_bn(F, w0, bn0, w1, bn1, eps, out=None):
+    """bn = (gamma, beta, running_mean, running_var) fp32 CUDA tensors -> folded parameter buffer."""
+    n = 32 * (F + 5) + 32 + 64 * 64 + 64
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=w0.device)
+    ts = [w0, *bn0, w1, *bn1]
+    for t in ts:
+        _need_cuda(t, "PFN parameter")
+        if t.dtype != torch.float32:
+            raise PnxError("PFN parameters must be fp32")
+    if tuple(w0.shape) != (32, F + 5) or tuple(w1.shape) != (64, 64):
+        raise PnxError(f"PFN weights {tuple(w0.shape)}, {tuple(w1.shape)}: kernels are built for num_filters=[64, 64] only")
+    check(lib().pnx_pfn_fold_bn(F, *[ptr(t) for t in ts[:5]], *[ptr(t) for t in ts[5:]], ctypes.c_float(eps), ptr(out), stream_ptr()),
+          "pnx_pfn_fold_bn")
+    return out
+
+
+def reader_forward(points, batch, geom, folded, ws, canvas=None, canvas_layout=PNX_NHWC, feat_max=None, coords=None, unq_inv=None,
+                   pillar_of_point=None, counts=None):
+    _need_cuda(points, "points")
+    if points.dtype != torch.float32 or points.dim() != 2:
+        raise PnxError("points must be (N, 1+F) fp32")
+    n, stride = points.shape
+    nbytes = lib().pnx_reader_workspace_bytes(n, batch, ctypes.byref(geom))
+    buf = ws.get(nbytes, points.device)
+    cap = 0
+    if feat_max is not None:
+        cap = feat_max.shape[0]
+    if coords is not None:
+        cap = coords.shape[0] if cap == 0 else min(cap, coords.shape[0])
+    cdt = _DT[canvas.dtype] if canvas is not None else PNX_F32
+    check(lib().pnx_reader_forward(ptr(points), n, stride, batch, ctypes.byref(geom), ptr(folded), ptr(canvas), cdt, canvas_layout,
+                                   ptr(feat_max), ptr(coords), cap, ptr(unq_inv), ptr(pillar_of_point), ptr(counts), ptr(buf),
+                                   buf.numel(), stream_ptr()), "pnx_reader_forward")
+
+
+def voxelize(points, batch, geom, ws, features=None, coords=None, unq_inv=None, pillar_of_point=None, counts=None):
+    _need_cuda(points, "points")
+    n, stride = points.shape
+    nbytes = lib().pnx_reader_workspace_bytes(n, batch, ctypes.byref(geom))
+    buf = ws.get(nbytes, points.device)
+    cap = coords.shape[0] if coords is not None else 0
+    check(lib().pnx_voxelize(ptr(points), n, stride, batch, ctypes.byref(geom), ptr(features), ptr(coords), cap, ptr(unq_inv),
+                             ptr(pillar_of_point), ptr(counts), ptr(buf), buf.numel(), stream_ptr()), "pnx_voxelize")
+
+
+def scatter_canvas(feat_max, coords, num_pillars_dev, batch, gy, gx, canvas, layout=PNX_NHWC):
+    _need_cuda(feat_max, "feat_max")
+    check(lib().pnx_scatter_canvas(ptr(feat_max), ptr(coords), ptr(num_pillars_dev), feat_max.shape[0], batch, gy, gx, ptr(canvas),
+                                   _DT[canvas.dtype], layout, stream_ptr()), "pnx_scatter_canvas")
+
+
+_SM_WS = Workspace()
+
+
+class ScatterMax(torch.autograd.Function):
+    """torch_scatter.scatter_max(x, index, dim=0)[0] with the argmax-routed gradient (pillar_encoder.py:43,180)."""
+
+    @staticmethod
+    def forward(ctx, x, index, num_pillars):
+        _need_cuda(x, "x")
+        x = x.float()
+        n, C = x.shape
+        out = torch.empty((num_pillars, C), dtype=torch.float32, device=x.device)
+        arg = torch.empty((num_pillars, C), dtype=torch.int64, device=x.device)
+        nbytes = lib().pnx_scatter_max_workspace_bytes(n, num_pillars)
+        buf = _SM_WS.get(nbytes, x.device)
+        check(lib().pnx_scatter_max(ptr(x), ptr(index), n, C, num_pillars, ptr(out), ptr(arg), ptr(buf), buf.numel(), stream_ptr()),
+              "pnx_scatter_max")
+        ctx.save_for_backward(arg)
+        ctx.n = n
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_arg):
+        (arg,) = ctx.saved_tensors
+        P, C = arg.shape
+        g = grad_out.contiguous().float()
+        gx = torch.empty((ctx.n, C), dtype=torch.float32, device=g.device)
+        check(lib().pnx_scatter_max_backward(ptr(g), ptr(arg), ctx.n, C, P, ptr(gx), stream_ptr()), "pnx_scatter_max_backward")
+        return gx, None, None
+
+
+def scatter_max(x, index, num_pillars):
+    return ScatterMax.apply(x.contiguous(), index.contiguous(), int(num_pillars))
+
+
+# --------------------------------------------------------------------------------------------- IoU / NMS
+def _boxes(t, name):
+    _need_cuda(t, name)
+    if t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != 7:
+        raise PnxError(f"{name} must be (N, 7) fp32")
+
+
+def boxes_overlap_bev(a, b, out):
+    _boxes(a, "boxes_a"), _boxes(b, "boxes_b"), _need_cuda(out, "out")
+    check(lib().pnx_boxes_overlap_bev(ptr(a), a.shape[0], ptr(b), b.shape[0], ptr(out), stream_ptr()), "pnx_boxes_overlap_bev")
+
+
+def boxes_iou_bev(a, b, out):
+    _boxes(a, "boxes_a"), _boxes(b, "boxes_b"), _need_cuda(out, "out")
+    check(lib().pnx_boxes_iou_bev(ptr(a), a.shape[0], ptr(b), b.shape[0], ptr(out), stream_ptr()), "pnx_boxes_iou_bev")
+
+
+def boxes_aligned_overlap_bev(a, b, out):
+    _boxes(a, "boxes_a"), _boxes(b, "boxes_b"), _need_cuda(out, "out")
+    if a.shape[0] != b.shape[0]:
+        raise PnxError("aligned overlap needs equally many boxes")
+    check(lib().pnx_boxes_aligned_overlap_bev(ptr(a), ptr(b), a.shape[0], ptr(out), stream_ptr()), "pnx_boxes_aligned_overlap_bev")
+
+
+def boxes_aligned_iou3d(a, b):
+    _boxes(a, "boxes_a"), _boxes(b, "boxes_b")
+    if a.shape[0] != b.shape[0]:
+        raise PnxError("aligned IoU needs equally many boxes")
+    out = torch.empty((a.shape[0], 1), dtype=torch.float32, device=a.device)
+    check(lib().pnx_boxes_aligned_iou3d(ptr(a), ptr(b), a.shape[0], ptr(out), stream_ptr()), "pnx_boxes_aligned_iou3d")
+    return out
+
+
+_NMS_WS = Workspace()
+
+
+def nms_batched(boxes, seg_offsets, thresh, max_seg_len, post_max=0, rotated=True):
+    """boxes (T,7) score-sorted inside each segment; seg_offsets int32 (S+1) device; thresh fp32 (S) device.
+    Returns keep (T) int32 [segment-local indices, ascending, first keep_count[s] valid per segment] and keep_count (S)."""
+    _boxes(boxes, "boxes")
+    S = seg_offsets.numel() - 1
+    T = boxes.shape[0]
+    keep = torch.empty((max(T, 1),), dtype=torch.int32, device=boxes.device)
+    cnt = torch.zeros((max(S, 1),), dtype=torch.int32, device=boxes.device)
+    nbytes = lib().pnx_nms_workspace_bytes(T, S, max_seg_len)
+    buf = _NMS_WS.get(nbytes, boxes.device)
+    fn = lib().pnx_nms_rotated_batched if rotated else lib().pnx_nms_normal_batched
+    check(fn(ptr(boxes), ptr(seg_offsets), S, int(max_seg_len), ptr(thresh), int(post_max), ptr(keep), ptr(cnt), ptr(buf), buf.numel(),
+             stream_ptr()), "pnx_nms_batched")
+    return keep, cnt
+
+
+def nms_single(boxes, thresh, rotated=True, post_max=0):
+    """One score-sorted list -> (keep int32 device tensor, count python int). Syncs once, like nms_gpu does."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int32, device=boxes.device), 0
+    off = torch.tensor([0, n], dtype=torch.int32, device=boxes.device)
+    thr = torch.tensor([float(thresh)], dtype=torch.float32, device=boxes.device)
+    keep, cnt = nms_batched(boxes, off, thr, n, post_max, rotated)
+    k = int(cnt[0].item())
+    return keep[:k], k

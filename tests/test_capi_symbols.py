@@ -1,0 +1,56 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly the symbols include/pnx.h declares."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "pnx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pnx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pillarnext_amd import _lib, build
+
+    build.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/pnx.h but not exported"
+    assert sorted(_lib.PROTOTYPES) == names, "pillarnext_amd/_lib.py PROTOTYPES out of sync with include/pnx.h"
+
+
+def test_host_helpers_without_gpu():
+    from pillarnext_amd import _lib
+
+    L = _lib.lib()
+    assert b"gfx950" in L.pnx_version()
+    g = _lib.make_geom([-50.4, -50.4, -5.0, 50.4, 50.4, 3.0], [0.075, 0.075, 8])
+    assert (g.gx, g.gy) == (1344, 1344)  # 100.8/0.075 = 1344.0000000000002 -> np.round -> 1344
+    g = _lib.make_geom([-76.8, -76.8, -2, 76.8, 76.8, 4], [0.075, 0.075, 6])
+    assert (g.gx, g.gy) == (2048, 2048)
+    assert abs(g.voxel[0] - 0.075) < 1e-8 and g.voxel[0] != 0.075  # fp32 cast of the fp64 config value
+    n = L.pnx_reader_workspace_bytes(300000, 1, ctypes.byref(g))
+    assert 0 < n < 1 << 30
+    # argument validation needs no GPU: null geometry, bad stride
+    rc = L.pnx_reader_forward(None, 10, 6, 1, None, None, None, 0, 0, None, None, 0, None, None, None, None, 0, None)
+    assert rc == -1 and b"geom" in L.pnx_last_error()
+    try:
+        _lib.make_geom([0, 0, 0, -1, 1, 1], [0.1, 0.1, 1])
+        assert False
+    except _lib.PnxError as e:
+        assert "bad range" in str(e)
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    pkg = os.path.join(ROOT, "pillarnext_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle" not in txt.replace("oracle/pnx_oracle.c's", "").lower() or f in ("iou3d.hip",), f
