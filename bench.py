@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""bench.py -- PillarNeXt-B inference frames/s on synthetic nuScenes-shaped clouds (BASELINE.json metric).
+
+A step = one batch of `--batch` frames through the whole path with inputs already resident in HBM:
+  HIP reader (voxelize + PFN + dense bf16 canvas)  ->  dense masked ResNet-18 + ASPP + CenterHead (PyTorch-ROCm,
+  bf16, channels_last, MIOpen)  ->  decode + batched rotated NMS (HIP).
+Rank 0 prints ONE JSON line (see the driver contract).  Extra objects:
+  roofline      the reader's dominant kernel (dense-canvas writer), HBM-bound; algorithmic bytes per launch =
+                (24*N + nx*ny*64*2) * frames per launch, duration from HIP events recorded on the
+                kernel's own stream inside libpnx_hip.so (pnx_profile_begin/end) during the timed steps
+  cpu_baseline  the CPU oracle ("port", one core) on a bounded sample of the same frames, hot path only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PNX_BENCH_BATCH", "4")), help="frames per GPU per step")
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "sweep"])
+    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, config, dist_name, frames):
+    """CPU oracle (plain-C port of the reference algorithm, single thread) on `frames` frames: voxelize+PFN+scatter."""
+    from oracle import oracle as O
+    from pillarnext_amd import synth
+
+    layers = synth.pfn_params()
+    t_total = 0.0
+    for f in range(frames):
+        pts = synth.make_batch(config, 1, dist_name, frame0=f)
+        t0 = time.perf_counter()
+        O.reader_forward(pts, cfg["pc_range"], cfg["voxel_size"], [64, 64], layers, B=1, want_canvas=True)
+        t_total += time.perf_counter() - t0
+    return {"value": round(frames / t_total, 3), "unit": "frames/s (voxelize+PFN+scatter only, fp32 canvas)", "cores": 1, "kind": "port",
+            "sample": f"{frames} frames of {config}/{dist_name}, oracle/pnx_oracle.c orc_reader_forward, 1 thread, host {os.cpu_count()} cores"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", init_method="env://")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from pillarnext_amd import _lib, synth
+    from pillarnext_amd.models import build_pillarnext_b
+
+    cfg = synth.CONFIGS[a.config]
+    torch.manual_seed(0)
+    model = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"]).to(dev).eval()
+    for m in (model.backbone, model.neck, model.head):
+        m.to(memory_format=torch.channels_last, dtype=torch.bfloat16)
+    # frames are sharded across ranks: rank r gets frames r*B .. r*B+B-1 (replicas only, no collective on the path)
+    pts = torch.from_numpy(synth.make_batch(a.config, a.batch, a.dist, frame0=rank * a.batch)).to(dev)
+    example = {"points": pts, "token": [f"r{rank}f{i}" for i in range(a.batch)], "batch_size": a.batch}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            model(example)
+        barrier()
+        L = _lib.lib()
+        _lib.check(L.pnx_profile_begin(max(a.steps, 1)), "pnx_profile_begin")
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = model(example)
+        barrier()
+        dt = time.perf_counter() - t0
+    import ctypes
+
+    r_us, c_us, ns = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
+    _lib.check(L.pnx_profile_end(ctypes.byref(r_us), ctypes.byref(c_us), ctypes.byref(ns)), "pnx_profile_end")
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frames = a.batch * world * a.steps
+    nx, ny = model.reader._geom.gx, model.reader._geom.gy
+    alg_bytes = (24 * pts.shape[0]) + a.batch * nx * ny * 64 * 2  # per launch (= per step per GPU)
+    achieved = alg_bytes / (c_us.value * 1e-6) / 1e9 if c_us.value > 0 else None
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tj):
+        try:
+            traffic = json.load(open(tj)).get(f"{a.config}_b{a.batch}_{a.dist}", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    res = {
+        "metric": "frames/s PillarNeXt-B nuScenes 300k-pt cloud (inference, end-to-end)", "value": round(frames / dt, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{a.config}: PillarNeXt-B nuScenes inference, {cfg['n']} pts/frame, voxel {cfg['voxel_size'][0]} m, BEV {nx}x{ny}, "
+                               f"6 tasks/10 classes, cloud={a.dist}, random-init weights", "frames_per_gpu_per_step": a.batch,
+                   "global_batch": a.batch * world, "parallelism": f"frame-sharded replicas x{world}", "reader_dtype": "fp32 PFN -> bf16 canvas"},
+        "roofline": {"bound": "hbm", "kernel": "k_canvas_nhwc<bf16> (dense-canvas writer of the reader)", "achieved": round(achieved, 1) if achieved else None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_us": round(c_us.value, 2), "reader_all_kernels_us": round(r_us.value, 2),
+                     "frac_all_reader_kernels": round(alg_bytes / (r_us.value * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if r_us.value > 0 else None,
+                     "samples": ns.value},
+    }
+    if rank == 0:
+        if world == 1 and a.cpu_frames > 0:
+            res["cpu_baseline"] = cpu_baseline(cfg, a.config, a.dist, a.cpu_frames)
+        else:
+            res["cpu_baseline"] = None
+        res["detections_last_step"] = int(sum(len(v["scores"]) for v in out.values()))
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

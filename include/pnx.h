@@ -80,6 +80,8 @@ size_t pnx_reader_workspace_bytes(int64_t n_points, int32_t batch, const pnx_geo
  * Outputs (each may be NULL):
  *   canvas      B x 64 x gy x gx in canvas_dtype / canvas_layout; every element is written exactly once
  *               (zeros where no pillar)  -- the dense input of the backbone
+ *   occupancy   B x gy x gx uint8, 1 where a pillar exists (the active-site set of the reference's
+ *               SparseConvTensor; needed because a pillar's features may all be zero); requires canvas
  *   feat_max    (pillar_capacity, 64) fp32, row r = pillar of rank r            (:180-182)
  *   coords      (pillar_capacity, 3) int32 [b, yi, xi], torch.unique order      (:110-111,125)
  *   unq_inv     (n_points) int64: pillar rank of the j-th KEPT point, in input order (:110)
@@ -88,9 +90,15 @@ size_t pnx_reader_workspace_bytes(int64_t n_points, int32_t batch, const pnx_geo
  * If P would exceed pillar_capacity the rows beyond it are not written (P is still reported).
  */
 int pnx_reader_forward(const float* points, int64_t n_points, int32_t row_stride, int32_t batch, const pnx_geom* geom_host,
-                       const float* pfn_folded, void* canvas, int32_t canvas_dtype, int32_t canvas_layout, float* feat_max,
-                       int32_t* coords, int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, int32_t* counts,
-                       void* workspace, size_t workspace_bytes, pnx_stream_t stream);
+                       const float* pfn_folded, void* canvas, int32_t canvas_dtype, int32_t canvas_layout, uint8_t* occupancy,
+                       float* feat_max, int32_t* coords, int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point,
+                       int32_t* counts, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
+
+/* Measurement hooks for bench.py (no effect on results): between begin and end every pnx_reader_forward records
+ * HIP events on ITS stream around (a) the whole reader and (b) the canvas kernel, its dominant kernel.
+ * pnx_profile_end synchronises those events and returns average microseconds per call. */
+int pnx_profile_begin(int32_t max_samples);
+int pnx_profile_end(float* reader_us_avg_host, float* canvas_us_avg_host, int32_t* samples_host);
 
 /* Voxelizer alone (PillarNet.forward :78-125): indices plus the decorated (N', F+5) features
  * (rows in kept-point order; may be NULL).  Used by the training path, where Linear/BN stay in
@@ -131,6 +139,8 @@ int pnx_boxes_aligned_iou3d(const float* boxes_a, const float* boxes_b, int64_t 
  * already score-sorted box lists laid end to end:  segment s = boxes[seg_offsets[s] .. seg_offsets[s+1]).
  * The bitmask AND the greedy scan run on the device (the reference copies the mask to the host).
  *   seg_offsets   int32[num_segments+1] (device)
+ *   seg_len       int32[num_segments] (device) or NULL: only the first seg_len[s] boxes of segment s take part
+ *                 (the `order[:pre_maxsize]` cut of box_torch_ops.py:14-15 without compacting the box list)
  *   thresh        fp32[num_segments] (device) IoU threshold per segment
  *   keep          int32, same length as boxes: keep[seg_offsets[s] + k] = index (within the segment) of the
  *                 k-th kept box, ascending -- exactly what nms_gpu writes into `keep`
@@ -138,10 +148,10 @@ int pnx_boxes_aligned_iou3d(const float* boxes_a, const float* boxes_b, int64_t 
  *   max_seg_len   an upper bound on any segment's length (host value; sizes the launch)
  */
 size_t pnx_nms_workspace_bytes(int64_t total_boxes, int32_t num_segments, int32_t max_seg_len);
-int pnx_nms_rotated_batched(const float* boxes, const int32_t* seg_offsets, int32_t num_segments, int32_t max_seg_len,
+int pnx_nms_rotated_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* seg_len, int32_t num_segments, int32_t max_seg_len,
                             const float* thresh, int32_t post_max, int32_t* keep, int32_t* keep_count, void* workspace,
                             size_t workspace_bytes, pnx_stream_t stream);
-int pnx_nms_normal_batched(const float* boxes, const int32_t* seg_offsets, int32_t num_segments, int32_t max_seg_len,
+int pnx_nms_normal_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* seg_len, int32_t num_segments, int32_t max_seg_len,
                            const float* thresh, int32_t post_max, int32_t* keep, int32_t* keep_count, void* workspace,
                            size_t workspace_bytes, pnx_stream_t stream);
 

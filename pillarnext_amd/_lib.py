@@ -31,8 +31,10 @@ PROTOTYPES = {
     "pnx_geom_init": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(PnxGeom)]),
     "pnx_pfn_fold_bn": (ctypes.c_int, [_i32] + [_vp] * 10 + [_f32, _vp, _vp]),
     "pnx_reader_workspace_bytes": (_sz, [_i64, _i32, ctypes.POINTER(PnxGeom)]),
-    "pnx_reader_forward": (ctypes.c_int, [_vp, _i64, _i32, _i32, ctypes.POINTER(PnxGeom), _vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp,
-                                          _vp, _sz, _vp]),
+    "pnx_reader_forward": (ctypes.c_int, [_vp, _i64, _i32, _i32, ctypes.POINTER(PnxGeom), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp,
+                                          _vp, _vp, _sz, _vp]),
+    "pnx_profile_begin": (ctypes.c_int, [_i32]),
+    "pnx_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]),
     "pnx_voxelize": (ctypes.c_int, [_vp, _i64, _i32, _i32, ctypes.POINTER(PnxGeom), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pnx_scatter_max_workspace_bytes": (_sz, [_i64, _i64]),
     "pnx_scatter_max": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
@@ -43,8 +45,8 @@ PROTOTYPES = {
     "pnx_boxes_aligned_overlap_bev": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "pnx_boxes_aligned_iou3d": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "pnx_nms_workspace_bytes": (_sz, [_i64, _i32, _i32]),
-    "pnx_nms_rotated_batched": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
-    "pnx_nms_normal_batched": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "pnx_nms_rotated_batched": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "pnx_nms_normal_batched": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _LIB = None

@@ -231,12 +231,19 @@ __global__ __launch_bounds__(256) void k_pairs(const float* __restrict__ a, int6
 // ---- NMS bitmask (nms_kernel cu:280-324 / nms_normal_kernel cu:341-385), batched over segments.
 // grid = (col tiles, row tiles, segments), one wave per tile; only tiles on or above the diagonal.
 // mask word (row i, col tile c) of a segment lives at mask[(off + i) * cbmax + c].
+__device__ __forceinline__ int seg_size(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_len, int seg) {
+  int n = seg_off[seg + 1] - seg_off[seg];
+  if (seg_len) n = min(n, max(seg_len[seg], 0));
+  return n;
+}
+
 template <bool ROTATED>
 __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int32_t* __restrict__ seg_off,
-                                                 const float* __restrict__ thresh, uint64_t* __restrict__ mask, int cbmax) {
+                                                 const int32_t* __restrict__ seg_len, const float* __restrict__ thresh,
+                                                 uint64_t* __restrict__ mask, int cbmax) {
   const int seg = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb) return;
-  const int off = seg_off[seg], n = seg_off[seg + 1] - off;
+  const int off = seg_off[seg], n = seg_size(seg_off, seg_len, seg);
   if (rb * 64 >= n || cb * 64 >= n) return;
   const float thr = thresh[seg];
   const int row_size = min(n - rb * 64, 64), col_size = min(n - cb * 64, 64);
@@ -280,11 +287,12 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes
 }
 
 // ---- greedy scan (nms_gpu host loop, iou3d_nms.cpp:139-155), one wave per segment, 64 boxes per step.
-__global__ __launch_bounds__(64) void k_nms_greedy(const uint64_t* __restrict__ mask, const int32_t* __restrict__ seg_off, int cbmax,
-                                                   int post_max, int32_t* __restrict__ keep, int32_t* __restrict__ keep_count) {
+__global__ __launch_bounds__(64) void k_nms_greedy(const uint64_t* __restrict__ mask, const int32_t* __restrict__ seg_off,
+                                                   const int32_t* __restrict__ seg_len, int cbmax, int post_max,
+                                                   int32_t* __restrict__ keep, int32_t* __restrict__ keep_count) {
   extern __shared__ uint64_t s_remv[];  // cbmax words
   const int seg = blockIdx.x, t = threadIdx.x;
-  const int off = seg_off[seg], n = seg_off[seg + 1] - off;
+  const int off = seg_off[seg], n = seg_size(seg_off, seg_len, seg);
   const int cb = (n + 63) >> 6;
   for (int j = t; j < cb; j += 64) s_remv[j] = 0;
   __syncthreads();
@@ -339,7 +347,7 @@ int launch_pairs(int mode, const float* a, int64_t n, const float* b, int64_t m,
 }
 
 template <bool ROTATED>
-int nms_batched(const float* boxes, const int32_t* seg_offsets, int32_t num_segments, int32_t max_seg_len, const float* thresh,
+int nms_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* seg_len, int32_t num_segments, int32_t max_seg_len, const float* thresh,
                 int32_t post_max, int32_t* keep, int32_t* keep_count, void* workspace, size_t workspace_bytes, hipStream_t st) {
   PNX_REQUIRE(num_segments >= 0 && max_seg_len >= 0, PNX_ERR_INVALID, "negative sizes");
   if (num_segments == 0) return PNX_OK;
@@ -357,8 +365,8 @@ int nms_batched(const float* boxes, const int32_t* seg_offsets, int32_t num_segm
   PNX_REQUIRE(((uintptr_t)workspace & 7) == 0 && workspace_bytes >= 8, PNX_ERR_WORKSPACE, "bad workspace");
   uint64_t* mask = (uint64_t*)workspace;
   dim3 grid(cbmax, cbmax, num_segments);
-  k_nms_mask<ROTATED><<<grid, 64, 0, st>>>(boxes, seg_offsets, thresh, mask, cbmax);
-  k_nms_greedy<<<num_segments, 64, cbmax * sizeof(uint64_t), st>>>(mask, seg_offsets, cbmax, post_max, keep, keep_count);
+  k_nms_mask<ROTATED><<<grid, 64, 0, st>>>(boxes, seg_offsets, seg_len, thresh, mask, cbmax);
+  k_nms_greedy<<<num_segments, 64, cbmax * sizeof(uint64_t), st>>>(mask, seg_offsets, seg_len, cbmax, post_max, keep, keep_count);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -386,16 +394,16 @@ size_t pnx_nms_workspace_bytes(int64_t total_boxes, int32_t num_segments, int32_
   return (size_t)total_boxes * (size_t)((max_seg_len + 63) / 64) * sizeof(uint64_t) + 8;
 }
 
-int pnx_nms_rotated_batched(const float* boxes, const int32_t* seg_offsets, int32_t num_segments, int32_t max_seg_len,
+int pnx_nms_rotated_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* seg_len, int32_t num_segments, int32_t max_seg_len,
                             const float* thresh, int32_t post_max, int32_t* keep, int32_t* keep_count, void* workspace,
                             size_t workspace_bytes, pnx_stream_t stream) {
-  return nms_batched<true>(boxes, seg_offsets, num_segments, max_seg_len, thresh, post_max, keep, keep_count, workspace, workspace_bytes,
+  return nms_batched<true>(boxes, seg_offsets, seg_len, num_segments, max_seg_len, thresh, post_max, keep, keep_count, workspace, workspace_bytes,
                            (hipStream_t)stream);
 }
-int pnx_nms_normal_batched(const float* boxes, const int32_t* seg_offsets, int32_t num_segments, int32_t max_seg_len,
+int pnx_nms_normal_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* seg_len, int32_t num_segments, int32_t max_seg_len,
                            const float* thresh, int32_t post_max, int32_t* keep, int32_t* keep_count, void* workspace,
                            size_t workspace_bytes, pnx_stream_t stream) {
-  return nms_batched<false>(boxes, seg_offsets, num_segments, max_seg_len, thresh, post_max, keep, keep_count, workspace, workspace_bytes,
+  return nms_batched<false>(boxes, seg_offsets, seg_len, num_segments, max_seg_len, thresh, post_max, keep, keep_count, workspace, workspace_bytes,
                             (hipStream_t)stream);
 }
 

@@ -20,6 +20,8 @@
 // Determinism: pillar membership, rank, coords and the max-pool do not depend on thread timing.  The
 // per-pillar mean is summed in fp64 (exact for LiDAR-range coordinates), so the atomic slot order does
 // not show in the results either.
+#include <vector>
+
 #include "pnx_common.h"
 #include "pnx_scan.h"
 
@@ -285,7 +287,7 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 template <int DT>
 __global__ __launch_bounds__(kBlock) void k_canvas_nhwc(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre,
                                                         const uint32_t* __restrict__ wblk, const float* __restrict__ g1, int64_t g1_rows,
-                                                        GeomDev g, void* __restrict__ canvas) {
+                                                        GeomDev g, void* __restrict__ canvas, uint8_t* __restrict__ occ) {
   constexpr int ESZ = (DT == PNX_F32) ? 4 : 2;
   constexpr int CH = 64 * ESZ / 16;  // 16-byte chunks per cell
   constexpr int VPC = 16 / ESZ;      // values per chunk
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(kBlock) void k_canvas_nhwc(const uint32_t* __restri
     if (xi >= g.gx) continue;
     const uint32_t word = s_word[xl];
     uint4 v = make_uint4(0, 0, 0, 0);
+    if (occ != nullptr && q == 0) occ[((int64_t)b * g.gy + (y0 + yl)) * g.gx + xi] = (uint8_t)((word >> yl) & 1u);
     if ((word >> yl) & 1u) {
       const int64_t r = (int64_t)s_pre[xl] + __popc(word & ((1u << yl) - 1u));
       if (r < g1_rows) {
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void k_canvas_nhwc(const uint32_t* __restri
 template <int DT>
 __global__ __launch_bounds__(kBlock) void k_canvas_nchw(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre,
                                                         const uint32_t* __restrict__ wblk, const float* __restrict__ g1, int64_t g1_rows,
-                                                        GeomDev g, void* __restrict__ canvas) {
+                                                        GeomDev g, void* __restrict__ canvas, uint8_t* __restrict__ occ) {
   __shared__ uint32_t s_word[32], s_pre[32];
   const int tiles_x = (g.gx + 31) >> 5, tiles_y = g.gyp >> 5;
   int tile = blockIdx.x;
@@ -367,9 +370,10 @@ __global__ __launch_bounds__(kBlock) void k_canvas_nchw(const uint32_t* __restri
   if (xi >= g.gx) return;
   const uint32_t word = s_word[xl];
   for (int yl = t >> 5; yl < rows; yl += kBlock / 32) {
-    const bool occ = (word >> yl) & 1u;
+    const bool occ_bit = (word >> yl) & 1u;
     const int64_t r = (int64_t)s_pre[xl] + __popc(word & ((1u << yl) - 1u));
-    const bool ok = occ && r < g1_rows;
+    if (occ != nullptr) occ[((int64_t)b * g.gy + (y0 + yl)) * g.gx + xi] = (uint8_t)occ_bit;
+    const bool ok = occ_bit && r < g1_rows;
     for (int c = 0; c < 64; c++) {
       const float v = ok ? g1[r * 64 + c] : 0.f;
       const int64_t o = (((int64_t)b * 64 + c) * g.gy + (y0 + yl)) * g.gx + xi;
@@ -409,6 +413,16 @@ __global__ __launch_bounds__(kBlock) void k_scatter_list(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------ host side
+// Optional event timing (pnx_profile_begin/end).
+struct Prof {
+  bool on = false;
+  int cap = 0, n = 0;
+  std::vector<hipEvent_t> ev;  // 4 per sample: reader start, canvas start, canvas stop, reader stop
+} g_prof;
+inline void prof_mark(int which, hipStream_t st) {
+  if (g_prof.on && g_prof.n < g_prof.cap) (void)hipEventRecord(g_prof.ev[g_prof.n * 4 + which], st);
+}
+
 struct ReaderWs {
   int32_t* counters;  // [0]=P [1]=N'
   uint32_t *bitmap, *wpre, *wblk;
@@ -521,12 +535,12 @@ int run_voxelize(const float* points, int64_t n, int32_t stride, const GeomDev& 
 }
 
 template <int DT>
-int launch_canvas(const ReaderWs& w, const float* g1, int64_t g1_rows, const GeomDev& gd, void* canvas, int layout, hipStream_t st) {
+int launch_canvas(const ReaderWs& w, const float* g1, int64_t g1_rows, const GeomDev& gd, void* canvas, uint8_t* occ, int layout, hipStream_t st) {
   const int tiles = ((gd.gx + 31) / 32) * (gd.gyp / 32) * gd.B;
   if (layout == PNX_NHWC)
-    k_canvas_nhwc<DT><<<tiles, kBlock, 0, st>>>(w.bitmap, w.wpre, w.wblk, g1, g1_rows, gd, canvas);
+    k_canvas_nhwc<DT><<<tiles, kBlock, 0, st>>>(w.bitmap, w.wpre, w.wblk, g1, g1_rows, gd, canvas, occ);
   else
-    k_canvas_nchw<DT><<<tiles, kBlock, 0, st>>>(w.bitmap, w.wpre, w.wblk, g1, g1_rows, gd, canvas);
+    k_canvas_nchw<DT><<<tiles, kBlock, 0, st>>>(w.bitmap, w.wpre, w.wblk, g1, g1_rows, gd, canvas, occ);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -557,7 +571,7 @@ int pnx_pfn_fold_bn(int32_t F, const float* w0, const float* gamma0, const float
 }
 
 int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t batch, const pnx_geom* g, const float* pfn_folded,
-                       void* canvas, int32_t canvas_dtype, int32_t canvas_layout, float* feat_max, int32_t* coords,
+                       void* canvas, int32_t canvas_dtype, int32_t canvas_layout, uint8_t* occupancy, float* feat_max, int32_t* coords,
                        int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, int32_t* counts, void* workspace,
                        size_t workspace_bytes, pnx_stream_t stream) {
   int rc = check_common(points, n, stride, batch, g, workspace, workspace_bytes);
@@ -566,12 +580,14 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   PNX_REQUIRE(canvas_dtype >= PNX_F32 && canvas_dtype <= PNX_F16, PNX_ERR_INVALID, "bad canvas_dtype %d", canvas_dtype);
   PNX_REQUIRE(canvas_layout == PNX_NHWC || canvas_layout == PNX_NCHW, PNX_ERR_INVALID, "bad canvas_layout %d", canvas_layout);
   PNX_REQUIRE(canvas == nullptr || ((uintptr_t)canvas & 15) == 0, PNX_ERR_INVALID, "canvas must be 16-byte aligned");
+  PNX_REQUIRE(occupancy == nullptr || canvas != nullptr, PNX_ERR_INVALID, "occupancy is produced by the canvas kernel: pass a canvas too");
   PNX_REQUIRE(feat_max == nullptr || ((uintptr_t)feat_max & 15) == 0, PNX_ERR_INVALID, "feat_max must be 16-byte aligned");
   PNX_REQUIRE((feat_max == nullptr && coords == nullptr) || pillar_capacity > 0, PNX_ERR_INVALID, "pillar_capacity must be > 0");
   hipStream_t st = (hipStream_t)stream;
   const ReaderWs w = carve(workspace, n, batch, g);
   const GeomDev gd = make_geom(g, batch);
 
+  prof_mark(0, st);
   rc = run_voxelize(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, unq_inv != nullptr, st);
   if (rc != PNX_OK) return rc;
 
@@ -601,13 +617,49 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
     PNX_CHECK_HIP(hipMemcpyAsync(feat_max, g1, (size_t)(pillar_capacity < w.pcap ? pillar_capacity : w.pcap) * 64 * sizeof(float),
                                  hipMemcpyDeviceToDevice, st));
   }
+  prof_mark(1, st);
   if (canvas) {
-    if (canvas_dtype == PNX_F32) rc = launch_canvas<PNX_F32>(w, g1, g1_rows, gd, canvas, canvas_layout, st);
-    else if (canvas_dtype == PNX_BF16) rc = launch_canvas<PNX_BF16>(w, g1, g1_rows, gd, canvas, canvas_layout, st);
-    else rc = launch_canvas<PNX_F16>(w, g1, g1_rows, gd, canvas, canvas_layout, st);
+    if (canvas_dtype == PNX_F32) rc = launch_canvas<PNX_F32>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
+    else if (canvas_dtype == PNX_BF16) rc = launch_canvas<PNX_BF16>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
+    else rc = launch_canvas<PNX_F16>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
     if (rc != PNX_OK) return rc;
   }
+  prof_mark(2, st);
   if (counts) PNX_CHECK_HIP(hipMemcpyAsync(counts, w.counters, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  prof_mark(3, st);
+  if (g_prof.on && g_prof.n < g_prof.cap) g_prof.n++;
+  return PNX_OK;
+}
+
+int pnx_profile_begin(int32_t max_samples) {
+  PNX_REQUIRE(max_samples > 0 && max_samples <= 65536, PNX_ERR_INVALID, "max_samples out of range");
+  while ((int)g_prof.ev.size() < max_samples * 4) {
+    hipEvent_t e;
+    PNX_CHECK_HIP(hipEventCreate(&e));
+    g_prof.ev.push_back(e);
+  }
+  g_prof.cap = max_samples;
+  g_prof.n = 0;
+  g_prof.on = true;
+  return PNX_OK;
+}
+
+int pnx_profile_end(float* reader_us, float* canvas_us, int32_t* samples) {
+  g_prof.on = false;
+  double r = 0, c = 0;
+  for (int i = 0; i < g_prof.n; i++) {
+    float ms = 0;
+    PNX_CHECK_HIP(hipEventSynchronize(g_prof.ev[i * 4 + 3]));
+    PNX_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[i * 4 + 0], g_prof.ev[i * 4 + 3]));
+    r += ms;
+    PNX_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[i * 4 + 1], g_prof.ev[i * 4 + 2]));
+    c += ms;
+  }
+  const int n = g_prof.n;
+  if (reader_us) *reader_us = n ? (float)(r * 1e3 / n) : 0.f;
+  if (canvas_us) *canvas_us = n ? (float)(c * 1e3 / n) : 0.f;
+  if (samples) *samples = n;
+  g_prof.n = 0;
   return PNX_OK;
 }
 

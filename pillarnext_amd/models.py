@@ -1,0 +1,434 @@
+"""PillarNeXt-B around the HIP hot path: dense (masked) 2-D ResNet-18 backbone, ASPP neck, CenterHead and the
+single-stage detector -- plain PyTorch-ROCm modules (nn.Conv2d -> MIOpen/MFMA), as BASELINE.json's north_star
+prescribes.  Module/parameter names follow the reference so its checkpoints and YAML `_target_`s map 1:1:
+
+    SparseResNet        det3d/models/backbones/sparse_resnet.py:10-68  (+ utils/sparse_conv.py:16-63)
+    ASPPNeck            det3d/models/necks/aspp.py:8-40                (+ utils/conv.py)
+    SepHead/CenterHead  det3d/models/heads/centerhead.py:12-136, predict :231-330, post_processing :332-384
+    SingleStageDetector det3d/models/detectors/single_stage.py:6-59
+
+The reference backbone is spconv; here it is dense convolution on the BEV canvas with the masked-dense rule
+that reproduces spconv's active-site semantics exactly in eval mode:
+    SubMConv2d            : out = conv(x) * mask_in
+    SparseConv2d(3,s,p=1) : mask_out = maxpool(mask_in, 3, s, 1);  out = conv(x) * mask_out
+    BatchNorm1d over sites: per-channel affine at active sites, zero elsewhere (all convs are bias-free).
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------------ backbone
+def _spconv_weight_to_conv2d(w, conv):
+    """spconv >= 2.2 stores (Cout, kH, kW, Cin); older (kH, kW, Cin, Cout).  nn.Conv2d wants (Cout, Cin, kH, kW)."""
+    want = tuple(conv.weight.shape)
+    if tuple(w.shape) == want:
+        return w
+    co, ci, kh, kw = want
+    if tuple(w.shape) == (co, kh, kw, ci):
+        return w.permute(0, 3, 1, 2).contiguous()
+    if tuple(w.shape) == (kh, kw, ci, co):
+        return w.permute(3, 2, 0, 1).contiguous()
+    raise RuntimeError(f"cannot map sparse-conv weight {tuple(w.shape)} onto Conv2d {want}")
+
+
+class _SpConv2d(nn.Conv2d):
+    """nn.Conv2d that accepts spconv-layout checkpoints."""
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        k = prefix + "weight"
+        if k in state_dict:
+            state_dict[k] = _spconv_weight_to_conv2d(state_dict[k], self)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class MaskedBatchNorm(nn.BatchNorm2d):
+    """BatchNorm1d over ACTIVE sites of a dense map (keys/shapes identical to the reference's BatchNorm1d).
+    eval: affine with running stats.  train: statistics over mask==1 positions only."""
+
+    def forward(self, x, mask=None):
+        if not self.training or mask is None:
+            return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, self.eps)
+        m = mask.to(torch.float32)
+        xf = x.float()
+        cnt = m.sum().clamp(min=1.0)
+        mean = (xf * m).sum(dim=(0, 2, 3)) / cnt
+        var = (((xf - mean.view(1, -1, 1, 1)) ** 2) * m).sum(dim=(0, 2, 3)) / cnt
+        with torch.no_grad():
+            mom = self.momentum
+            self.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            self.running_var.mul_(1 - mom).add_(var * cnt / (cnt - 1).clamp(min=1.0), alpha=mom)
+            self.num_batches_tracked += 1
+        y = (xf - mean.view(1, -1, 1, 1)) * torch.rsqrt(var + self.eps).view(1, -1, 1, 1)
+        return (y * self.weight.view(1, -1, 1, 1) + self.bias.view(1, -1, 1, 1)).to(x.dtype)
+
+
+class SparseConvBlock(nn.Module):
+    """conv + BN + ReLU on active sites (sparse_conv.py:16-39).  stride 1 & use_subm -> submanifold."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, use_subm=True, bias=False):
+        super().__init__()
+        self.subm = stride == 1 and use_subm
+        self.stride = stride
+        self.kernel_size = kernel_size
+        self.conv = _SpConv2d(in_channels, out_channels, kernel_size, stride=stride, padding=kernel_size // 2, bias=bias)
+        self.norm = MaskedBatchNorm(out_channels, eps=1e-3, momentum=0.01)
+
+    def forward(self, x, mask):
+        if not self.subm:
+            mask = F.max_pool2d(mask, self.kernel_size, self.stride, self.kernel_size // 2)
+        out = self.conv(x)
+        out = F.relu(self.norm(out, mask)) * mask
+        return out, mask
+
+
+class SparseBasicBlock(nn.Module):
+    """Residual block of two submanifold convs (sparse_conv.py:42-63)."""
+
+    def __init__(self, channels, kernel_size):
+        super().__init__()
+        self.block1 = SparseConvBlock(channels, channels, kernel_size, 1)
+        self.conv2 = _SpConv2d(channels, channels, kernel_size, stride=1, padding=kernel_size // 2, bias=False)
+        self.norm2 = MaskedBatchNorm(channels, eps=1e-3, momentum=0.01)
+
+    def forward(self, x, mask):
+        out, _ = self.block1(x, mask)
+        out = self.norm2(self.conv2(out), mask)
+        out = F.relu(out + x) * mask
+        return out, mask
+
+
+class _Seq(nn.ModuleList):
+    def forward(self, x, mask):
+        for m in self:
+            x, mask = m(x, mask)
+        return x, mask
+
+
+class SparseResNet(nn.Module):
+    """Same constructor/keys as the reference's spconv SparseResNet; consumes the dense canvas."""
+
+    def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, num_input_features, kernel_size=(3, 3, 3, 3), out_channels=256):
+        super().__init__()
+        assert len(ds_layer_strides) == len(layer_nums) == len(ds_num_filters)
+        in_filters = [num_input_features, *ds_num_filters[:-1]]
+        blocks = []
+        for i, n in enumerate(layer_nums):
+            layers = [SparseConvBlock(in_filters[i], ds_num_filters[i], kernel_size[i], ds_layer_strides[i], use_subm=False)]
+            layers += [SparseBasicBlock(ds_num_filters[i], kernel_size[i]) for _ in range(n)]
+            blocks.append(_Seq(layers))
+        self.blocks = nn.ModuleList(blocks)
+        self.mapping = nn.ModuleList([_SpConv2d(ds_num_filters[-1], out_channels, 1, 1, bias=False),
+                                      MaskedBatchNorm(out_channels, eps=1e-3, momentum=0.01)])
+        self.num_input_features = num_input_features
+
+    def forward_dense(self, canvas, mask):
+        """canvas (B,C,ny,nx), mask (B,1,ny,nx) in canvas dtype -> (B,256,ny/8,nx/8) dense, zero at inactive sites."""
+        x = canvas
+        for blk in self.blocks:
+            x, mask = blk(x, mask)
+        x = F.relu(self.mapping[1](self.mapping[0](x), mask)) * mask
+        return x
+
+    def forward(self, pillar_features, coors, input_shape, batch_size=None):
+        """Reference signature (sparse_resnet.py:61): builds the canvas from the sparse list first."""
+        ny, nx = int(input_shape[0]), int(input_shape[1])
+        if batch_size is None:
+            batch_size = len(torch.unique(coors[:, 0]))  # the reference's own rule (:62)
+        dev, dt = pillar_features.device, pillar_features.dtype
+        canvas = torch.zeros((batch_size, ny, nx, pillar_features.shape[1]), dtype=dt, device=dev)
+        mask = torch.zeros((batch_size, ny, nx, 1), dtype=dt, device=dev)
+        c = coors.long()
+        canvas[c[:, 0], c[:, 1], c[:, 2]] = pillar_features
+        mask[c[:, 0], c[:, 1], c[:, 2]] = 1
+        return self.forward_dense(canvas.permute(0, 3, 1, 2), mask.permute(0, 3, 1, 2))
+
+
+# ------------------------------------------------------------------------------------------------ neck
+class Conv(nn.Module):
+    def __init__(self, inplanes, planes, kernel_size, stride, conv_layer=nn.Conv2d, bias=False, **kwargs):
+        super().__init__()
+        padding = kwargs.get("padding", kernel_size // 2)
+        self.conv = conv_layer(inplanes, planes, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, inplanes, planes, kernel_size, stride=1, conv_layer=nn.Conv2d, norm_layer=nn.BatchNorm2d, act_layer=nn.ReLU, **kwargs):
+        super().__init__()
+        padding = kwargs.get("padding", kernel_size // 2)
+        self.conv = Conv(inplanes, planes, kernel_size=kernel_size, stride=stride, padding=padding, bias=False, conv_layer=conv_layer)
+        self.norm = norm_layer(planes)
+        self.act = act_layer()
+
+    def forward(self, x):
+        return self.act(self.norm(self.conv(x)))
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, inplanes, kernel_size=3):
+        super().__init__()
+        self.block1 = ConvBlock(inplanes, inplanes, kernel_size=kernel_size)
+        self.block2 = ConvBlock(inplanes, inplanes, kernel_size=kernel_size)
+        self.act = nn.ReLU()
+
+    def forward(self, x):
+        return self.act(self.block2(self.block1(x)) + x)
+
+
+class ASPPNeck(nn.Module):
+    """One shared 3x3 weight applied at dilation 1/6/12/18 + 1x1 + identity, concatenated (aspp.py:19-32)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.pre_conv = BasicBlock(in_channels)
+        self.conv1x1 = nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, bias=False, padding=0)
+        self.weight = nn.Parameter(torch.randn(in_channels, in_channels, 3, 3))
+        self.post_conv = ConvBlock(in_channels * 6, in_channels, kernel_size=1, stride=1)
+
+    def _forward(self, x):
+        x = self.pre_conv(x)
+        w = self.weight.to(x.dtype)
+        outs = [x, self.conv1x1(x)] + [F.conv2d(x, w, stride=1, bias=None, padding=d, dilation=d) for d in (1, 6, 12, 18)]
+        return self.post_conv(torch.cat(outs, dim=1))
+
+    def forward(self, x):
+        if x.requires_grad:
+            return torch.utils.checkpoint.checkpoint(self._forward, x, use_reentrant=False)
+        return self._forward(x)
+
+
+# ------------------------------------------------------------------------------------------------ head
+class SepHead(nn.Module):
+    def __init__(self, in_channels, heads, stride=1, head_conv=64, final_kernel=1, bn=True, init_bias=-2.19, **kwargs):
+        super().__init__()
+        if stride > 1:
+            self.deblock = ConvBlock(in_channels, head_conv, kernel_size=int(stride), stride=int(stride), padding=0, conv_layer=nn.ConvTranspose2d)
+            in_channels = head_conv
+        else:
+            self.deblock = nn.Identity()
+        self.heads = heads
+        for head, (classes, num_conv) in heads.items():
+            fc = nn.Sequential()
+            for _ in range(num_conv - 1):
+                fc.append(nn.Conv2d(in_channels, head_conv, kernel_size=final_kernel, stride=1, padding=final_kernel // 2, bias=True))
+                if bn:
+                    fc.append(nn.BatchNorm2d(head_conv))
+                fc.append(nn.ReLU())
+            fc.append(nn.Conv2d(head_conv, classes, kernel_size=final_kernel, stride=1, padding=final_kernel // 2, bias=True))
+            if "hm" in head:
+                fc[-1].bias.data.fill_(init_bias)
+            setattr(self, head, fc)
+
+    def forward(self, x):
+        x = self.deblock(x)
+        return {head: getattr(self, head)(x) for head in self.heads}
+
+
+def _cfg_get(cfg, name):
+    return cfg[name] if isinstance(cfg, dict) else getattr(cfg, name)
+
+
+class CenterHead(nn.Module):
+    def __init__(self, in_channels, tasks, weight, code_weights, common_heads, strides, init_bias=-2.19, share_conv_channel=64,
+                 num_hm_conv=2, with_reg_iou=False, voxel_size=None, pc_range=None, out_size_factor=None,
+                 rectifier=((0.0,), (0.0,), (0.0,))):
+        super().__init__()
+        self.num_classes = [len(t) for t in tasks]
+        self.class_names = tasks
+        self.code_weights = code_weights
+        self.weight = weight
+        self.in_channels = in_channels
+        self.with_reg_iou = with_reg_iou
+        self.with_iou = "iou" in common_heads
+        self.voxel_size, self.pc_range, self.out_size_factor = voxel_size, pc_range, out_size_factor
+        self.strides = strides
+        self.rectifier = rectifier
+        self.shared_conv = nn.Sequential(nn.Conv2d(in_channels, share_conv_channel, kernel_size=3, padding=1, bias=True),
+                                         nn.BatchNorm2d(share_conv_channel), nn.ReLU(inplace=True))
+        self.tasks = nn.ModuleList()
+        for num_cls, stride in zip(self.num_classes, strides):
+            heads = copy.deepcopy(dict(common_heads))
+            heads.update(dict(hm=(num_cls, num_hm_conv)))
+            self.tasks.append(SepHead(share_conv_channel, heads, stride=stride, bn=True, init_bias=init_bias, final_kernel=3))
+
+    def forward(self, x, *kwargs):
+        x = self.shared_conv(x)
+        return [task(x) for task in self.tasks]
+
+    # ---- inference: decode + per-class rotated NMS (centerhead.py:231-384)
+    @torch.no_grad()
+    def predict(self, example, preds_dicts, test_cfg):
+        nms_cfg = _cfg_get(test_cfg, "nms")
+        pre_max = int(_cfg_get(nms_cfg, "nms_pre_max_size"))
+        post_max = int(_cfg_get(nms_cfg, "nms_post_max_size"))
+        thr_cfg = _cfg_get(nms_cfg, "nms_iou_threshold")
+        score_thr = float(_cfg_get(test_cfg, "score_threshold"))
+        osf = _cfg_get(test_cfg, "out_size_factor")
+        vs = _cfg_get(test_cfg, "voxel_size")
+        pcr = _cfg_get(test_cfg, "pc_range")
+        lim = _cfg_get(test_cfg, "post_center_limit_range")
+        dev = preds_dicts[0]["hm"].device
+        lim_t = torch.tensor(list(lim), dtype=torch.float32, device=dev) if len(lim) > 0 else None
+        B = preds_dicts[0]["hm"].shape[0]
+        tokens = example["token"] if ("token" in example and len(example["token"]) > 0) else [None] * B
+
+        per_task = []
+        flag = 0
+        for t, pd in enumerate(preds_dicts):
+            hm = torch.sigmoid(pd["hm"].float()).permute(0, 2, 3, 1)           # (B,H,W,ncls)
+            _, H, W, ncls = hm.shape
+            dim = torch.exp(pd["dim"].float()).permute(0, 2, 3, 1).reshape(B, H * W, 3)
+            rot = pd["rot"].float()
+            rot = torch.atan2(rot[:, 0], rot[:, 1]).reshape(B, H * W, 1)
+            reg = pd["reg"].float().permute(0, 2, 3, 1).reshape(B, H * W, 2)
+            hei = pd["height"].float().permute(0, 2, 3, 1).reshape(B, H * W, 1)
+            vel = pd["vel"].float().permute(0, 2, 3, 1).reshape(B, H * W, 2)
+            if "iou" in pd:
+                iou = ((pd["iou"].float().squeeze(1) + 1) * 0.5).reshape(B, H * W)
+            else:
+                iou = torch.ones((B, H * W), dtype=torch.float32, device=dev)
+            ys, xs = torch.meshgrid(torch.arange(0, H, device=dev), torch.arange(0, W, device=dev), indexing="ij")
+            xs = xs.reshape(1, H * W, 1).float() + reg[:, :, 0:1]
+            ys = ys.reshape(1, H * W, 1).float() + reg[:, :, 1:2]
+            xs = xs * osf[t] * vs[0] + pcr[0]
+            ys = ys * osf[t] * vs[1] + pcr[1]
+            boxes = torch.cat([xs, ys, hei, dim, vel, rot], dim=2)                 # (B,HW,9)
+            scores, labels = torch.max(hm.reshape(B, H * W, ncls), dim=-1)
+            mask = scores > score_thr
+            if lim_t is not None:
+                mask &= (boxes[..., :3] >= lim_t[:3]).all(-1) & (boxes[..., :3] <= lim_t[3:]).all(-1)
+            rect = torch.tensor(list(self.rectifier[t]), dtype=torch.float32, device=dev)[labels]
+            scores = torch.pow(scores, 1 - rect) * torch.pow(torch.clamp(iou, min=0.0, max=1.0), rect)
+            thr = torch.tensor([float(v) for v in thr_cfg[t]], dtype=torch.float32, device=dev)
+            per_task.append(_task_nms(boxes, scores, labels, mask, ncls, thr, pre_max, post_max, flag))
+            flag += ncls
+
+        ret_list = []
+        for i in range(B):
+            ret = {"box3d_lidar": torch.cat([pt[i][0] for pt in per_task]), "scores": torch.cat([pt[i][1] for pt in per_task]),
+                   "label_preds": torch.cat([pt[i][2] for pt in per_task]), "token": tokens[i]}
+            ret_list.append(ret)
+        return ret_list
+
+
+def _task_nms(boxes, scores, labels, mask, ncls, thr, pre_max, post_max, label_offset):
+    """All (sample, class) segments of one task through ONE sort and ONE batched NMS launch.
+    Equivalent to the per-sample / per-class loop of CenterHead.post_processing (centerhead.py:337-374)."""
+    B, HW, _ = boxes.shape
+    dev = boxes.device
+    S = B * ncls
+    seg = torch.arange(B, device=dev).view(B, 1) * ncls + labels                          # (B,HW) segment id
+    seg = torch.where(mask, seg, torch.full_like(seg, S))                                 # dropped cells -> bin S
+    # sort by (segment, score desc): scores are in [0,1], so key = seg*4 - score is monotone
+    key = seg.reshape(-1).double() * 4.0 - scores.reshape(-1).double()
+    order = torch.argsort(key, stable=True)
+    counts = torch.bincount(seg.reshape(-1), minlength=S + 1)[:S]
+    off = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+    off[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    total = int(off[-1].item())                                                           # the one host sync of the task
+    order = order[:total]
+    flat_boxes = boxes.reshape(B * HW, 9)[order]
+    nms_boxes = flat_boxes[:, [0, 1, 2, 3, 4, 5, 8]].contiguous()
+    seg_len = torch.clamp(counts, max=pre_max).to(torch.int32)
+    keep, cnt = ops.nms_batched(nms_boxes, off, thr.repeat(B), min(pre_max, max(total, 1)), post_max=post_max, seg_len=seg_len)
+    cnt_l = cnt[:S].tolist()
+    off_l = off.tolist()
+    flat_scores = scores.reshape(-1)[order]
+    out = []
+    for b in range(B):
+        bb, ss, ll = [], [], []
+        for c in range(ncls):
+            s = b * ncls + c
+            k = keep[off_l[s]: off_l[s] + cnt_l[s]].long() + off_l[s]
+            bb.append(flat_boxes[k])
+            ss.append(flat_scores[k])
+            ll.append(torch.full((cnt_l[s],), c + label_offset, dtype=torch.int64, device=dev))
+        out.append((torch.cat(bb), torch.cat(ss), torch.cat(ll)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ detector
+class SingleStageDetector(nn.Module):
+    """reader -> backbone -> neck -> head (single_stage.py).  On MI355X the reader writes the dense channels-last
+    canvas + occupancy directly (fused path) whenever reader and backbone are ours; otherwise the reference's
+    tuple hand-off `backbone(*reader(points))` is used."""
+
+    def __init__(self, reader, backbone=None, neck=None, head=None, post_processing=None, compute_dtype=torch.bfloat16, **kwargs):
+        super().__init__()
+        self.reader, self.backbone, self.neck, self.head = reader, backbone, neck, head
+        self.post_processing = post_processing
+        self.compute_dtype = compute_dtype
+
+    def extract_feat(self, points, batch_size=None):
+        if hasattr(self.reader, "forward_dense") and hasattr(self.backbone, "forward_dense"):
+            if batch_size is None:
+                batch_size = int(points[:, 0].max().item()) + 1
+            dt = self.compute_dtype if not self.training else torch.float32
+            ny, nx = (int(v) for v in self.reader.grid_size)
+            occ = torch.empty((batch_size, ny, nx), dtype=torch.uint8, device=points.device)
+            canvas = self.reader.forward_dense(points, batch_size, dtype=dt, occupancy=occ)
+            x = self.backbone.forward_dense(canvas, occ.unsqueeze(1).to(dt))
+        else:
+            x = self.reader(points)
+            if self.backbone is not None:
+                x = self.backbone(*x)
+        if self.neck is not None:
+            x = self.neck(x)
+        return x
+
+    def _forward(self, example):
+        x = self.extract_feat(example["points"], example.get("batch_size"))
+        return self.head(x)
+
+    def forward(self, example):
+        return self.training_step(example) if self.training else self.validation_step(example)
+
+    def training_step(self, example):
+        preds = self._forward(example)
+        return self.head.loss(example, preds)
+
+    @torch.no_grad()
+    def validation_step(self, example):
+        preds = self._forward(example)
+        outputs = self.head.predict(example, preds, self.post_processing)
+        detections = {}
+        for output in outputs:
+            token = output["token"]
+            for k, v in output.items():
+                if k != "token":
+                    output[k] = v.to(torch.device("cpu"))
+            detections[token] = output
+        return detections
+
+
+NUSC_TASKS = [["car"], ["truck", "construction_vehicle"], ["bus", "trailer"], ["barrier"], ["motorcycle", "bicycle"], ["pedestrian", "traffic_cone"]]
+
+
+def build_pillarnext_b(pc_range, voxel_size, tasks=None, num_point_features=5, ds_layer_strides=(1, 2, 2, 2), with_iou_head=False,
+                       rectifier=None, post_processing=None):
+    """PillarNeXt-B as configured by configs/experiments/nusc_det_pp18_aspp_iou_sp.yaml (geometry is a parameter)."""
+    from .reader import PillarFeatureNet
+
+    tasks = tasks or NUSC_TASKS
+    common = {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)}
+    if with_iou_head:
+        common["iou"] = (1, 2)
+    reader = PillarFeatureNet(num_point_features, [64, 64], list(voxel_size), list(pc_range))
+    backbone = SparseResNet([2, 2, 2, 2], list(ds_layer_strides), [64, 128, 256, 256], 64)
+    neck = ASPPNeck(256)
+    rect = rectifier or [[0.5] * len(t) for t in tasks]
+    head = CenterHead(256, tasks, 0.25, [1.0] * 6 + [0.2, 0.2, 1.0, 1.0], common, [2] * len(tasks), with_reg_iou=True,
+                      voxel_size=list(voxel_size), pc_range=list(pc_range), out_size_factor=[4] * len(tasks), rectifier=rect)
+    if post_processing is None:
+        post_processing = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], score_threshold=0.1,
+                               nms=dict(nms_pre_max_size=1000, nms_post_max_size=83, nms_iou_threshold=[[0.2] * len(t) for t in tasks]),
+                               out_size_factor=[4] * len(tasks), voxel_size=list(voxel_size), pc_range=list(pc_range))
+    return SingleStageDetector(reader, backbone, neck, head, post_processing)

@@ -47,8 +47,8 @@ def fold_bn(F, w0, bn0, w1, bn1, eps, out=None):
     return out
 
 
-def reader_forward(points, batch, geom, folded, ws, canvas=None, canvas_layout=PNX_NHWC, feat_max=None, coords=None, unq_inv=None,
-                   pillar_of_point=None, counts=None):
+def reader_forward(points, batch, geom, folded, ws, canvas=None, canvas_layout=PNX_NHWC, occupancy=None, feat_max=None, coords=None,
+                   unq_inv=None, pillar_of_point=None, counts=None):
     _need_cuda(points, "points")
     if points.dtype != torch.float32 or points.dim() != 2:
         raise PnxError("points must be (N, 1+F) fp32")
@@ -62,7 +62,7 @@ def reader_forward(points, batch, geom, folded, ws, canvas=None, canvas_layout=P
         cap = coords.shape[0] if cap == 0 else min(cap, coords.shape[0])
     cdt = _DT[canvas.dtype] if canvas is not None else PNX_F32
     check(lib().pnx_reader_forward(ptr(points), n, stride, batch, ctypes.byref(geom), ptr(folded), ptr(canvas), cdt, canvas_layout,
-                                   ptr(feat_max), ptr(coords), cap, ptr(unq_inv), ptr(pillar_of_point), ptr(counts), ptr(buf),
+                                   ptr(occupancy), ptr(feat_max), ptr(coords), cap, ptr(unq_inv), ptr(pillar_of_point), ptr(counts), ptr(buf),
                                    buf.numel(), stream_ptr()), "pnx_reader_forward")
 
 
@@ -154,7 +154,7 @@ def boxes_aligned_iou3d(a, b):
 _NMS_WS = Workspace()
 
 
-def nms_batched(boxes, seg_offsets, thresh, max_seg_len, post_max=0, rotated=True):
+def nms_batched(boxes, seg_offsets, thresh, max_seg_len, post_max=0, rotated=True, seg_len=None):
     """boxes (T,7) score-sorted inside each segment; seg_offsets int32 (S+1) device; thresh fp32 (S) device.
     Returns keep (T) int32 [segment-local indices, ascending, first keep_count[s] valid per segment] and keep_count (S)."""
     _boxes(boxes, "boxes")
@@ -165,7 +165,7 @@ def nms_batched(boxes, seg_offsets, thresh, max_seg_len, post_max=0, rotated=Tru
     nbytes = lib().pnx_nms_workspace_bytes(T, S, max_seg_len)
     buf = _NMS_WS.get(nbytes, boxes.device)
     fn = lib().pnx_nms_rotated_batched if rotated else lib().pnx_nms_normal_batched
-    check(fn(ptr(boxes), ptr(seg_offsets), S, int(max_seg_len), ptr(thresh), int(post_max), ptr(keep), ptr(cnt), ptr(buf), buf.numel(),
+    check(fn(ptr(boxes), ptr(seg_offsets), ptr(seg_len), S, int(max_seg_len), ptr(thresh), int(post_max), ptr(keep), ptr(cnt), ptr(buf), buf.numel(),
              stream_ptr()), "pnx_nms_batched")
     return keep, cnt
 

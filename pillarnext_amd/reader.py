@@ -143,7 +143,7 @@ class PillarFeatureNet(nn.Module):
         return feat_max, coords, grid_size
 
     # ------------------------------------------------------------------ MI355X dense path
-    def forward_dense(self, points, batch_size, dtype=torch.bfloat16, channels_last=True, out=None, counts=None):
+    def forward_dense(self, points, batch_size, dtype=torch.bfloat16, channels_last=True, out=None, counts=None, occupancy=None):
         """points -> dense BEV canvas (B, 64, ny, nx).  Eval mode: single fused call, no host sync, every canvas
         byte written exactly once.  Train mode: unfused path + scatter (gradients flow to the PFN parameters)."""
         ny, nx = int(self._geom.gy), int(self._geom.gx)
@@ -153,6 +153,9 @@ class PillarFeatureNet(nn.Module):
             canvas = torch.zeros((batch_size, ny, nx, 64), dtype=feat_max.dtype, device=dev)
             c = coords.long()
             canvas[c[:, 0], c[:, 1], c[:, 2]] = feat_max
+            if occupancy is not None:
+                occupancy.zero_()
+                occupancy[c[:, 0], c[:, 1], c[:, 2]] = 1
             return canvas.permute(0, 3, 1, 2).to(dtype)
         points = points.contiguous().float()
         if out is None:
@@ -166,5 +169,5 @@ class PillarFeatureNet(nn.Module):
             raise PnxError("canvas must be channels_last or contiguous")
         with torch.no_grad():
             ops.reader_forward(points, batch_size, self._geom, self.folded_params(), self._ws, canvas=out, canvas_layout=layout,
-                               counts=counts)
+                               occupancy=occupancy, counts=counts)
         return out

@@ -37,7 +37,7 @@ def test_host_helpers_without_gpu():
     n = L.pnx_reader_workspace_bytes(300000, 1, ctypes.byref(g))
     assert 0 < n < 1 << 30
     # argument validation needs no GPU: null geometry, bad stride
-    rc = L.pnx_reader_forward(None, 10, 6, 1, None, None, None, 0, 0, None, None, 0, None, None, None, None, 0, None)
+    rc = L.pnx_reader_forward(None, 10, 6, 1, None, None, None, 0, 0, None, None, None, 0, None, None, None, None, 0, None)
     assert rc == -1 and b"geom" in L.pnx_last_error()
     try:
         _lib.make_geom([0, 0, 0, -1, 1, 1], [0.1, 0.1, 1])
