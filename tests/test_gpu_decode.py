@@ -36,6 +36,7 @@ def test_detector_end_to_end_runs_and_is_deterministic():
 
     cfg = synth.CONFIGS["C1"]
     torch.manual_seed(0)
+    torch.backends.cudnn.deterministic = True  # MIOpen: deterministic conv algorithms (the HIP path is deterministic by construction)
     model = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"], tasks=[["car"]]).cuda().eval()
     model.backbone.to(memory_format=torch.channels_last, dtype=torch.bfloat16)
     model.neck.to(memory_format=torch.channels_last, dtype=torch.bfloat16)
