@@ -1,7 +1,7 @@
 // pfn_mfma.hip -- the PFN (pillar_encoder.py:35-50 x2, :174-182) as a wave-tiled fp32-MFMA kernel.
 //
-// Input: the CSR of points per pillar built by reader.hip (points of one pillar are contiguous "slots",
-// pillars in torch.unique order).  One wave owns the pillars whose first slot lies in its window of R slots
+// Input: the per-slot records built by reader.hip's k_fill (points of one pillar are contiguous "slots", pillars in
+// torch.unique order; 32 bytes per slot = point row + pillar rank, so every load here is coalesced).  One wave owns the pillars whose first slot lies in its window of R slots
 // and walks their points in tiles of 32 (the M/N size of v_mfma_f32_32x32x2_f32, which is an exact fp32
 // fmaf chain at the fp32 vector rate -- MI355X_MICROARCH.md).  Two lanes share a point: lane = (point, h)
 // with h = lane>>5 picking the even/odd K element, which is exactly the A/B fragment layout
@@ -47,257 +47,284 @@ __device__ __forceinline__ void decorate_pt(const float* __restrict__ p, float m
 
 #define PNX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// One 32-byte record per CSR slot: words 0..F-1 = x, y, z, f.. ; word 7 = pillar rank (written by k_fill).
+struct Rec {
+  uint4 a, b;
+};
+__device__ __forceinline__ Rec load_rec(const uint32_t* __restrict__ rec, uint32_t slot) {
+  const uint4* p = reinterpret_cast<const uint4*>(rec + (int64_t)slot * 8);
+  Rec r;
+  r.a = p[0];
+  r.b = p[1];
+  return r;
+}
+
+template <int F>
+__device__ __forceinline__ void decorate_rec(const Rec& q, float mx, float my, float mz, const PnxGeomDev& g, float* f) {
+  const float w[7] = {__uint_as_float(q.a.x), __uint_as_float(q.a.y), __uint_as_float(q.a.z), __uint_as_float(q.a.w),
+                      __uint_as_float(q.b.x), __uint_as_float(q.b.y), __uint_as_float(q.b.z)};
+#pragma unroll
+  for (int k = 0; k < F; k++) f[k] = w[k];
+  const float x = w[0], y = w[1], z = w[2];
+  f[F + 0] = __fsub_rn(x, mx);
+  f[F + 1] = __fsub_rn(y, my);
+  f[F + 2] = __fsub_rn(z, mz);
+  const float cx = __fdiv_rn(__fsub_rn(x, g.minx), g.vx);
+  const float cy = __fdiv_rn(__fsub_rn(y, g.miny), g.vy);
+  const float xi = (float)(int)cx, yi = (float)(int)cy;
+  const float ctrx = __fadd_rn(__fadd_rn(__fmul_rn(xi, g.vx), __fdiv_rn(g.vx, 2.0f)), g.minx);
+  const float ctry = __fadd_rn(__fadd_rn(__fmul_rn(yi, g.vy), __fdiv_rn(g.vy, 2.0f)), g.miny);
+  f[F + 3] = __fsub_rn(x, ctrx);
+  f[F + 4] = __fsub_rn(y, ctry);
+}
+
 template <int F, int R>
-__global__ __launch_bounds__(64) void k_pfn_mfma(const float* __restrict__ pts, PnxGeomDev g, const int32_t* __restrict__ plist,
-                                                 const int32_t* __restrict__ rank, const uint32_t* __restrict__ count,
+__global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ rec, PnxGeomDev g, const uint32_t* __restrict__ count,
                                                  const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
                                                  const int32_t* __restrict__ counters, const float* __restrict__ P,
                                                  float* __restrict__ g1, int64_t g1_rows) {
   constexpr int C0 = F + 5, KS = (C0 + 1) / 2;
-  constexpr int OW0 = 0, OS0 = 32 * C0, OW1 = OS0 + 32, OS1 = OW1 + 64 * 64;
-  constexpr int GST = 36;  // G0 row stride in floats: 16-byte aligned rows, banks spread
+  constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;  // start of the fragment-ordered block (k_fold_bn)
+  constexpr int GST = 36;                          // G0 row stride in floats: 16-byte aligned rows, banks spread
   __shared__ __attribute__((aligned(16))) float sG0[R * GST];
   __shared__ float sMean[R * 3];
 
   const int l = threadIdx.x, col = l & 31, h = l >> 5;
   const int n_kept = counters[1], Ptot = counters[0];
-  const int64_t slot0 = (int64_t)blockIdx.x * R;
-  if (slot0 >= n_kept) return;
-  const int64_t slot1 = (slot0 + R < n_kept) ? slot0 + R : n_kept;
 
-  // pillars owned by this wave = those whose first slot is in [slot0, slot1)
-  const int q0 = rank[plist[slot0]];
-  const uint32_t st0 = pstart(q0, cpre, cblk);
-  const int p_lo = (st0 == (uint32_t)slot0) ? q0 : q0 + 1;
-  const uint32_t base = (st0 == (uint32_t)slot0) ? st0 : st0 + count[q0];
-  int p_hi;
-  uint32_t end;
-  if (slot1 >= n_kept) {
-    p_hi = Ptot;
-    end = (uint32_t)n_kept;
-  } else {
-    const int q1 = rank[plist[slot1]];
-    const uint32_t st1 = pstart(q1, cpre, cblk);
-    if (st1 == (uint32_t)slot1) {
-      p_hi = q1;
-      end = st1;
-    } else {
-      p_hi = q1 + 1;
-      end = st1 + count[q1];
-    }
-  }
-  if (p_lo >= p_hi) return;
-  const int nown = p_hi - p_lo;  // <= R
-
-  // ---- phase 0: per-pillar mean of xyz (scatter_mean, pe:113-114): fp64 sum, fp32 divide
-  for (int s = l; s < nown; s += 64) {
-    const int q = p_lo + s;
-    const uint32_t st = pstart(q, cpre, cblk), c = count[q];
-    double sx = 0, sy = 0, sz = 0;
-    for (uint32_t k = 0; k < c; k++) {
-      const float* p = pts + (int64_t)plist[st + k] * (F + 1);
-      sx += (double)p[1];
-      sy += (double)p[2];
-      sz += (double)p[3];
-    }
-    const float fc = (float)c;
-    sMean[s * 3 + 0] = __fdiv_rn((float)sx, fc);
-    sMean[s * 3 + 1] = __fdiv_rn((float)sy, fc);
-    sMean[s * 3 + 2] = __fdiv_rn((float)sz, fc);
-  }
-
-  // ---- weight fragments (resident for the whole kernel)
+  // ---- weight fragments: coalesced loads, once per (persistent) wave
+  const float* __restrict__ FP = P + FR + l;
   float w0f[KS];
 #pragma unroll
-  for (int kk = 0; kk < KS; kk++) {
-    const int k = 2 * kk + h;
-    w0f[kk] = (k < C0) ? P[OW0 + col * C0 + k] : 0.f;
-  }
-  const float s0n = P[OS0 + col];
+  for (int kk = 0; kk < KS; kk++) w0f[kk] = FP[kk * 64];
+  const float s0n = FP[6 * 64];
   v16f s0v;
 #pragma unroll
-  for (int i = 0; i < 16; i++) s0v[i] = P[OS0 + (i & 3) + 8 * (i >> 2) + 4 * h];
+  for (int i = 0; i < 16; i++) s0v[i] = FP[(7 + i) * 64];
   float w1a[32], w1b[32];
 #pragma unroll
   for (int i = 0; i < 32; i++) {
-    const int ii = i & 15;
-    const int k = (i < 16 ? 0 : 32) + (ii & 3) + 8 * (ii >> 2) + 4 * h;
-    w1a[i] = P[OW1 + col * 64 + k];
-    w1b[i] = P[OW1 + (32 + col) * 64 + k];
+    w1a[i] = FP[(23 + i) * 64];
+    w1b[i] = FP[(55 + i) * 64];
   }
-  const float s1a = P[OS1 + col], s1b = P[OS1 + 32 + col];
-  __syncthreads();
+  const float s1a = FP[87 * 64], s1b = FP[88 * 64];
 
-  const int ntiles = (int)((end - base + 31) >> 5);
-
-  // ---- phase 1: layer 0, per-pillar max -> G0
-  {
-    float m = 0.f;
-    int seg = 0;
-    bool open = false;
-    for (int t = 0; t < ntiles; t++) {
-      const uint32_t slot = base + 32u * t + col;
-      const bool act = slot < end;
-      float ff[KS];
-      bool is_head = false;
-      if (act) {
-        const int i = plist[slot];
-        const int r = rank[i];
-        is_head = pstart(r, cpre, cblk) == slot;
-        const int sl = r - p_lo;
-        float f[C0 + 1];
-        decorate_pt<F>(pts + (int64_t)i * (F + 1), sMean[sl * 3], sMean[sl * 3 + 1], sMean[sl * 3 + 2], g, f);
-        f[C0] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) ff[kk] = h ? f[2 * kk + 1] : f[2 * kk];
+  for (int64_t slot0 = (int64_t)blockIdx.x * R; slot0 < n_kept; slot0 += (int64_t)gridDim.x * R) {
+    const int64_t slot1 = (slot0 + R < n_kept) ? slot0 + R : n_kept;
+    // pillars owned by this pass = those whose first slot is in [slot0, slot1)
+    const int q0 = (int)rec[slot0 * 8 + 7];
+    const uint32_t st0 = pstart(q0, cpre, cblk);
+    const int p_lo = (st0 == (uint32_t)slot0) ? q0 : q0 + 1;
+    const uint32_t base = (st0 == (uint32_t)slot0) ? st0 : st0 + count[q0] + 1u;
+    int p_hi;
+    uint32_t end;
+    if (slot1 >= n_kept) {
+      p_hi = Ptot;
+      end = (uint32_t)n_kept;
+    } else {
+      const int q1 = (int)rec[slot1 * 8 + 7];
+      const uint32_t st1 = pstart(q1, cpre, cblk);
+      if (st1 == (uint32_t)slot1) {
+        p_hi = q1;
+        end = st1;
       } else {
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) ff[kk] = 0.f;
-      }
-      v16f acc;
-#pragma unroll
-      for (int i = 0; i < 16; i++) acc[i] = s0n;
-#pragma unroll
-      for (int kk = 0; kk < KS; kk++) acc = PNX_MFMA(ff[kk], w0f[kk], acc);
-      float p0[16], p1[16];
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const float v = fmaxf(acc[i], 0.f);
-        const float y = __shfl_xor(v, 32);
-        p0[i] = h ? y : v;
-        p1[i] = h ? v : y;
-      }
-      const uint32_t heads = (uint32_t)__ballot(act && is_head && h == 0);
-      const uint32_t valid = (uint32_t)__ballot(act && h == 0);
-#pragma unroll
-      for (int p = 0; p < 32; p++) {
-        const int i = (p & 3) + 4 * (p >> 3);
-        const float v = ((p >> 2) & 1) ? p1[i] : p0[i];
-        if ((heads >> p) & 1u) {
-          if (open) {
-            if (l < 32) sG0[seg * GST + l] = m;
-            seg++;
-          }
-          m = 0.f;
-          open = true;
-        }
-        if ((valid >> p) & 1u) m = fmaxf(m, v);
+        p_hi = q1 + 1;
+        end = st1 + count[q1] + 1u;
       }
     }
-    if (open && l < 32) sG0[seg * GST + l] = m;
-  }
-  __syncthreads();
+    if (p_lo >= p_hi) continue;
+    const int nown = p_hi - p_lo;  // <= R
+    __syncthreads();               // previous pass done with sG0 / sMean
 
-  // ---- phase 2: layer 0 again (other orientation) chained into layer 1, per-pillar max -> feat_max rows
-  {
-    float m = 0.f;
-    int seg = 0;
-    bool open = false;
-    for (int t = 0; t < ntiles; t++) {
-      const uint32_t slot = base + 32u * t + col;
-      const bool act = slot < end;
-      float ff[KS];
-      bool is_head = false;
-      int sl = 0;
-      if (act) {
-        const int i = plist[slot];
-        const int r = rank[i];
-        is_head = pstart(r, cpre, cblk) == slot;
-        sl = r - p_lo;
-        float f[C0 + 1];
-        decorate_pt<F>(pts + (int64_t)i * (F + 1), sMean[sl * 3], sMean[sl * 3 + 1], sMean[sl * 3 + 2], g, f);
-        f[C0] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) ff[kk] = h ? f[2 * kk + 1] : f[2 * kk];
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) ff[kk] = 0.f;
+    // ---- phase 0: per-pillar mean of xyz (scatter_mean, pe:113-114): fp64 sum, fp32 divide
+    for (int s = l; s < nown; s += 64) {
+      const int q = p_lo + s;
+      const uint32_t st = pstart(q, cpre, cblk), c = count[q] + 1u;
+      double sx = 0, sy = 0, sz = 0;
+      for (uint32_t k = 0; k < c; k++) {
+        const uint4 a = *reinterpret_cast<const uint4*>(rec + (int64_t)(st + k) * 8);
+        sx += (double)__uint_as_float(a.x);
+        sy += (double)__uint_as_float(a.y);
+        sz += (double)__uint_as_float(a.z);
       }
-      v16f d0 = s0v;
-#pragma unroll
-      for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], ff[kk], d0);
-      // "max" half of the concat: G0[pillar][8j + 4h .. +3], j = 0..3  == channel order of d0's registers
-      float4 gq[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) gq[j] = *reinterpret_cast<const float4*>(&sG0[sl * GST + 8 * j + 4 * h]);
-      v16f da, db;
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        da[i] = s1a;
-        db[i] = s1b;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const float a = fmaxf(d0[i], 0.f);
-        da = PNX_MFMA(a, w1a[i], da);
-        db = PNX_MFMA(a, w1b[i], db);
-      }
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const float4 q = gq[i >> 2];
-        const float a = (i & 3) == 0 ? q.x : (i & 3) == 1 ? q.y : (i & 3) == 2 ? q.z : q.w;
-        da = PNX_MFMA(a, w1a[16 + i], da);
-        db = PNX_MFMA(a, w1b[16 + i], db);
-      }
-      float p0[16], p1[16];
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const float va = fmaxf(da[i], 0.f), vb = fmaxf(db[i], 0.f);
-        const float y = __shfl_xor(h ? va : vb, 32);
-        p0[i] = h ? y : va;
-        p1[i] = h ? vb : y;
-      }
-      const uint32_t heads = (uint32_t)__ballot(act && is_head && h == 0);
-      const uint32_t valid = (uint32_t)__ballot(act && h == 0);
-#pragma unroll
-      for (int p = 0; p < 32; p++) {
-        const int i = (p & 3) + 4 * (p >> 3);
-        const float v = ((p >> 2) & 1) ? p1[i] : p0[i];
-        if ((heads >> p) & 1u) {
-          if (open) {
-            if ((int64_t)(p_lo + seg) < g1_rows) g1[(int64_t)(p_lo + seg) * 64 + l] = m;
-            seg++;
-          }
-          m = 0.f;
-          open = true;
-        }
-        if ((valid >> p) & 1u) m = fmaxf(m, v);
-      }
+      const float fc = (float)c;
+      sMean[s * 3 + 0] = __fdiv_rn((float)sx, fc);
+      sMean[s * 3 + 1] = __fdiv_rn((float)sy, fc);
+      sMean[s * 3 + 2] = __fdiv_rn((float)sz, fc);
     }
-    if (open && (int64_t)(p_lo + seg) < g1_rows) g1[(int64_t)(p_lo + seg) * 64 + l] = m;
+    __syncthreads();
+
+    const int ntiles = (int)((end - base + 31) >> 5);
+
+    // ---- phase 1: layer 0, per-pillar max -> G0
+    {
+      float m = 0.f;
+      int seg = 0;
+      bool open = false;
+      int prev_rank = p_lo - 1;  // rank of the slot before the tile (wave-uniform)
+      Rec cur = load_rec(rec, min(base + (uint32_t)col, end - 1));
+      for (int t = 0; t < ntiles; t++) {
+        const uint32_t slot = base + 32u * t + col;
+        const bool act = slot < end;
+        const Rec nxt = load_rec(rec, min(slot + 32u, end - 1));  // prefetch the next tile's record
+        const int r = (int)cur.b.w;
+        int rp = __shfl_up(r, 1);
+        if (col == 0) rp = prev_rank;
+        const bool is_head = act && (r != rp);
+        float ff[KS];
+        {
+          const int sl = act ? r - p_lo : 0;
+          float f[C0 + 1];
+          decorate_rec<F>(cur, sMean[sl * 3], sMean[sl * 3 + 1], sMean[sl * 3 + 2], g, f);
+          f[C0] = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < KS; kk++) ff[kk] = act ? (h ? f[2 * kk + 1] : f[2 * kk]) : 0.f;
+        }
+        v16f acc;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = s0n;
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) acc = PNX_MFMA(ff[kk], w0f[kk], acc);
+        float p0[16], p1[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const float v = fmaxf(acc[i], 0.f);
+          const float y = __shfl_xor(v, 32);
+          p0[i] = h ? y : v;
+          p1[i] = h ? v : y;
+        }
+        const uint32_t heads = (uint32_t)__ballot(is_head && h == 0);
+        const uint32_t valid = (uint32_t)__ballot(act && h == 0);
+#pragma unroll
+        for (int p = 0; p < 32; p++) {
+          const int i = (p & 3) + 4 * (p >> 3);
+          const float v = ((p >> 2) & 1) ? p1[i] : p0[i];
+          if ((heads >> p) & 1u) {
+            if (open) {
+              if (l < 32) sG0[seg * GST + l] = m;
+              seg++;
+            }
+            m = 0.f;
+            open = true;
+          }
+          if ((valid >> p) & 1u) m = fmaxf(m, v);
+        }
+        prev_rank = __shfl(r, 31);
+        cur = nxt;
+      }
+      if (open && l < 32) sG0[seg * GST + l] = m;
+    }
+    __syncthreads();
+
+    // ---- phase 2: layer 0 again (other orientation) chained into layer 1, per-pillar max -> feat_max rows
+    {
+      float m = 0.f;
+      int seg = 0;
+      bool open = false;
+      int prev_rank = p_lo - 1;
+      Rec cur = load_rec(rec, min(base + (uint32_t)col, end - 1));
+      for (int t = 0; t < ntiles; t++) {
+        const uint32_t slot = base + 32u * t + col;
+        const bool act = slot < end;
+        const Rec nxt = load_rec(rec, min(slot + 32u, end - 1));
+        const int r = (int)cur.b.w;
+        int rp = __shfl_up(r, 1);
+        if (col == 0) rp = prev_rank;
+        const bool is_head = act && (r != rp);
+        const int sl = act ? r - p_lo : 0;
+        float ff[KS];
+        {
+          float f[C0 + 1];
+          decorate_rec<F>(cur, sMean[sl * 3], sMean[sl * 3 + 1], sMean[sl * 3 + 2], g, f);
+          f[C0] = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < KS; kk++) ff[kk] = act ? (h ? f[2 * kk + 1] : f[2 * kk]) : 0.f;
+        }
+        v16f d0 = s0v;
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], ff[kk], d0);
+        // "max" half of the concat: G0[pillar][8j + 4h .. +3], j = 0..3  == channel order of d0's registers
+        float4 gq[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) gq[j] = *reinterpret_cast<const float4*>(&sG0[sl * GST + 8 * j + 4 * h]);
+        v16f da, db;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          da[i] = s1a;
+          db[i] = s1b;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const float a = fmaxf(d0[i], 0.f);
+          da = PNX_MFMA(a, w1a[i], da);
+          db = PNX_MFMA(a, w1b[i], db);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const float4 q = gq[i >> 2];
+          const float a = (i & 3) == 0 ? q.x : (i & 3) == 1 ? q.y : (i & 3) == 2 ? q.z : q.w;
+          da = PNX_MFMA(a, w1a[16 + i], da);
+          db = PNX_MFMA(a, w1b[16 + i], db);
+        }
+        float p0[16], p1[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const float va = fmaxf(da[i], 0.f), vb = fmaxf(db[i], 0.f);
+          const float y = __shfl_xor(h ? va : vb, 32);
+          p0[i] = h ? y : va;
+          p1[i] = h ? vb : y;
+        }
+        const uint32_t heads = (uint32_t)__ballot(is_head && h == 0);
+        const uint32_t valid = (uint32_t)__ballot(act && h == 0);
+#pragma unroll
+        for (int p = 0; p < 32; p++) {
+          const int i = (p & 3) + 4 * (p >> 3);
+          const float v = ((p >> 2) & 1) ? p1[i] : p0[i];
+          if ((heads >> p) & 1u) {
+            if (open) {
+              if ((int64_t)(p_lo + seg) < g1_rows) g1[(int64_t)(p_lo + seg) * 64 + l] = m;
+              seg++;
+            }
+            m = 0.f;
+            open = true;
+          }
+          if ((valid >> p) & 1u) m = fmaxf(m, v);
+        }
+        prev_rank = __shfl(r, 31);
+        cur = nxt;
+      }
+      if (open && (int64_t)(p_lo + seg) < g1_rows) g1[(int64_t)(p_lo + seg) * 64 + l] = m;
+    }
   }
 }
 
 template <int F>
-int launch_f(int R, const float* points, const PnxGeomDev& g, const int32_t* plist, const int32_t* rank, const uint32_t* count,
-             const uint32_t* cpre, const uint32_t* cblk, const int32_t* counters, const float* folded, float* g1, int64_t g1_rows,
-             int64_t n, hipStream_t st) {
-  if (R == 128) {
-    const int nb = (int)((n + 127) / 128);
-    k_pfn_mfma<F, 128><<<nb, 64, 0, st>>>(points, g, plist, rank, count, cpre, cblk, counters, folded, g1, g1_rows);
-  } else if (R == 32) {
-    const int nb = (int)((n + 31) / 32);
-    k_pfn_mfma<F, 32><<<nb, 64, 0, st>>>(points, g, plist, rank, count, cpre, cblk, counters, folded, g1, g1_rows);
-  } else {
-    const int nb = (int)((n + 63) / 64);
-    k_pfn_mfma<F, 64><<<nb, 64, 0, st>>>(points, g, plist, rank, count, cpre, cblk, counters, folded, g1, g1_rows);
-  }
+int launch_f(int R, const uint32_t* rec, const PnxGeomDev& g, const uint32_t* count, const uint32_t* cpre, const uint32_t* cblk,
+             const int32_t* counters, const float* folded, float* g1, int64_t g1_rows, int64_t n, int max_blocks, hipStream_t st) {
+  int64_t nb = (n + R - 1) / R;
+  if (nb > max_blocks) nb = max_blocks;  // persistent: each wave strides over the slot windows
+  if (nb < 1) nb = 1;
+  if (R == 128) k_pfn_mfma<F, 128><<<(int)nb, 64, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows);
+  else if (R == 32) k_pfn_mfma<F, 32><<<(int)nb, 64, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows);
+  else k_pfn_mfma<F, 64><<<(int)nb, 64, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
 
 }  // namespace
 
-int pnx_launch_pfn_mfma(int F, const float* points, const PnxGeomDev& geom, const int32_t* plist, const int32_t* rank,
-                        const uint32_t* count, const uint32_t* cpre, const uint32_t* cblk, const int32_t* counters, const float* folded,
-                        float* g1, int64_t g1_rows, int64_t n_points, hipStream_t st) {
-  const char* r_env = getenv("PNX_PFN_R");  // slots per wave: 32 | 64 | 128
+int pnx_launch_pfn_mfma(int F, const uint32_t* rec, const PnxGeomDev& geom, const uint32_t* count, const uint32_t* cpre,
+                        const uint32_t* cblk, const int32_t* counters, const float* folded, float* g1, int64_t g1_rows, int64_t n_points,
+                        hipStream_t st) {
+  const char* r_env = getenv("PNX_PFN_R");  // slots per pass: 32 | 64 | 128
   const int R = r_env ? atoi(r_env) : 64;
+  const char* b_env = getenv("PNX_PFN_BLOCKS");  // resident waves: 256 CUs x 8 (2 per SIMD at 226 VGPRs)
+  const int max_blocks = b_env ? atoi(b_env) : 2048;
   switch (F) {
-    case 3: return launch_f<3>(R, points, geom, plist, rank, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, st);
-    case 4: return launch_f<4>(R, points, geom, plist, rank, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, st);
-    case 5: return launch_f<5>(R, points, geom, plist, rank, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, st);
-    case 6: return launch_f<6>(R, points, geom, plist, rank, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, st);
+    case 3: return launch_f<3>(R, rec, geom, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, max_blocks, st);
+    case 4: return launch_f<4>(R, rec, geom, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, max_blocks, st);
+    case 5: return launch_f<5>(R, rec, geom, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, max_blocks, st);
+    case 6: return launch_f<6>(R, rec, geom, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, max_blocks, st);
   }
   pnx_set_error("num_point_features %d not in 3..6", F);
   return PNX_ERR_UNSUPPORTED;

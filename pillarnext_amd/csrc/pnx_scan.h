@@ -10,7 +10,7 @@ namespace {
 
 constexpr int kBlock = 256;
 
-enum { SCAN_POPC = 0, SCAN_IDENT = 1, SCAN_KEPT = 2 };
+enum { SCAN_POPC = 0, SCAN_IDENT = 1, SCAN_KEPT = 2, SCAN_PLUS1 = 3 };
 
 template <int MODE>
 __device__ __forceinline__ uint32_t scan_value(uint32_t v) {
@@ -22,7 +22,8 @@ __device__ __forceinline__ uint32_t scan_value(uint32_t v) {
 // Level 1: each block scans PNX_SCAN_ITEMS items; out_local = exclusive prefix inside the block.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_scan_local(const uint32_t* __restrict__ in, int64_t n,
-                                                       uint32_t* __restrict__ out_local, uint32_t* __restrict__ blk_tot) {
+                                                       uint32_t* __restrict__ out_local, uint32_t* __restrict__ blk_tot,
+                                                       const int32_t* __restrict__ limit = nullptr) {
   __shared__ uint32_t s_wave[kBlock / 64];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -37,9 +38,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_local(const uint32_t* __restric
     for (int k = 0; k < 8; k++) v[k] = (base + k < n) ? in[base + k] : (MODE == SCAN_KEPT ? 0xFFFFFFFFu : 0u);
   }
   uint32_t sum = 0;
+  const int64_t lim = (MODE == SCAN_PLUS1) ? (int64_t)limit[0] : 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     uint32_t x = scan_value<MODE>(v[k]);
+    if (MODE == SCAN_PLUS1) x = (base + k < lim) ? v[k] + 1u : 0u;  // items are "extra" counts: value+1 below the limit
     v[k] = sum;
     sum += x;
   }

@@ -33,7 +33,7 @@ using GeomDev = PnxGeomDev;
 // pe:91-109.  fp32 subtract then IEEE divide (never a reciprocal multiply -- SURVEY H1), compares on the
 // float coordinate, truncation, key.  Rows whose batch index is outside [0,B) are dropped.
 __global__ __launch_bounds__(kBlock) void k_keys(const float* __restrict__ pts, int64_t n, int stride, GeomDev g,
-                                                 int32_t* __restrict__ key_out, uint32_t* __restrict__ bitmap) {
+                                                 int32_t* __restrict__ key_out, uint8_t* __restrict__ bytemap, int32_t* __restrict__ owner) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const float* p = pts + i * stride;
@@ -46,9 +46,56 @@ __global__ __launch_bounds__(kBlock) void k_keys(const float* __restrict__ pts, 
   if (keep) {
     const int xi = (int)cx, yi = (int)cy, bi = (int)bf;
     key = (bi * g.gx + xi) * g.gyp + yi;
-    atomicOr(&bitmap[key >> 5], 1u << (key & 31));
+    // Plain stores instead of atomics (agent-scope atomics run at ~20/ns on the fabric: measured 17 us for 300 k):
+    //  - occupancy as one BYTE per cell: every writer stores the same value, byte-granular dirty masks merge across XCDs
+    //  - owner[cell] = some point of the cell (last writer wins): that point takes slot 0 without an atomic
+    bytemap[key] = 1;
+    owner[key] = (int32_t)i;
   }
   key_out[i] = key;
+}
+
+// 32 occupancy bytes -> one bitmap word, fused with level 1 of the popcount scan.
+__device__ __forceinline__ uint32_t nib4(uint32_t v) { return ((v * 0x00204081u) >> 21) & 0xFu; }  // 4 bytes (0/1) -> 4 bits
+
+__global__ __launch_bounds__(kBlock) void k_pack_scan(const uint8_t* __restrict__ bytemap, int64_t nwords, uint32_t* __restrict__ bitmap,
+                                                      uint32_t* __restrict__ out_local, uint32_t* __restrict__ blk_tot) {
+  __shared__ uint32_t s_wave[kBlock / 64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t base = (int64_t)blockIdx.x * PNX_SCAN_ITEMS + (int64_t)t * 8;
+  uint32_t w[8], pre[8];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    uint32_t bits = 0;
+    if (base + k < nwords) {
+      const uint4* src = reinterpret_cast<const uint4*>(bytemap + (base + k) * 32);
+      const uint4 a = src[0], b = src[1];
+      bits = nib4(a.x) | (nib4(a.y) << 4) | (nib4(a.z) << 8) | (nib4(a.w) << 12) | (nib4(b.x) << 16) | (nib4(b.y) << 20) |
+             (nib4(b.z) << 24) | (nib4(b.w) << 28);
+    }
+    w[k] = bits;
+    pre[k] = sum;
+    sum += (uint32_t)__popc(bits);
+  }
+  uint32_t inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(inc, d);
+    if (lane >= d) inc += y;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int q = 0; q < wave; q++) woff += s_wave[q];
+  const uint32_t excl = woff + inc - sum;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (base + k < nwords) {
+      bitmap[base + k] = w[k];
+      out_local[base + k] = excl + pre[k];
+    }
+  if (t == kBlock - 1) blk_tot[blockIdx.x] = excl + sum;
 }
 
 __device__ __forceinline__ int32_t cell_rank(int32_t key, const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre,
@@ -59,11 +106,13 @@ __device__ __forceinline__ int32_t cell_rank(int32_t key, const uint32_t* __rest
 }
 
 // rank of every point (== unq_inv of the reference for kept points), slot inside the pillar, coords.
+// The cell's owner point takes slot 0 (and writes coords) without an atomic; the others draw slots 1.. from
+// extra[rank].  A pillar therefore holds extra[rank] + 1 points.
 __global__ __launch_bounds__(kBlock) void k_rank(const int32_t* __restrict__ key, int64_t n, GeomDev g,
                                                  const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre,
-                                                 const uint32_t* __restrict__ wblk, int32_t* __restrict__ rank_out,
-                                                 int32_t* __restrict__ slot_out, uint32_t* __restrict__ count,
-                                                 int32_t* __restrict__ coords, int64_t pillar_capacity,
+                                                 const uint32_t* __restrict__ wblk, const int32_t* __restrict__ owner,
+                                                 int32_t* __restrict__ rank_out, int32_t* __restrict__ slot_out,
+                                                 uint32_t* __restrict__ extra, int32_t* __restrict__ coords, int64_t pillar_capacity,
                                                  int32_t* __restrict__ pillar_of_point) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -71,15 +120,18 @@ __global__ __launch_bounds__(kBlock) void k_rank(const int32_t* __restrict__ key
   int32_t r = -1;
   if (k >= 0) {
     r = cell_rank(k, bitmap, wpre, wblk);
-    const uint32_t s = atomicAdd(&count[r], 1u);
-    slot_out[i] = (int32_t)s;
-    if (s == 0 && coords != nullptr && r < pillar_capacity) {
-      const int yi = k % g.gyp;
-      const int t = k / g.gyp;
-      const int xi = t % g.gx, bi = t / g.gx;
-      coords[(int64_t)r * 3 + 0] = bi;  // [b, yi, xi]  (pe:125 swaps x/y)
-      coords[(int64_t)r * 3 + 1] = yi;
-      coords[(int64_t)r * 3 + 2] = xi;
+    if (owner[k] == (int32_t)i) {
+      slot_out[i] = 0;
+      if (coords != nullptr && r < pillar_capacity) {
+        const int yi = k % g.gyp;
+        const int t = k / g.gyp;
+        const int xi = t % g.gx, bi = t / g.gx;
+        coords[(int64_t)r * 3 + 0] = bi;  // [b, yi, xi]  (pe:125 swaps x/y)
+        coords[(int64_t)r * 3 + 1] = yi;
+        coords[(int64_t)r * 3 + 2] = xi;
+      }
+    } else {
+      slot_out[i] = 1 + (int32_t)atomicAdd(&extra[r], 1u);
     }
   }
   rank_out[i] = r;
@@ -90,14 +142,25 @@ __device__ __forceinline__ uint32_t pillar_start(int32_t r, const uint32_t* __re
   return cblk[r >> PNX_SCAN_SHIFT] + cpre[r];
 }
 
-// CSR fill: plist[start(rank) + slot] = point id.
-__global__ __launch_bounds__(kBlock) void k_fill(const int32_t* __restrict__ rank, const int32_t* __restrict__ slot, int64_t n,
-                                                 const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
-                                                 int32_t* __restrict__ plist) {
+// CSR fill: plist[start(rank) + slot] = point id, plus a 32-byte record per slot [x, y, z, f.., (pad), rank] so the PFN
+// kernel streams its input with coalesced loads instead of chasing plist -> rank -> point row.
+__global__ __launch_bounds__(kBlock) void k_fill(const float* __restrict__ pts, int stride, const int32_t* __restrict__ rank,
+                                                 const int32_t* __restrict__ slot, int64_t n, const uint32_t* __restrict__ cpre,
+                                                 const uint32_t* __restrict__ cblk, int32_t* __restrict__ plist, uint32_t* __restrict__ rec) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const int32_t r = rank[i];
-  if (r >= 0) plist[pillar_start(r, cpre, cblk) + (uint32_t)slot[i]] = (int32_t)i;
+  if (r < 0) return;
+  const uint32_t pos = pillar_start(r, cpre, cblk) + (uint32_t)slot[i];
+  plist[pos] = (int32_t)i;
+  const float* p = pts + i * stride;
+  uint32_t v[8];
+#pragma unroll
+  for (int k = 0; k < 7; k++) v[k] = (k < stride - 1) ? __float_as_uint(p[1 + k]) : 0u;
+  v[7] = (uint32_t)r;
+  uint4* o = reinterpret_cast<uint4*>(rec + (int64_t)pos * 8);
+  o[0] = make_uint4(v[0], v[1], v[2], v[3]);
+  o[1] = make_uint4(v[4], v[5], v[6], v[7]);
 }
 
 // unq_inv (pe:110): pillar rank of the j-th kept point, j = exclusive count of kept rows before it.
@@ -116,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_pillar_mean(const float* __restrict_
                                                         float* __restrict__ mean) {
   const int32_t r = blockIdx.x * kBlock + threadIdx.x;
   if (r >= counters[0]) return;
-  const uint32_t s = pillar_start(r, cpre, cblk), c = count[r];
+  const uint32_t s = pillar_start(r, cpre, cblk), c = count[r] + 1u;  // count[] holds the non-owner points
   double sx = 0, sy = 0, sz = 0;
   for (uint32_t k = 0; k < c; k++) {
     const float* p = pts + (int64_t)plist[s + k] * stride;
@@ -196,6 +259,38 @@ __global__ void k_fold_bn(int C0, const float* w0, const float* g0, const float*
     const float a = __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v1[t], eps))), g1[t]);
     out[S1 + t] = __fsub_rn(b1[t], __fmul_rn(m1[t], a));
   }
+  // Fragment-ordered copy for k_pfn_mfma: register j of lane l at FR + j*64 + l.
+  //   j 0..5   W0'[col][2j+h]            (A/B fragment of layer 0, zero past C0)
+  //   j 6      s0[col]
+  //   j 7..22  s0[ch(i,h)]               ch(i,h) = (i&3) + 8*(i>>2) + 4h  (accumulator-register channel order)
+  //   j 23..54 W1'[col][k(i,h)]          k(i,h) = (i<16 ? ch(i,h) : 32 + ch(i-16,h))
+  //   j 55..86 W1'[32+col][k(i,h)]
+  //   j 87, 88 s1[col], s1[32+col]
+  const int FR = S1 + 64;
+  for (int idx = t; idx < 64 * 89; idx += gridDim.x * blockDim.x) {
+    const int j = idx >> 6, l = idx & 63, col = l & 31, h = l >> 5;
+    auto fold0 = [&](int c, int k) { return __fmul_rn(w0[c * C0 + k], __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v0[c], eps))), g0[c])); };
+    auto fold1 = [&](int c, int k) { return __fmul_rn(w1[c * 64 + k], __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v1[c], eps))), g1[c])); };
+    auto shift0 = [&](int c) { return __fsub_rn(b0[c], __fmul_rn(m0[c], __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v0[c], eps))), g0[c]))); };
+    auto shift1 = [&](int c) { return __fsub_rn(b1[c], __fmul_rn(m1[c], __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v1[c], eps))), g1[c]))); };
+    float v;
+    if (j < 6) {
+      const int k = 2 * j + h;
+      v = k < C0 ? fold0(col, k) : 0.f;
+    } else if (j == 6) {
+      v = shift0(col);
+    } else if (j < 23) {
+      const int i = j - 7;
+      v = shift0((i & 3) + 8 * (i >> 2) + 4 * h);
+    } else if (j < 87) {
+      const int i = (j - 23) & 31, ii = i & 15;
+      const int k = (i < 16 ? 0 : 32) + (ii & 3) + 8 * (ii >> 2) + 4 * h;
+      v = fold1((j < 55 ? 0 : 32) + col, k);
+    } else {
+      v = shift1((j == 87 ? 0 : 32) + col);
+    }
+    out[FR + idx] = v;
+  }
 }
 
 // h0[c] = relu(W0'[c,:] . f + s0[c])
@@ -223,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void k_pfn_pillar(const float* __restrict__
   using L = Folded<F>;
   const int32_t r = blockIdx.x * kBlock + threadIdx.x;
   if (r >= counters[0] || r >= g1_rows) return;
-  const uint32_t s = pillar_start(r, cpre, cblk), c = count[r];
+  const uint32_t s = pillar_start(r, cpre, cblk), c = count[r] + 1u;  // count[] holds the non-owner points
   double sx = 0, sy = 0, sz = 0;
   for (uint32_t k = 0; k < c; k++) {
     const float* p = pts + (int64_t)plist[s + k] * (F + 1);
@@ -426,6 +521,10 @@ inline void prof_mark(int which, hipStream_t st) {
 struct ReaderWs {
   int32_t* counters;  // [0]=P [1]=N'
   uint32_t *bitmap, *wpre, *wblk;
+  uint8_t* bytemap;
+  int32_t* owner;
+  uint32_t* rec;
+  size_t zero_bytes;  // counters | count | bytemap are contiguous: one memset per call
   int32_t *key, *rank, *slot;
   uint32_t *count, *cpre, *cblk;
   int32_t* plist;
@@ -454,13 +553,17 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   w.nblk_k = (int)((n + PNX_SCAN_ITEMS - 1) / PNX_SCAN_ITEMS);
   if (w.nblk_k < 1) w.nblk_k = 1;
   w.counters = c.take<int32_t>(64);
+  w.count = c.take<uint32_t>(w.pcap + 8);
+  w.bytemap = c.take<uint8_t>(cells + 64);
+  w.zero_bytes = c.used();
+  w.owner = c.take<int32_t>(cells + 8);
+  w.rec = c.take<uint32_t>((n + 8) * 8);
   w.bitmap = c.take<uint32_t>(w.nwords + 8);
   w.wpre = c.take<uint32_t>(w.nwords + 8);
   w.wblk = c.take<uint32_t>(w.nblk_w + 8);
   w.key = c.take<int32_t>(n + 8);
   w.rank = c.take<int32_t>(n + 8);
   w.slot = c.take<int32_t>(n + 8);
-  w.count = c.take<uint32_t>(w.pcap + 8);
   w.cpre = c.take<uint32_t>(w.pcap + 8);
   w.cblk = c.take<uint32_t>(w.nblk_c + 8);
   w.plist = c.take<int32_t>(n + 8);
@@ -500,26 +603,24 @@ int check_common(const float* points, int64_t n, int32_t stride, int32_t batch, 
 // Steps 1-4: keys, bitmap scan, rank/slots/coords, CSR.  Leaves counters = {P, N'}.
 int run_voxelize(const float* points, int64_t n, int32_t stride, const GeomDev& gd, const ReaderWs& w, int32_t* coords,
                  int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, bool need_kept_scan, hipStream_t st) {
-  PNX_CHECK_HIP(hipMemsetAsync(w.counters, 0, 64 * sizeof(int32_t), st));
-  PNX_CHECK_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)w.nwords * 4, st));
-  PNX_CHECK_HIP(hipMemsetAsync(w.count, 0, (size_t)w.pcap * 4, st));
+  PNX_CHECK_HIP(hipMemsetAsync(w.counters, 0, w.zero_bytes, st));  // counters | count | bytemap
   if (n > 0) {
-    k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bitmap);
+    k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bytemap, w.owner);
     PNX_LAUNCH_CHECK();
   }
-  k_scan_local<SCAN_POPC><<<w.nblk_w, kBlock, 0, st>>>(w.bitmap, w.nwords, w.wpre, w.wblk);
+  k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk);
   k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
   PNX_LAUNCH_CHECK();
   if (n > 0) {
-    k_rank<<<nblocks(n), kBlock, 0, st>>>(w.key, n, gd, w.bitmap, w.wpre, w.wblk, w.rank, w.slot, w.count, coords, pillar_capacity,
-                                          pillar_of_point);
+    k_rank<<<nblocks(n), kBlock, 0, st>>>(w.key, n, gd, w.bitmap, w.wpre, w.wblk, w.owner, w.rank, w.slot, w.count, coords,
+                                          pillar_capacity, pillar_of_point);
     PNX_LAUNCH_CHECK();
   }
-  k_scan_local<SCAN_IDENT><<<w.nblk_c, kBlock, 0, st>>>(w.count, w.pcap, w.cpre, w.cblk);
+  k_scan_local<SCAN_PLUS1><<<w.nblk_c, kBlock, 0, st>>>(w.count, w.pcap, w.cpre, w.cblk, w.counters + 0);
   k_scan_blocks<<<1, kBlock, 0, st>>>(w.cblk, w.nblk_c, w.counters + 1);
   PNX_LAUNCH_CHECK();
   if (n > 0) {
-    k_fill<<<nblocks(n), kBlock, 0, st>>>(w.rank, w.slot, n, w.cpre, w.cblk, w.plist);
+    k_fill<<<nblocks(n), kBlock, 0, st>>>(points, stride, w.rank, w.slot, n, w.cpre, w.cblk, w.plist, w.rec);
     PNX_LAUNCH_CHECK();
     if (need_kept_scan) {
       k_scan_local<SCAN_KEPT><<<w.nblk_k, kBlock, 0, st>>>(reinterpret_cast<const uint32_t*>(w.key), n, w.kpre, w.kblk);
@@ -548,7 +649,7 @@ int launch_canvas(const ReaderWs& w, const float* g1, int64_t g1_rows, const Geo
 }  // namespace
 
 // implemented in pfn_mfma.hip: the wave-tiled fp32-MFMA PFN kernel (PNX_PFN_IMPL=1, default)
-int pnx_launch_pfn_mfma(int F, const float* points, const PnxGeomDev& geom, const int32_t* plist, const int32_t* rank,
+int pnx_launch_pfn_mfma(int F, const uint32_t* rec, const PnxGeomDev& geom,
                         const uint32_t* count, const uint32_t* cpre, const uint32_t* cblk, const int32_t* counters, const float* folded,
                         float* g1, int64_t g1_rows, int64_t n_points, hipStream_t st);
 
@@ -608,7 +709,7 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
       }
       PNX_LAUNCH_CHECK();
     } else {
-      rc = pnx_launch_pfn_mfma(F, points, gd, w.plist, w.rank, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows, n, st);
+      rc = pnx_launch_pfn_mfma(F, w.rec, gd, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows, n, st);
       if (rc != PNX_OK) return rc;
     }
   }
