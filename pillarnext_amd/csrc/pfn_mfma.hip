@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
                                                  const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
                                                  const int32_t* __restrict__ counters, const float* __restrict__ P,
                                                  float* __restrict__ g1, int64_t g1_rows) {
-  constexpr int C0 = F + 5, KS = (C0 + 1) / 2;
+  constexpr int C0 = F + 5, KS = (C0 + 2) / 2;  // K = C0 features + one constant-1 column that carries the folded BN shift
   constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;  // start of the fragment-ordered block (k_fold_bn)
   constexpr int GST = 36;                          // G0 row stride in floats: 16-byte aligned rows, banks spread
   __shared__ __attribute__((aligned(16))) float sG0[R * GST];
@@ -97,10 +97,6 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
   float w0f[KS];
 #pragma unroll
   for (int kk = 0; kk < KS; kk++) w0f[kk] = FP[kk * 64];
-  const float s0n = FP[6 * 64];
-  v16f s0v;
-#pragma unroll
-  for (int i = 0; i < 16; i++) s0v[i] = FP[(7 + i) * 64];
   float w1a[32], w1b[32];
 #pragma unroll
   for (int i = 0; i < 32; i++) {
@@ -160,11 +156,11 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
     {
       float m = 0.f;
       int seg = 0;
-      bool open = false;
       int prev_rank = p_lo - 1;  // rank of the slot before the tile (wave-uniform)
       Rec cur = load_rec(rec, min(base + (uint32_t)col, end - 1));
       for (int t = 0; t < ntiles; t++) {
-        const uint32_t slot = base + 32u * t + col;
+        const uint32_t slot0_of_tile = base + 32u * t;
+        const uint32_t slot = slot0_of_tile + col;
         const bool act = slot < end;
         const Rec nxt = load_rec(rec, min(slot + 32u, end - 1));  // prefetch the next tile's record
         const int r = (int)cur.b.w;
@@ -174,15 +170,16 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
         float ff[KS];
         {
           const int sl = act ? r - p_lo : 0;
-          float f[C0 + 1];
+          float f[C0 + 2];
           decorate_rec<F>(cur, sMean[sl * 3], sMean[sl * 3 + 1], sMean[sl * 3 + 2], g, f);
-          f[C0] = 0.f;
+          f[C0] = 1.f;
+          f[C0 + 1] = 0.f;
 #pragma unroll
           for (int kk = 0; kk < KS; kk++) ff[kk] = act ? (h ? f[2 * kk + 1] : f[2 * kk]) : 0.f;
         }
         v16f acc;
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[i] = s0n;
+        for (int i = 0; i < 16; i++) acc[i] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) acc = PNX_MFMA(ff[kk], w0f[kk], acc);
         float p0[16], p1[16];
@@ -195,24 +192,23 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
         }
         const uint32_t heads = (uint32_t)__ballot(is_head && h == 0);
         const uint32_t valid = (uint32_t)__ballot(act && h == 0);
+        // point p ends a pillar if p+1 is invalid or a head; for p = 31 look at the prefetched first record of the next tile
+        const int r_last = __shfl(r, 31), r_next = __shfl((int)nxt.b.w, 0);
+        const uint32_t t31 = (slot0_of_tile + 32u >= end || r_next != r_last) ? 0x80000000u : 0u;
+        const uint32_t tails = valid & ((((heads >> 1) | ~(valid >> 1)) & 0x7fffffffu) | t31);
 #pragma unroll
         for (int p = 0; p < 32; p++) {
           const int i = (p & 3) + 4 * (p >> 3);
           const float v = ((p >> 2) & 1) ? p1[i] : p0[i];
-          if ((heads >> p) & 1u) {
-            if (open) {
-              if (l < 32) sG0[seg * GST + l] = m;
-              seg++;
-            }
-            m = 0.f;
-            open = true;
+          m = fmaxf(((heads >> p) & 1u) ? 0.f : m, ((valid >> p) & 1u) ? v : 0.f);
+          if ((tails >> p) & 1u) {
+            if (l < 32) sG0[(seg + __builtin_popcount(heads & ((2u << p) - 1u)) - 1) * GST + l] = m;
           }
-          if ((valid >> p) & 1u) m = fmaxf(m, v);
         }
-        prev_rank = __shfl(r, 31);
+        seg += __builtin_popcount(heads);
+        prev_rank = r_last;
         cur = nxt;
       }
-      if (open && l < 32) sG0[seg * GST + l] = m;
     }
     __syncthreads();
 
@@ -220,11 +216,11 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
     {
       float m = 0.f;
       int seg = 0;
-      bool open = false;
       int prev_rank = p_lo - 1;
       Rec cur = load_rec(rec, min(base + (uint32_t)col, end - 1));
       for (int t = 0; t < ntiles; t++) {
-        const uint32_t slot = base + 32u * t + col;
+        const uint32_t slot0_of_tile = base + 32u * t;
+        const uint32_t slot = slot0_of_tile + col;
         const bool act = slot < end;
         const Rec nxt = load_rec(rec, min(slot + 32u, end - 1));
         const int r = (int)cur.b.w;
@@ -234,13 +230,16 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
         const int sl = act ? r - p_lo : 0;
         float ff[KS];
         {
-          float f[C0 + 1];
+          float f[C0 + 2];
           decorate_rec<F>(cur, sMean[sl * 3], sMean[sl * 3 + 1], sMean[sl * 3 + 2], g, f);
-          f[C0] = 0.f;
+          f[C0] = 1.f;
+          f[C0 + 1] = 0.f;
 #pragma unroll
           for (int kk = 0; kk < KS; kk++) ff[kk] = act ? (h ? f[2 * kk + 1] : f[2 * kk]) : 0.f;
         }
-        v16f d0 = s0v;
+        v16f d0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) d0[i] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], ff[kk], d0);
         // "max" half of the concat: G0[pillar][8j + 4h .. +3], j = 0..3  == channel order of d0's registers
@@ -276,24 +275,24 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
         }
         const uint32_t heads = (uint32_t)__ballot(is_head && h == 0);
         const uint32_t valid = (uint32_t)__ballot(act && h == 0);
+        // point p ends a pillar if p+1 is invalid or a head; for p = 31 look at the prefetched first record of the next tile
+        const int r_last = __shfl(r, 31), r_next = __shfl((int)nxt.b.w, 0);
+        const uint32_t t31 = (slot0_of_tile + 32u >= end || r_next != r_last) ? 0x80000000u : 0u;
+        const uint32_t tails = valid & ((((heads >> 1) | ~(valid >> 1)) & 0x7fffffffu) | t31);
 #pragma unroll
         for (int p = 0; p < 32; p++) {
           const int i = (p & 3) + 4 * (p >> 3);
           const float v = ((p >> 2) & 1) ? p1[i] : p0[i];
-          if ((heads >> p) & 1u) {
-            if (open) {
-              if ((int64_t)(p_lo + seg) < g1_rows) g1[(int64_t)(p_lo + seg) * 64 + l] = m;
-              seg++;
-            }
-            m = 0.f;
-            open = true;
+          m = fmaxf(((heads >> p) & 1u) ? 0.f : m, ((valid >> p) & 1u) ? v : 0.f);
+          if ((tails >> p) & 1u) {
+            const int64_t row = (int64_t)(p_lo + seg + __builtin_popcount(heads & ((2u << p) - 1u)) - 1);
+            if (row < g1_rows) g1[row * 64 + l] = m;
           }
-          if ((valid >> p) & 1u) m = fmaxf(m, v);
         }
-        prev_rank = __shfl(r, 31);
+        seg += __builtin_popcount(heads);
+        prev_rank = r_last;
         cur = nxt;
       }
-      if (open && (int64_t)(p_lo + seg) < g1_rows) g1[(int64_t)(p_lo + seg) * 64 + l] = m;
     }
   }
 }
@@ -304,6 +303,11 @@ int launch_f(int R, const uint32_t* rec, const PnxGeomDev& g, const uint32_t* co
   int64_t nb = (n + R - 1) / R;
   if (nb > max_blocks) nb = max_blocks;  // persistent: each wave strides over the slot windows
   if (nb < 1) nb = 1;
+  if (getenv("PNX_DEBUG")) {
+    int occ = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pfn_mfma<F, 64>, 64, 0);
+    fprintf(stderr, "[pnx] k_pfn_mfma<%d,64>: occupancy API says %d blocks(waves)/CU, launching %lld blocks, R=%d\n", F, occ, (long long)nb, R);
+  }
   if (R == 128) k_pfn_mfma<F, 128><<<(int)nb, 64, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows);
   else if (R == 32) k_pfn_mfma<F, 32><<<(int)nb, 64, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows);
   else k_pfn_mfma<F, 64><<<(int)nb, 64, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows);

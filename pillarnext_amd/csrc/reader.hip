@@ -260,7 +260,7 @@ __global__ void k_fold_bn(int C0, const float* w0, const float* g0, const float*
     out[S1 + t] = __fsub_rn(b1[t], __fmul_rn(m1[t], a));
   }
   // Fragment-ordered copy for k_pfn_mfma: register j of lane l at FR + j*64 + l.
-  //   j 0..5   W0'[col][2j+h]            (A/B fragment of layer 0, zero past C0)
+  //   j 0..5   W0'[col][2j+h]            (A/B fragment of layer 0; column C0 = s0[col] for the constant-1 feature)
   //   j 6      s0[col]
   //   j 7..22  s0[ch(i,h)]               ch(i,h) = (i&3) + 8*(i>>2) + 4h  (accumulator-register channel order)
   //   j 23..54 W1'[col][k(i,h)]          k(i,h) = (i<16 ? ch(i,h) : 32 + ch(i-16,h))
@@ -276,7 +276,7 @@ __global__ void k_fold_bn(int C0, const float* w0, const float* g0, const float*
     float v;
     if (j < 6) {
       const int k = 2 * j + h;
-      v = k < C0 ? fold0(col, k) : 0.f;
+      v = k < C0 ? fold0(col, k) : (k == C0 ? shift0(col) : 0.f);  // column C0 multiplies the constant-1 feature
     } else if (j == 6) {
       v = shift0(col);
     } else if (j < 23) {
