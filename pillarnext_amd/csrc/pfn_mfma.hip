@@ -18,6 +18,8 @@
 //   one exchange lane l holds channel l for all 32 points, and the same sequential scan emits one coalesced
 //   256-byte feat_max row per pillar.
 // No atomics, no cross-wave traffic, deterministic.  BN is pre-folded (reader.hip k_fold_bn).
+#include <vector>
+
 #include "pnx_common.h"
 
 namespace {
@@ -44,6 +46,13 @@ __device__ __forceinline__ void decorate_pt(const float* __restrict__ p, float m
   f[F + 3] = __fsub_rn(x, ctrx);
   f[F + 4] = __fsub_rn(y, ctry);
 }
+
+// LDS traffic of one wave is executed in order; this only stops the compiler from moving accesses across the point.
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+  } while (0)
 
 #define PNX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -79,17 +88,31 @@ __device__ __forceinline__ void decorate_rec(const Rec& q, float mx, float my, f
 }
 
 template <int F, int R>
-__global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ rec, PnxGeomDev g, const uint32_t* __restrict__ count,
+__global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ rec, PnxGeomDev g, const uint32_t* __restrict__ count,
                                                  const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
                                                  const int32_t* __restrict__ counters, const float* __restrict__ P,
-                                                 float* __restrict__ g1, int64_t g1_rows) {
+                                                 float* __restrict__ g1, int64_t g1_rows, unsigned long long* __restrict__ dbg) {
   constexpr int C0 = F + 5, KS = (C0 + 2) / 2;  // K = C0 features + one constant-1 column that carries the folded BN shift
   constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;  // start of the fragment-ordered block (k_fold_bn)
   constexpr int GST = 36;                          // G0 row stride in floats: 16-byte aligned rows, banks spread
-  __shared__ __attribute__((aligned(16))) float sG0[R * GST];
-  __shared__ float sMean[R * 3];
+  // 4 independent waves per workgroup (one per SIMD by construction); each wave owns a private LDS slice and never
+  // synchronises with the others (they run different trip counts), so only wave-level ordering is used.
+  __shared__ __attribute__((aligned(16))) float sG0_all[4][R * GST];
+  __shared__ float sMean_all[4][R * 3];
+  const int wv = threadIdx.x >> 6;
+  float* sG0 = sG0_all[wv];
+  float* sMean = sMean_all[wv];
 
-  const int l = threadIdx.x, col = l & 31, h = l >> 5;
+  const int l = threadIdx.x & 63, col = l & 31, h = l >> 5;
+  unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tk = 0;
+#define TICK() (dbg ? __builtin_amdgcn_s_memtime() : 0ULL)
+#define TOCK(k)                          \
+  if (dbg) {                             \
+    const unsigned long long _n = __builtin_amdgcn_s_memtime(); \
+    T[k] += _n - tk;                     \
+    tk = _n;                             \
+  }
   const int n_kept = counters[1], Ptot = counters[0];
 
   // ---- weight fragments: coalesced loads, once per (persistent) wave
@@ -105,8 +128,9 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
   }
   const float s1a = FP[87 * 64], s1b = FP[88 * 64];
 
-  for (int64_t slot0 = (int64_t)blockIdx.x * R; slot0 < n_kept; slot0 += (int64_t)gridDim.x * R) {
+  for (int64_t slot0 = (int64_t)(blockIdx.x * 4 + wv) * R; slot0 < n_kept; slot0 += (int64_t)gridDim.x * 4 * R) {
     const int64_t slot1 = (slot0 + R < n_kept) ? slot0 + R : n_kept;
+    tk = TICK();
     // pillars owned by this pass = those whose first slot is in [slot0, slot1)
     const int q0 = (int)rec[slot0 * 8 + 7];
     const uint32_t st0 = pstart(q0, cpre, cblk);
@@ -130,7 +154,8 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
     }
     if (p_lo >= p_hi) continue;
     const int nown = p_hi - p_lo;  // <= R
-    __syncthreads();               // previous pass done with sG0 / sMean
+    TOCK(0);
+    WAVE_SYNC();                   // previous pass done with sG0 / sMean
 
     // ---- phase 0: per-pillar mean of xyz (scatter_mean, pe:113-114): fp64 sum, fp32 divide
     for (int s = l; s < nown; s += 64) {
@@ -148,9 +173,10 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
       sMean[s * 3 + 1] = __fdiv_rn((float)sy, fc);
       sMean[s * 3 + 2] = __fdiv_rn((float)sz, fc);
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     const int ntiles = (int)((end - base + 31) >> 5);
+    TOCK(1);
 
     // ---- phase 1: layer 0, per-pillar max -> G0
     {
@@ -210,8 +236,9 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
         cur = nxt;
       }
     }
-    __syncthreads();
+    WAVE_SYNC();
 
+    TOCK(2);
     // ---- phase 2: layer 0 again (other orientation) chained into layer 1, per-pillar max -> feat_max rows
     {
       float m = 0.f;
@@ -242,6 +269,7 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
         for (int i = 0; i < 16; i++) d0[i] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], ff[kk], d0);
+        TOCK(3);
         // "max" half of the concat: G0[pillar][8j + 4h .. +3], j = 0..3  == channel order of d0's registers
         float4 gq[4];
 #pragma unroll
@@ -273,6 +301,8 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
           p0[i] = h ? y : va;
           p1[i] = h ? vb : y;
         }
+        if (dbg) { asm volatile("" :: "v"(p0[0]), "v"(p1[15])); }
+        TOCK(4);
         const uint32_t heads = (uint32_t)__ballot(is_head && h == 0);
         const uint32_t valid = (uint32_t)__ballot(act && h == 0);
         // point p ends a pillar if p+1 is invalid or a head; for p = 31 look at the prefetched first record of the next tile
@@ -292,26 +322,46 @@ __global__ __launch_bounds__(64) void k_pfn_mfma(const uint32_t* __restrict__ re
         seg += __builtin_popcount(heads);
         prev_rank = r_last;
         cur = nxt;
+        TOCK(5);
       }
     }
+  }
+  if (dbg && l == 0) {
+    const int gw = blockIdx.x * 4 + wv;
+#pragma unroll
+    for (int k = 0; k < 8; k++) dbg[gw * 8 + k] = T[k];
   }
 }
 
 template <int F>
 int launch_f(int R, const uint32_t* rec, const PnxGeomDev& g, const uint32_t* count, const uint32_t* cpre, const uint32_t* cblk,
              const int32_t* counters, const float* folded, float* g1, int64_t g1_rows, int64_t n, int max_blocks, hipStream_t st) {
-  int64_t nb = (n + R - 1) / R;
-  if (nb > max_blocks) nb = max_blocks;  // persistent: each wave strides over the slot windows
+  static unsigned long long* dbg = nullptr;
+  static int dbg_calls = 0;
+  const bool want_dbg = getenv("PNX_PFN_TIMING") != nullptr;
+  if (want_dbg && !dbg) (void)hipMalloc(&dbg, 8192 * 4 * 8 * sizeof(unsigned long long));
+  int64_t nb = ((n + R - 1) / R + 3) / 4;  // 4 waves per block, one slot window per wave and pass
+  if (nb > max_blocks) nb = max_blocks;    // persistent: each wave strides over the slot windows
   if (nb < 1) nb = 1;
   if (getenv("PNX_DEBUG")) {
     int occ = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pfn_mfma<F, 64>, 64, 0);
-    fprintf(stderr, "[pnx] k_pfn_mfma<%d,64>: occupancy API says %d blocks(waves)/CU, launching %lld blocks, R=%d\n", F, occ, (long long)nb, R);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pfn_mfma<F, 64>, 256, 0);
+    fprintf(stderr, "[pnx] k_pfn_mfma<%d,64>: occupancy API says %d blocks (x4 waves)/CU, launching %lld blocks, R=%d\n", F, occ, (long long)nb, R);
   }
-  if (R == 128) k_pfn_mfma<F, 128><<<(int)nb, 64, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows);
-  else if (R == 32) k_pfn_mfma<F, 32><<<(int)nb, 64, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows);
-  else k_pfn_mfma<F, 64><<<(int)nb, 64, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows);
+  if (R == 128) k_pfn_mfma<F, 128><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows, want_dbg ? dbg : nullptr);
+  else if (R == 32) k_pfn_mfma<F, 32><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows, want_dbg ? dbg : nullptr);
+  else k_pfn_mfma<F, 64><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows, want_dbg ? dbg : nullptr);
   PNX_LAUNCH_CHECK();
+  if (want_dbg && ++dbg_calls == 20) {
+    std::vector<unsigned long long> hbuf((size_t)nb * 4 * 8);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(hbuf.data(), dbg, hbuf.size() * 8, hipMemcpyDeviceToHost);
+    double acc[8] = {0};
+    for (size_t w = 0; w < (size_t)nb * 4; w++)
+      for (int k = 0; k < 8; k++) acc[k] += (double)hbuf[w * 8 + k];
+    const char* names[8] = {"ownership loads", "phase0 mean", "phase1 total", "p2: load+decorate+d0", "p2: 64 MFMA + exchange", "p2: scan+stores", "", ""};
+    for (int k = 0; k < 6; k++) fprintf(stderr, "[pnx-timing] %-24s %10.0f ticks/wave\n", names[k], acc[k] / (nb * 4));
+  }
   return PNX_OK;
 }
 
@@ -322,8 +372,8 @@ int pnx_launch_pfn_mfma(int F, const uint32_t* rec, const PnxGeomDev& geom, cons
                         hipStream_t st) {
   const char* r_env = getenv("PNX_PFN_R");  // slots per pass: 32 | 64 | 128
   const int R = r_env ? atoi(r_env) : 64;
-  const char* b_env = getenv("PNX_PFN_BLOCKS");  // resident waves: 256 CUs x 8 (2 per SIMD at 226 VGPRs)
-  const int max_blocks = b_env ? atoi(b_env) : 2048;
+  const char* b_env = getenv("PNX_PFN_BLOCKS");
+  const int max_blocks = b_env ? atoi(b_env) : 512;  // 256 CUs x 2 blocks x 4 waves = 2 waves per SIMD at ~230 VGPRs
   switch (F) {
     case 3: return launch_f<3>(R, rec, geom, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, max_blocks, st);
     case 4: return launch_f<4>(R, rec, geom, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, max_blocks, st);

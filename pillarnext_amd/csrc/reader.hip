@@ -512,10 +512,10 @@ __global__ __launch_bounds__(kBlock) void k_scatter_list(const float* __restrict
 struct Prof {
   bool on = false;
   int cap = 0, n = 0;
-  std::vector<hipEvent_t> ev;  // 4 per sample: reader start, canvas start, canvas stop, reader stop
+  std::vector<hipEvent_t> ev;  // 6 per sample: reader start, canvas start, canvas stop, reader stop, pfn start, pfn stop
 } g_prof;
 inline void prof_mark(int which, hipStream_t st) {
-  if (g_prof.on && g_prof.n < g_prof.cap) (void)hipEventRecord(g_prof.ev[g_prof.n * 4 + which], st);
+  if (g_prof.on && g_prof.n < g_prof.cap) (void)hipEventRecord(g_prof.ev[g_prof.n * 6 + which], st);
 }
 
 struct ReaderWs {
@@ -709,8 +709,10 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
       }
       PNX_LAUNCH_CHECK();
     } else {
+      prof_mark(4, st);
       rc = pnx_launch_pfn_mfma(F, w.rec, gd, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows, n, st);
       if (rc != PNX_OK) return rc;
+      prof_mark(5, st);
     }
   }
   if (feat_max && g1 != feat_max) {
@@ -734,7 +736,7 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
 
 int pnx_profile_begin(int32_t max_samples) {
   PNX_REQUIRE(max_samples > 0 && max_samples <= 65536, PNX_ERR_INVALID, "max_samples out of range");
-  while ((int)g_prof.ev.size() < max_samples * 4) {
+  while ((int)g_prof.ev.size() < max_samples * 6) {
     hipEvent_t e;
     PNX_CHECK_HIP(hipEventCreate(&e));
     g_prof.ev.push_back(e);
@@ -747,15 +749,17 @@ int pnx_profile_begin(int32_t max_samples) {
 
 int pnx_profile_end(float* reader_us, float* canvas_us, int32_t* samples) {
   g_prof.on = false;
-  double r = 0, c = 0;
+  double r = 0, c = 0, f = 0;
   for (int i = 0; i < g_prof.n; i++) {
     float ms = 0;
-    PNX_CHECK_HIP(hipEventSynchronize(g_prof.ev[i * 4 + 3]));
-    PNX_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[i * 4 + 0], g_prof.ev[i * 4 + 3]));
+    PNX_CHECK_HIP(hipEventSynchronize(g_prof.ev[i * 6 + 3]));
+    PNX_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[i * 6 + 0], g_prof.ev[i * 6 + 3]));
     r += ms;
-    PNX_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[i * 4 + 1], g_prof.ev[i * 4 + 2]));
+    PNX_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[i * 6 + 1], g_prof.ev[i * 6 + 2]));
     c += ms;
+    if (hipEventElapsedTime(&ms, g_prof.ev[i * 6 + 4], g_prof.ev[i * 6 + 5]) == hipSuccess) f += ms;
   }
+  if (getenv("PNX_DEBUG") && g_prof.n) fprintf(stderr, "[pnx] profile: pfn kernel %.2f us avg over %d calls\n", f * 1e3 / g_prof.n, g_prof.n);
   const int n = g_prof.n;
   if (reader_us) *reader_us = n ? (float)(r * 1e3 / n) : 0.f;
   if (canvas_us) *canvas_us = n ? (float)(c * 1e3 / n) : 0.f;

@@ -30,11 +30,19 @@ def main():
         net.forward_dense(pts, a.batch, out=out, counts=counts)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    import ctypes
+    from pillarnext_amd import _lib
+    L = _lib.lib()
+    L.pnx_profile_begin(a.iters)
     e0.record()
     for _ in range(a.iters):
         net.forward_dense(pts, a.batch, out=out, counts=counts)
     e1.record()
     torch.cuda.synchronize()
+    r_us, c_us, ns = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
+    os.environ.setdefault("PNX_DEBUG", "1")
+    L.pnx_profile_end(ctypes.byref(r_us), ctypes.byref(c_us), ctypes.byref(ns))
+    print(f"events: reader {r_us.value:.1f} us, canvas kernel {c_us.value:.1f} us")
     us = e0.elapsed_time(e1) * 1e3 / a.iters
     P, m = counts.tolist()
     esz = out.element_size()
