@@ -71,8 +71,13 @@ def main():
     cfg = synth.CONFIGS[a.config]
     torch.manual_seed(0)
     model = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"]).to(dev).eval()
-    for m in (model.backbone, model.neck, model.head):
-        m.to(memory_format=torch.channels_last, dtype=torch.bfloat16)
+    if os.environ.get("PNX_BENCH_UNFUSED"):
+        for m in (model.backbone, model.neck, model.head):
+            m.to(memory_format=torch.channels_last, dtype=torch.bfloat16)
+    else:
+        from pillarnext_amd.models import FusedPillarNeXt
+
+        model = FusedPillarNeXt(model).to(dev).eval()  # same network: eval-BN folded, HIP epilogues, merged head branches
     # frames are sharded across ranks: rank r gets frames r*B .. r*B+B-1 (replicas only, no collective on the path)
     pts = torch.from_numpy(synth.make_batch(a.config, a.batch, a.dist, frame0=rank * a.batch)).to(dev)
     example = {"points": pts, "token": [f"r{rank}f{i}" for i in range(a.batch)], "batch_size": a.batch}

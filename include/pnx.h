@@ -124,6 +124,17 @@ int pnx_scatter_canvas(const float* feat_max, const int32_t* coords, const int32
                        pnx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Epilogue of the masked-dense backbone (the dense stand-in for det3d/models/utils/sparse_conv.py:16-63 with BatchNorm
+ * folded into the conv):  out = [relu]( x + bias[c] [+ residual] ) * mask[site]   in one pass, bf16 NHWC.
+ *   x, residual, out  (sites, channels) bf16 (residual may be NULL; out may alias x)
+ *   bias              fp32[channels];  mask  uint8[sites] or NULL (= all active)
+ */
+int pnx_bias_act_mask(const void* x, const void* residual, const float* bias, const uint8_t* mask, void* out, int64_t sites,
+                      int32_t channels, int32_t dtype, int32_t relu, pnx_stream_t stream);
+/* Active-site rule of SparseConv2d(k=3, stride, pad=1): mask_out = maxpool3x3(mask_in, stride, 1); uint8 (B,h,w) -> (B,ho,wo). */
+int pnx_mask_pool3(const uint8_t* mask_in, int32_t batch, int32_t h, int32_t w, int32_t stride, uint8_t* mask_out, pnx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Rotated IoU / NMS.  Boxes are (n,7) fp32 [x, y, z, dx, dy, dz, heading].
  * Arithmetic = iou3d_nms_kernel.cu:35-234 in fp32, with cos/sin/atan2 from pnx_detmath.h.
  */

@@ -1,0 +1,119 @@
+// dense_ops.hip -- elementwise epilogue of the masked-dense backbone stand-in, gfx950.
+//
+// After BatchNorm(eval) is folded into the preceding bias-free convolution, every spconv block of the reference
+// (det3d/models/utils/sparse_conv.py:31-36, 52-61) reduces to
+//        y = relu(conv(x) + b[c] (+ identity)) * mask[site]
+// MIOpen computes conv(x); this kernel does the rest in ONE pass over the NHWC tensor (16-byte vector loads/stores,
+// 8 bf16 per lane), instead of the 3-4 separate elementwise passes (BN, add, ReLU, mask) a module-by-module
+// PyTorch graph makes.  HBM-bound: 2 (3 with residual) x tensor bytes.
+#include "pnx_common.h"
+
+namespace {
+
+__device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// x, res, out: bf16 NHWC with C channels (C % 8 == 0); bias fp32[C]; mask u8[sites] (or null) ; one thread = 8 channels
+template <bool HAS_RES, bool HAS_MASK, bool RELU>
+__global__ __launch_bounds__(256) void k_bias_act_mask_bf16(const uint4* __restrict__ x, const uint4* __restrict__ res,
+                                                            const float* __restrict__ bias, const uint8_t* __restrict__ mask,
+                                                            uint4* __restrict__ out, int64_t n_vec, int cvec) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * 256) {
+    const int64_t site = i / cvec;
+    const int c0 = (int)(i - site * cvec) * 8;
+    uint4 o = make_uint4(0, 0, 0, 0);
+    const bool on = !HAS_MASK || mask[site] != 0;
+    if (on) {
+      const uint4 v = x[i];
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (HAS_RES) r = res[i];
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + c0), b1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
+      const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, rw[4] = {r.x, r.y, r.z, r.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      uint32_t ow[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float lo = bf2f(vw[k] & 0xffffu) + bb[2 * k], hi = bf2f(vw[k] >> 16) + bb[2 * k + 1];
+        if (HAS_RES) {
+          lo += bf2f(rw[k] & 0xffffu);
+          hi += bf2f(rw[k] >> 16);
+        }
+        if (RELU) {
+          lo = fmaxf(lo, 0.f);
+          hi = fmaxf(hi, 0.f);
+        }
+        ow[k] = f2bf(lo) | (f2bf(hi) << 16);
+      }
+      o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+    out[i] = o;
+  }
+}
+
+// 3x3 / stride-s / pad-1 max-pool of the occupancy mask (the active-site rule of a strided sparse conv).
+__global__ __launch_bounds__(256) void k_mask_pool(const uint8_t* __restrict__ in, int B, int H, int W, int stride, uint8_t* __restrict__ out,
+                                                   int Ho, int Wo) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * Ho * Wo) return;
+  const int xo = (int)(idx % Wo), yo = (int)((idx / Wo) % Ho), b = (int)(idx / ((int64_t)Wo * Ho));
+  uint8_t m = 0;
+  for (int dy = -1; dy <= 1; dy++) {
+    const int y = yo * stride + dy;
+    if (y < 0 || y >= H) continue;
+    for (int dx = -1; dx <= 1; dx++) {
+      const int x = xo * stride + dx;
+      if (x < 0 || x >= W) continue;
+      m |= in[((int64_t)b * H + y) * W + x];
+    }
+  }
+  out[idx] = m ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pnx_bias_act_mask(const void* x, const void* residual, const float* bias, const uint8_t* mask, void* out, int64_t sites,
+                      int32_t channels, int32_t dtype, int32_t relu, pnx_stream_t stream) {
+  PNX_REQUIRE(x && bias && out, PNX_ERR_INVALID, "null pointer");
+  PNX_REQUIRE(dtype == PNX_BF16, PNX_ERR_UNSUPPORTED, "pnx_bias_act_mask is built for bf16 NHWC tensors");
+  PNX_REQUIRE(channels > 0 && channels % 8 == 0 && sites >= 0, PNX_ERR_INVALID, "channels must be a positive multiple of 8");
+  PNX_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)bias) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
+  if (sites == 0) return PNX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int cvec = channels / 8;
+  const int64_t n_vec = sites * cvec;
+  int64_t nb = (n_vec + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+  const uint4 *xv = (const uint4*)x, *rv = (const uint4*)residual;
+  uint4* ov = (uint4*)out;
+#define PNX_LAUNCH_BAM(R_, M_, A_) k_bias_act_mask_bf16<R_, M_, A_><<<(unsigned)nb, 256, 0, st>>>(xv, rv, bias, mask, ov, n_vec, cvec)
+  const bool r = residual != nullptr, m = mask != nullptr, a = relu != 0;
+  if (r && m && a) PNX_LAUNCH_BAM(true, true, true);
+  else if (r && m) PNX_LAUNCH_BAM(true, true, false);
+  else if (r && a) PNX_LAUNCH_BAM(true, false, true);
+  else if (r) PNX_LAUNCH_BAM(true, false, false);
+  else if (m && a) PNX_LAUNCH_BAM(false, true, true);
+  else if (m) PNX_LAUNCH_BAM(false, true, false);
+  else if (a) PNX_LAUNCH_BAM(false, false, true);
+  else PNX_LAUNCH_BAM(false, false, false);
+#undef PNX_LAUNCH_BAM
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+int pnx_mask_pool3(const uint8_t* mask_in, int32_t batch, int32_t h, int32_t w, int32_t stride, uint8_t* mask_out, pnx_stream_t stream) {
+  PNX_REQUIRE(mask_in && mask_out && batch > 0 && h > 0 && w > 0 && stride >= 1, PNX_ERR_INVALID, "bad arguments");
+  const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
+  const int64_t n = (int64_t)batch * ho * wo;
+  k_mask_pool<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(mask_in, batch, h, w, stride, mask_out, ho, wo);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+}  // extern "C"

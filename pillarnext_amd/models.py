@@ -432,3 +432,143 @@ def build_pillarnext_b(pc_range, voxel_size, tasks=None, num_point_features=5, d
                                nms=dict(nms_pre_max_size=1000, nms_post_max_size=83, nms_iou_threshold=[[0.2] * len(t) for t in tasks]),
                                out_size_factor=[4] * len(tasks), voxel_size=list(voxel_size), pc_range=list(pc_range))
     return SingleStageDetector(reader, backbone, neck, head, post_processing)
+
+
+# ------------------------------------------------------------------------------------------------ fused inference graph
+def _fold_bn(weight, bn, conv_bias=None, transposed=False):
+    """Fold an eval-mode BatchNorm into the preceding conv: returns (weight', bias') in fp32."""
+    w = weight.detach().float()
+    a = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+    shape = (1, -1, 1, 1) if transposed else (-1, 1, 1, 1)
+    b0 = conv_bias.detach().float() if conv_bias is not None else torch.zeros_like(a)
+    return w * a.view(shape), (b0 - bn.running_mean.detach().float()) * a + bn.bias.detach().float()
+
+
+class _FusedConv(nn.Module):
+    """conv (BN folded, no bias inside MIOpen) + ONE HIP epilogue pass: [relu](y + b [+ res]) * mask."""
+
+    def __init__(self, weight, bias, stride=1, padding=0, dilation=1, relu=True, transposed=False, dtype=torch.bfloat16):
+        super().__init__()
+        self.register_buffer("weight", weight.to(dtype).contiguous(memory_format=torch.channels_last) if weight.dim() == 4 else weight.to(dtype))
+        self.register_buffer("bias", bias.float().contiguous())
+        self.stride, self.padding, self.dilation, self.relu, self.transposed = stride, padding, dilation, relu, transposed
+
+    def forward(self, x, mask=None, residual=None):
+        if self.transposed:
+            y = F.conv_transpose2d(x, self.weight, None, self.stride, self.padding)
+        else:
+            y = F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        return ops.bias_act_mask_(y, self.bias, mask, residual, self.relu)
+
+
+class FusedPillarNeXt(nn.Module):
+    """Inference-only re-expression of SingleStageDetector (eval BN folded, epilogues fused, the 6-7 SepHead branches of a
+    task merged into two convolutions).  Mathematically the same network; weights come from the trained modules."""
+
+    def __init__(self, det, dtype=torch.bfloat16):
+        super().__init__()
+        self.reader = det.reader
+        self.post_processing = det.post_processing
+        self.head_ref = det.head  # predict() / rectifier / class bookkeeping
+        self.dtype = dtype
+        bb = det.backbone
+        self.stages = nn.ModuleList()
+        self.stage_meta = []
+        for blk in bb.blocks:
+            mods = nn.ModuleList()
+            first = blk[0]
+            w, b = _fold_bn(first.conv.weight, first.norm)
+            mods.append(_FusedConv(w, b, first.stride, first.kernel_size // 2, dtype=dtype))
+            for rb in list(blk)[1:]:
+                w1, b1 = _fold_bn(rb.block1.conv.weight, rb.block1.norm)
+                w2, b2 = _fold_bn(rb.conv2.weight, rb.norm2)
+                mods.append(_FusedConv(w1, b1, 1, rb.block1.kernel_size // 2, dtype=dtype))
+                mods.append(_FusedConv(w2, b2, 1, rb.conv2.kernel_size[0] // 2, dtype=dtype))
+            self.stages.append(mods)
+            self.stage_meta.append((first.stride, first.subm))
+        w, b = _fold_bn(bb.mapping[0].weight, bb.mapping[1])
+        self.mapping = _FusedConv(w, b, 1, 0, dtype=dtype)
+        nk = det.neck
+        self.pre1 = _FusedConv(*_fold_bn(nk.pre_conv.block1.conv.conv.weight, nk.pre_conv.block1.norm), 1, 1, dtype=dtype)
+        self.pre2 = _FusedConv(*_fold_bn(nk.pre_conv.block2.conv.conv.weight, nk.pre_conv.block2.norm), 1, 1, dtype=dtype)
+        # ASPP: the 1x1 branch and the four dilated branches have no BN/activation of their own; post_conv is 1x1 over the concat
+        self.register_buffer("aspp_1x1", nk.conv1x1.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last))
+        self.register_buffer("aspp_w", nk.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last))
+        self.post = _FusedConv(*_fold_bn(nk.post_conv.conv.conv.weight, nk.post_conv.norm), 1, 0, dtype=dtype)
+        hd = det.head
+        self.shared = _FusedConv(*_fold_bn(hd.shared_conv[0].weight, hd.shared_conv[1], hd.shared_conv[0].bias), 1, 1, dtype=dtype)
+        self.task_deblock = nn.ModuleList()
+        self.task_conv1 = nn.ModuleList()
+        self.task_conv2 = nn.ModuleList()
+        self.task_split = []
+        for task in hd.tasks:
+            db = task.deblock
+            w, b = _fold_bn(db.conv.conv.weight, db.norm, transposed=True)
+            self.task_deblock.append(_FusedConv(w, b, db.conv.conv.stride, 0, transposed=True, dtype=dtype))
+            names = list(task.heads.keys())
+            w1s, b1s, w2s, b2s, outs = [], [], [], [], []
+            for nme in names:
+                fc = getattr(task, nme)
+                assert len(fc) == 4, "merged head expects conv-bn-relu-conv branches"
+                w1, b1 = _fold_bn(fc[0].weight, fc[1], fc[0].bias)
+                w1s.append(w1)
+                b1s.append(b1)
+                w2s.append(fc[3].weight.detach().float())
+                b2s.append(fc[3].bias.detach().float())
+                outs.append(fc[3].weight.shape[0])
+            hc = w1s[0].shape[0]
+            W1 = torch.cat(w1s, 0)                                   # (nh*hc, 64, 3, 3)
+            tot = sum(outs)
+            tot_p = (tot + 7) // 8 * 8                               # epilogue kernel wants channels % 8 == 0
+            W2 = torch.zeros((tot_p, hc * len(names), 3, 3), dtype=torch.float32, device=W1.device)
+            B2 = torch.zeros((tot_p,), dtype=torch.float32, device=W1.device)
+            o = 0
+            for j, (w2, b2) in enumerate(zip(w2s, b2s)):             # block-diagonal: branch j only sees its own 64 channels
+                W2[o:o + w2.shape[0], j * hc:(j + 1) * hc] = w2
+                B2[o:o + w2.shape[0]] = b2
+                o += w2.shape[0]
+            self.task_conv1.append(_FusedConv(W1, torch.cat(b1s), 1, 1, dtype=dtype))
+            self.task_conv2.append(_FusedConv(W2, B2, 1, 1, relu=False, dtype=dtype))
+            self.task_split.append((names, outs))
+
+    @torch.no_grad()
+    def forward_preds(self, points, batch_size):
+        ny, nx = (int(v) for v in self.reader.grid_size)
+        occ = torch.empty((batch_size, ny, nx), dtype=torch.uint8, device=points.device)
+        x = self.reader.forward_dense(points, batch_size, dtype=self.dtype, occupancy=occ)
+        mask = occ
+        for mods, (stride, subm) in zip(self.stages, self.stage_meta):
+            if not subm:
+                mask = ops.mask_pool3(mask, stride)
+            x = mods[0](x, mask)
+            for j in range(1, len(mods), 2):
+                y = mods[j](x, mask)
+                x = mods[j + 1](y, mask, residual=x)
+        x = self.mapping(x, mask)
+        # BasicBlock (utils/conv.py): act(block2(block1(x)) + x) where block2 already ends in a ReLU, so the residual is added
+        # AFTER that ReLU; both terms are >= 0, which makes the trailing act() the identity.
+        x = self.pre2(self.pre1(x)) + x
+        outs = [x, F.conv2d(x, self.aspp_1x1)] + [F.conv2d(x, self.aspp_w, None, 1, d, d) for d in (1, 6, 12, 18)]
+        x = self.post(torch.cat(outs, dim=1))
+        x = self.shared(x)
+        preds = []
+        for db, c1, c2, (names, outs_n) in zip(self.task_deblock, self.task_conv1, self.task_conv2, self.task_split):
+            t = c2(c1(db(x)))
+            d, o = {}, 0
+            for nme, k in zip(names, outs_n):
+                d[nme] = t[:, o:o + k]
+                o += k
+            preds.append(d)
+        return preds
+
+    @torch.no_grad()
+    def forward(self, example):
+        preds = self.forward_preds(example["points"], example["batch_size"])
+        outputs = self.head_ref.predict(example, preds, self.post_processing)
+        det = {}
+        for o in outputs:
+            tok = o.pop("token")
+            det[tok] = {k: v.to("cpu") for k, v in o.items()}
+        return det

@@ -180,3 +180,25 @@ def nms_single(boxes, thresh, rotated=True, post_max=0):
     keep, cnt = nms_batched(boxes, off, thr, n, post_max, rotated)
     k = int(cnt[0].item())
     return keep[:k], k
+
+
+# --------------------------------------------------------------------------------------------- dense epilogue
+def bias_act_mask_(x, bias, mask=None, residual=None, relu=True):
+    """In place on a channels_last bf16 (B,C,H,W) tensor: x = [relu](x + bias[c] [+ residual]) * mask[b,h,w]."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise PnxError("bias_act_mask_ needs a channels_last bf16 CUDA tensor")
+    B, C, H, W = x.shape
+    if residual is not None and not (residual.dtype == x.dtype and residual.shape == x.shape and residual.is_contiguous(memory_format=torch.channels_last)):
+        raise PnxError("residual must match x (bf16, channels_last)")
+    check(lib().pnx_bias_act_mask(ptr(x), ptr(residual), ptr(bias), ptr(mask), ptr(x), B * H * W, C, PNX_BF16, 1 if relu else 0, stream_ptr()),
+          "pnx_bias_act_mask")
+    return x
+
+
+def mask_pool3(mask, stride):
+    """uint8 (B,H,W) occupancy -> occupancy after a 3x3/stride/pad-1 sparse conv."""
+    B, H, W = mask.shape
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    out = torch.empty((B, Ho, Wo), dtype=torch.uint8, device=mask.device)
+    check(lib().pnx_mask_pool3(ptr(mask), B, H, W, stride, ptr(out), stream_ptr()), "pnx_mask_pool3")
+    return out

@@ -49,3 +49,40 @@ def test_detector_end_to_end_runs_and_is_deterministic():
     for k in d1:
         assert d1[k]["box3d_lidar"].shape[1] == 9 and d1[k]["box3d_lidar"].shape[0] <= 83
         assert torch.equal(d1[k]["box3d_lidar"], d2[k]["box3d_lidar"]) and torch.equal(d1[k]["scores"], d2[k]["scores"])
+
+
+def test_fused_inference_graph_matches_module_graph():
+    """BN folding + fused HIP epilogues + merged SepHead branches == the module-by-module network (bf16 tolerance)."""
+    from pillarnext_amd import synth
+    from pillarnext_amd.models import FusedPillarNeXt, build_pillarnext_b
+
+    cfg = synth.CONFIGS["C1"]
+    torch.manual_seed(1)
+    torch.backends.cudnn.deterministic = True
+    model = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"], tasks=[["car"], ["truck", "bus"]], with_iou_head=True).cuda().eval()
+    with torch.no_grad():  # non-trivial BN statistics everywhere
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.6, 1.4)
+                m.bias.uniform_(-0.2, 0.2)
+    fused = FusedPillarNeXt(model).cuda().eval()
+    for mm in (model.backbone, model.neck, model.head):
+        mm.to(memory_format=torch.channels_last, dtype=torch.bfloat16)
+    pts = torch.from_numpy(synth.make_batch("C1", 2, "sweep", n=30_000)).cuda()
+    with torch.no_grad():
+        ref = model._forward({"points": pts, "batch_size": 2})
+        got = fused.forward_preds(pts, 2)
+    assert len(ref) == len(got) == 2
+    for r, g in zip(ref, got):
+        assert set(r) == set(g)
+        for k in r:
+            a, b = r[k].float(), g[k].float()
+            assert a.shape == b.shape
+            err = (a - b).abs().max().item()
+            scale = a.abs().max().item() + 1e-3
+            assert err <= 0.08 * scale + 0.05, (k, err, scale)  # two bf16 graphs with different rounding points
+            assert torch.corrcoef(torch.stack([a.flatten(), b.flatten()]))[0, 1] > 0.995, k
+    d = fused({"points": pts, "token": ["a", "b"], "batch_size": 2})
+    assert set(d) == {"a", "b"} and d["a"]["box3d_lidar"].shape[1] == 9
