@@ -1,0 +1,113 @@
+"""Fused CenterHead.predict for packed head outputs (host side of csrc/decode.hip).
+
+Semantics = det3d/models/heads/centerhead.py:231-384 (decode, score/range mask, IoU-rectified score, per-class
+sort + top pre_max, rotated NMS, top post_max, task merge with label offsets), restructured so that the whole frame
+batch needs one key kernel per task, ONE device sort, one box kernel, ONE batched NMS and ONE device->host copy."""
+import ctypes
+import struct
+
+import torch
+
+from . import ops
+from ._lib import PNX_BF16, PNX_F32, check, lib, ptr, stream_ptr
+
+
+def _get(cfg, name):
+    return cfg[name] if isinstance(cfg, dict) else getattr(cfg, name)
+
+
+def pack_task(C, has_iou, ncls, cls_off, H, W, osf, vs, pc_range, score_thr, lim, rect):
+    """Host descriptor matching `struct DecodeTask` in csrc/decode.hip."""
+    lim6 = [float(v) for v in lim] if len(lim) > 0 else [0.0] * 6
+    r4 = [float(v) for v in rect] + [0.0] * (4 - len(rect))
+    blob = struct.pack("6i6f6fi4f", int(C), int(bool(has_iou)), int(ncls), int(cls_off), int(H), int(W),
+                       float(osf), float(vs[0]), float(vs[1]), float(pc_range[0]), float(pc_range[1]), float(score_thr),
+                       *lim6, int(len(lim) > 0), *r4)
+    assert len(blob) == lib().pnx_decode_task_desc_bytes(), "DecodeTask layout drifted"
+    return blob
+
+
+class PackedDecoder:
+    def __init__(self, num_classes, rectifier, test_cfg, has_iou, channels_per_task):
+        self.num_classes = list(num_classes)
+        self.nc_total = sum(num_classes)
+        self.rectifier = rectifier
+        self.has_iou = has_iou
+        self.channels = list(channels_per_task)
+        nms = _get(test_cfg, "nms")
+        self.pre_max = int(_get(nms, "nms_pre_max_size"))
+        self.post_max = int(_get(nms, "nms_post_max_size"))
+        self.thr = [float(v) for t in _get(nms, "nms_iou_threshold") for v in t]
+        self.cfg = test_cfg
+        self._dev = {}
+
+    def _descs(self, shapes):
+        cfg = self.cfg
+        out, off = [], 0
+        for t, (H, W) in enumerate(shapes):
+            out.append(pack_task(self.channels[t], self.has_iou, self.num_classes[t], off, H, W, _get(cfg, "out_size_factor")[t],
+                                 _get(cfg, "voxel_size"), _get(cfg, "pc_range"), _get(cfg, "score_threshold"),
+                                 _get(cfg, "post_center_limit_range"), self.rectifier[t]))
+            off += self.num_classes[t]
+        return out
+
+    @torch.no_grad()
+    def __call__(self, packed, tokens=None):
+        """packed: list (one per task) of (B, C_t, H, W) channels_last tensors, fp32 or bf16 (all the same dtype)."""
+        B = packed[0].shape[0]
+        dev = packed[0].device
+        dt = PNX_F32 if packed[0].dtype == torch.float32 else PNX_BF16
+        T = len(packed)
+        shapes = [(p.shape[2], p.shape[3]) for p in packed]
+        for p in packed:
+            assert p.is_contiguous(memory_format=torch.channels_last), "packed head outputs must be channels_last"
+        descs = self._descs(shapes)
+        sizes = [B * h * w for h, w in shapes]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        keys = torch.empty((offs[-1],), dtype=torch.int64, device=dev)
+        L = lib()
+        for t, p in enumerate(packed):
+            kp = ctypes.c_void_p(keys.data_ptr() + 8 * offs[t])
+            check(L.pnx_decode_keys(ptr(p), dt, B, self.nc_total, descs[t], kp, stream_ptr()), "pnx_decode_keys")
+        # keys are non-negative when valid ... as int64 the all-ones key is -1: sort as unsigned by flipping the sign bit
+        skeys, order = torch.sort(keys ^ (-0x8000000000000000), stable=True)
+        skeys = skeys ^ (-0x8000000000000000)
+        S = B * self.nc_total
+        bounds = (torch.arange(S + 1, device=dev, dtype=torch.int64) << 32) ^ (-0x8000000000000000)
+        seg_start = torch.searchsorted(skeys ^ (-0x8000000000000000), bounds)
+        seg_len = torch.clamp(seg_start[1:] - seg_start[:-1], max=self.pre_max).to(torch.int32)
+        ck = (B, T, dt, tuple(shapes))
+        if ck not in self._dev:
+            tdesc = torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev)
+            koff = torch.tensor(offs, dtype=torch.int64, device=dev)
+            seg_off = (torch.arange(S + 1, dtype=torch.int32, device=dev) * self.pre_max).contiguous()
+            thr = torch.tensor(self.thr, dtype=torch.float32, device=dev).repeat(B)
+            self._dev[ck] = (tdesc, koff, seg_off, thr)
+        tdesc, koff, seg_off, thr = self._dev[ck]
+        tptr = torch.tensor([p.data_ptr() for p in packed], dtype=torch.int64, device=dev)
+        n_rows = S * self.pre_max
+        boxes9 = torch.empty((n_rows, 9), dtype=torch.float32, device=dev)
+        boxes7 = torch.zeros((n_rows, 7), dtype=torch.float32, device=dev)
+        scores = torch.empty((n_rows,), dtype=torch.float32, device=dev)
+        check(L.pnx_decode_boxes(ptr(tptr), ptr(tdesc), ptr(koff), T, dt, B, ptr(skeys), ptr(order), ptr(seg_start), ptr(seg_len), S,
+                                 self.pre_max, ptr(boxes9), ptr(boxes7), ptr(scores), stream_ptr()), "pnx_decode_boxes")
+        keep, cnt = ops.nms_batched(boxes7, seg_off, thr, self.pre_max, post_max=self.post_max, seg_len=seg_len)
+        out = torch.empty((S, self.post_max, 10), dtype=torch.float32, device=dev)
+        check(L.pnx_gather_kept(ptr(boxes9), ptr(scores), ptr(keep), ptr(cnt), S, self.pre_max, self.post_max, ptr(out), stream_ptr()),
+              "pnx_gather_kept")
+        out_c = out.cpu()            # the one device->host hand-off of the frame batch
+        cnt_c = cnt[:S].cpu().tolist()
+        tokens = tokens if tokens else [None] * B
+        res = []
+        for b in range(B):
+            bb, ss, ll = [], [], []
+            for c in range(self.nc_total):
+                k = cnt_c[b * self.nc_total + c]
+                blk = out_c[b * self.nc_total + c, :k]
+                bb.append(blk[:, :9])
+                ss.append(blk[:, 9])
+                ll.append(torch.full((k,), c, dtype=torch.int64))
+            res.append({"box3d_lidar": torch.cat(bb), "scores": torch.cat(ss), "label_preds": torch.cat(ll), "token": tokens[b]})
+        return res

@@ -473,6 +473,7 @@ class FusedPillarNeXt(nn.Module):
         self.post_processing = det.post_processing
         self.head_ref = det.head  # predict() / rectifier / class bookkeeping
         self.dtype = dtype
+        self._decoder = None
         bb = det.backbone
         self.stages = nn.ModuleList()
         self.stage_meta = []
@@ -534,41 +535,65 @@ class FusedPillarNeXt(nn.Module):
             self.task_split.append((names, outs))
 
     @torch.no_grad()
-    def forward_preds(self, points, batch_size):
+    def forward_preds(self, points, batch_size, marks=None, packed_out=None):
+        def mark(name):
+            if marks is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append((name, e))
+
+        mark("start")
         ny, nx = (int(v) for v in self.reader.grid_size)
         occ = torch.empty((batch_size, ny, nx), dtype=torch.uint8, device=points.device)
         x = self.reader.forward_dense(points, batch_size, dtype=self.dtype, occupancy=occ)
+        mark("reader")
         mask = occ
-        for mods, (stride, subm) in zip(self.stages, self.stage_meta):
+        for si, (mods, (stride, subm)) in enumerate(zip(self.stages, self.stage_meta)):
             if not subm:
                 mask = ops.mask_pool3(mask, stride)
             x = mods[0](x, mask)
             for j in range(1, len(mods), 2):
                 y = mods[j](x, mask)
                 x = mods[j + 1](y, mask, residual=x)
+            mark(f"backbone.stage{si}")
         x = self.mapping(x, mask)
         # BasicBlock (utils/conv.py): act(block2(block1(x)) + x) where block2 already ends in a ReLU, so the residual is added
         # AFTER that ReLU; both terms are >= 0, which makes the trailing act() the identity.
         x = self.pre2(self.pre1(x)) + x
         outs = [x, F.conv2d(x, self.aspp_1x1)] + [F.conv2d(x, self.aspp_w, None, 1, d, d) for d in (1, 6, 12, 18)]
         x = self.post(torch.cat(outs, dim=1))
+        mark("mapping+neck")
         x = self.shared(x)
         preds = []
         for db, c1, c2, (names, outs_n) in zip(self.task_deblock, self.task_conv1, self.task_conv2, self.task_split):
             t = c2(c1(db(x)))
+            if packed_out is not None:
+                packed_out.append(t)
+                continue
             d, o = {}, 0
             for nme, k in zip(names, outs_n):
                 d[nme] = t[:, o:o + k]
                 o += k
             preds.append(d)
+        mark("head")
         return preds
+
+    def decoder(self):
+        if self._decoder is None:
+            from .decode import PackedDecoder
+
+            hd = self.head_ref
+            chans = [c2.weight.shape[0] for c2 in self.task_conv2]
+            self._decoder = PackedDecoder(hd.num_classes, hd.rectifier, self.post_processing, hd.with_iou, chans)
+        return self._decoder
 
     @torch.no_grad()
     def forward(self, example):
-        preds = self.forward_preds(example["points"], example["batch_size"])
-        outputs = self.head_ref.predict(example, preds, self.post_processing)
+        packed = []
+        self.forward_preds(example["points"], example["batch_size"], packed_out=packed)
+        outputs = self.decoder()(packed, example.get("token"))
         det = {}
         for o in outputs:
             tok = o.pop("token")
-            det[tok] = {k: v.to("cpu") for k, v in o.items()}
+            det[tok] = o  # already on the host
         return det
