@@ -63,6 +63,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", init_method="env://")
     torch.cuda.set_device(local)
+    if not os.environ.get("PNX_NO_MIOPEN_BENCH"):
+        torch.backends.cudnn.benchmark = True  # MIOpen times its applicable solvers once per conv shape (during warm-up)
     dev = torch.device("cuda", local)
 
     from pillarnext_amd import _lib, synth

@@ -14,14 +14,16 @@ ap.add_argument("--dist", default="uniform")
 a = ap.parse_args()
 cfg = synth.CONFIGS["C2"]
 torch.manual_seed(0)
+torch.backends.cudnn.benchmark = True
 model = FusedPillarNeXt(build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"]).cuda().eval()).cuda().eval()
 pts = torch.from_numpy(synth.make_batch("C2", a.batch, a.dist)).cuda()
 ex = {"points": pts, "token": [str(i) for i in range(a.batch)], "batch_size": a.batch}
 acc = defaultdict(float)
 for it in range(a.iters + 2):
     marks = []
-    preds = model.forward_preds(pts, a.batch, marks)
-    out = model.head_ref.predict(ex, preds, model.post_processing)
+    packed = []
+    model.forward_preds(pts, a.batch, marks, packed_out=packed)
+    out = model.decoder()(packed, ex["token"])
     e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(("predict", e))
     torch.cuda.synchronize()
     if it >= 2:
