@@ -1,23 +1,24 @@
-// pfn_mfma.hip -- the PFN (pillar_encoder.py:35-50 x2, :174-182) as a wave-tiled fp32-MFMA kernel.
+// pfn_mfma.hip -- the PFN (pillar_encoder.py:35-50 x2, :174-182) as a single-pass fp32-MFMA kernel.
 //
-// Input: the per-slot records built by reader.hip's k_fill (points of one pillar are contiguous "slots", pillars in
-// torch.unique order; 32 bytes per slot = point row + pillar rank, so every load here is coalesced).  One wave owns the pillars whose first slot lies in its window of R slots
-// and walks their points in tiles of 32 (the M/N size of v_mfma_f32_32x32x2_f32, which is an exact fp32
-// fmaf chain at the fp32 vector rate -- MI355X_MICROARCH.md).  Two lanes share a point: lane = (point, h)
-// with h = lane>>5 picking the even/odd K element, which is exactly the A/B fragment layout
-//   A[i = lane&31][k = lane>>5],  B[k = lane>>5][j = lane&31],  D: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5).
+// Input: the per-slot records built by reader.hip's k_fill.  Points of one pillar occupy contiguous "slots", pillars are
+// in torch.unique order; a record is 32 bytes: [x y z f4 f5 f6 | idx,rem | rank] where idx = position inside the pillar
+// and rem = points still to come, so heads (idx==0), tails (rem==0) and pillar sizes need no other array.
 //
-// Phase 1 (per tile): H0^T-orientation  D = F(points x K) * W0'(K x 32ch): a lane holds ONE channel for 16
-//   points; one cross-half exchange gives it all 32 points, and the per-pillar max is a sequential in-register
-//   scan driven by two wave-uniform bit masks (ballots: "first point of a pillar", "valid point").  Pillars may
-//   straddle tiles: the running max simply carries over.  Maxima go to LDS G0[pillar][32].
-// Phase 2 (per tile): H0-orientation  D = W0'(32ch x K) * F^T(K x points): now a lane holds 16 CHANNELS of one
-//   point -- precisely the A fragment of the next GEMM if K is visited in the order the accumulator registers
-//   are laid out (channel (i&3)+8*(i>>2)+4h at step i).  So layer 0 feeds layer 1 with no transpose; the
-//   "max" half of the concat comes from G0 with four ds_read_b128.  64 MFMAs give H1 for 64 channels; after
-//   one exchange lane l holds channel l for all 32 points, and the same sequential scan emits one coalesced
-//   256-byte feat_max row per pillar.
-// No atomics, no cross-wave traffic, deterministic.  BN is pre-folded (reader.hip k_fold_bn).
+// One wave = one tile of <= 32 points at a time, cut at pillar boundaries (a pillar never straddles tiles; pillars with
+// more than 32 points take the k_pfn_big path).  Two lanes share a point: lane = (point, h), h = lane>>5 selecting the
+// even/odd K element -- exactly the operand layout of v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain at the fp32
+// vector rate, MI355X_MICROARCH.md):  A[i = lane&31][k = lane>>5],  B[k = lane>>5][j = lane&31],
+// D: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+//
+//   layer 0   D0 = W0'(32ch x K) * F^T(K x points)   (bias rides on a constant-1 K column): a lane now holds 16 CHANNELS of
+//             its point -- which is precisely the B fragment of the next GEMM if K is visited in accumulator-register order
+//             (channel (i&3)+8*(i>>2)+4h at step i).  Layer 0 feeds layer 1 with no transpose and no LDS.
+//   max       per-pillar max = segmented scan ACROSS LANES with DPP row shifts (row_shr:1,2,4,8 + row_bcast:15), the segment
+//             test is `idx >= d`; steps no pillar of the tile needs are skipped by a ballot.  The pillar total is fetched from
+//             the tail lane with one ds_bpermute per register (the "max" half of the concat, pe:44,49).
+//   layer 1   D1 = W1'(64ch x 64) * U^T: 64 MFMAs, scan again; relu(max(x) + s) == max(relu(x + s)) lets bias and ReLU run on
+//             tail lanes only, which store their 32 channels as eight 16-byte pieces of the pillar's feat_max row.
+// No LDS, no atomics (except the rare big-pillar list), no cross-wave traffic, deterministic.  BN is pre-folded (k_fold_bn).
 #include <vector>
 
 #include "pnx_common.h"
@@ -26,37 +27,65 @@ namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+#define PNX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {  // lanes without a source get 0.0
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// which scan steps the tile needs: s<d> set if some lane has idx >= d (wave-uniform)
+struct ScanPlan {
+  bool s1, s2, s4, s8;
+};
+
+// Segmented inclusive max along the 32 lanes of each half; idx = position of the lane's point inside its pillar.
+__device__ __forceinline__ float seg_max(float v, int idx, int col, const ScanPlan& pl) {
+  const float NI = -__builtin_inff();
+  if (pl.s1) { const float t = dpp_f<DPP_ROW_SHR1, 0xF>(NI, v); v = fmaxf(v, idx >= 1 ? t : NI); }
+  if (pl.s2) { const float t = dpp_f<DPP_ROW_SHR2, 0xF>(NI, v); v = fmaxf(v, idx >= 2 ? t : NI); }
+  if (pl.s4) { const float t = dpp_f<DPP_ROW_SHR4, 0xF>(NI, v); v = fmaxf(v, idx >= 4 ? t : NI); }
+  if (pl.s8) { const float t = dpp_f<DPP_ROW_SHR8, 0xF>(NI, v); v = fmaxf(v, idx >= 8 ? t : NI); }
+  if (pl.s1) {  // a pillar may straddle the two 16-lane rows of a half: take lane 15's running value
+    const float t = dpp_f<DPP_ROW_BCAST15, 0xA>(NI, v);
+    v = fmaxf(v, idx > (col & 15) ? t : NI);
+  }
+  return v;
+}
+__device__ __forceinline__ double seg_sum(double v, int idx, int col, const ScanPlan& pl) {
+  if (pl.s1) { const double t = dpp_d<DPP_ROW_SHR1, 0xF>(v); v += idx >= 1 ? t : 0.0; }
+  if (pl.s2) { const double t = dpp_d<DPP_ROW_SHR2, 0xF>(v); v += idx >= 2 ? t : 0.0; }
+  if (pl.s4) { const double t = dpp_d<DPP_ROW_SHR4, 0xF>(v); v += idx >= 4 ? t : 0.0; }
+  if (pl.s8) { const double t = dpp_d<DPP_ROW_SHR8, 0xF>(v); v += idx >= 8 ? t : 0.0; }
+  if (pl.s1) {
+    const double t = dpp_d<DPP_ROW_BCAST15, 0xA>(v);
+    v += idx > (col & 15) ? t : 0.0;
+  }
+  return v;
+}
+__device__ __forceinline__ float from_lane(float v, int src_lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ double from_lane_d(double v, int src_lane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffLL));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
 __device__ __forceinline__ uint32_t pstart(int32_t r, const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk) {
   return cblk[r >> PNX_SCAN_SHIFT] + cpre[r];
 }
 
-template <int F>
-__device__ __forceinline__ void decorate_pt(const float* __restrict__ p, float mx, float my, float mz, const PnxGeomDev& g, float* f) {
-#pragma unroll
-  for (int k = 0; k < F; k++) f[k] = p[1 + k];
-  const float x = p[1], y = p[2], z = p[3];
-  f[F + 0] = __fsub_rn(x, mx);
-  f[F + 1] = __fsub_rn(y, my);
-  f[F + 2] = __fsub_rn(z, mz);
-  const float cx = __fdiv_rn(__fsub_rn(x, g.minx), g.vx);
-  const float cy = __fdiv_rn(__fsub_rn(y, g.miny), g.vy);
-  const float xi = (float)(int)cx, yi = (float)(int)cy;
-  const float ctrx = __fadd_rn(__fadd_rn(__fmul_rn(xi, g.vx), __fdiv_rn(g.vx, 2.0f)), g.minx);
-  const float ctry = __fadd_rn(__fadd_rn(__fmul_rn(yi, g.vy), __fdiv_rn(g.vy, 2.0f)), g.miny);
-  f[F + 3] = __fsub_rn(x, ctrx);
-  f[F + 4] = __fsub_rn(y, ctry);
-}
-
-// LDS traffic of one wave is executed in order; this only stops the compiler from moving accesses across the point.
-#define WAVE_SYNC()                                        \
-  do {                                                     \
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
-    __builtin_amdgcn_wave_barrier();                       \
-  } while (0)
-
-#define PNX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
-// One 32-byte record per CSR slot: words 0..F-1 = x, y, z, f.. ; word 7 = pillar rank (written by k_fill).
 struct Rec {
   uint4 a, b;
 };
@@ -68,10 +97,11 @@ __device__ __forceinline__ Rec load_rec(const uint32_t* __restrict__ rec, uint32
   return r;
 }
 
+// Decorated point features (pe:116-123): [raw F | xyz - mean | xy - pillar centre | 1 (bias column) | 0].
 template <int F>
 __device__ __forceinline__ void decorate_rec(const Rec& q, float mx, float my, float mz, const PnxGeomDev& g, float* f) {
-  const float w[7] = {__uint_as_float(q.a.x), __uint_as_float(q.a.y), __uint_as_float(q.a.z), __uint_as_float(q.a.w),
-                      __uint_as_float(q.b.x), __uint_as_float(q.b.y), __uint_as_float(q.b.z)};
+  const float w[6] = {__uint_as_float(q.a.x), __uint_as_float(q.a.y), __uint_as_float(q.a.z),
+                      __uint_as_float(q.a.w), __uint_as_float(q.b.x), __uint_as_float(q.b.y)};
 #pragma unroll
   for (int k = 0; k < F; k++) f[k] = w[k];
   const float x = w[0], y = w[1], z = w[2];
@@ -85,35 +115,31 @@ __device__ __forceinline__ void decorate_rec(const Rec& q, float mx, float my, f
   const float ctry = __fadd_rn(__fadd_rn(__fmul_rn(yi, g.vy), __fdiv_rn(g.vy, 2.0f)), g.miny);
   f[F + 3] = __fsub_rn(x, ctrx);
   f[F + 4] = __fsub_rn(y, ctry);
+  f[F + 5] = 1.f;
+  f[F + 6] = 0.f;
 }
 
+// End of the pillar that contains `slot` (= first slot of the next pillar), from the record's idx|rem word; falls back to
+// the prefix arrays when the 16-bit fields are saturated (pillars with >= 65535 points).
+__device__ __forceinline__ uint32_t pillar_end_at(const uint32_t* __restrict__ rec, int64_t slot, const uint32_t* __restrict__ count,
+                                                  const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk, bool* is_head) {
+  const uint4 w = *reinterpret_cast<const uint4*>(rec + slot * 8 + 4);  // words 4..7
+  const uint32_t idx = w.z & 0xFFFFu, rem = w.z >> 16;
+  *is_head = idx == 0;
+  if (idx < 0xFFFFu && rem < 0xFFFFu) return (uint32_t)slot + rem + 1u;
+  return pstart((int)w.w, cpre, cblk) + count[w.w] + 1u;
+}
+
+// counters[2] = next slot window to hand out (dynamic load balance), counters[3] = number of big pillars
 template <int F, int R>
 __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ rec, PnxGeomDev g, const uint32_t* __restrict__ count,
                                                  const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
-                                                 const int32_t* __restrict__ counters, const float* __restrict__ P,
-                                                 float* __restrict__ g1, int64_t g1_rows, unsigned long long* __restrict__ dbg) {
-  constexpr int C0 = F + 5, KS = (C0 + 2) / 2;  // K = C0 features + one constant-1 column that carries the folded BN shift
+                                                 int32_t* __restrict__ counters, int32_t* __restrict__ biglist, int bigcap,
+                                                 const float* __restrict__ P, float* __restrict__ g1, int64_t g1_rows) {
+  constexpr int C0 = F + 5, KS = (C0 + 2) / 2;     // K = C0 features + one constant-1 column that carries the folded BN shift
   constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;  // start of the fragment-ordered block (k_fold_bn)
-  constexpr int GST = 36;                          // G0 row stride in floats: 16-byte aligned rows, banks spread
-  // 4 independent waves per workgroup (one per SIMD by construction); each wave owns a private LDS slice and never
-  // synchronises with the others (they run different trip counts), so only wave-level ordering is used.
-  __shared__ __attribute__((aligned(16))) float sG0_all[4][R * GST];
-  __shared__ float sMean_all[4][R * 3];
-  const int wv = threadIdx.x >> 6;
-  float* sG0 = sG0_all[wv];
-  float* sMean = sMean_all[wv];
-
   const int l = threadIdx.x & 63, col = l & 31, h = l >> 5;
-  unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tk = 0;
-#define TICK() (dbg ? __builtin_amdgcn_s_memtime() : 0ULL)
-#define TOCK(k)                          \
-  if (dbg) {                             \
-    const unsigned long long _n = __builtin_amdgcn_s_memtime(); \
-    T[k] += _n - tk;                     \
-    tk = _n;                             \
-  }
-  const int n_kept = counters[1], Ptot = counters[0];
+  const int n_kept = counters[1];
 
   // ---- weight fragments: coalesced loads, once per (persistent) wave
   const float* __restrict__ FP = P + FR + l;
@@ -126,259 +152,274 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
     w1a[i] = FP[(23 + i) * 64];
     w1b[i] = FP[(55 + i) * 64];
   }
-  const float s1a = FP[87 * 64], s1b = FP[88 * 64];
+  const float4* __restrict__ s1lane = reinterpret_cast<const float4*>(P + FR + 64 * 89 + l * 32);  // s1 in this lane's channel order
 
-  for (int64_t slot0 = (int64_t)(blockIdx.x * 4 + wv) * R; slot0 < n_kept; slot0 += (int64_t)gridDim.x * 4 * R) {
+  for (;;) {
+    // ---- next window of R slots (one returning atomic per pass, by one lane)
+    int pass = 0;
+    if (l == 0) pass = atomicAdd(&counters[2], 1);
+    pass = __builtin_amdgcn_readfirstlane(pass);
+    const int64_t slot0 = (int64_t)pass * R;
+    if (slot0 >= n_kept) break;
     const int64_t slot1 = (slot0 + R < n_kept) ? slot0 + R : n_kept;
-    tk = TICK();
-    // pillars owned by this pass = those whose first slot is in [slot0, slot1)
-    const int q0 = (int)rec[slot0 * 8 + 7];
-    const uint32_t st0 = pstart(q0, cpre, cblk);
-    const int p_lo = (st0 == (uint32_t)slot0) ? q0 : q0 + 1;
-    const uint32_t base = (st0 == (uint32_t)slot0) ? st0 : st0 + count[q0] + 1u;
-    int p_hi;
-    uint32_t end;
-    if (slot1 >= n_kept) {
-      p_hi = Ptot;
-      end = (uint32_t)n_kept;
-    } else {
-      const int q1 = (int)rec[slot1 * 8 + 7];
-      const uint32_t st1 = pstart(q1, cpre, cblk);
-      if (st1 == (uint32_t)slot1) {
-        p_hi = q1;
-        end = st1;
-      } else {
-        p_hi = q1 + 1;
-        end = st1 + count[q1] + 1u;
-      }
+    // pillars owned by this pass = those whose first slot lies in [slot0, slot1)
+    bool head0;
+    const uint32_t e0 = pillar_end_at(rec, slot0, count, cpre, cblk, &head0);
+    const uint32_t base = head0 ? (uint32_t)slot0 : e0;
+    uint32_t end = (uint32_t)n_kept;
+    if (slot1 < n_kept) {
+      bool head1;
+      const uint32_t e1 = pillar_end_at(rec, slot1, count, cpre, cblk, &head1);
+      end = head1 ? (uint32_t)slot1 : e1;
     }
-    if (p_lo >= p_hi) continue;
-    const int nown = p_hi - p_lo;  // <= R
-    TOCK(0);
-    WAVE_SYNC();                   // previous pass done with sG0 / sMean
+    if (base >= end) continue;
 
-    // ---- phase 0: per-pillar mean of xyz (scatter_mean, pe:113-114): fp64 sum, fp32 divide
-    for (int s = l; s < nown; s += 64) {
-      const int q = p_lo + s;
-      const uint32_t st = pstart(q, cpre, cblk), c = count[q] + 1u;
-      double sx = 0, sy = 0, sz = 0;
-      for (uint32_t k = 0; k < c; k++) {
-        const uint4 a = *reinterpret_cast<const uint4*>(rec + (int64_t)(st + k) * 8);
-        sx += (double)__uint_as_float(a.x);
-        sy += (double)__uint_as_float(a.y);
-        sz += (double)__uint_as_float(a.z);
+    uint32_t ts = base;
+    Rec nxt = load_rec(rec, min(ts + (uint32_t)col, end - 1));
+    while (ts < end) {
+      const Rec cur = nxt;
+      const bool in_range = ts + (uint32_t)col < end;
+      const int idx = (int)(cur.b.z & 0xFFFFu), rem = (int)(cur.b.z >> 16);
+      const int r = (int)cur.b.w;
+      const bool complete = in_range && (col + rem <= 31);
+      const uint32_t V = (uint32_t)__ballot(complete && h == 0);
+      const int nv = __builtin_popcount(V);
+      if (nv == 0) {
+        // the pillar at ts has more than 32 points: hand it to k_pfn_big and step over it
+        const int q = __builtin_amdgcn_readfirstlane(r);
+        const uint32_t c = count[q] + 1u;
+        if (l == 0) {
+          const int at = atomicAdd(&counters[3], 1);
+          if (at < bigcap) biglist[at] = q;
+        }
+        ts += c;
+        if (ts < end) nxt = load_rec(rec, min(ts + (uint32_t)col, end - 1));
+        continue;
       }
-      const float fc = (float)c;
-      sMean[s * 3 + 0] = __fdiv_rn((float)sx, fc);
-      sMean[s * 3 + 1] = __fdiv_rn((float)sy, fc);
-      sMean[s * 3 + 2] = __fdiv_rn((float)sz, fc);
-    }
-    WAVE_SYNC();
+      const uint32_t ts_next = ts + (uint32_t)nv;
+      nxt = load_rec(rec, min(ts_next + (uint32_t)col, end - 1));  // prefetch the next tile while this one computes
+      const bool act = col < nv;
+      const int cnt = idx + rem + 1;
+      const int tail_lane = act ? l + rem : l;  // same half
+      ScanPlan pl;
+      pl.s1 = __ballot(act && idx >= 1) != 0;
+      pl.s2 = __ballot(act && idx >= 2) != 0;
+      pl.s4 = __ballot(act && idx >= 4) != 0;
+      pl.s8 = __ballot(act && idx >= 8) != 0;
 
-    const int ntiles = (int)((end - base + 31) >> 5);
-    TOCK(1);
-
-    // ---- phase 1: layer 0, per-pillar max -> G0
-    {
-      float m = 0.f;
-      int seg = 0;
-      int prev_rank = p_lo - 1;  // rank of the slot before the tile (wave-uniform)
-      Rec cur = load_rec(rec, min(base + (uint32_t)col, end - 1));
-      for (int t = 0; t < ntiles; t++) {
-        const uint32_t slot0_of_tile = base + 32u * t;
-        const uint32_t slot = slot0_of_tile + col;
-        const bool act = slot < end;
-        const Rec nxt = load_rec(rec, min(slot + 32u, end - 1));  // prefetch the next tile's record
-        const int r = (int)cur.b.w;
-        int rp = __shfl_up(r, 1);
-        if (col == 0) rp = prev_rank;
-        const bool is_head = act && (r != rp);
-        float ff[KS];
-        {
-          const int sl = act ? r - p_lo : 0;
-          float f[C0 + 2];
-          decorate_rec<F>(cur, sMean[sl * 3], sMean[sl * 3 + 1], sMean[sl * 3 + 2], g, f);
-          f[C0] = 1.f;
-          f[C0 + 1] = 0.f;
-#pragma unroll
-          for (int kk = 0; kk < KS; kk++) ff[kk] = act ? (h ? f[2 * kk + 1] : f[2 * kk]) : 0.f;
+      // ---- per-pillar mean of xyz (scatter_mean, pe:113-114): exact fp64 sum, fp32 divide
+      float mx, my, mz;
+      {
+        double sx = act ? (double)__uint_as_float(cur.a.x) : 0.0;
+        double sy = act ? (double)__uint_as_float(cur.a.y) : 0.0;
+        double sz = act ? (double)__uint_as_float(cur.a.z) : 0.0;
+        if (pl.s1) {
+          sx = from_lane_d(seg_sum(sx, idx, col, pl), tail_lane);
+          sy = from_lane_d(seg_sum(sy, idx, col, pl), tail_lane);
+          sz = from_lane_d(seg_sum(sz, idx, col, pl), tail_lane);
         }
-        v16f acc;
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[i] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) acc = PNX_MFMA(ff[kk], w0f[kk], acc);
-        float p0[16], p1[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const float v = fmaxf(acc[i], 0.f);
-          const float y = __shfl_xor(v, 32);
-          p0[i] = h ? y : v;
-          p1[i] = h ? v : y;
-        }
-        const uint32_t heads = (uint32_t)__ballot(is_head && h == 0);
-        const uint32_t valid = (uint32_t)__ballot(act && h == 0);
-        // point p ends a pillar if p+1 is invalid or a head; for p = 31 look at the prefetched first record of the next tile
-        const int r_last = __shfl(r, 31), r_next = __shfl((int)nxt.b.w, 0);
-        const uint32_t t31 = (slot0_of_tile + 32u >= end || r_next != r_last) ? 0x80000000u : 0u;
-        const uint32_t tails = valid & ((((heads >> 1) | ~(valid >> 1)) & 0x7fffffffu) | t31);
-#pragma unroll
-        for (int p = 0; p < 32; p++) {
-          const int i = (p & 3) + 4 * (p >> 3);
-          const float v = ((p >> 2) & 1) ? p1[i] : p0[i];
-          m = fmaxf(((heads >> p) & 1u) ? 0.f : m, ((valid >> p) & 1u) ? v : 0.f);
-          if ((tails >> p) & 1u) {
-            if (l < 32) sG0[(seg + __builtin_popcount(heads & ((2u << p) - 1u)) - 1) * GST + l] = m;
-          }
-        }
-        seg += __builtin_popcount(heads);
-        prev_rank = r_last;
-        cur = nxt;
+        const float fc = (float)cnt;
+        mx = __fdiv_rn((float)sx, fc);
+        my = __fdiv_rn((float)sy, fc);
+        mz = __fdiv_rn((float)sz, fc);
       }
-    }
-    WAVE_SYNC();
-
-    TOCK(2);
-    // ---- phase 2: layer 0 again (other orientation) chained into layer 1, per-pillar max -> feat_max rows
-    {
-      float m = 0.f;
-      int seg = 0;
-      int prev_rank = p_lo - 1;
-      Rec cur = load_rec(rec, min(base + (uint32_t)col, end - 1));
-      for (int t = 0; t < ntiles; t++) {
-        const uint32_t slot0_of_tile = base + 32u * t;
-        const uint32_t slot = slot0_of_tile + col;
-        const bool act = slot < end;
-        const Rec nxt = load_rec(rec, min(slot + 32u, end - 1));
-        const int r = (int)cur.b.w;
-        int rp = __shfl_up(r, 1);
-        if (col == 0) rp = prev_rank;
-        const bool is_head = act && (r != rp);
-        const int sl = act ? r - p_lo : 0;
-        float ff[KS];
-        {
-          float f[C0 + 2];
-          decorate_rec<F>(cur, sMean[sl * 3], sMean[sl * 3 + 1], sMean[sl * 3 + 2], g, f);
-          f[C0] = 1.f;
-          f[C0 + 1] = 0.f;
+      // ---- layer 0 (lane = point, registers = channels)
+      float ff[KS];
+      {
+        float f[C0 + 2];
+        decorate_rec<F>(cur, mx, my, mz, g, f);
 #pragma unroll
-          for (int kk = 0; kk < KS; kk++) ff[kk] = act ? (h ? f[2 * kk + 1] : f[2 * kk]) : 0.f;
-        }
-        v16f d0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) d0[i] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], ff[kk], d0);
-        TOCK(3);
-        // "max" half of the concat: G0[pillar][8j + 4h .. +3], j = 0..3  == channel order of d0's registers
-        float4 gq[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) gq[j] = *reinterpret_cast<const float4*>(&sG0[sl * GST + 8 * j + 4 * h]);
-        v16f da, db;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          da[i] = s1a;
-          db[i] = s1b;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const float a = fmaxf(d0[i], 0.f);
-          da = PNX_MFMA(a, w1a[i], da);
-          db = PNX_MFMA(a, w1b[i], db);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const float4 q = gq[i >> 2];
-          const float a = (i & 3) == 0 ? q.x : (i & 3) == 1 ? q.y : (i & 3) == 2 ? q.z : q.w;
-          da = PNX_MFMA(a, w1a[16 + i], da);
-          db = PNX_MFMA(a, w1b[16 + i], db);
-        }
-        float p0[16], p1[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const float va = fmaxf(da[i], 0.f), vb = fmaxf(db[i], 0.f);
-          const float y = __shfl_xor(h ? va : vb, 32);
-          p0[i] = h ? y : va;
-          p1[i] = h ? vb : y;
-        }
-        if (dbg) { asm volatile("" :: "v"(p0[0]), "v"(p1[15])); }
-        TOCK(4);
-        const uint32_t heads = (uint32_t)__ballot(is_head && h == 0);
-        const uint32_t valid = (uint32_t)__ballot(act && h == 0);
-        // point p ends a pillar if p+1 is invalid or a head; for p = 31 look at the prefetched first record of the next tile
-        const int r_last = __shfl(r, 31), r_next = __shfl((int)nxt.b.w, 0);
-        const uint32_t t31 = (slot0_of_tile + 32u >= end || r_next != r_last) ? 0x80000000u : 0u;
-        const uint32_t tails = valid & ((((heads >> 1) | ~(valid >> 1)) & 0x7fffffffu) | t31);
-#pragma unroll
-        for (int p = 0; p < 32; p++) {
-          const int i = (p & 3) + 4 * (p >> 3);
-          const float v = ((p >> 2) & 1) ? p1[i] : p0[i];
-          m = fmaxf(((heads >> p) & 1u) ? 0.f : m, ((valid >> p) & 1u) ? v : 0.f);
-          if ((tails >> p) & 1u) {
-            const int64_t row = (int64_t)(p_lo + seg + __builtin_popcount(heads & ((2u << p) - 1u)) - 1);
-            if (row < g1_rows) g1[row * 64 + l] = m;
-          }
-        }
-        seg += __builtin_popcount(heads);
-        prev_rank = r_last;
-        cur = nxt;
-        TOCK(5);
+        for (int kk = 0; kk < KS; kk++) ff[kk] = act ? (h ? f[2 * kk + 1] : f[2 * kk]) : 0.f;
       }
+      v16f d0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) d0[i] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], ff[kk], d0);
+      // ---- "max" half of the concat: per-pillar max of layer 0, delivered to every point of the pillar
+      float g0[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        float v = d0[i];
+        if (pl.s1) v = from_lane(seg_max(v, idx, col, pl), tail_lane);
+        g0[i] = fmaxf(v, 0.f);  // relu(max(x)) == max(relu(x))
+      }
+      // ---- layer 1: 64 output channels as two 32-row tiles, K in accumulator-register order
+      v16f da, db;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        da[i] = 0.f;
+        db[i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const float u = fmaxf(d0[i], 0.f);
+        da = PNX_MFMA(w1a[i], u, da);
+        db = PNX_MFMA(w1b[i], u, db);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        da = PNX_MFMA(w1a[16 + i], g0[i], da);
+        db = PNX_MFMA(w1b[16 + i], g0[i], db);
+      }
+      // ---- per-pillar max of layer 1; bias + ReLU on the tail lane only; 8 x 16-byte pieces of the feat_max row
+      float ya[16], yb[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        ya[i] = da[i];
+        yb[i] = db[i];
+        if (pl.s1) {
+          ya[i] = seg_max(ya[i], idx, col, pl);
+          yb[i] = seg_max(yb[i], idx, col, pl);
+        }
+      }
+      if (act && rem == 0 && (int64_t)r < g1_rows) {
+        float* row = g1 + (int64_t)r * 64;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float4 sa = s1lane[j], sb = s1lane[4 + j];
+          float4 oa, ob;
+          oa.x = fmaxf(ya[4 * j + 0] + sa.x, 0.f);
+          oa.y = fmaxf(ya[4 * j + 1] + sa.y, 0.f);
+          oa.z = fmaxf(ya[4 * j + 2] + sa.z, 0.f);
+          oa.w = fmaxf(ya[4 * j + 3] + sa.w, 0.f);
+          ob.x = fmaxf(yb[4 * j + 0] + sb.x, 0.f);
+          ob.y = fmaxf(yb[4 * j + 1] + sb.y, 0.f);
+          ob.z = fmaxf(yb[4 * j + 2] + sb.z, 0.f);
+          ob.w = fmaxf(yb[4 * j + 3] + sb.w, 0.f);
+          *reinterpret_cast<float4*>(row + 8 * j + 4 * h) = oa;
+          *reinterpret_cast<float4*>(row + 32 + 8 * j + 4 * h) = ob;
+        }
+      }
+      ts = ts_next;
     }
   }
-  if (dbg && l == 0) {
-    const int gw = blockIdx.x * 4 + wv;
+}
+
+// ---- pillars with more than 32 points: one wave per pillar, points strided over lanes, plain fp32 FMAs with the weights
+// coming through scalar loads (wave-uniform addresses), wave reductions by xor-shuffles.  Rare at PillarNeXt-B resolution.
+template <int F>
+__global__ __launch_bounds__(256) void k_pfn_big(const uint32_t* __restrict__ rec, PnxGeomDev g, const uint32_t* __restrict__ count,
+                                                const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
+                                                const int32_t* __restrict__ counters, const int32_t* __restrict__ biglist, int bigcap,
+                                                const float* __restrict__ P, float* __restrict__ g1, int64_t g1_rows) {
+  constexpr int C0 = F + 5;
+  constexpr int OW0 = 0, OS0 = 32 * C0, OW1 = OS0 + 32, OS1 = OW1 + 64 * 64;
+  const int l = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  int nbig = counters[3];
+  if (nbig > bigcap) nbig = bigcap;
+  for (int b = wave; b < nbig; b += nwaves) {
+    const int q = biglist[b];
+    if ((int64_t)q >= g1_rows) continue;
+    const uint32_t st = pstart(q, cpre, cblk), c = count[q] + 1u;
+    double sx = 0, sy = 0, sz = 0;
+    for (uint32_t k = l; k < c; k += 64) {
+      const uint4 a = *reinterpret_cast<const uint4*>(rec + (int64_t)(st + k) * 8);
+      sx += (double)__uint_as_float(a.x);
+      sy += (double)__uint_as_float(a.y);
+      sz += (double)__uint_as_float(a.z);
+    }
 #pragma unroll
-    for (int k = 0; k < 8; k++) dbg[gw * 8 + k] = T[k];
+    for (int d = 32; d >= 1; d >>= 1) {
+      sx += __shfl_xor(sx, d);
+      sy += __shfl_xor(sy, d);
+      sz += __shfl_xor(sz, d);
+    }
+    const float fc = (float)c;
+    const float mx = __fdiv_rn((float)sx, fc), my = __fdiv_rn((float)sy, fc), mz = __fdiv_rn((float)sz, fc);
+    float g0[32];
+#pragma unroll
+    for (int ch = 0; ch < 32; ch++) g0[ch] = 0.f;
+    for (uint32_t k = l; k < c; k += 64) {
+      float f[C0 + 2];
+      decorate_rec<F>(load_rec(rec, st + k), mx, my, mz, g, f);
+#pragma unroll
+      for (int ch = 0; ch < 32; ch++) {
+        float acc = P[OS0 + ch];
+#pragma unroll
+        for (int kk = 0; kk < C0; kk++) acc = __builtin_fmaf(f[kk], P[OW0 + ch * C0 + kk], acc);
+        g0[ch] = fmaxf(g0[ch], acc);
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 32; ch++)
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) g0[ch] = fmaxf(g0[ch], __shfl_xor(g0[ch], d));
+    for (int c0 = 0; c0 < 64; c0 += 16) {  // 16 output channels at a time keeps the register count low
+      float out[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) out[j] = 0.f;
+      for (uint32_t k = l; k < c; k += 64) {
+        float f[C0 + 2], h0[32];
+        decorate_rec<F>(load_rec(rec, st + k), mx, my, mz, g, f);
+#pragma unroll
+        for (int ch = 0; ch < 32; ch++) {
+          float acc = P[OS0 + ch];
+#pragma unroll
+          for (int kk = 0; kk < C0; kk++) acc = __builtin_fmaf(f[kk], P[OW0 + ch * C0 + kk], acc);
+          h0[ch] = fmaxf(acc, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const float* wr = P + OW1 + (c0 + j) * 64;
+          float acc = P[OS1 + c0 + j];
+#pragma unroll
+          for (int kk = 0; kk < 32; kk++) acc = __builtin_fmaf(h0[kk], wr[kk], acc);
+#pragma unroll
+          for (int kk = 0; kk < 32; kk++) acc = __builtin_fmaf(g0[kk], wr[32 + kk], acc);
+          out[j] = fmaxf(out[j], acc);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) out[j] = fmaxf(out[j], __shfl_xor(out[j], d));
+      }
+      if (l == 0) {
+        float4* o = reinterpret_cast<float4*>(g1 + (int64_t)q * 64 + c0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = make_float4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
+      }
+    }
   }
 }
 
 template <int F>
 int launch_f(int R, const uint32_t* rec, const PnxGeomDev& g, const uint32_t* count, const uint32_t* cpre, const uint32_t* cblk,
-             const int32_t* counters, const float* folded, float* g1, int64_t g1_rows, int64_t n, int max_blocks, hipStream_t st) {
-  static unsigned long long* dbg = nullptr;
-  static int dbg_calls = 0;
-  const bool want_dbg = getenv("PNX_PFN_TIMING") != nullptr;
-  if (want_dbg && !dbg) (void)hipMalloc(&dbg, 8192 * 4 * 8 * sizeof(unsigned long long));
-  int64_t nb = ((n + R - 1) / R + 3) / 4;  // 4 waves per block, one slot window per wave and pass
-  if (nb > max_blocks) nb = max_blocks;    // persistent: each wave strides over the slot windows
+             int32_t* counters, int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows, int64_t n, int max_blocks,
+             hipStream_t st) {
+  int64_t nb = ((n + R - 1) / R + 3) / 4;  // 4 waves per block; windows are handed out dynamically
+  if (nb > max_blocks) nb = max_blocks;
   if (nb < 1) nb = 1;
   if (getenv("PNX_DEBUG")) {
     int occ = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pfn_mfma<F, 64>, 256, 0);
-    fprintf(stderr, "[pnx] k_pfn_mfma<%d,64>: occupancy API says %d blocks (x4 waves)/CU, launching %lld blocks, R=%d\n", F, occ, (long long)nb, R);
+    fprintf(stderr, "[pnx] k_pfn_mfma<%d,%d>: occupancy API %d blocks (x4 waves)/CU, %lld blocks\n", F, R, occ, (long long)nb);
   }
-  if (R == 128) k_pfn_mfma<F, 128><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows, want_dbg ? dbg : nullptr);
-  else if (R == 32) k_pfn_mfma<F, 32><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows, want_dbg ? dbg : nullptr);
-  else k_pfn_mfma<F, 64><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, folded, g1, g1_rows, want_dbg ? dbg : nullptr);
+  const int bc = (int)(bigcap > 0x7fffffff ? 0x7fffffff : bigcap);
+  if (R == 128) k_pfn_mfma<F, 128><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows);
+  else if (R == 32) k_pfn_mfma<F, 32><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows);
+  else k_pfn_mfma<F, 64><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows);
+  k_pfn_big<F><<<128, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows);
   PNX_LAUNCH_CHECK();
-  if (want_dbg && ++dbg_calls == 20) {
-    std::vector<unsigned long long> hbuf((size_t)nb * 4 * 8);
-    (void)hipStreamSynchronize(st);
-    (void)hipMemcpy(hbuf.data(), dbg, hbuf.size() * 8, hipMemcpyDeviceToHost);
-    double acc[8] = {0};
-    for (size_t w = 0; w < (size_t)nb * 4; w++)
-      for (int k = 0; k < 8; k++) acc[k] += (double)hbuf[w * 8 + k];
-    const char* names[8] = {"ownership loads", "phase0 mean", "phase1 total", "p2: load+decorate+d0", "p2: 64 MFMA + exchange", "p2: scan+stores", "", ""};
-    for (int k = 0; k < 6; k++) fprintf(stderr, "[pnx-timing] %-24s %10.0f ticks/wave\n", names[k], acc[k] / (nb * 4));
-  }
   return PNX_OK;
 }
 
 }  // namespace
 
 int pnx_launch_pfn_mfma(int F, const uint32_t* rec, const PnxGeomDev& geom, const uint32_t* count, const uint32_t* cpre,
-                        const uint32_t* cblk, const int32_t* counters, const float* folded, float* g1, int64_t g1_rows, int64_t n_points,
-                        hipStream_t st) {
-  const char* r_env = getenv("PNX_PFN_R");  // slots per pass: 32 | 64 | 128
+                        const uint32_t* cblk, int32_t* counters, int32_t* biglist, int64_t bigcap, const float* folded, float* g1,
+                        int64_t g1_rows, int64_t n_points, hipStream_t st) {
+  const char* r_env = getenv("PNX_PFN_R");  // slots per window: 32 | 64 | 128
   const int R = r_env ? atoi(r_env) : 64;
   const char* b_env = getenv("PNX_PFN_BLOCKS");
-  const int max_blocks = b_env ? atoi(b_env) : 512;  // 256 CUs x 2 blocks x 4 waves = 2 waves per SIMD at ~230 VGPRs
+  const int max_blocks = b_env ? atoi(b_env) : 512;  // 256 CUs x 2 blocks x 4 waves = 2 waves per SIMD
   switch (F) {
-    case 3: return launch_f<3>(R, rec, geom, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, max_blocks, st);
-    case 4: return launch_f<4>(R, rec, geom, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, max_blocks, st);
-    case 5: return launch_f<5>(R, rec, geom, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, max_blocks, st);
-    case 6: return launch_f<6>(R, rec, geom, count, cpre, cblk, counters, folded, g1, g1_rows, n_points, max_blocks, st);
+    case 3: return launch_f<3>(R, rec, geom, count, cpre, cblk, counters, biglist, bigcap, folded, g1, g1_rows, n_points, max_blocks, st);
+    case 4: return launch_f<4>(R, rec, geom, count, cpre, cblk, counters, biglist, bigcap, folded, g1, g1_rows, n_points, max_blocks, st);
+    case 5: return launch_f<5>(R, rec, geom, count, cpre, cblk, counters, biglist, bigcap, folded, g1, g1_rows, n_points, max_blocks, st);
+    case 6: return launch_f<6>(R, rec, geom, count, cpre, cblk, counters, biglist, bigcap, folded, g1, g1_rows, n_points, max_blocks, st);
   }
   pnx_set_error("num_point_features %d not in 3..6", F);
   return PNX_ERR_UNSUPPORTED;

@@ -142,11 +142,12 @@ __device__ __forceinline__ uint32_t pillar_start(int32_t r, const uint32_t* __re
   return cblk[r >> PNX_SCAN_SHIFT] + cpre[r];
 }
 
-// CSR fill: plist[start(rank) + slot] = point id, plus a 32-byte record per slot [x, y, z, f.., (pad), rank] so the PFN
+// CSR fill: plist[start(rank) + slot] = point id, plus a 32-byte record per slot [x, y, z, f.. (6 words), idx|rem, rank] so the PFN
 // kernel streams its input with coalesced loads instead of chasing plist -> rank -> point row.
 __global__ __launch_bounds__(kBlock) void k_fill(const float* __restrict__ pts, int stride, const int32_t* __restrict__ rank,
-                                                 const int32_t* __restrict__ slot, int64_t n, const uint32_t* __restrict__ cpre,
-                                                 const uint32_t* __restrict__ cblk, int32_t* __restrict__ plist, uint32_t* __restrict__ rec) {
+                                                 const int32_t* __restrict__ slot, int64_t n, const uint32_t* __restrict__ count,
+                                                 const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
+                                                 int32_t* __restrict__ plist, uint32_t* __restrict__ rec) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const int32_t r = rank[i];
@@ -156,7 +157,11 @@ __global__ __launch_bounds__(kBlock) void k_fill(const float* __restrict__ pts, 
   const float* p = pts + i * stride;
   uint32_t v[8];
 #pragma unroll
-  for (int k = 0; k < 7; k++) v[k] = (k < stride - 1) ? __float_as_uint(p[1 + k]) : 0u;
+  for (int k = 0; k < 6; k++) v[k] = (k < stride - 1) ? __float_as_uint(p[1 + k]) : 0u;
+  // word 6: position inside the pillar and points still to come (both clamped to 16 bits) -> the PFN kernel knows
+  // heads (idx == 0), tails (rem == 0) and pillar sizes without touching any other array
+  const uint32_t idx = (uint32_t)slot[i], rem = count[r] - idx;  // count[] = size - 1
+  v[6] = min(idx, 0xFFFFu) | (min(rem, 0xFFFFu) << 16);
   v[7] = (uint32_t)r;
   uint4* o = reinterpret_cast<uint4*>(rec + (int64_t)pos * 8);
   o[0] = make_uint4(v[0], v[1], v[2], v[3]);
@@ -266,9 +271,15 @@ __global__ void k_fold_bn(int C0, const float* w0, const float* g0, const float*
   //   j 23..54 W1'[col][k(i,h)]          k(i,h) = (i<16 ? ch(i,h) : 32 + ch(i-16,h))
   //   j 55..86 W1'[32+col][k(i,h)]
   //   j 87, 88 s1[col], s1[32+col]
+  //   then 64 x 32: s1[ch(i,h)] (i<16) | s1[32+ch(i-16,h)], contiguous per lane (tail-lane epilogue of k_pfn_mfma)
   const int FR = S1 + 64;
-  for (int idx = t; idx < 64 * 89; idx += gridDim.x * blockDim.x) {
-    const int j = idx >> 6, l = idx & 63, col = l & 31, h = l >> 5;
+  for (int idx = t; idx < 64 * 121; idx += gridDim.x * blockDim.x) {
+    int j = idx >> 6, l = idx & 63;
+    if (idx >= 64 * 89) {  // rows 89..120: s1 in each lane's own channel order, 32 contiguous floats per lane
+      l = (idx - 64 * 89) >> 5;
+      j = 89 + ((idx - 64 * 89) & 31);
+    }
+    const int col = l & 31, h = l >> 5;
     auto fold0 = [&](int c, int k) { return __fmul_rn(w0[c * C0 + k], __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v0[c], eps))), g0[c])); };
     auto fold1 = [&](int c, int k) { return __fmul_rn(w1[c * 64 + k], __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v1[c], eps))), g1[c])); };
     auto shift0 = [&](int c) { return __fsub_rn(b0[c], __fmul_rn(m0[c], __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v0[c], eps))), g0[c]))); };
@@ -286,8 +297,11 @@ __global__ void k_fold_bn(int C0, const float* w0, const float* g0, const float*
       const int i = (j - 23) & 31, ii = i & 15;
       const int k = (i < 16 ? 0 : 32) + (ii & 3) + 8 * (ii >> 2) + 4 * h;
       v = fold1((j < 55 ? 0 : 32) + col, k);
-    } else {
+    } else if (j < 89) {
       v = shift1((j == 87 ? 0 : 32) + col);
+    } else {
+      const int i = j - 89, ii = i & 15;
+      v = shift1((i < 16 ? 0 : 32) + (ii & 3) + 8 * (ii >> 2) + 4 * h);
     }
     out[FR + idx] = v;
   }
@@ -524,6 +538,8 @@ struct ReaderWs {
   uint8_t* bytemap;
   int32_t* owner;
   uint32_t* rec;
+  int32_t* biglist;  // pillars with more than 32 points (handled by k_pfn_big)
+  int64_t bigcap;
   size_t zero_bytes;  // counters | count | bytemap are contiguous: one memset per call
   int32_t *key, *rank, *slot;
   uint32_t *count, *cpre, *cblk;
@@ -558,6 +574,8 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   w.zero_bytes = c.used();
   w.owner = c.take<int32_t>(cells + 8);
   w.rec = c.take<uint32_t>((n + 8) * 8);
+  w.bigcap = n / 33 + 8;
+  w.biglist = c.take<int32_t>(w.bigcap);
   w.bitmap = c.take<uint32_t>(w.nwords + 8);
   w.wpre = c.take<uint32_t>(w.nwords + 8);
   w.wblk = c.take<uint32_t>(w.nblk_w + 8);
@@ -620,7 +638,7 @@ int run_voxelize(const float* points, int64_t n, int32_t stride, const GeomDev& 
   k_scan_blocks<<<1, kBlock, 0, st>>>(w.cblk, w.nblk_c, w.counters + 1);
   PNX_LAUNCH_CHECK();
   if (n > 0) {
-    k_fill<<<nblocks(n), kBlock, 0, st>>>(points, stride, w.rank, w.slot, n, w.cpre, w.cblk, w.plist, w.rec);
+    k_fill<<<nblocks(n), kBlock, 0, st>>>(points, stride, w.rank, w.slot, n, w.count, w.cpre, w.cblk, w.plist, w.rec);
     PNX_LAUNCH_CHECK();
     if (need_kept_scan) {
       k_scan_local<SCAN_KEPT><<<w.nblk_k, kBlock, 0, st>>>(reinterpret_cast<const uint32_t*>(w.key), n, w.kpre, w.kblk);
@@ -649,9 +667,9 @@ int launch_canvas(const ReaderWs& w, const float* g1, int64_t g1_rows, const Geo
 }  // namespace
 
 // implemented in pfn_mfma.hip: the wave-tiled fp32-MFMA PFN kernel (PNX_PFN_IMPL=1, default)
-int pnx_launch_pfn_mfma(int F, const uint32_t* rec, const PnxGeomDev& geom,
-                        const uint32_t* count, const uint32_t* cpre, const uint32_t* cblk, const int32_t* counters, const float* folded,
-                        float* g1, int64_t g1_rows, int64_t n_points, hipStream_t st);
+int pnx_launch_pfn_mfma(int F, const uint32_t* rec, const PnxGeomDev& geom, const uint32_t* count, const uint32_t* cpre,
+                        const uint32_t* cblk, int32_t* counters, int32_t* biglist, int64_t bigcap, const float* folded, float* g1,
+                        int64_t g1_rows, int64_t n_points, hipStream_t st);
 
 extern "C" {
 
@@ -710,7 +728,7 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
       PNX_LAUNCH_CHECK();
     } else {
       prof_mark(4, st);
-      rc = pnx_launch_pfn_mfma(F, w.rec, gd, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows, n, st);
+      rc = pnx_launch_pfn_mfma(F, w.rec, gd, w.count, w.cpre, w.cblk, w.counters, w.biglist, w.bigcap, pfn_folded, g1, g1_rows, n, st);
       if (rc != PNX_OK) return rc;
       prof_mark(5, st);
     }
