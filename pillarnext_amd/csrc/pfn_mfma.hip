@@ -48,18 +48,24 @@ struct ScanPlan {
   bool s1, s2, s4, s8;
 };
 
-// Segmented inclusive max along the 32 lanes of each half; idx = position of the lane's point inside its pillar.
-__device__ __forceinline__ float seg_max(float v, int idx, int col, const ScanPlan& pl) {
-  const float NI = -__builtin_inff();
-  if (pl.s1) { const float t = dpp_f<DPP_ROW_SHR1, 0xF>(NI, v); v = fmaxf(v, idx >= 1 ? t : NI); }
-  if (pl.s2) { const float t = dpp_f<DPP_ROW_SHR2, 0xF>(NI, v); v = fmaxf(v, idx >= 2 ? t : NI); }
-  if (pl.s4) { const float t = dpp_f<DPP_ROW_SHR4, 0xF>(NI, v); v = fmaxf(v, idx >= 4 ? t : NI); }
-  if (pl.s8) { const float t = dpp_f<DPP_ROW_SHR8, 0xF>(NI, v); v = fmaxf(v, idx >= 8 ? t : NI); }
-  if (pl.s1) {  // a pillar may straddle the two 16-lane rows of a half: take lane 15's running value
-    const float t = dpp_f<DPP_ROW_BCAST15, 0xA>(NI, v);
-    v = fmaxf(v, idx > (col & 15) ? t : NI);
+// One Hillis-Steele step of a segmented inclusive max along the 32 lanes of each half, for N registers at once.
+// Lanes whose DPP source is outside the 16-lane row receive their own value (old = v), which max() ignores.
+template <int CTRL, int ROW_MASK, int N>
+__device__ __forceinline__ void max_step(float* v, bool take) {
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const float t = dpp_f<CTRL, ROW_MASK>(v[i], v[i]);
+    v[i] = fmaxf(v[i], take ? t : v[i]);
   }
-  return v;
+}
+// idx = position of the lane's point inside its pillar: lane l-d belongs to the same pillar iff idx >= d.
+template <int N>
+__device__ __forceinline__ void seg_max_n(float* v, int idx, int col, const ScanPlan& pl) {
+  if (pl.s1) max_step<DPP_ROW_SHR1, 0xF, N>(v, idx >= 1);
+  if (pl.s2) max_step<DPP_ROW_SHR2, 0xF, N>(v, idx >= 2);
+  if (pl.s4) max_step<DPP_ROW_SHR4, 0xF, N>(v, idx >= 4);
+  if (pl.s8) max_step<DPP_ROW_SHR8, 0xF, N>(v, idx >= 8);
+  if (pl.s1) max_step<DPP_ROW_BCAST15, 0xA, N>(v, idx > (col & 15));  // pillar straddling the two 16-lane rows of a half
 }
 __device__ __forceinline__ double seg_sum(double v, int idx, int col, const ScanPlan& pl) {
   if (pl.s1) { const double t = dpp_d<DPP_ROW_SHR1, 0xF>(v); v += idx >= 1 ? t : 0.0; }
@@ -135,11 +141,24 @@ template <int F, int R>
 __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ rec, PnxGeomDev g, const uint32_t* __restrict__ count,
                                                  const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
                                                  int32_t* __restrict__ counters, int32_t* __restrict__ biglist, int bigcap,
-                                                 const float* __restrict__ P, float* __restrict__ g1, int64_t g1_rows) {
+                                                 const float* __restrict__ P, float* __restrict__ g1, int64_t g1_rows,
+                                                 unsigned long long* __restrict__ dbg) {
   constexpr int C0 = F + 5, KS = (C0 + 2) / 2;     // K = C0 features + one constant-1 column that carries the folded BN shift
   constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;  // start of the fragment-ordered block (k_fold_bn)
   const int l = threadIdx.x & 63, col = l & 31, h = l >> 5;
   const int n_kept = counters[1];
+#ifdef PNX_PFN_TIMERS  // section timers (build with -DPNX_PFN_TIMERS; costs ~18 VGPRs)
+  unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tk = __builtin_amdgcn_s_memtime();
+#define TOCK(k)                                                 \
+  {                                                             \
+    const unsigned long long _n = __builtin_amdgcn_s_memtime(); \
+    T[k] += _n - tk;                                            \
+    tk = _n;                                                    \
+  }
+#else
+#define TOCK(k)
+#endif
 
   // ---- weight fragments: coalesced loads, once per (persistent) wave
   const float* __restrict__ FP = P + FR + l;
@@ -154,12 +173,36 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
   }
   const float4* __restrict__ s1lane = reinterpret_cast<const float4*>(P + FR + 64 * 89 + l * 32);  // s1 in this lane's channel order
 
-  for (;;) {
-    // ---- next window of R slots (one returning atomic per pass, by one lane)
-    int pass = 0;
-    if (l == 0) pass = atomicAdd(&counters[2], 1);
-    pass = __builtin_amdgcn_readfirstlane(pass);
-    const int64_t slot0 = (int64_t)pass * R;
+  TOCK(0);
+  // results of the previous tile, stored one tile late so that the record prefetch never waits behind fresh stores
+  float pa[16], pb[16];
+  bool p_store = false;
+  int p_rank = 0;
+  auto flush = [&]() {
+    if (p_store) {
+      float* row = g1 + (int64_t)p_rank * 64;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float4 sa = s1lane[j], sb = s1lane[4 + j];
+        float4 oa, ob;  // bias + ReLU after the max: relu(max(x) + s) == max(relu(x + s))
+        oa.x = fmaxf(pa[4 * j + 0] + sa.x, 0.f);
+        oa.y = fmaxf(pa[4 * j + 1] + sa.y, 0.f);
+        oa.z = fmaxf(pa[4 * j + 2] + sa.z, 0.f);
+        oa.w = fmaxf(pa[4 * j + 3] + sa.w, 0.f);
+        ob.x = fmaxf(pb[4 * j + 0] + sb.x, 0.f);
+        ob.y = fmaxf(pb[4 * j + 1] + sb.y, 0.f);
+        ob.z = fmaxf(pb[4 * j + 2] + sb.z, 0.f);
+        ob.w = fmaxf(pb[4 * j + 3] + sb.w, 0.f);
+        *reinterpret_cast<float4*>(row + 8 * j + 4 * h) = oa;
+        *reinterpret_cast<float4*>(row + 32 + 8 * j + 4 * h) = ob;
+      }
+    }
+    p_store = false;
+  };
+
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  for (int64_t pass = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);; pass += n_waves) {
+    const int64_t slot0 = pass * R;
     if (slot0 >= n_kept) break;
     const int64_t slot1 = (slot0 + R < n_kept) ? slot0 + R : n_kept;
     // pillars owned by this pass = those whose first slot lies in [slot0, slot1)
@@ -172,6 +215,7 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
       const uint32_t e1 = pillar_end_at(rec, slot1, count, cpre, cblk, &head1);
       end = head1 ? (uint32_t)slot1 : e1;
     }
+    TOCK(1);
     if (base >= end) continue;
 
     uint32_t ts = base;
@@ -198,6 +242,7 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
       }
       const uint32_t ts_next = ts + (uint32_t)nv;
       nxt = load_rec(rec, min(ts_next + (uint32_t)col, end - 1));  // prefetch the next tile while this one computes
+      flush();                                                      // previous tile's rows (issued behind the prefetch)
       const bool act = col < nv;
       const int cnt = idx + rem + 1;
       const int tail_lane = act ? l + rem : l;  // same half
@@ -206,6 +251,7 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
       pl.s2 = __ballot(act && idx >= 2) != 0;
       pl.s4 = __ballot(act && idx >= 4) != 0;
       pl.s8 = __ballot(act && idx >= 8) != 0;
+      TOCK(2);
 
       // ---- per-pillar mean of xyz (scatter_mean, pe:113-114): exact fp64 sum, fp32 divide
       float mx, my, mz;
@@ -223,6 +269,7 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
         my = __fdiv_rn((float)sy, fc);
         mz = __fdiv_rn((float)sz, fc);
       }
+      TOCK(3);
       // ---- layer 0 (lane = point, registers = channels)
       float ff[KS];
       {
@@ -239,11 +286,15 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
       // ---- "max" half of the concat: per-pillar max of layer 0, delivered to every point of the pillar
       float g0[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        float v = d0[i];
-        if (pl.s1) v = from_lane(seg_max(v, idx, col, pl), tail_lane);
-        g0[i] = fmaxf(v, 0.f);  // relu(max(x)) == max(relu(x))
+      for (int i = 0; i < 16; i++) g0[i] = d0[i];
+      if (pl.s1) {
+        seg_max_n<16>(g0, idx, col, pl);
+#pragma unroll
+        for (int i = 0; i < 16; i++) g0[i] = from_lane(g0[i], tail_lane);
       }
+#pragma unroll
+      for (int i = 0; i < 16; i++) g0[i] = fmaxf(g0[i], 0.f);  // relu(max(x)) == max(relu(x))
+      TOCK(4);
       // ---- layer 1: 64 output channels as two 32-row tiles, K in accumulator-register order
       v16f da, db;
 #pragma unroll
@@ -262,38 +313,29 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
         da = PNX_MFMA(w1a[16 + i], g0[i], da);
         db = PNX_MFMA(w1b[16 + i], g0[i], db);
       }
-      // ---- per-pillar max of layer 1; bias + ReLU on the tail lane only; 8 x 16-byte pieces of the feat_max row
-      float ya[16], yb[16];
+      TOCK(5);
+      // ---- per-pillar max of layer 1 (raw accumulators; bias/ReLU/stores happen in flush(), one tile later)
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        ya[i] = da[i];
-        yb[i] = db[i];
-        if (pl.s1) {
-          ya[i] = seg_max(ya[i], idx, col, pl);
-          yb[i] = seg_max(yb[i], idx, col, pl);
-        }
+        pa[i] = da[i];
+        pb[i] = db[i];
       }
-      if (act && rem == 0 && (int64_t)r < g1_rows) {
-        float* row = g1 + (int64_t)r * 64;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float4 sa = s1lane[j], sb = s1lane[4 + j];
-          float4 oa, ob;
-          oa.x = fmaxf(ya[4 * j + 0] + sa.x, 0.f);
-          oa.y = fmaxf(ya[4 * j + 1] + sa.y, 0.f);
-          oa.z = fmaxf(ya[4 * j + 2] + sa.z, 0.f);
-          oa.w = fmaxf(ya[4 * j + 3] + sa.w, 0.f);
-          ob.x = fmaxf(yb[4 * j + 0] + sb.x, 0.f);
-          ob.y = fmaxf(yb[4 * j + 1] + sb.y, 0.f);
-          ob.z = fmaxf(yb[4 * j + 2] + sb.z, 0.f);
-          ob.w = fmaxf(yb[4 * j + 3] + sb.w, 0.f);
-          *reinterpret_cast<float4*>(row + 8 * j + 4 * h) = oa;
-          *reinterpret_cast<float4*>(row + 32 + 8 * j + 4 * h) = ob;
-        }
-      }
+      seg_max_n<16>(pa, idx, col, pl);
+      seg_max_n<16>(pb, idx, col, pl);
+      p_store = act && rem == 0 && (int64_t)r < g1_rows;
+      p_rank = r;
       ts = ts_next;
+      TOCK(6);
     }
   }
+  flush();
+#ifdef PNX_PFN_TIMERS
+  if (dbg && l == 0) {
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+#pragma unroll
+    for (int k = 0; k < 8; k++) dbg[gw * 8 + k] = T[k];
+  }
+#endif
 }
 
 // ---- pillars with more than 32 points: one wave per pillar, points strided over lanes, plain fp32 FMAs with the weights
@@ -389,6 +431,10 @@ template <int F>
 int launch_f(int R, const uint32_t* rec, const PnxGeomDev& g, const uint32_t* count, const uint32_t* cpre, const uint32_t* cblk,
              int32_t* counters, int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows, int64_t n, int max_blocks,
              hipStream_t st) {
+  static unsigned long long* dbg = nullptr;
+  static int dbg_calls = 0;
+  const bool want_dbg = getenv("PNX_PFN_TIMING") != nullptr;
+  if (want_dbg && !dbg) (void)hipMalloc(&dbg, 8192 * 4 * 8 * sizeof(unsigned long long));
   int64_t nb = ((n + R - 1) / R + 3) / 4;  // 4 waves per block; windows are handed out dynamically
   if (nb > max_blocks) nb = max_blocks;
   if (nb < 1) nb = 1;
@@ -398,10 +444,20 @@ int launch_f(int R, const uint32_t* rec, const PnxGeomDev& g, const uint32_t* co
     fprintf(stderr, "[pnx] k_pfn_mfma<%d,%d>: occupancy API %d blocks (x4 waves)/CU, %lld blocks\n", F, R, occ, (long long)nb);
   }
   const int bc = (int)(bigcap > 0x7fffffff ? 0x7fffffff : bigcap);
-  if (R == 128) k_pfn_mfma<F, 128><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows);
-  else if (R == 32) k_pfn_mfma<F, 32><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows);
-  else k_pfn_mfma<F, 64><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows);
-  k_pfn_big<F><<<128, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows);
+  if (R == 128) k_pfn_mfma<F, 128><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows, want_dbg ? dbg : nullptr);
+  else if (R == 32) k_pfn_mfma<F, 32><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows, want_dbg ? dbg : nullptr);
+  else k_pfn_mfma<F, 64><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows, want_dbg ? dbg : nullptr);
+  if (want_dbg && ++dbg_calls == 20) {
+    std::vector<unsigned long long> hbuf((size_t)nb * 4 * 8);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(hbuf.data(), dbg, hbuf.size() * 8, hipMemcpyDeviceToHost);
+    double acc[8] = {0};
+    for (size_t w = 0; w < (size_t)nb * 4; w++)
+      for (int k = 0; k < 8; k++) acc[k] += (double)hbuf[w * 8 + k];
+    const char* names[8] = {"weight frags", "dequeue+ownership", "rec wait+plan", "mean", "layer0+g0 scan", "layer1 MFMA", "scan+store", ""};
+    for (int k = 0; k < 7; k++) fprintf(stderr, "[pnx-timing] %-20s %10.0f ticks/wave\n", names[k], acc[k] / (nb * 4));
+  }
+  if (!getenv("PNX_SKIP_BIG")) k_pfn_big<F><<<128, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
