@@ -136,7 +136,116 @@ __device__ __forceinline__ uint32_t pillar_end_at(const uint32_t* __restrict__ r
   return pstart((int)w.w, cpre, cblk) + count[w.w] + 1u;
 }
 
-// counters[2] = next slot window to hand out (dynamic load balance), counters[3] = number of big pillars
+// A pillar with more than 32 points, processed by the wave that meets it: three sweeps over its tiles (mean; layer-0 max;
+// layer 1 + max) with per-lane running maxima, then one all-lane reduction per register.  Same MFMA fragments as the
+// main path; rare at PillarNeXt-B resolution, common only for coarse voxels.
+template <int F, int KS>
+__device__ __forceinline__ void big_pillar(const uint32_t* __restrict__ rec, const PnxGeomDev& g, uint32_t st, uint32_t c, int r,
+                                           const float* w0f, const float* w1a, const float* w1b, const float4* __restrict__ s1lane,
+                                           float* __restrict__ g1, int64_t g1_rows, int l) {
+  constexpr int C0 = F + 5;
+  const int col = l & 31, h = l >> 5;
+  const float NI = -__builtin_inff();
+  double sx = 0, sy = 0, sz = 0;
+  for (uint32_t t = col; t < c; t += 32) {
+    const uint4 a = *reinterpret_cast<const uint4*>(rec + (int64_t)(st + t) * 8);
+    sx += (double)__uint_as_float(a.x);
+    sy += (double)__uint_as_float(a.y);
+    sz += (double)__uint_as_float(a.z);
+  }
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) {  // both halves hold the same points: reduce inside each half
+    sx += __shfl_xor(sx, d);
+    sy += __shfl_xor(sy, d);
+    sz += __shfl_xor(sz, d);
+  }
+  const float fc = (float)c;
+  const float mx = __fdiv_rn((float)sx, fc), my = __fdiv_rn((float)sy, fc), mz = __fdiv_rn((float)sz, fc);
+  float g0[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) g0[i] = NI;
+  for (uint32_t t0 = 0; t0 < c; t0 += 32) {
+    const bool act = t0 + col < c;
+    const Rec cur = load_rec(rec, st + min(t0 + (uint32_t)col, c - 1));
+    float f[C0 + 2], ff[KS];
+    decorate_rec<F>(cur, mx, my, mz, g, f);
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) ff[kk] = act ? (h ? f[2 * kk + 1] : f[2 * kk]) : 0.f;
+    v16f d0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) d0[i] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], ff[kk], d0);
+#pragma unroll
+    for (int i = 0; i < 16; i++) g0[i] = fmaxf(g0[i], act ? d0[i] : NI);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) g0[i] = fmaxf(g0[i], __shfl_xor(g0[i], d));
+    g0[i] = fmaxf(g0[i], 0.f);
+  }
+  float pa[16], pb[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    pa[i] = NI;
+    pb[i] = NI;
+  }
+  for (uint32_t t0 = 0; t0 < c; t0 += 32) {
+    const bool act = t0 + col < c;
+    const Rec cur = load_rec(rec, st + min(t0 + (uint32_t)col, c - 1));
+    float f[C0 + 2], ff[KS];
+    decorate_rec<F>(cur, mx, my, mz, g, f);
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) ff[kk] = act ? (h ? f[2 * kk + 1] : f[2 * kk]) : 0.f;
+    v16f d0, da, db;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      d0[i] = 0.f;
+      da[i] = 0.f;
+      db[i] = 0.f;
+    }
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], ff[kk], d0);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const float u = fmaxf(d0[i], 0.f);
+      da = PNX_MFMA(w1a[i], u, da);
+      db = PNX_MFMA(w1b[i], u, db);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      da = PNX_MFMA(w1a[16 + i], g0[i], da);
+      db = PNX_MFMA(w1b[16 + i], g0[i], db);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      pa[i] = fmaxf(pa[i], act ? da[i] : NI);
+      pb[i] = fmaxf(pb[i], act ? db[i] : NI);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {
+      pa[i] = fmaxf(pa[i], __shfl_xor(pa[i], d));
+      pb[i] = fmaxf(pb[i], __shfl_xor(pb[i], d));
+    }
+  }
+  if (col == 0 && (int64_t)r < g1_rows) {
+    float* row = g1 + (int64_t)r * 64;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float4 sa = s1lane[j], sb = s1lane[4 + j];
+      *reinterpret_cast<float4*>(row + 8 * j + 4 * h) = make_float4(fmaxf(pa[4 * j] + sa.x, 0.f), fmaxf(pa[4 * j + 1] + sa.y, 0.f),
+                                                                   fmaxf(pa[4 * j + 2] + sa.z, 0.f), fmaxf(pa[4 * j + 3] + sa.w, 0.f));
+      *reinterpret_cast<float4*>(row + 32 + 8 * j + 4 * h) = make_float4(fmaxf(pb[4 * j] + sb.x, 0.f), fmaxf(pb[4 * j + 1] + sb.y, 0.f),
+                                                                        fmaxf(pb[4 * j + 2] + sb.z, 0.f), fmaxf(pb[4 * j + 3] + sb.w, 0.f));
+    }
+  }
+}
+
+// counters[3] = number of big pillars appended to biglist
 template <int F, int R>
 __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ rec, PnxGeomDev g, const uint32_t* __restrict__ count,
                                                  const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
@@ -229,7 +338,7 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
       const uint32_t V = (uint32_t)__ballot(complete && h == 0);
       const int nv = __builtin_popcount(V);
       if (nv == 0) {
-        // the pillar at ts has more than 32 points: hand it to k_pfn_big and step over it
+        // the pillar at ts has more than 32 points: hand it to k_pfn_big (keeps this kernel's register budget) and step over it
         const int q = __builtin_amdgcn_readfirstlane(r);
         const uint32_t c = count[q] + 1u;
         if (l == 0) {
@@ -338,92 +447,32 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
 #endif
 }
 
-// ---- pillars with more than 32 points: one wave per pillar, points strided over lanes, plain fp32 FMAs with the weights
-// coming through scalar loads (wave-uniform addresses), wave reductions by xor-shuffles.  Rare at PillarNeXt-B resolution.
+// Pillars with more than 32 points: one wave per pillar (see big_pillar).
 template <int F>
 __global__ __launch_bounds__(256) void k_pfn_big(const uint32_t* __restrict__ rec, PnxGeomDev g, const uint32_t* __restrict__ count,
                                                 const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
                                                 const int32_t* __restrict__ counters, const int32_t* __restrict__ biglist, int bigcap,
                                                 const float* __restrict__ P, float* __restrict__ g1, int64_t g1_rows) {
-  constexpr int C0 = F + 5;
-  constexpr int OW0 = 0, OS0 = 32 * C0, OW1 = OS0 + 32, OS1 = OW1 + 64 * 64;
+  constexpr int C0 = F + 5, KS = (C0 + 2) / 2;
+  constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;
   const int l = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   int nbig = counters[3];
   if (nbig > bigcap) nbig = bigcap;
+  if (wave >= nbig) return;
+  const float* __restrict__ FP = P + FR + l;
+  float w0f[KS], w1a[32], w1b[32];
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) w0f[kk] = FP[kk * 64];
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    w1a[i] = FP[(23 + i) * 64];
+    w1b[i] = FP[(55 + i) * 64];
+  }
+  const float4* __restrict__ s1lane = reinterpret_cast<const float4*>(P + FR + 64 * 89 + l * 32);
   for (int b = wave; b < nbig; b += nwaves) {
     const int q = biglist[b];
-    if ((int64_t)q >= g1_rows) continue;
-    const uint32_t st = pstart(q, cpre, cblk), c = count[q] + 1u;
-    double sx = 0, sy = 0, sz = 0;
-    for (uint32_t k = l; k < c; k += 64) {
-      const uint4 a = *reinterpret_cast<const uint4*>(rec + (int64_t)(st + k) * 8);
-      sx += (double)__uint_as_float(a.x);
-      sy += (double)__uint_as_float(a.y);
-      sz += (double)__uint_as_float(a.z);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      sx += __shfl_xor(sx, d);
-      sy += __shfl_xor(sy, d);
-      sz += __shfl_xor(sz, d);
-    }
-    const float fc = (float)c;
-    const float mx = __fdiv_rn((float)sx, fc), my = __fdiv_rn((float)sy, fc), mz = __fdiv_rn((float)sz, fc);
-    float g0[32];
-#pragma unroll
-    for (int ch = 0; ch < 32; ch++) g0[ch] = 0.f;
-    for (uint32_t k = l; k < c; k += 64) {
-      float f[C0 + 2];
-      decorate_rec<F>(load_rec(rec, st + k), mx, my, mz, g, f);
-#pragma unroll
-      for (int ch = 0; ch < 32; ch++) {
-        float acc = P[OS0 + ch];
-#pragma unroll
-        for (int kk = 0; kk < C0; kk++) acc = __builtin_fmaf(f[kk], P[OW0 + ch * C0 + kk], acc);
-        g0[ch] = fmaxf(g0[ch], acc);
-      }
-    }
-#pragma unroll
-    for (int ch = 0; ch < 32; ch++)
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) g0[ch] = fmaxf(g0[ch], __shfl_xor(g0[ch], d));
-    for (int c0 = 0; c0 < 64; c0 += 16) {  // 16 output channels at a time keeps the register count low
-      float out[16];
-#pragma unroll
-      for (int j = 0; j < 16; j++) out[j] = 0.f;
-      for (uint32_t k = l; k < c; k += 64) {
-        float f[C0 + 2], h0[32];
-        decorate_rec<F>(load_rec(rec, st + k), mx, my, mz, g, f);
-#pragma unroll
-        for (int ch = 0; ch < 32; ch++) {
-          float acc = P[OS0 + ch];
-#pragma unroll
-          for (int kk = 0; kk < C0; kk++) acc = __builtin_fmaf(f[kk], P[OW0 + ch * C0 + kk], acc);
-          h0[ch] = fmaxf(acc, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-          const float* wr = P + OW1 + (c0 + j) * 64;
-          float acc = P[OS1 + c0 + j];
-#pragma unroll
-          for (int kk = 0; kk < 32; kk++) acc = __builtin_fmaf(h0[kk], wr[kk], acc);
-#pragma unroll
-          for (int kk = 0; kk < 32; kk++) acc = __builtin_fmaf(g0[kk], wr[32 + kk], acc);
-          out[j] = fmaxf(out[j], acc);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) out[j] = fmaxf(out[j], __shfl_xor(out[j], d));
-      }
-      if (l == 0) {
-        float4* o = reinterpret_cast<float4*>(g1 + (int64_t)q * 64 + c0);
-#pragma unroll
-        for (int j = 0; j < 4; j++) o[j] = make_float4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
-      }
-    }
+    big_pillar<F, KS>(rec, g, pstart(q, cpre, cblk), count[q] + 1u, q, w0f, w1a, w1b, s1lane, g1, g1_rows, l);
   }
 }
 
@@ -457,7 +506,7 @@ int launch_f(int R, const uint32_t* rec, const PnxGeomDev& g, const uint32_t* co
     const char* names[8] = {"weight frags", "dequeue+ownership", "rec wait+plan", "mean", "layer0+g0 scan", "layer1 MFMA", "scan+store", ""};
     for (int k = 0; k < 7; k++) fprintf(stderr, "[pnx-timing] %-20s %10.0f ticks/wave\n", names[k], acc[k] / (nb * 4));
   }
-  if (!getenv("PNX_SKIP_BIG")) k_pfn_big<F><<<128, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows);
+  k_pfn_big<F><<<64, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
