@@ -88,6 +88,43 @@ __device__ __forceinline__ double from_lane_d(double v, int src_lane) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+// Where the reader writes a pillar's 64 features: an fp32 feat_max row and/or the pillar's cell of the dense NHWC canvas.
+struct PfnOut {
+  float* g1;               // (rows, 64) fp32 or null
+  int64_t g1_rows;
+  void* canvas;            // NHWC canvas or null
+  const int32_t* cell;     // linear cell index (b*gy + yi)*gx + xi of every pillar
+  int dt;                  // PNX_F32 / PNX_BF16 / PNX_F16
+};
+__device__ __forceinline__ uint32_t bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);  // inputs are finite post-ReLU values
+  return u >> 16;
+}
+__device__ __forceinline__ uint32_t f16_rne(float f) {
+  const _Float16 hv = (_Float16)f;
+  return (uint32_t)__builtin_bit_cast(unsigned short, hv);
+}
+// four consecutive channels starting at chan0 (multiple of 4) of pillar `r`
+__device__ __forceinline__ void store_piece(const PfnOut& o, int r, int64_t cell, int chan0, float4 v) {
+  if (o.g1 != nullptr && (int64_t)r < o.g1_rows) *reinterpret_cast<float4*>(o.g1 + (int64_t)r * 64 + chan0) = v;
+  if (o.canvas != nullptr) {
+    if (o.dt == PNX_F32) {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(o.canvas) + cell * 64 + chan0) = v;
+    } else {
+      uint2 p;
+      if (o.dt == PNX_BF16) {
+        p.x = bf16_rne(v.x) | (bf16_rne(v.y) << 16);
+        p.y = bf16_rne(v.z) | (bf16_rne(v.w) << 16);
+      } else {
+        p.x = f16_rne(v.x) | (f16_rne(v.y) << 16);
+        p.y = f16_rne(v.z) | (f16_rne(v.w) << 16);
+      }
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(o.canvas) + cell * 64 + chan0) = p;
+    }
+  }
+}
+
 __device__ __forceinline__ uint32_t pstart(int32_t r, const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk) {
   return cblk[r >> PNX_SCAN_SHIFT] + cpre[r];
 }
@@ -142,7 +179,7 @@ __device__ __forceinline__ uint32_t pillar_end_at(const uint32_t* __restrict__ r
 template <int F, int KS>
 __device__ __forceinline__ void big_pillar(const uint32_t* __restrict__ rec, const PnxGeomDev& g, uint32_t st, uint32_t c, int r,
                                            const float* w0f, const float* w1a, const float* w1b, const float4* __restrict__ s1lane,
-                                           float* __restrict__ g1, int64_t g1_rows, int l) {
+                                           const PfnOut& out, int l) {
   constexpr int C0 = F + 5;
   const int col = l & 31, h = l >> 5;
   const float NI = -__builtin_inff();
@@ -232,15 +269,15 @@ __device__ __forceinline__ void big_pillar(const uint32_t* __restrict__ rec, con
       pb[i] = fmaxf(pb[i], __shfl_xor(pb[i], d));
     }
   }
-  if (col == 0 && (int64_t)r < g1_rows) {
-    float* row = g1 + (int64_t)r * 64;
+  if (col == 0) {
+    const int64_t cell = out.canvas ? (int64_t)out.cell[r] : 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const float4 sa = s1lane[j], sb = s1lane[4 + j];
-      *reinterpret_cast<float4*>(row + 8 * j + 4 * h) = make_float4(fmaxf(pa[4 * j] + sa.x, 0.f), fmaxf(pa[4 * j + 1] + sa.y, 0.f),
-                                                                   fmaxf(pa[4 * j + 2] + sa.z, 0.f), fmaxf(pa[4 * j + 3] + sa.w, 0.f));
-      *reinterpret_cast<float4*>(row + 32 + 8 * j + 4 * h) = make_float4(fmaxf(pb[4 * j] + sb.x, 0.f), fmaxf(pb[4 * j + 1] + sb.y, 0.f),
-                                                                        fmaxf(pb[4 * j + 2] + sb.z, 0.f), fmaxf(pb[4 * j + 3] + sb.w, 0.f));
+      store_piece(out, r, cell, 8 * j + 4 * h, make_float4(fmaxf(pa[4 * j] + sa.x, 0.f), fmaxf(pa[4 * j + 1] + sa.y, 0.f),
+                                                          fmaxf(pa[4 * j + 2] + sa.z, 0.f), fmaxf(pa[4 * j + 3] + sa.w, 0.f)));
+      store_piece(out, r, cell, 32 + 8 * j + 4 * h, make_float4(fmaxf(pb[4 * j] + sb.x, 0.f), fmaxf(pb[4 * j + 1] + sb.y, 0.f),
+                                                               fmaxf(pb[4 * j + 2] + sb.z, 0.f), fmaxf(pb[4 * j + 3] + sb.w, 0.f)));
     }
   }
 }
@@ -250,8 +287,7 @@ template <int F, int R>
 __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ rec, PnxGeomDev g, const uint32_t* __restrict__ count,
                                                  const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
                                                  int32_t* __restrict__ counters, int32_t* __restrict__ biglist, int bigcap,
-                                                 const float* __restrict__ P, float* __restrict__ g1, int64_t g1_rows,
-                                                 unsigned long long* __restrict__ dbg) {
+                                                 const float* __restrict__ P, PfnOut out, unsigned long long* __restrict__ dbg) {
   constexpr int C0 = F + 5, KS = (C0 + 2) / 2;     // K = C0 features + one constant-1 column that carries the folded BN shift
   constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;  // start of the fragment-ordered block (k_fold_bn)
   const int l = threadIdx.x & 63, col = l & 31, h = l >> 5;
@@ -289,7 +325,7 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
   int p_rank = 0;
   auto flush = [&]() {
     if (p_store) {
-      float* row = g1 + (int64_t)p_rank * 64;
+      const int64_t cell = out.canvas ? (int64_t)out.cell[p_rank] : 0;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const float4 sa = s1lane[j], sb = s1lane[4 + j];
@@ -302,8 +338,8 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
         ob.y = fmaxf(pb[4 * j + 1] + sb.y, 0.f);
         ob.z = fmaxf(pb[4 * j + 2] + sb.z, 0.f);
         ob.w = fmaxf(pb[4 * j + 3] + sb.w, 0.f);
-        *reinterpret_cast<float4*>(row + 8 * j + 4 * h) = oa;
-        *reinterpret_cast<float4*>(row + 32 + 8 * j + 4 * h) = ob;
+        store_piece(out, p_rank, cell, 8 * j + 4 * h, oa);
+        store_piece(out, p_rank, cell, 32 + 8 * j + 4 * h, ob);
       }
     }
     p_store = false;
@@ -431,7 +467,7 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
       }
       seg_max_n<16>(pa, idx, col, pl);
       seg_max_n<16>(pb, idx, col, pl);
-      p_store = act && rem == 0 && (int64_t)r < g1_rows;
+      p_store = act && rem == 0;
       p_rank = r;
       ts = ts_next;
       TOCK(6);
@@ -452,7 +488,7 @@ template <int F>
 __global__ __launch_bounds__(256) void k_pfn_big(const uint32_t* __restrict__ rec, PnxGeomDev g, const uint32_t* __restrict__ count,
                                                 const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk,
                                                 const int32_t* __restrict__ counters, const int32_t* __restrict__ biglist, int bigcap,
-                                                const float* __restrict__ P, float* __restrict__ g1, int64_t g1_rows) {
+                                                const float* __restrict__ P, PfnOut out) {
   constexpr int C0 = F + 5, KS = (C0 + 2) / 2;
   constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;
   const int l = threadIdx.x & 63;
@@ -472,13 +508,13 @@ __global__ __launch_bounds__(256) void k_pfn_big(const uint32_t* __restrict__ re
   const float4* __restrict__ s1lane = reinterpret_cast<const float4*>(P + FR + 64 * 89 + l * 32);
   for (int b = wave; b < nbig; b += nwaves) {
     const int q = biglist[b];
-    big_pillar<F, KS>(rec, g, pstart(q, cpre, cblk), count[q] + 1u, q, w0f, w1a, w1b, s1lane, g1, g1_rows, l);
+    big_pillar<F, KS>(rec, g, pstart(q, cpre, cblk), count[q] + 1u, q, w0f, w1a, w1b, s1lane, out, l);
   }
 }
 
 template <int F>
 int launch_f(int R, const uint32_t* rec, const PnxGeomDev& g, const uint32_t* count, const uint32_t* cpre, const uint32_t* cblk,
-             int32_t* counters, int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows, int64_t n, int max_blocks,
+             int32_t* counters, int32_t* biglist, int64_t bigcap, const float* folded, const PfnOut& out, int64_t n, int max_blocks,
              hipStream_t st) {
   static unsigned long long* dbg = nullptr;
   static int dbg_calls = 0;
@@ -493,9 +529,9 @@ int launch_f(int R, const uint32_t* rec, const PnxGeomDev& g, const uint32_t* co
     fprintf(stderr, "[pnx] k_pfn_mfma<%d,%d>: occupancy API %d blocks (x4 waves)/CU, %lld blocks\n", F, R, occ, (long long)nb);
   }
   const int bc = (int)(bigcap > 0x7fffffff ? 0x7fffffff : bigcap);
-  if (R == 128) k_pfn_mfma<F, 128><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows, want_dbg ? dbg : nullptr);
-  else if (R == 32) k_pfn_mfma<F, 32><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows, want_dbg ? dbg : nullptr);
-  else k_pfn_mfma<F, 64><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows, want_dbg ? dbg : nullptr);
+  if (R == 128) k_pfn_mfma<F, 128><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, out, want_dbg ? dbg : nullptr);
+  else if (R == 32) k_pfn_mfma<F, 32><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, out, want_dbg ? dbg : nullptr);
+  else k_pfn_mfma<F, 64><<<(int)nb, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, out, want_dbg ? dbg : nullptr);
   if (want_dbg && ++dbg_calls == 20) {
     std::vector<unsigned long long> hbuf((size_t)nb * 4 * 8);
     (void)hipStreamSynchronize(st);
@@ -506,7 +542,7 @@ int launch_f(int R, const uint32_t* rec, const PnxGeomDev& g, const uint32_t* co
     const char* names[8] = {"weight frags", "dequeue+ownership", "rec wait+plan", "mean", "layer0+g0 scan", "layer1 MFMA", "scan+store", ""};
     for (int k = 0; k < 7; k++) fprintf(stderr, "[pnx-timing] %-20s %10.0f ticks/wave\n", names[k], acc[k] / (nb * 4));
   }
-  k_pfn_big<F><<<64, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, g1, g1_rows);
+  k_pfn_big<F><<<64, 256, 0, st>>>(rec, g, count, cpre, cblk, counters, biglist, bc, folded, out);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -515,16 +551,22 @@ int launch_f(int R, const uint32_t* rec, const PnxGeomDev& g, const uint32_t* co
 
 int pnx_launch_pfn_mfma(int F, const uint32_t* rec, const PnxGeomDev& geom, const uint32_t* count, const uint32_t* cpre,
                         const uint32_t* cblk, int32_t* counters, int32_t* biglist, int64_t bigcap, const float* folded, float* g1,
-                        int64_t g1_rows, int64_t n_points, hipStream_t st) {
+                        int64_t g1_rows, void* canvas, const int32_t* cell_of_pillar, int canvas_dt, int64_t n_points, hipStream_t st) {
+  PfnOut out;
+  out.g1 = g1;
+  out.g1_rows = g1_rows;
+  out.canvas = canvas;
+  out.cell = cell_of_pillar;
+  out.dt = canvas_dt;
   const char* r_env = getenv("PNX_PFN_R");  // slots per window: 32 | 64 | 128
   const int R = r_env ? atoi(r_env) : 64;
   const char* b_env = getenv("PNX_PFN_BLOCKS");
   const int max_blocks = b_env ? atoi(b_env) : 512;  // 256 CUs x 2 blocks x 4 waves = 2 waves per SIMD
   switch (F) {
-    case 3: return launch_f<3>(R, rec, geom, count, cpre, cblk, counters, biglist, bigcap, folded, g1, g1_rows, n_points, max_blocks, st);
-    case 4: return launch_f<4>(R, rec, geom, count, cpre, cblk, counters, biglist, bigcap, folded, g1, g1_rows, n_points, max_blocks, st);
-    case 5: return launch_f<5>(R, rec, geom, count, cpre, cblk, counters, biglist, bigcap, folded, g1, g1_rows, n_points, max_blocks, st);
-    case 6: return launch_f<6>(R, rec, geom, count, cpre, cblk, counters, biglist, bigcap, folded, g1, g1_rows, n_points, max_blocks, st);
+    case 3: return launch_f<3>(R, rec, geom, count, cpre, cblk, counters, biglist, bigcap, folded, out, n_points, max_blocks, st);
+    case 4: return launch_f<4>(R, rec, geom, count, cpre, cblk, counters, biglist, bigcap, folded, out, n_points, max_blocks, st);
+    case 5: return launch_f<5>(R, rec, geom, count, cpre, cblk, counters, biglist, bigcap, folded, out, n_points, max_blocks, st);
+    case 6: return launch_f<6>(R, rec, geom, count, cpre, cblk, counters, biglist, bigcap, folded, out, n_points, max_blocks, st);
   }
   pnx_set_error("num_point_features %d not in 3..6", F);
   return PNX_ERR_UNSUPPORTED;

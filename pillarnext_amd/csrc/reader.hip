@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void k_rank(const int32_t* __restrict__ key
                                                  const uint32_t* __restrict__ wblk, const int32_t* __restrict__ owner,
                                                  int32_t* __restrict__ rank_out, int32_t* __restrict__ slot_out,
                                                  uint32_t* __restrict__ extra, int32_t* __restrict__ coords, int64_t pillar_capacity,
-                                                 int32_t* __restrict__ pillar_of_point) {
+                                                 int32_t* __restrict__ pillar_of_point, int32_t* __restrict__ cell_of_pillar) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const int32_t k = key[i];
@@ -122,10 +122,11 @@ __global__ __launch_bounds__(kBlock) void k_rank(const int32_t* __restrict__ key
     r = cell_rank(k, bitmap, wpre, wblk);
     if (owner[k] == (int32_t)i) {
       slot_out[i] = 0;
+      const int yi = k % g.gyp;
+      const int t = k / g.gyp;
+      const int xi = t % g.gx, bi = t / g.gx;
+      cell_of_pillar[r] = (bi * g.gy + yi) * g.gx + xi;  // NHWC canvas cell of the pillar
       if (coords != nullptr && r < pillar_capacity) {
-        const int yi = k % g.gyp;
-        const int t = k / g.gyp;
-        const int xi = t % g.gx, bi = t / g.gx;
         coords[(int64_t)r * 3 + 0] = bi;  // [b, yi, xi]  (pe:125 swaps x/y)
         coords[(int64_t)r * 3 + 1] = yi;
         coords[(int64_t)r * 3 + 2] = xi;
@@ -448,6 +449,42 @@ __global__ __launch_bounds__(kBlock) void k_canvas_nhwc(const uint32_t* __restri
   }
 }
 
+// NHWC canvas, direct-write mode: the PFN kernel stores every pillar's 64 features straight into its cell; this kernel
+// writes the zeros of all OTHER cells (and the occupancy bytes).  Together they still write each canvas byte exactly once,
+// and the (P,64) fp32 intermediate disappears from the traffic.
+template <int DT>
+__global__ __launch_bounds__(kBlock) void k_canvas_fill_nhwc(const uint32_t* __restrict__ bitmap, GeomDev g, void* __restrict__ canvas,
+                                                             uint8_t* __restrict__ occ) {
+  constexpr int ESZ = (DT == PNX_F32) ? 4 : 2;
+  constexpr int CH = 64 * ESZ / 16;  // 16-byte chunks per cell
+  __shared__ uint32_t s_word[32];
+  const int tiles_x = (g.gx + 31) >> 5, tiles_y = g.gyp >> 5;
+  int tile = blockIdx.x;
+  const int tx = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty = tile % tiles_y, b = tile / tiles_y;
+  const int x0 = tx << 5, y0 = ty << 5;
+  const int t = threadIdx.x;
+  if (t < 32) {
+    const int xi = x0 + t;
+    s_word[t] = xi < g.gx ? bitmap[((b * g.gx + xi) * g.gyp + y0) >> 5] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  uint4* out = reinterpret_cast<uint4*>(canvas);
+  const int rows = min(32, g.gy - y0);
+  for (int idx = t; idx < rows * 32 * CH; idx += kBlock) {
+    const int q = idx % CH;
+    const int xl = (idx / CH) & 31;
+    const int yl = idx / (CH * 32);
+    const int xi = x0 + xl;
+    if (xi >= g.gx) continue;
+    const uint32_t bit = (s_word[xl] >> yl) & 1u;
+    const int64_t cell = ((int64_t)b * g.gy + (y0 + yl)) * g.gx + xi;
+    if (occ != nullptr && q == 0) occ[cell] = (uint8_t)bit;
+    if (!bit) out[cell * CH + q] = make_uint4(0, 0, 0, 0);
+  }
+}
+
 // NCHW canvas (what .dense() returns).  Not the performance layout; same tile scheme, one element per store.
 template <int DT>
 __global__ __launch_bounds__(kBlock) void k_canvas_nchw(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre,
@@ -539,6 +576,7 @@ struct ReaderWs {
   int32_t* owner;
   uint32_t* rec;
   int32_t* biglist;  // pillars with more than 32 points (handled by k_pfn_big)
+  int32_t* cell;     // canvas cell of every pillar
   int64_t bigcap;
   size_t zero_bytes;  // counters | count | bytemap are contiguous: one memset per call
   int32_t *key, *rank, *slot;
@@ -576,6 +614,7 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   w.rec = c.take<uint32_t>((n + 8) * 8);
   w.bigcap = n / 33 + 8;
   w.biglist = c.take<int32_t>(w.bigcap);
+  w.cell = c.take<int32_t>((w.pcap > 0 ? w.pcap : 1) + 8);
   w.bitmap = c.take<uint32_t>(w.nwords + 8);
   w.wpre = c.take<uint32_t>(w.nwords + 8);
   w.wblk = c.take<uint32_t>(w.nblk_w + 8);
@@ -631,7 +670,7 @@ int run_voxelize(const float* points, int64_t n, int32_t stride, const GeomDev& 
   PNX_LAUNCH_CHECK();
   if (n > 0) {
     k_rank<<<nblocks(n), kBlock, 0, st>>>(w.key, n, gd, w.bitmap, w.wpre, w.wblk, w.owner, w.rank, w.slot, w.count, coords,
-                                          pillar_capacity, pillar_of_point);
+                                          pillar_capacity, pillar_of_point, w.cell);
     PNX_LAUNCH_CHECK();
   }
   k_scan_local<SCAN_PLUS1><<<w.nblk_c, kBlock, 0, st>>>(w.count, w.pcap, w.cpre, w.cblk, w.counters + 0);
@@ -669,7 +708,7 @@ int launch_canvas(const ReaderWs& w, const float* g1, int64_t g1_rows, const Geo
 // implemented in pfn_mfma.hip: the wave-tiled fp32-MFMA PFN kernel (PNX_PFN_IMPL=1, default)
 int pnx_launch_pfn_mfma(int F, const uint32_t* rec, const PnxGeomDev& geom, const uint32_t* count, const uint32_t* cpre,
                         const uint32_t* cblk, int32_t* counters, int32_t* biglist, int64_t bigcap, const float* folded, float* g1,
-                        int64_t g1_rows, int64_t n_points, hipStream_t st);
+                        int64_t g1_rows, void* canvas, const int32_t* cell_of_pillar, int canvas_dt, int64_t n_points, hipStream_t st);
 
 extern "C" {
 
@@ -710,13 +749,48 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   rc = run_voxelize(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, unq_inv != nullptr, st);
   if (rc != PNX_OK) return rc;
 
+  const char* impl_env = getenv("PNX_PFN_IMPL");  // 0 = per-pillar cross-check kernel
+  const int impl = impl_env ? atoi(impl_env) : 1;
+  const int F = stride - 1;
+  // Direct mode (NHWC canvas, MFMA PFN): the PFN kernel stores each pillar straight into its canvas cell and a fill kernel
+  // writes the zeros of every other cell -- no (P,64) fp32 intermediate, every canvas byte still written exactly once.
+  const bool direct = canvas != nullptr && canvas_layout == PNX_NHWC && impl != 0;
   // feat_max doubles as the PFN output buffer when it can hold every possible pillar
   float* g1 = (feat_max && pillar_capacity >= w.pcap) ? feat_max : w.g1;
+  if (direct && feat_max == nullptr) g1 = nullptr;
   const int64_t g1_rows = (g1 == feat_max) ? pillar_capacity : w.pcap;
+
+  static hipStream_t side = nullptr;
+  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  const bool overlap = direct && getenv("PNX_READER_OVERLAP") != nullptr;  // zero-fill on a second stream, concurrent with the PFN
+  if (overlap && side == nullptr) {
+    PNX_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
+  auto launch_fill = [&](hipStream_t fs) -> int {
+    const int tiles = ((gd.gx + 31) / 32) * (gd.gyp / 32) * gd.B;
+    if (canvas_dtype == PNX_F32) k_canvas_fill_nhwc<PNX_F32><<<tiles, kBlock, 0, fs>>>(w.bitmap, gd, canvas, occupancy);
+    else if (canvas_dtype == PNX_BF16) k_canvas_fill_nhwc<PNX_BF16><<<tiles, kBlock, 0, fs>>>(w.bitmap, gd, canvas, occupancy);
+    else k_canvas_fill_nhwc<PNX_F16><<<tiles, kBlock, 0, fs>>>(w.bitmap, gd, canvas, occupancy);
+    PNX_LAUNCH_CHECK();
+    return PNX_OK;
+  };
+  if (direct) {
+    if (overlap) {
+      PNX_CHECK_HIP(hipEventRecord(ev_fork, st));
+      PNX_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+      rc = launch_fill(side);
+      if (rc != PNX_OK) return rc;
+      PNX_CHECK_HIP(hipEventRecord(ev_join, side));
+    } else {
+      prof_mark(1, st);
+      rc = launch_fill(st);
+      if (rc != PNX_OK) return rc;
+      prof_mark(2, st);
+    }
+  }
   if (n > 0) {
-    const char* impl_env = getenv("PNX_PFN_IMPL");  // 0 = per-pillar cross-check kernel
-    const int impl = impl_env ? atoi(impl_env) : 1;
-    const int F = stride - 1;
     if (impl == 0) {
       const int nb = nblocks(w.pcap);
       switch (F) {
@@ -728,7 +802,8 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
       PNX_LAUNCH_CHECK();
     } else {
       prof_mark(4, st);
-      rc = pnx_launch_pfn_mfma(F, w.rec, gd, w.count, w.cpre, w.cblk, w.counters, w.biglist, w.bigcap, pfn_folded, g1, g1_rows, n, st);
+      rc = pnx_launch_pfn_mfma(F, w.rec, gd, w.count, w.cpre, w.cblk, w.counters, w.biglist, w.bigcap, pfn_folded, g1, g1_rows,
+                               direct ? canvas : nullptr, w.cell, canvas_dtype, n, st);
       if (rc != PNX_OK) return rc;
       prof_mark(5, st);
     }
@@ -738,14 +813,22 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
     PNX_CHECK_HIP(hipMemcpyAsync(feat_max, g1, (size_t)(pillar_capacity < w.pcap ? pillar_capacity : w.pcap) * 64 * sizeof(float),
                                  hipMemcpyDeviceToDevice, st));
   }
-  prof_mark(1, st);
-  if (canvas) {
-    if (canvas_dtype == PNX_F32) rc = launch_canvas<PNX_F32>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
-    else if (canvas_dtype == PNX_BF16) rc = launch_canvas<PNX_BF16>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
-    else rc = launch_canvas<PNX_F16>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
-    if (rc != PNX_OK) return rc;
+  if (direct) {
+    if (overlap) {
+      PNX_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
+      prof_mark(1, st);
+      prof_mark(2, st);
+    }
+  } else {
+    prof_mark(1, st);
+    if (canvas) {
+      if (canvas_dtype == PNX_F32) rc = launch_canvas<PNX_F32>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
+      else if (canvas_dtype == PNX_BF16) rc = launch_canvas<PNX_BF16>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
+      else rc = launch_canvas<PNX_F16>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
+      if (rc != PNX_OK) return rc;
+    }
+    prof_mark(2, st);
   }
-  prof_mark(2, st);
   if (counts) PNX_CHECK_HIP(hipMemcpyAsync(counts, w.counters, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   prof_mark(3, st);
   if (g_prof.on && g_prof.n < g_prof.cap) g_prof.n++;
