@@ -111,8 +111,18 @@ def main():
         dt = float(t.item())
     frames = a.batch * world * a.steps
     nx, ny = model.reader._geom.gx, model.reader._geom.gy
-    alg_bytes = (24 * pts.shape[0]) + a.batch * nx * ny * 64 * 2  # per launch (= per step per GPU)
-    achieved = alg_bytes / (c_us.value * 1e-6) / 1e9 if c_us.value > 0 else None
+    pfn_us = float(L.pnx_profile_last_pfn_us())
+    canvas_bytes = a.batch * nx * ny * 64 * 2
+    frame_alg_bytes = 24 * pts.shape[0] + canvas_bytes           # 24*N + nx*ny*64*e per frame, x frames per launch
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    model.reader.forward_dense(pts, a.batch, counts=counts)
+    P, n_kept = (int(v) for v in counts.tolist())
+    # the HBM-bound kernel of the reader is the canvas zero-fill (k_canvas_fill_nhwc): it writes every cell that holds no pillar;
+    # the P occupied cells (128 B each) are written by the PFN kernel's epilogue.  Its own algorithmic bytes per launch:
+    fill_bytes = canvas_bytes - P * 128
+    achieved = fill_bytes / (c_us.value * 1e-6) / 1e9 if c_us.value > 0 else None
+    pfn_flops = 2.0 * n_kept * (10 * 32 + 64 * 64)              # 8 832 FLOP per kept point
+    pfn_tf = pfn_flops / (pfn_us * 1e-6) / 1e12 if pfn_us > 0 else None
     traffic = None
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tj):
@@ -126,12 +136,17 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{a.config}: PillarNeXt-B nuScenes inference, {cfg['n']} pts/frame, voxel {cfg['voxel_size'][0]} m, BEV {nx}x{ny}, "
                                f"6 tasks/10 classes, cloud={a.dist}, random-init weights", "frames_per_gpu_per_step": a.batch,
-                   "global_batch": a.batch * world, "parallelism": f"frame-sharded replicas x{world}", "reader_dtype": "fp32 PFN -> bf16 canvas"},
-        "roofline": {"bound": "hbm", "kernel": "k_canvas_nhwc<bf16> (dense-canvas writer of the reader)", "achieved": round(achieved, 1) if achieved else None,
+                   "global_batch": a.batch * world, "parallelism": f"frame-sharded replicas x{world}", "reader_dtype": "fp32 MFMA PFN -> bf16 canvas",
+                   "pillars_per_launch": P, "kept_points_per_launch": n_kept},
+        "roofline": {"bound": "hbm", "kernel": "k_canvas_fill_nhwc<bf16> (writes every pillar-free cell of the dense BEV canvas; occupied cells "
+                                               "come from the PFN epilogue)", "achieved": round(achieved, 1) if achieved else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_us": round(c_us.value, 2), "reader_all_kernels_us": round(r_us.value, 2),
-                     "frac_all_reader_kernels": round(alg_bytes / (r_us.value * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if r_us.value > 0 else None,
-                     "samples": ns.value},
+                     "algorithmic_bytes_per_launch": fill_bytes, "kernel_us": round(c_us.value, 2), "samples": ns.value,
+                     "reader_all_kernels_us": round(r_us.value, 2), "reader_algorithmic_bytes_per_launch": frame_alg_bytes,
+                     "frac_all_reader_kernels": round(frame_alg_bytes / (r_us.value * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if r_us.value > 0 else None},
+        "roofline_pfn": {"bound": "mfma", "kernel": "k_pfn_mfma<5,64> (+ k_pfn_big): fp32 v_mfma_f32_32x32x2_f32", "achieved": round(pfn_tf, 2) if pfn_tf else None,
+                         "peak": 157.3, "unit": "TFLOP/s", "frac": round(pfn_tf / 157.3, 4) if pfn_tf else None, "kernel_us": round(pfn_us, 2),
+                         "algorithmic_flops_per_launch": pfn_flops},
     }
     if rank == 0:
         if world == 1 and a.cpu_frames > 0:

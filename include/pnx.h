@@ -96,10 +96,11 @@ int pnx_reader_forward(const float* points, int64_t n_points, int32_t row_stride
                        int32_t* counts, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
 
 /* Measurement hooks for bench.py (no effect on results): between begin and end every pnx_reader_forward records
- * HIP events on ITS stream around (a) the whole reader and (b) the canvas kernel, its dominant kernel.
+ * HIP events on ITS stream around (a) the whole reader, (b) the canvas writer (HBM-bound) and (c) the PFN kernel (MFMA-bound).
  * pnx_profile_end synchronises those events and returns average microseconds per call. */
 int pnx_profile_begin(int32_t max_samples);
 int pnx_profile_end(float* reader_us_avg_host, float* canvas_us_avg_host, int32_t* samples_host);
+float pnx_profile_last_pfn_us(void); /* average PFN-kernel microseconds of the interval closed by the last pnx_profile_end */
 
 /* Voxelizer alone (PillarNet.forward :78-125): indices plus the decorated (N', F+5) features
  * (rows in kept-point order; may be NULL).  Used by the training path, where Linear/BN stay in

@@ -848,6 +848,9 @@ int pnx_profile_begin(int32_t max_samples) {
   return PNX_OK;
 }
 
+static float g_last_pfn_us = 0.f;
+float pnx_profile_last_pfn_us(void) { return g_last_pfn_us; }
+
 int pnx_profile_end(float* reader_us, float* canvas_us, int32_t* samples) {
   g_prof.on = false;
   double r = 0, c = 0, f = 0;
@@ -862,6 +865,7 @@ int pnx_profile_end(float* reader_us, float* canvas_us, int32_t* samples) {
   }
   if (getenv("PNX_DEBUG") && g_prof.n) fprintf(stderr, "[pnx] profile: pfn kernel %.2f us avg over %d calls\n", f * 1e3 / g_prof.n, g_prof.n);
   const int n = g_prof.n;
+  g_last_pfn_us = n ? (float)(f * 1e3 / n) : 0.f;
   if (reader_us) *reader_us = n ? (float)(r * 1e3 / n) : 0.f;
   if (canvas_us) *canvas_us = n ? (float)(c * 1e3 / n) : 0.f;
   if (samples) *samples = n;
