@@ -309,6 +309,74 @@ def gen_decode():
     np.savez_compressed(os.path.join(OUT, "decode_2task.npz"), **out)
 
 
+def gen_loss():
+    """CenterHead.loss of the reference (centerhead.py:142-229 + loss/centerloss.py) on random head outputs and labels,
+    with gradients.  The native aligned-overlap op it calls (iou3d_nms_utils.py:75) is served by the pinned oracle."""
+    from det3d.models.heads.centerhead import CenterHead
+
+    ext = sys.modules["det3d.core.iou3d_nms.iou3d_nms_cuda"]
+
+    def boxes_aligned_overlap_bev_gpu(a, b, out):
+        out[:, 0] = torch.from_numpy(O.boxes_aligned_overlap_bev(a.detach().numpy(), b.detach().numpy(), "libm"))
+        return 1
+
+    ext.boxes_aligned_overlap_bev_gpu = boxes_aligned_overlap_bev_gpu
+    torch.cuda.FloatTensor = torch.FloatTensor
+    torch.manual_seed(11)
+    tasks = [["car"], ["pedestrian", "cyclist"]]
+    common = {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2), "iou": (1, 2)}
+    pc_range, voxel = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [0.2, 0.2, 8]
+    head = CenterHead(in_channels=16, tasks=tasks, weight=0.25, code_weights=[1.0] * 6 + [0.2, 0.2, 1.0, 1.0], common_heads=common,
+                      strides=[2, 2], share_conv_channel=16, with_reg_iou=True, voxel_size=voxel, pc_range=pc_range, out_size_factor=[4, 4])
+    B, H, W, M = 2, 32, 32, 20
+    rng = np.random.default_rng(17)
+    out, preds, feeds, example = {}, [], [], {"hm": [], "ind": [], "mask": [], "cat": [], "anno_box": [], "gt_boxes": []}
+    for t, names in enumerate(tasks):
+        d = {}
+        for k, c in [("reg", 2), ("height", 1), ("dim", 3), ("rot", 2), ("vel", 2), ("iou", 1), ("hm", len(names))]:
+            a = (rng.standard_normal((B, c, H, W)) * 0.5).astype(np.float32)
+            out[f"t{t}_{k}"] = a
+            d[k] = torch.from_numpy(a.copy()).requires_grad_(True)
+        preds.append(d)
+        feeds.append({k: v * 1.0 for k, v in d.items()})  # non-leaf views: the reference applies sigmoid_ in place
+        n_pos = [7, 12]
+        ind = np.zeros((B, M), np.int64)
+        mask = np.zeros((B, M), np.uint8)
+        cat = np.zeros((B, M), np.int64)
+        anno = np.zeros((B, M, 10), np.float32)
+        gtb = np.zeros((B, M, 7), np.float32)
+        hm = rng.uniform(0, 0.3, (B, len(names), H, W)).astype(np.float32)
+        for b in range(B):
+            cells = rng.choice(H * W, n_pos[b], replace=False)
+            ind[b, : n_pos[b]] = cells
+            mask[b, : n_pos[b]] = 1
+            cat[b, : n_pos[b]] = rng.integers(0, len(names), n_pos[b])
+            hm[b, cat[b, : n_pos[b]], cells // W, cells % W] = 1.0
+            anno[b, : n_pos[b]] = rng.standard_normal((n_pos[b], 10)).astype(np.float32) * 0.4
+            anno[b, 0, 6] = np.nan  # the reference tolerates NaN velocity targets (centerloss.py:55-56)
+            cx = (cells % W + 0.5) * 4 * voxel[0] + pc_range[0]
+            cy = (cells // W + 0.5) * 4 * voxel[1] + pc_range[1]
+            gtb[b, : n_pos[b]] = np.stack([cx + rng.normal(0, 0.3, n_pos[b]), cy + rng.normal(0, 0.3, n_pos[b]), rng.normal(-1, 0.3, n_pos[b]),
+                                           rng.uniform(1.5, 4.5, n_pos[b]), rng.uniform(0.6, 2.0, n_pos[b]), rng.uniform(1.2, 2.0, n_pos[b]),
+                                           rng.uniform(-3, 3, n_pos[b])], 1).astype(np.float32)
+        for k, v in [("hm", hm), ("ind", ind), ("mask", mask), ("cat", cat), ("anno_box", anno), ("gt_boxes", gtb)]:
+            example[k].append(torch.from_numpy(v.copy()))
+            out[f"t{t}_label_{k}"] = v
+    loss, rets = head.loss(example, feeds)
+    loss.backward()
+    out["total_loss"] = np.float32(loss.item())
+    for t, r in enumerate(rets):
+        for k in ("loss", "hm_loss", "loc_loss", "iou_loss", "iou_reg_loss"):
+            out[f"t{t}_out_{k}"] = np.float32(float(r[k]))
+        out[f"t{t}_out_loc_loss_elem"] = r["loc_loss_elem"].numpy()
+        for k in ("reg", "height", "dim", "rot", "vel", "iou", "hm"):
+            out[f"t{t}_grad_{k}"] = preds[t][k].grad.numpy()
+    out["pc_range"] = np.asarray(pc_range, np.float64)
+    out["voxel_size"] = np.asarray(voxel, np.float64)
+    np.savez_compressed(os.path.join(OUT, "head_loss_2task.npz"), **out)
+    print(f"[golden] head_loss_2task: total {loss.item():.5f}")
+
+
 def main():
     assert os.path.isdir(REF), "gen_golden.py needs the reference tree"
     os.makedirs(OUT, exist_ok=True)
@@ -318,13 +386,15 @@ def main():
     install_numba_identity()
     install_iou3d_nms()
     sys.path.insert(0, REF)
-    what = sys.argv[1:] or ["reader", "iou", "decode"]
+    what = sys.argv[1:] or ["reader", "iou", "decode", "loss"]
     if "reader" in what:
         gen_reader()
     if "iou" in what:
         gen_iou_nms()
     if "decode" in what:
         gen_decode()
+    if "loss" in what:
+        gen_loss()
 
 
 if __name__ == "__main__":

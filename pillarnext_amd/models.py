@@ -263,6 +263,44 @@ class CenterHead(nn.Module):
         x = self.shared_conv(x)
         return [task(x) for task in self.tasks]
 
+    # ---- training loss (centerhead.py:142-229)
+    def loss(self, example, preds_dicts, **kwargs):
+        from collections import OrderedDict
+
+        from .losses import FastFocalLoss, IouLoss, IouRegLoss, RegLoss, gather_at  # noqa: F401
+
+        crit, crit_reg = FastFocalLoss(), RegLoss()
+        rets, total = [], None
+        for t, pd in enumerate(preds_dicts):
+            hm = torch.clamp(torch.sigmoid(pd["hm"].float()), min=1e-4, max=1 - 1e-4)
+            hm_loss = crit(hm, example["hm"][t], example["ind"][t], example["mask"][t], example["cat"][t])
+            anno = torch.cat((pd["reg"], pd["height"], pd["dim"], pd["vel"], pd["rot"]), dim=1).float()
+            box_loss = crit_reg(anno, example["mask"][t], example["ind"][t], example["anno_box"][t])
+            loc_loss = (box_loss * box_loss.new_tensor(self.code_weights)).sum()
+            loss = hm_loss + self.weight * loc_loss
+            ret = OrderedDict(task=self.class_names[t], loss=loss, hm_loss=hm_loss.detach().cpu(), loc_loss=loc_loss.detach().cpu(),
+                              loc_loss_elem=box_loss.detach().cpu(), num_positive=example["mask"][t].float().sum().cpu())
+            if self.with_iou or self.with_reg_iou:
+                B, _, H, W = pd["dim"].shape
+                dim = torch.exp(torch.clamp(pd["dim"].float(), min=-5, max=5))
+                rot = torch.atan2(pd["rot"][:, 0:1].float(), pd["rot"][:, 1:2].float())
+                ys, xs = torch.meshgrid(torch.arange(H, device=dim.device), torch.arange(W, device=dim.device), indexing="ij")
+                xs = (xs.view(1, 1, H, W).float() + pd["reg"][:, 0:1].float()) * self.out_size_factor[t] * self.voxel_size[0] + self.pc_range[0]
+                ys = (ys.view(1, 1, H, W).float() + pd["reg"][:, 1:2].float()) * self.out_size_factor[t] * self.voxel_size[1] + self.pc_range[1]
+                boxes = torch.cat([xs, ys, pd["height"].float(), dim, rot], dim=1)          # (B,7,H,W)
+                if self.with_iou:
+                    iou_loss = IouLoss()(pd["iou"].float(), example["mask"][t], example["ind"][t], boxes.detach(), example["gt_boxes"][t])
+                    loss = loss + iou_loss
+                    ret["iou_loss"] = iou_loss.detach().cpu()
+                if self.with_reg_iou:
+                    iou_reg = IouRegLoss()(boxes, example["mask"][t], example["ind"][t], example["gt_boxes"][t])
+                    loss = loss + self.weight * iou_reg
+                    ret["iou_reg_loss"] = iou_reg.detach().cpu()
+                ret["loss"] = loss
+            rets.append(ret)
+            total = loss if total is None else total + loss
+        return total, rets
+
     # ---- inference: decode + per-class rotated NMS (centerhead.py:231-384)
     @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg):

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Data-parallel training step of PillarNeXt-B on synthetic frames + labels (one process per GPU, torchrun / RCCL).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/train_step.py --batch 4
+
+Mirrors tools/train.py:26-67 + trainer/trainer/trainer.py:94-108 of the reference: SyncBatchNorm conversion, DDP wrap
+(bucketed gradient all-reduce overlapped with backward), AdamW(0.9,0.99,wd .01), clip 35."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pillarnext_amd import dist_utils, synth  # noqa: E402
+from pillarnext_amd.models import NUSC_TASKS, build_pillarnext_b  # noqa: E402
+
+
+def synthetic_labels(tasks, B, H, W, M, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    ex = {k: [] for k in ("hm", "ind", "mask", "cat", "anno_box", "gt_boxes")}
+    for names in tasks:
+        ex["hm"].append(torch.rand((B, len(names), H, W), device=dev, generator=g) * 0.2)
+        ex["ind"].append(torch.randint(0, H * W, (B, M), device=dev, generator=g))
+        m = torch.zeros((B, M), dtype=torch.uint8, device=dev)
+        m[:, : M // 8] = 1
+        ex["mask"].append(m)
+        ex["cat"].append(torch.randint(0, len(names), (B, M), device=dev, generator=g))
+        ex["anno_box"].append(torch.randn((B, M, 10), device=dev, generator=g) * 0.3)
+        ex["gt_boxes"].append(torch.rand((B, M, 7), device=dev, generator=g) + torch.tensor([0, 0, -1, 1.5, 0.6, 1.2, 0], device=dev))
+    return ex
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--config", default="C2")
+    a = ap.parse_args()
+    rank, world, local = dist_utils.init()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg = synth.CONFIGS[a.config]
+    torch.manual_seed(0)
+    model = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"]).to(dev).train()
+    model = dist_utils.wrap_ddp(model, device_ids=[local])
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.01)
+    pts = torch.from_numpy(synth.make_batch(a.config, a.batch, "sweep", frame0=rank * a.batch)).to(dev)
+    net = model.module if hasattr(model, "module") else model
+    ny, nx = (int(v) for v in net.reader.grid_size)
+    ex = synthetic_labels(NUSC_TASKS, a.batch, ny // 4, nx // 4, 500, dev, 100 + rank)
+    ex.update(points=pts, batch_size=a.batch)
+    for it in range(a.steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss, _ = model(ex)
+        opt.zero_grad()
+        loss.backward()                                   # DDP: bucketed all-reduce over RCCL overlapped with backward
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 35)
+        opt.step()
+        torch.cuda.synchronize()
+        dt = dist_utils.max_over_ranks(time.perf_counter() - t0, dev)
+        if rank == 0:
+            print(f"step {it}: loss {loss.item():.4f}  {dt*1e3:.1f} ms  ({a.batch * world / dt:.1f} frames/s over {world} GPU)")
+
+
+if __name__ == "__main__":
+    main()
