@@ -296,7 +296,7 @@ class CenterHead(nn.Module):
                     iou_reg = IouRegLoss()(boxes, example["mask"][t], example["ind"][t], example["gt_boxes"][t])
                     loss = loss + self.weight * iou_reg
                     ret["iou_reg_loss"] = iou_reg.detach().cpu()
-                ret["loss"] = loss
+                # ret['loss'] keeps the pre-IoU value, as the reference's log dict does (centerhead.py:165,212-222)
             rets.append(ret)
             total = loss if total is None else total + loss
         return total, rets
