@@ -237,6 +237,67 @@ __device__ __forceinline__ int seg_size(const int32_t* __restrict__ seg_off, con
   return n;
 }
 
+// Rotated variant.  The reference lets every lane walk its 64 columns serially through the full polygon clipping
+// (cu:311-321), although almost all pairs are far apart.  Here a tile works in two phases:
+//   1. every lane (= row) builds the 64-bit set of columns whose bounding circles touch its own (a dozen flops per pair);
+//   2. the surviving (row, col) pairs of the whole tile are packed into one LDS list and dealt out evenly to the 64 lanes,
+//      so the expensive clipping runs with all lanes busy; results are OR-ed into the row masks with LDS atomics.
+// Pairs rejected in phase 1 have overlap exactly 0 in the reference too (cnt = 0), so the mask is bit-identical.
+__global__ __launch_bounds__(64) void k_nms_mask_rot(const float* __restrict__ boxes, const int32_t* __restrict__ seg_off,
+                                                     const int32_t* __restrict__ seg_len, const float* __restrict__ thresh,
+                                                     uint64_t* __restrict__ mask, int cbmax) {
+  const int seg = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;
+  const int off = seg_off[seg], n = seg_size(seg_off, seg_len, seg);
+  if (rb * 64 >= n || cb * 64 >= n) return;
+  const float thr = thresh[seg];
+  const int row_size = min(n - rb * 64, 64), col_size = min(n - cb * 64, 64);
+  const int t = threadIdx.x;
+  __shared__ BoxPre s_col[64], s_row[64];
+  __shared__ unsigned short s_pairs[4096];
+  __shared__ unsigned int s_bits[64 * 2];
+  __shared__ float spx[kMaxPts * 64], spy[kMaxPts * 64], sang[kMaxPts * 64];
+  if (t < col_size) s_col[t] = make_box(boxes + (int64_t)(off + cb * 64 + t) * 7);
+  if (t < row_size) s_row[t] = make_box(boxes + (int64_t)(off + rb * 64 + t) * 7);
+  s_bits[t] = 0;
+  s_bits[64 + t] = 0;
+  __syncthreads();
+  // phase 1: candidate columns of my row
+  uint64_t cand = 0;
+  if (t < row_size) {
+    const BoxPre A = s_row[t];
+    const int start = (rb == cb) ? t + 1 : 0;
+    for (int k = start; k < col_size; k++)
+      if (thr < 0.f || !far_apart(A, s_col[k])) cand |= 1ULL << k;  // iou 0 > thr only for a negative threshold
+  }
+  // pack the pairs: exclusive prefix of the per-row counts across the wave
+  const int cnt = __popcll(cand);
+  int inc = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(inc, d);
+    if (t >= d) inc += y;
+  }
+  const int total = __shfl(inc, 63);
+  int o = inc - cnt;
+  uint64_t c = cand;
+  while (c) {
+    const int k = __ffsll((long long)c) - 1;
+    c &= c - 1;
+    s_pairs[o++] = (unsigned short)((t << 6) | k);
+  }
+  __syncthreads();
+  // phase 2: the real work, evenly spread
+  for (int e = t; e < total; e += 64) {
+    const int pr = s_pairs[e];
+    const int i = pr >> 6, k = pr & 63;
+    const float v = iou_bev<64>(s_row[i], s_col[k], spx, spy, sang, t);  // row box first, as cu:317
+    if (v > thr) atomicOr(&s_bits[2 * i + (k >> 5)], 1u << (k & 31));
+  }
+  __syncthreads();
+  if (t < row_size) mask[(int64_t)(off + rb * 64 + t) * cbmax + cb] = (uint64_t)s_bits[2 * t] | ((uint64_t)s_bits[2 * t + 1] << 32);
+}
+
 template <bool ROTATED>
 __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int32_t* __restrict__ seg_off,
                                                  const int32_t* __restrict__ seg_len, const float* __restrict__ thresh,
@@ -248,40 +309,23 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes
   const float thr = thresh[seg];
   const int row_size = min(n - rb * 64, 64), col_size = min(n - cb * 64, 64);
   const int t = threadIdx.x;
-  __shared__ BoxPre s_col[64];
   __shared__ float s_raw[64 * 7];
-  __shared__ float spx[kMaxPts * 64], spy[kMaxPts * 64], sang[kMaxPts * 64];
   if (t < col_size) {
     const float* p = boxes + (int64_t)(off + cb * 64 + t) * 7;
-    if (ROTATED) {
-      s_col[t] = make_box(p);
-    } else {
 #pragma unroll
-      for (int k = 0; k < 7; k++) s_raw[t * 7 + k] = p[k];
-    }
+    for (int k = 0; k < 7; k++) s_raw[t * 7 + k] = p[k];
   }
   __syncthreads();
   if (t < row_size) {
     const int i = rb * 64 + t;
     const float* pr = boxes + (int64_t)(off + i) * 7;
-    BoxPre A;
     float ra[7];
-    if (ROTATED) {
-      A = make_box(pr);
-    } else {
 #pragma unroll
-      for (int k = 0; k < 7; k++) ra[k] = pr[k];
-    }
+    for (int k = 0; k < 7; k++) ra[k] = pr[k];
     uint64_t bits = 0;
     const int start = (rb == cb) ? t + 1 : 0;
-    for (int k = start; k < col_size; k++) {
-      float v;
-      if (ROTATED)
-        v = iou_bev<64>(A, s_col[k], spx, spy, sang, t);
-      else
-        v = iou_normal(ra, s_raw + k * 7);
-      if (v > thr) bits |= 1ULL << k;
-    }
+    for (int k = start; k < col_size; k++)
+      if (iou_normal(ra, s_raw + k * 7) > thr) bits |= 1ULL << k;
     mask[(int64_t)(off + i) * cbmax + cb] = bits;
   }
 }
@@ -365,7 +409,8 @@ int nms_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* s
   PNX_REQUIRE(((uintptr_t)workspace & 7) == 0 && workspace_bytes >= 8, PNX_ERR_WORKSPACE, "bad workspace");
   uint64_t* mask = (uint64_t*)workspace;
   dim3 grid(cbmax, cbmax, num_segments);
-  k_nms_mask<ROTATED><<<grid, 64, 0, st>>>(boxes, seg_offsets, seg_len, thresh, mask, cbmax);
+  if (ROTATED) k_nms_mask_rot<<<grid, 64, 0, st>>>(boxes, seg_offsets, seg_len, thresh, mask, cbmax);
+  else k_nms_mask<false><<<grid, 64, 0, st>>>(boxes, seg_offsets, seg_len, thresh, mask, cbmax);
   k_nms_greedy<<<num_segments, 64, cbmax * sizeof(uint64_t), st>>>(mask, seg_offsets, seg_len, cbmax, post_max, keep, keep_count);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
