@@ -54,8 +54,8 @@ template <int CTRL, int ROW_MASK, int N>
 __device__ __forceinline__ void max_step(float* v, bool take) {
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    const float t = dpp_f<CTRL, ROW_MASK>(v[i], v[i]);
-    v[i] = fmaxf(v[i], take ? t : v[i]);
+    const float m = fmaxf(dpp_f<CTRL, ROW_MASK>(v[i], v[i]), v[i]);  // one v_max_f32_dpp
+    v[i] = take ? m : v[i];
   }
 }
 // idx = position of the lane's point inside its pillar: lane l-d belongs to the same pillar iff idx >= d.
