@@ -1,0 +1,54 @@
+"""GPU: the fused dense epilogue / mask-pool kernels vs their PyTorch statement, and the point uploader."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("residual", [False, True])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("relu", [False, True])
+def test_bias_act_mask_matches_torch(residual, masked, relu):
+    from pillarnext_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    B, C, H, W = 2, 24, 37, 53
+    x = torch.randn((B, C, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = torch.randn((B, C, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if residual else None
+    bias = torch.randn((C,), device="cuda", generator=g)
+    mask = (torch.rand((B, H, W), device="cuda", generator=g) > 0.6).to(torch.uint8) if masked else None
+    ref = x.float() + bias.view(1, -1, 1, 1)
+    if residual:
+        ref = ref + res.float()
+    if relu:
+        ref = torch.relu(ref)
+    ref = ref.to(torch.bfloat16)                       # one rounding, as in the kernel
+    if masked:
+        ref = ref * mask.unsqueeze(1).to(torch.bfloat16)
+    got = ops.bias_act_mask_(x.clone(memory_format=torch.channels_last), bias, mask, res, relu)
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_mask_pool3_matches_maxpool(stride):
+    from pillarnext_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(1)
+    m = (torch.rand((3, 45, 62), device="cuda", generator=g) > 0.9).to(torch.uint8)
+    ref = torch.nn.functional.max_pool2d(m.float().unsqueeze(1), 3, stride, 1).squeeze(1).to(torch.uint8)
+    assert torch.equal(ops.mask_pool3(m, stride), ref)
+
+
+def test_point_uploader_roundtrip():
+    from pillarnext_amd.io import PointUploader, collate_points
+
+    rng = np.random.default_rng(0)
+    up = PointUploader(10_000)
+    for it in range(5):
+        clouds = [rng.standard_normal((int(rng.integers(100, 2000)), 5)).astype(np.float32) for _ in range(3)]
+        dev, B = up.upload(clouds)
+        assert B == 3
+        ref = collate_points(clouds)
+        assert np.array_equal(dev.cpu().numpy(), ref)
+        assert np.array_equal(np.unique(ref[:, 0]), [0, 1, 2])
