@@ -226,3 +226,68 @@ def test_product_fails_loudly_without_library(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(os.path.dirname(_lib.LIB_PATH), "does_not_exist.so"))
     with pytest.raises(_lib.PnxError):
         _lib.lib()
+
+
+@pytest.mark.parametrize("F", [3, 4, 6])
+def test_other_point_feature_counts_vs_oracle(oracle, F, pfn_impl):
+    """The fused kernels are instantiated for 3..6 point features (x,y,z + 0..3 extras); each against the oracle."""
+    from pillarnext_amd import synth
+
+    cfg = synth.CONFIGS["C1"]
+    rng = np.random.default_rng(F)
+    base = synth.make_batch("C1", 2, "sweep", n=15_000)
+    pts = np.concatenate([base[:, :4], rng.uniform(0, 1, (len(base), max(F - 3, 0))).astype(np.float32)], axis=1)[:, : 1 + F]
+    layers = synth.pfn_params(F, (64, 64), seed=F)
+    o = oracle.reader_forward(pts, cfg["pc_range"], cfg["voxel_size"], [64, 64], layers, B=2)
+    net = make_net(cfg["pc_range"], cfg["voxel_size"], layers, F=F)
+    fm, coords, _ = net(torch.from_numpy(pts).cuda(), 2)
+    assert np.array_equal(coords.cpu().numpy(), o["coords"])
+    np.testing.assert_allclose(fm.cpu().numpy(), o["feat_max"], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("num_filters", [(32,), (64,), (32, 64), (64, 64, 128)])
+def test_other_pfn_shapes_take_the_unfused_path(oracle, num_filters):
+    """num_filters other than [64,64]: HIP voxelizer + HIP scatter-max + torch Linear/BN (eval) == oracle."""
+    from pillarnext_amd import synth
+
+    cfg = synth.CONFIGS["C1"]
+    pts = synth.make_batch("C1", 1, "sweep", n=6_000)
+    layers = synth.pfn_params(5, num_filters, seed=3)
+    o = oracle.reader_forward(pts, cfg["pc_range"], cfg["voxel_size"], list(num_filters), layers, B=1)
+    net = make_net(cfg["pc_range"], cfg["voxel_size"], layers, num_filters=num_filters)
+    assert not net._fused_supported()
+    with torch.no_grad():
+        fm, coords, _ = net(torch.from_numpy(pts).cuda(), 1)
+    assert np.array_equal(coords.cpu().numpy(), o["coords"])
+    np.testing.assert_allclose(fm.cpu().numpy(), o["feat_max"], rtol=RTOL, atol=ATOL)
+
+
+def test_many_points_in_one_pillar_and_clamped_record_fields():
+    """A pillar with far more than 65535 points (the 16-bit idx/rem fields of the slot records saturate) next to normal ones."""
+    from pillarnext_amd import synth
+
+    cfg = synth.CONFIGS["C1"]
+    layers = synth.pfn_params()
+    net = make_net(cfg["pc_range"], cfg["voxel_size"], layers)
+    rng = np.random.default_rng(9)
+    n_big = 70_000
+    big = np.zeros((n_big, 6), np.float32)
+    big[:, 1] = 10.0 + rng.uniform(0, 0.19, n_big)
+    big[:, 2] = -20.0 + rng.uniform(0, 0.19, n_big)
+    big[:, 3] = rng.uniform(-2, 1, n_big)
+    big[:, 4:] = rng.uniform(0, 1, (n_big, 2))
+    rest = synth.make_batch("C1", 1, "uniform", n=3000)
+    pts = np.concatenate([rest[:1500], big, rest[1500:]])
+    tp = torch.from_numpy(pts).cuda()
+    fm_a, co_a, _ = net(tp, 1)
+    import os
+    os.environ["PNX_PFN_IMPL"] = "0"
+    try:
+        fm_b, co_b, _ = net(tp, 1)
+    finally:
+        del os.environ["PNX_PFN_IMPL"]
+    assert torch.equal(co_a, co_b)
+    torch.testing.assert_close(fm_a, fm_b, rtol=1e-4, atol=1e-4)
+    canvas = net.forward_dense(tp, 1)
+    c = co_a.long()
+    assert torch.equal(canvas.permute(0, 2, 3, 1)[c[:, 0], c[:, 1], c[:, 2]], fm_a.to(torch.bfloat16))
