@@ -501,12 +501,36 @@ class _FusedConv(nn.Module):
         return ops.bias_act_mask_(y, self.bias, mask, residual, self.relu)
 
 
+class _HipConv3x3(nn.Module):
+    """3x3 masked conv + folded BN + [residual] + ReLU + mask in ONE HIP kernel (csrc/conv3x3.hip) -- no MIOpen, no epilogue pass."""
+
+    def __init__(self, weight, bias, stride=1):
+        super().__init__()
+        self.cout, self.stride = weight.shape[0], int(stride)
+        self.register_buffer("wfrag", ops.conv3x3_pack_weights(weight))
+        self.register_buffer("bias", bias.float().contiguous())
+
+    def forward(self, x, mask=None, residual=None):
+        return ops.conv3x3_masked(x, self.wfrag, self.bias, self.cout, self.stride, mask, residual, True)
+
+
+def _backbone_conv(weight, bias, stride, padding, dtype, hip_conv):
+    co, ci, kh, kw = weight.shape
+    if hip_conv and dtype == torch.bfloat16 and (kh, kw) == (3, 3) and padding == 1 and (ci, co) in ops.CONV3X3_SHAPES and stride in (1, 2):
+        return _HipConv3x3(weight, bias, stride)
+    return _FusedConv(weight, bias, stride, padding, dtype=dtype)
+
+
 class FusedPillarNeXt(nn.Module):
     """Inference-only re-expression of SingleStageDetector (eval BN folded, epilogues fused, the 6-7 SepHead branches of a
     task merged into two convolutions).  Mathematically the same network; weights come from the trained modules."""
 
-    def __init__(self, det, dtype=torch.bfloat16):
+    def __init__(self, det, dtype=torch.bfloat16, hip_conv=None):
         super().__init__()
+        if hip_conv is None:
+            import os
+
+            hip_conv = os.environ.get("PNX_HIP_CONV", "1") != "0"
         self.reader = det.reader
         self.post_processing = det.post_processing
         self.head_ref = det.head  # predict() / rectifier / class bookkeeping
@@ -519,12 +543,12 @@ class FusedPillarNeXt(nn.Module):
             mods = nn.ModuleList()
             first = blk[0]
             w, b = _fold_bn(first.conv.weight, first.norm)
-            mods.append(_FusedConv(w, b, first.stride, first.kernel_size // 2, dtype=dtype))
+            mods.append(_backbone_conv(w, b, first.stride, first.kernel_size // 2, dtype, hip_conv))
             for rb in list(blk)[1:]:
                 w1, b1 = _fold_bn(rb.block1.conv.weight, rb.block1.norm)
                 w2, b2 = _fold_bn(rb.conv2.weight, rb.norm2)
-                mods.append(_FusedConv(w1, b1, 1, rb.block1.kernel_size // 2, dtype=dtype))
-                mods.append(_FusedConv(w2, b2, 1, rb.conv2.kernel_size[0] // 2, dtype=dtype))
+                mods.append(_backbone_conv(w1, b1, 1, rb.block1.kernel_size // 2, dtype, hip_conv))
+                mods.append(_backbone_conv(w2, b2, 1, rb.conv2.kernel_size[0] // 2, dtype, hip_conv))
             self.stages.append(mods)
             self.stage_meta.append((first.stride, first.subm))
         w, b = _fold_bn(bb.mapping[0].weight, bb.mapping[1])

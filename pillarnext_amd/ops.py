@@ -202,3 +202,26 @@ def mask_pool3(mask, stride):
     out = torch.empty((B, Ho, Wo), dtype=torch.uint8, device=mask.device)
     check(lib().pnx_mask_pool3(ptr(mask), B, H, W, stride, ptr(out), stream_ptr()), "pnx_mask_pool3")
     return out
+
+
+CONV3X3_SHAPES = {(64, 64), (64, 128), (128, 128)}
+
+
+def conv3x3_pack_weights(w):
+    """(Cout, Cin, 3, 3) -> bf16 MFMA-fragment order [tap][cin/16][cout/32][lane = kb*32 + n][8]  (csrc/conv3x3.hip)."""
+    co, ci = w.shape[:2]
+    v = w.detach().float().reshape(co // 32, 32, ci // 16, 2, 8, 3, 3)         # (mt, n, cb, kb, e, ky, kx)
+    v = v.permute(5, 6, 2, 0, 3, 1, 4).contiguous()                               # (ky, kx, cb, mt, kb, n, e)
+    return v.reshape(-1).to(torch.bfloat16).contiguous()
+
+
+def conv3x3_masked(x, wfrag, bias, cout, stride=1, mask=None, residual=None, relu=True):
+    """x (B,Cin,H,W) channels_last bf16 -> (B,Cout,Ho,Wo) channels_last bf16; mask uint8 (B,Ho,Wo) of the OUTPUT sites."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise PnxError("conv3x3_masked needs a channels_last bf16 CUDA tensor")
+    B, ci, H, W = x.shape
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    y = torch.empty((B, cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    check(lib().pnx_conv3x3_bf16(ptr(x), ptr(wfrag), ptr(bias), ptr(residual), ptr(mask), ptr(y), B, H, W, ci, cout, stride, 1 if relu else 0,
+                                 stream_ptr()), "pnx_conv3x3_bf16")
+    return y

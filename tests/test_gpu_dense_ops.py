@@ -52,3 +52,35 @@ def test_point_uploader_roundtrip():
         ref = collate_points(clouds)
         assert np.array_equal(dev.cpu().numpy(), ref)
         assert np.array_equal(np.unique(ref[:, 0]), [0, 1, 2])
+
+
+@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 128, 2), (128, 128, 1), (64, 64, 2)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_conv3x3_masked_matches_torch(cin, cout, stride, residual):
+    from pillarnext_amd import ops
+
+    if residual and (stride != 1 or cin != cout):
+        pytest.skip("residual only on submanifold blocks")
+    g = torch.Generator(device="cuda").manual_seed(cin + cout + stride)
+    B, H, W = 2, 45, 70
+    x = (torch.randn((B, cin, H, W), device="cuda", generator=g) * (torch.rand((B, 1, H, W), device="cuda", generator=g) > 0.5)).to(torch.bfloat16)
+    x = x.contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((cout, cin, 3, 3), device="cuda", generator=g) / (3 * cin ** 0.5)).to(torch.bfloat16)
+    bias = torch.randn((cout,), device="cuda", generator=g)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    mask = (torch.rand((B, Ho, Wo), device="cuda", generator=g) > 0.4).to(torch.uint8)
+    mask[0, :9] = 0            # whole tiles without an active site
+    mask[1, :, 33:] = 0
+    res = torch.randn((B, cout, Ho, Wo), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if residual else None
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), None, stride, 1) + bias.view(1, -1, 1, 1)
+    if residual:
+        ref = ref + res.float()
+    ref = torch.relu(ref) * mask.unsqueeze(1).float()
+    got = ops.conv3x3_masked(x, ops.conv3x3_pack_weights(w), bias, cout, stride, mask, res, True).float()
+    assert got.shape == ref.shape
+    assert bool((got[(mask == 0).unsqueeze(1).expand_as(got)] == 0).all())
+    torch.testing.assert_close(got, ref, rtol=1.6e-2, atol=2e-2)      # one bf16 rounding of an fp32-accumulated sum
+    # unmasked / no relu
+    got2 = ops.conv3x3_masked(x, ops.conv3x3_pack_weights(w), bias, cout, stride, None, None, False).float()
+    ref2 = torch.nn.functional.conv2d(x.float(), w.float(), None, stride, 1) + bias.view(1, -1, 1, 1)
+    torch.testing.assert_close(got2, ref2, rtol=1.6e-2, atol=2e-2)
