@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
         }
         __syncthreads();
         if (any) {
-          for (int tap = 0; tap < 9; tap++) {
+          for (int tap = 0; tap < 9; tap++) {  // not unrolled: a full unroll spills (measured: 484 B scratch, 25 % slower)
             const int dy = tap / 3, dx = tap % 3;  // halo coordinates: +1 already included
             const int c = px + dx;
 #pragma unroll
