@@ -135,7 +135,7 @@ int pnx_bias_act_mask(const void* x, const void* residual, const float* bias, co
 /* Masked 3x3 convolution (pad 1, stride 1 or 2) with the same epilogue fused, bf16 NHWC, fp32 accumulation on MFMA:
  *   y = mask_out * [relu]( conv3x3(x, W) + bias [+ residual] ),  rows/tiles of the output without an active site are skipped.
  *   x (B,h,w,cin), y/residual (B,ho,wo,cout), mask uint8 (B,ho,wo) or NULL; wfrag = weights in MFMA-fragment order
- *   (pillarnext_amd/ops.py::conv3x3_pack_weights).  Built for (cin,cout) in {(64,64), (64,128), (128,128)}. */
+ *   (pillarnext_amd/ops.py::conv3x3_pack_weights).  Built for (cin,cout) in {(64,64), (64,128), (128,128)} at stride 1|2 and {(64,320), (64,384), (64,448)} at stride 1. */
 int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, pnx_stream_t stream);
 /* Active-site rule of SparseConv2d(k=3, stride, pad=1): mask_out = maxpool3x3(mask_in, stride, 1); uint8 (B,h,w) -> (B,ho,wo). */

@@ -146,16 +146,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const uint16_t* __restrict__
 // ds_read_b128 of a B fragment does not pile onto one bank column, and then serves all 9 taps of all 4 waves -- the direct
 // kernel above re-reads every pixel line 9 times through L1/L2 (measured: 4.8 GB of L2->L1 traffic per 1440x1440 frame).
 // Weights (fragment order, 1 KiB per wave-load, shared by every wave on the chip) come straight from L2.  CIN > 64 is
-// processed as successive 64-channel slabs.
+// processed as successive 64-channel slabs; COUT > 64 as successive 64-channel passes over the same staged tile (the merged
+// SepHead convolution 64 -> 384 stages its input once and reuses it six times).
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                      const float* __restrict__ bias, const uint16_t* __restrict__ res,
                                                      const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
                                                      int relu) {
-  constexpr int CB = CIN / 16, MT = COUT / 32;
-  constexpr int NT = (MT <= 2) ? 4 : 2;  // rows per wave
-  constexpr int TH = 4 * NT;             // rows per workgroup
-  constexpr int HW_ = 34;                // halo tile width
+  constexpr int CB = CIN / 16;
+  constexpr int MTALL = COUT / 32;           // 32-channel output tiles in total
+  constexpr int MT = 2;                      // ... handled two at a time (64 output channels per pass over the staged tile)
+  constexpr int NT = 4;                      // rows per wave
+  constexpr int TH = 4 * NT;                 // rows per workgroup
+  constexpr int HW_ = 34;                    // halo tile width
+  constexpr int NSLAB = CIN / 64;            // 64-channel input slabs (LDS holds them all: 78 KiB each -> CIN 64 only; else one at a time)
   __shared__ uint4 s_in[(TH + 2) * HW_ * 8];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int px = lane & 31, kb = lane >> 5;
@@ -178,80 +182,102 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
       any = any || any_row[j];
     }
     const bool wg_any = __syncthreads_or(any ? 1 : 0) != 0;  // also: everybody is done with the previous tile's LDS
-    v16f acc[NT][MT];
+
+    for (int mg = 0; mg < MTALL; mg += MT) {  // 64 output channels per pass
+      v16f acc[NT][MT];
 #pragma unroll
-    for (int j = 0; j < NT; j++)
+      for (int j = 0; j < NT; j++)
 #pragma unroll
-      for (int m = 0; m < MT; m++)
+        for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[j][m][i] = 0.f;
-    if (wg_any) {
-      for (int ch0 = 0; ch0 < CIN; ch0 += 64) {
-        if (ch0 > 0) __syncthreads();
-        for (int idx = threadIdx.x; idx < (TH + 2) * HW_ * 8; idx += 256) {
-          const int chunk = idx & 7, pix = idx >> 3;
-          const int r = pix / HW_, c = pix - r * HW_;
-          const int iy = y0 - 1 + r, ix = x0 - 1 + c;
-          uint4 q = make_uint4(0, 0, 0, 0);
-          if (iy >= 0 && iy < H && ix >= 0 && ix < W) q = *reinterpret_cast<const uint4*>(x + (((int64_t)b * H + iy) * W + ix) * CIN + ch0 + chunk * 8);
-          s_in[pix * 8 + (chunk ^ (c & 7))] = q;
-        }
-        __syncthreads();
-        if (any) {
-          for (int tap = 0; tap < 9; tap++) {  // not unrolled: a full unroll spills (measured: 484 B scratch, 25 % slower)
-            const int dy = tap / 3, dx = tap % 3;  // halo coordinates: +1 already included
-            const int c = px + dx;
+          for (int i = 0; i < 16; i++) acc[j][m][i] = 0.f;
+      if (wg_any) {
+        for (int slab = 0; slab < NSLAB; slab++) {
+          const int ch0 = slab * 64;
+          if (NSLAB > 1 || mg == 0) {  // with a single slab the staged tile serves every output-channel pass
+            if (slab > 0 || mg > 0) __syncthreads();
+#pragma unroll 5
+            for (int idx = threadIdx.x; idx < (TH + 2) * HW_ * 8; idx += 256) {
+              const int chunk = idx & 7, pix = idx >> 3;
+              const int r = pix / HW_, c = pix - r * HW_;
+              const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+              uint4 q = make_uint4(0, 0, 0, 0);
+              if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                q = *reinterpret_cast<const uint4*>(x + (((int64_t)b * H + iy) * W + ix) * CIN + ch0 + chunk * 8);
+              s_in[pix * 8 + (chunk ^ (c & 7))] = q;
+            }
+            __syncthreads();
+          }
+          if (any) {
+            // weight fragments of one tap (4 k-steps x 2 channel tiles) are fetched one tap ahead of their MFMAs
+            uint4 wn[4][MT];
 #pragma unroll
-            for (int cbl = 0; cbl < 4; cbl++) {
-              const int ks = tap * CB + (ch0 >> 4) + cbl;
-              bf16x8 af[MT];
+            for (int cbl = 0; cbl < 4; cbl++)
 #pragma unroll
-              for (int m = 0; m < MT; m++) af[m] = __builtin_bit_cast(bf16x8, wfrag[(ks * MT + m) * 64 + lane]);
+              for (int m = 0; m < MT; m++) wn[cbl][m] = wfrag[((0 * CB + (ch0 >> 4) + cbl) * MTALL + mg + m) * 64 + lane];
+            for (int tap = 0; tap < 9; tap++) {  // not unrolled: a full unroll spills (measured: 484 B scratch, 25 % slower)
+              const int dy = tap / 3, dx = tap % 3;  // halo coordinates: +1 already included
+              const int c = px + dx;
+              uint4 wc[4][MT];
 #pragma unroll
-              for (int j = 0; j < NT; j++) {
-                if (!any_row[j]) continue;  // wave-uniform
-                const uint4 q = s_in[((wv * NT + j + dy) * HW_ + c) * 8 + ((cbl * 2 + kb) ^ (c & 7))];
-                const bf16x8 bfr = __builtin_bit_cast(bf16x8, q);
+              for (int cbl = 0; cbl < 4; cbl++)
 #pragma unroll
-                for (int m = 0; m < MT; m++) acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr, acc[j][m], 0, 0, 0);
+                for (int m = 0; m < MT; m++) wc[cbl][m] = wn[cbl][m];
+              if (tap < 8) {
+#pragma unroll
+                for (int cbl = 0; cbl < 4; cbl++)
+#pragma unroll
+                  for (int m = 0; m < MT; m++) wn[cbl][m] = wfrag[(((tap + 1) * CB + (ch0 >> 4) + cbl) * MTALL + mg + m) * 64 + lane];
+              }
+#pragma unroll
+              for (int cbl = 0; cbl < 4; cbl++) {
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                  if (!any_row[j]) continue;  // wave-uniform
+                  const uint4 q = s_in[((wv * NT + j + dy) * HW_ + c) * 8 + ((cbl * 2 + kb) ^ (c & 7))];
+                  const bf16x8 bfr = __builtin_bit_cast(bf16x8, q);
+#pragma unroll
+                  for (int m = 0; m < MT; m++)
+                    acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wc[cbl][m]), bfr, acc[j][m], 0, 0, 0);
+                }
               }
             }
           }
         }
       }
-    }
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-      const int oy = oy0 + j;
-      if (!(ox < W && oy < H)) continue;
-      const int64_t o = (((int64_t)b * H + oy) * W + ox) * COUT;
+      for (int j = 0; j < NT; j++) {
+        const int oy = oy0 + j;
+        if (!(ox < W && oy < H)) continue;
+        const int64_t o = (((int64_t)b * H + oy) * W + ox) * COUT;
 #pragma unroll
-      for (int m = 0; m < MT; m++) {
+        for (int m = 0; m < MT; m++) {
 #pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-          const int c0 = m * 32 + 8 * gq + 4 * kb;
-          uint2 p = make_uint2(0, 0);
-          if (act[j]) {
-            const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
-            float v0 = acc[j][m][4 * gq + 0] + bv.x, v1 = acc[j][m][4 * gq + 1] + bv.y;
-            float v2 = acc[j][m][4 * gq + 2] + bv.z, v3 = acc[j][m][4 * gq + 3] + bv.w;
-            if (res != nullptr) {
-              const uint2 r = *reinterpret_cast<const uint2*>(res + o + c0);
-              v0 += bf2f_lo(r.x);
-              v1 += bf2f_hi(r.x);
-              v2 += bf2f_lo(r.y);
-              v3 += bf2f_hi(r.y);
+          for (int gq = 0; gq < 4; gq++) {
+            const int c0 = (mg + m) * 32 + 8 * gq + 4 * kb;
+            uint2 p = make_uint2(0, 0);
+            if (act[j]) {
+              const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+              float v0 = acc[j][m][4 * gq + 0] + bv.x, v1 = acc[j][m][4 * gq + 1] + bv.y;
+              float v2 = acc[j][m][4 * gq + 2] + bv.z, v3 = acc[j][m][4 * gq + 3] + bv.w;
+              if (res != nullptr) {
+                const uint2 r = *reinterpret_cast<const uint2*>(res + o + c0);
+                v0 += bf2f_lo(r.x);
+                v1 += bf2f_hi(r.x);
+                v2 += bf2f_lo(r.y);
+                v3 += bf2f_hi(r.y);
+              }
+              if (relu) {
+                v0 = fmaxf(v0, 0.f);
+                v1 = fmaxf(v1, 0.f);
+                v2 = fmaxf(v2, 0.f);
+                v3 = fmaxf(v3, 0.f);
+              }
+              p.x = f2bf_rne(v0) | (f2bf_rne(v1) << 16);
+              p.y = f2bf_rne(v2) | (f2bf_rne(v3) << 16);
             }
-            if (relu) {
-              v0 = fmaxf(v0, 0.f);
-              v1 = fmaxf(v1, 0.f);
-              v2 = fmaxf(v2, 0.f);
-              v3 = fmaxf(v3, 0.f);
-            }
-            p.x = f2bf_rne(v0) | (f2bf_rne(v1) << 16);
-            p.y = f2bf_rne(v2) | (f2bf_rne(v3) << 16);
+            *reinterpret_cast<uint2*>(y + o + c0) = p;
           }
-          *reinterpret_cast<uint2*>(y + o + c0) = p;
         }
       }
     }
@@ -261,10 +287,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
 template <int CIN, int COUT>
 int launch_lds(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
                hipStream_t st) {
-  constexpr int TH = 4 * ((COUT / 32 <= 2) ? 4 : 2);
+  constexpr int TH = 16;
   const int64_t n_tiles = (int64_t)B * ((H + TH - 1) / TH) * ((W + 31) / 32);
   int64_t nb = n_tiles;
-  const int64_t cap = 256 * ((COUT / 32 <= 2) ? 2 : 3);  // resident workgroups (LDS: 78 KiB / 43 KiB per workgroup)
+  const int64_t cap = 256 * 2;  // resident workgroups (LDS: 78 KiB per workgroup)
   if (nb > cap) nb = cap;
   k_conv3x3_lds<CIN, COUT><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B,
                                                         H, W, relu);
@@ -310,6 +336,9 @@ int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const 
   if (stride == 1 && getenv("PNX_CONV_DIRECT") == nullptr) {
     if (cin == 64 && cout == 64) return launch_lds<64, 64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
     if (cin == 128 && cout == 128) return launch_lds<128, 128>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
+    if (cin == 64 && cout == 384) return launch_lds<64, 384>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
+    if (cin == 64 && cout == 320) return launch_lds<64, 320>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
+    if (cin == 64 && cout == 448) return launch_lds<64, 448>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
   }
 #define PNX_CONV_CASE(CI, CO)                                                                                          \
   if (cin == CI && cout == CO) {                                                                                       \

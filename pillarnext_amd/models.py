@@ -592,7 +592,10 @@ class FusedPillarNeXt(nn.Module):
                 W2[o:o + w2.shape[0], j * hc:(j + 1) * hc] = w2
                 B2[o:o + w2.shape[0]] = b2
                 o += w2.shape[0]
-            self.task_conv1.append(_FusedConv(W1, torch.cat(b1s), 1, 1, dtype=dtype))
+            if hip_conv and dtype == torch.bfloat16 and (W1.shape[1], W1.shape[0]) in ops.CONV3X3_SHAPES_S1:
+                self.task_conv1.append(_HipConv3x3(W1, torch.cat(b1s), 1))   # input tile staged once, reused for all 64-channel passes
+            else:
+                self.task_conv1.append(_FusedConv(W1, torch.cat(b1s), 1, 1, dtype=dtype))
             self.task_conv2.append(_FusedConv(W2, B2, 1, 1, relu=False, dtype=dtype))
             self.task_split.append((names, outs))
 

@@ -54,7 +54,7 @@ def test_point_uploader_roundtrip():
         assert np.array_equal(np.unique(ref[:, 0]), [0, 1, 2])
 
 
-@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 128, 2), (128, 128, 1), (64, 64, 2)])
+@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 128, 2), (128, 128, 1), (64, 64, 2), (64, 384, 1), (64, 320, 1)])
 @pytest.mark.parametrize("residual", [False, True])
 def test_conv3x3_masked_matches_torch(cin, cout, stride, residual):
     from pillarnext_amd import ops
