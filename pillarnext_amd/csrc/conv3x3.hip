@@ -27,6 +27,134 @@ __device__ __forceinline__ uint32_t f2bf_rne(float f) {
   return u >> 16;
 }
 
+// Epilogue.  The MFMA leaves lane (px, kb) with channels {8g + 4kb + i} of pixel px: four 8-byte pieces per 32-channel tile,
+// i.e. 32 scattered 8-byte stores per row of 32 pixels.  Measured, that store pattern -- not the MFMAs -- bounded the kernel
+// (42-50 % of wave time: the vector-memory path pays per distinct line an instruction touches, here 32 lines for 512 bytes).
+// Two steps fix it:
+//  (1) pack_tile: v_permlane32_swap trades the odd 4-channel groups between the two half-waves (MI355X guide T21) so each lane
+//      holds 8 consecutive channels; residual add / ReLU / bf16 rounding / active-site mask happen here in fp32;
+//  (2) store_row64: the four 16-byte slots a lane holds for one pixel (64 output channels = one 128-byte line, lanes kb=0/1
+//      holding the even/odd chunks) are transposed across lanes with ds_bpermute (LDS crossbar, no LDS storage): slot index
+//      <-> pixel-octet index, the classic rotate / permute / rotate scheme (16 bpermutes + 64 selects per row).  Afterwards
+//      store d of lane L is chunk L&7 of pixel 8d + (L>>3): every store instruction writes 8 complete 128-byte lines.
+// Both must be called by all 64 lanes.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void pack_tile(const v16f& a, bool act, int relu, uint4 (&out)[2]) {
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[8 * t + i]), __float_as_uint(a[8 * t + 4 + i]), false, false);
+      v[i] = __uint_as_float(r.x);
+      v[4 + i] = __uint_as_float(r.y);
+    }
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = fmaxf(v[i], 0.f);
+    }
+    uint4 p;  // v_cvt_pk_bf16_f32: round-to-nearest-even, one instruction per channel pair
+    p.x = pack_bf16(v[0], v[1]);
+    p.y = pack_bf16(v[2], v[3]);
+    p.z = pack_bf16(v[4], v[5]);
+    p.w = pack_bf16(v[6], v[7]);
+    if (!act) p = make_uint4(0, 0, 0, 0);
+    out[t] = p;
+  }
+}
+
+__device__ __forceinline__ void cswap(bool c, uint4& x, uint4& y) {
+  const uint4 a = x, b = y;
+  x.x = c ? b.x : a.x, x.y = c ? b.y : a.y, x.z = c ? b.z : a.z, x.w = c ? b.w : a.w;
+  y.x = c ? a.x : b.x, y.y = c ? a.y : b.y, y.z = c ? a.z : b.z, y.w = c ? a.w : b.w;
+}
+
+// R[s], s = 2*(tile within the 64-channel group) + t: chunk 2s + kb of pixel px = lane & 31.  On return R[d] of lane L is chunk
+// L & 7 of pixel 8d + (L >> 3).
+__device__ __forceinline__ void transpose_row64(uint4 (&R)[4], int lane) {
+  const int a_src = (lane & 31) >> 3;       // pixel octet of this lane as a source
+  const int s_dst = (lane & 7) >> 1;        // slot this lane stores as a destination
+  // rotate: U[k] = R[k ^ a_src]
+  cswap(a_src & 1, R[0], R[1]);
+  cswap(a_src & 1, R[2], R[3]);
+  cswap(a_src & 2, R[0], R[2]);
+  cswap(a_src & 2, R[1], R[3]);
+  // permute: round k fetches slot register k of source lane (octet k ^ s_dst, pixel-in-octet L>>3, half L&1)
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int src = (8 * (k ^ s_dst) + (lane >> 3)) + 32 * (lane & 1);
+    R[k].x = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)R[k].x);
+    R[k].y = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)R[k].y);
+    R[k].z = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)R[k].z);
+    R[k].w = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)R[k].w);
+  }
+  // rotate back: D[d] = V[d ^ s_dst]
+  cswap(s_dst & 1, R[0], R[1]);
+  cswap(s_dst & 1, R[2], R[3]);
+  cswap(s_dst & 2, R[0], R[2]);
+  cswap(s_dst & 2, R[1], R[3]);
+}
+
+// `row` (wave-uniform) points at channel 0 of the 64-channel group for pixel 0 of the 32-pixel row segment; pixels >= n_valid
+// are not stored; CSTRIDE = channels per pixel.  Uniform base + 32-bit lane offset: no per-store 64-bit address arithmetic.
+template <int CSTRIDE>
+__device__ __forceinline__ void store_row64(const uint4 (&D)[4], uint16_t* __restrict__ row, int n_valid, int lane) {
+  const uint32_t voff = (uint32_t)((lane >> 3) * CSTRIDE + (lane & 7) * 8) * 2u;
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    const int P = 8 * d + (lane >> 3);
+    if (P < n_valid) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(row) + voff + (uint32_t)(d * 8 * CSTRIDE * 2)) = D[d];
+  }
+}
+
+// The accumulators start from the (folded-BN) bias: register i of a lane's 32-channel tile is channel (i&3) + 8*(i>>2) + 4*kb.
+__device__ __forceinline__ v16f bias_tile(const float* __restrict__ bias, int cbase, int kb) {
+  v16f r;
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const float4 q = *reinterpret_cast<const float4*>(bias + cbase + 8 * g + 4 * kb);
+    r[4 * g + 0] = q.x, r[4 * g + 1] = q.y, r[4 * g + 2] = q.z, r[4 * g + 3] = q.w;
+  }
+  return r;
+}
+
+// The residual (identity branch of a BasicBlock) is folded into the accumulators BEFORE the MFMAs, like the bias: its lines are
+// loaded 16 bytes per lane (the layout pack_tile produces) and moved into MFMA register order by the same half-wave swap, which
+// is its own inverse.  The loads overlap the staging of the input tile and the epilogue is left without a single load -- on
+// gfx9 a load's s_waitcnt also waits for every OLDER store, so a load between stores serialises on HBM write acknowledgements.
+// `res_px` = residual line of this lane's pixel (+ channel base of the 64-channel group); must be called by all 64 lanes.
+__device__ __forceinline__ void load_residual(uint4 (&rq)[2][2], const uint16_t* __restrict__ res_px, bool act, int kb) {
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      rq[m][t] = make_uint4(0, 0, 0, 0);
+      if (act) rq[m][t] = *reinterpret_cast<const uint4*>(res_px + m * 32 + 16 * t + 8 * kb);
+    }
+}
+__device__ __forceinline__ void add_residual(v16f (&acc2)[2], const uint4 (&rq)[2][2]) {
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const uint4 r = rq[m][t];
+      const uint32_t lo[4] = {r.x << 16, r.x & 0xffff0000u, r.y << 16, r.y & 0xffff0000u};
+      const uint32_t hi[4] = {r.z << 16, r.z & 0xffff0000u, r.w << 16, r.w & 0xffff0000u};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const u32x2 q = __builtin_amdgcn_permlane32_swap(lo[i], hi[i], false, false);
+        acc2[m][8 * t + i] += __uint_as_float(q.x);
+        acc2[m][8 * t + 4 + i] += __uint_as_float(q.y);
+      }
+    }
+}
+
 // wfrag layout: [kstep = tap * (CIN/16) + cb][mtile][lane][8 bf16], lane = kb*32 + n :
 //   W[out = mtile*32 + n][ky][kx][cin = cb*16 + 8*kb + e]   (host: pillarnext_amd/ops.py::conv3x3_pack_weights)
 template <int CIN, int COUT, int STRIDE, bool W_LDS>
@@ -64,11 +192,27 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const uint16_t* __restrict__
     }
     v16f acc[NT][MT];
 #pragma unroll
-    for (int j = 0; j < NT; j++)
+    for (int m = 0; m < MT; m++) {
+      const v16f bq = bias_tile(bias, m * 32, kb);
 #pragma unroll
-      for (int m = 0; m < MT; m++)
+      for (int j = 0; j < NT; j++) acc[j][m] = bq;
+    }
+
+    if (res != nullptr) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[j][m][i] = 0.f;
+      for (int j = 0; j < NT; j++) {
+        const bool in = ox < Wo && oy0 + j < Ho;
+        const uint16_t* rp = res + (in ? (((int64_t)b * Ho + oy0 + j) * Wo + ox) * COUT : 0);
+#pragma unroll
+        for (int m0 = 0; m0 < MT; m0 += 2) {
+          uint4 rq[2][2];
+          load_residual(rq, rp + m0 * 32, act[j], kb);
+          v16f a2[2] = {acc[j][m0], acc[j][m0 + 1]};
+          add_residual(a2, rq);
+          acc[j][m0] = a2[0], acc[j][m0 + 1] = a2[1];
+        }
+      }
+    }
 
     if (any) {
       for (int tap = 0; tap < 9; tap++) {
@@ -102,198 +246,298 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const uint16_t* __restrict__
         }
       }
     }
-    // ---- epilogue: lane = (pixel px, half kb); register i of tile m = out channel m*32 + (i&3) + 8*(i>>2) + 4*kb
+    // ---- epilogue (see pack_tile / store_row64)
+    const int n_valid = Wo - tx * 32;  // pixels of this row segment inside the image (>= 32: all)
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-      const int oy = oy0 + j;
-      if (!(ox < Wo && oy < Ho)) continue;
-      const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * COUT;
+      const bool row_in = oy0 + j < Ho;  // wave-uniform
+      uint16_t* row = y + (((int64_t)b * Ho + (row_in ? oy0 + j : 0)) * Wo + tx * 32) * COUT;
 #pragma unroll
-      for (int m = 0; m < MT; m++) {
+      for (int m0 = 0; m0 < MT; m0 += 2) {
+        uint4 R[4];
 #pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-          const int c0 = m * 32 + 8 * gq + 4 * kb;
-          uint2 p = make_uint2(0, 0);
-          if (act[j]) {
-            const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
-            float v0 = acc[j][m][4 * gq + 0] + bv.x, v1 = acc[j][m][4 * gq + 1] + bv.y;
-            float v2 = acc[j][m][4 * gq + 2] + bv.z, v3 = acc[j][m][4 * gq + 3] + bv.w;
-            if (res != nullptr) {
-              const uint2 r = *reinterpret_cast<const uint2*>(res + o + c0);
-              v0 += bf2f_lo(r.x);
-              v1 += bf2f_hi(r.x);
-              v2 += bf2f_lo(r.y);
-              v3 += bf2f_hi(r.y);
-            }
-            if (relu) {
-              v0 = fmaxf(v0, 0.f);
-              v1 = fmaxf(v1, 0.f);
-              v2 = fmaxf(v2, 0.f);
-              v3 = fmaxf(v3, 0.f);
-            }
-            p.x = f2bf_rne(v0) | (f2bf_rne(v1) << 16);
-            p.y = f2bf_rne(v2) | (f2bf_rne(v3) << 16);
-          }
-          *reinterpret_cast<uint2*>(y + o + c0) = p;
+        for (int m = 0; m < 2; m++) {
+          uint4 pk[2];
+          pack_tile(acc[j][m0 + m], act[j], relu, pk);
+          R[2 * m] = pk[0], R[2 * m + 1] = pk[1];
         }
+        transpose_row64(R, lane);
+        store_row64<COUT>(R, row + m0 * 32, row_in ? n_valid : 0, lane);
       }
     }
   }
 }
 
-// Stride-1 variant with the INPUT tile staged in LDS: a workgroup owns TH x 32 output pixels; the (TH+2) x 34 halo tile of
-// 64 input channels (128 B per pixel) is loaded once with coalesced 16-byte loads, XOR-swizzled (chunk ^ (column & 7)) so the
-// ds_read_b128 of a B fragment does not pile onto one bank column, and then serves all 9 taps of all 4 waves -- the direct
-// kernel above re-reads every pixel line 9 times through L1/L2 (measured: 4.8 GB of L2->L1 traffic per 1440x1440 frame).
-// Weights (fragment order, 1 KiB per wave-load, shared by every wave on the chip) come straight from L2.  CIN > 64 is
-// processed as successive 64-channel slabs; COUT > 64 as successive 64-channel passes over the same staged tile (the merged
-// SepHead convolution 64 -> 384 stages its input once and reuses it six times).
-template <int CIN, int COUT>
+// Stride-1, 64-input-channel variant with the INPUT tile staged in LDS: a workgroup owns 16 x 32 output pixels; the 18 x 34 halo tile of 64
+// input channels (128 B per pixel) is loaded once with coalesced 16-byte loads (all loads of a batch in flight before the first
+// ds_write), XOR-swizzled so that each 16-lane service group of a ds_read_b128 B-fragment read covers all 64 banks, and then
+// serves all 9 taps of all 4 waves -- the direct kernel above re-reads every pixel line 9 times through L1/L2 (measured:
+// 4.8 GB of L2->L1 traffic per 1440x1440 frame).  Sparsity: the 16 row segments of a tile that hold at least one active site
+// are dealt round-robin to the 4 waves (row indices live in SGPRs), each wave runs a branch-free tap loop specialised on its
+// row count NR = 1..4 (LDS reads pipeline ahead of the MFMAs), halo rows no active row needs are not staged, and rows without
+// an active site are zero-filled without touching the MFMA pipe.  Weights (fragment order, 1 KiB per wave-load, shared by every
+// wave on the chip) come straight from L1/L2, one tap ahead of their use.  CIN > 64 is processed as successive 64-channel
+// slabs; COUT > 64 as successive 64-channel passes over the same staged tile (the merged SepHead convolution 64 -> 384 stages
+// its input once and reuses it six times).
+#ifdef PNX_CONV_TIMERS  // section timers (build with PNX_CONV_TIMERS=1 in the environment of build.py)
+__device__ unsigned long long g_conv_T[8];
+#define CT_DECL unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk = __builtin_amdgcn_s_memtime();
+#define CT_TOCK(k)                                              \
+  {                                                             \
+    const unsigned long long _n = __builtin_amdgcn_s_memtime(); \
+    T[k] += _n - tk;                                            \
+    tk = _n;                                                    \
+  }
+#define CT_FLUSH                                                                     \
+  if ((threadIdx.x & 63) == 0) {                                                     \
+    for (int k = 0; k < 8; k++) atomicAdd(&g_conv_T[k], T[k]);                        \
+  }
+#else
+#define CT_DECL
+#define CT_TOCK(k)
+#define CT_FLUSH
+#endif
+
+constexpr int LDS_TH = 16;    // rows per workgroup tile
+constexpr int LDS_HW = 34;    // halo tile width
+constexpr int LDS_NSTAGE = (LDS_TH + 2) * LDS_HW * 8;  // uint4 per staged tile (64 input channels)
+
+__device__ __forceinline__ int lds_swz(int c) { return (c & 7) ^ ((c >> 3) & 1); }
+
+// One 64-output-channel pass of a wave over its NR rows: 9 taps x 4 k-steps, software-pipelined in registers -- B fragments one
+// k-step ahead (LDS), weight fragments one tap ahead (L1/L2; each register pair is refilled for the next tap right after its
+// last MFMA of this tap).
+template <int NR, int MTALL>
+__device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __restrict__ s_in, const uint4* __restrict__ wfrag, const int (&rbase)[4],
+                                          int mg, int px, int kb, int lane) {
+  constexpr int CB = 4;
+  uint4 w[4][2];
+#pragma unroll
+  for (int cbl = 0; cbl < 4; cbl++)
+#pragma unroll
+    for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[(cbl * MTALL + mg + m) * 64 + lane];
+  uint4 qn[NR];
+  {
+    const int sw = lds_swz(px);
+#pragma unroll
+    for (int j = 0; j < NR; j++) qn[j] = s_in[rbase[j] + px * 8 + (kb ^ sw)];
+  }
+#pragma unroll 1
+  for (int tap = 0; tap < 9; tap++) {  // not unrolled: a full unroll spills
+    const int tn = tap + 1;
+    const int dyn = tn / 3, dxn = tn - 3 * dyn;  // next tap (halo coordinates: +1 already included)
+    const int dy = tap / 3, dx = tap - 3 * dy;
+    const int c = px + dx, cn = px + dxn;
+    const int sw = lds_swz(c), swn = lds_swz(cn);
+    const int cbase = (dy * LDS_HW + c) * 8, cbasen = (dyn * LDS_HW + cn) * 8;
+#pragma unroll
+    for (int cbl = 0; cbl < 4; cbl++) {
+      uint4 qc[NR];
+#pragma unroll
+      for (int j = 0; j < NR; j++) qc[j] = qn[j];
+      if (cbl < 3) {
+        const int chunk = ((cbl + 1) * 2 + kb) ^ sw;
+#pragma unroll
+        for (int j = 0; j < NR; j++) qn[j] = s_in[rbase[j] + cbase + chunk];
+      } else if (tap < 8) {
+        const int chunk = kb ^ swn;
+#pragma unroll
+        for (int j = 0; j < NR; j++) qn[j] = s_in[rbase[j] + cbasen + chunk];
+      }
+#pragma unroll
+      for (int j = 0; j < NR; j++) {
+        const bf16x8 bfr = __builtin_bit_cast(bf16x8, qc[j]);
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+          acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[cbl][m]), bfr, acc[j][m], 0, 0, 0);
+      }
+      if (tap < 8) {
+#pragma unroll
+        for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[((tn * CB + cbl) * MTALL + mg + m) * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// Everything a wave does for its NR active rows once the tile is staged: per 64-channel pass, accumulators = bias (+ residual),
+// the taps, and the epilogue.  No barrier inside.
+template <int NR, int COUT, bool HAS_RES>
+__device__ __forceinline__ void conv_rows(const uint4* __restrict__ s_in, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+                                          const uint4 (&rq)[4][2][2], const int (&rbase)[4], const uint32_t (&rmask)[4], uint16_t* const (&yrow)[4],
+                                          int n_valid, int relu, int px, int kb, int lane) {
+  constexpr int MTALL = COUT / 32;
+#pragma unroll 1
+  for (int mg = 0; mg < MTALL; mg += 2) {  // 64 output channels per pass over the staged tile
+    v16f acc[NR][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      const v16f bq = bias_tile(bias, (mg + m) * 32, kb);
+#pragma unroll
+      for (int j = 0; j < NR; j++) acc[j][m] = bq;
+    }
+    if (HAS_RES) {  // single pass (COUT == 64) by construction
+#pragma unroll
+      for (int j = 0; j < NR; j++) add_residual(acc[j], rq[j]);
+    }
+    conv_taps<NR, MTALL>(acc, s_in, wfrag, rbase, mg, px, kb, lane);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+      const bool act = (rmask[j] >> px) & 1u;
+      uint4 D[4];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        uint4 pk[2];
+        pack_tile(acc[j][m], act, relu, pk);
+        D[2 * m] = pk[0], D[2 * m + 1] = pk[1];
+      }
+      transpose_row64(D, lane);
+      store_row64<COUT>(D, yrow[j] + mg * 32, n_valid, lane);
+    }
+  }
+}
+
+template <int COUT, bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                      const float* __restrict__ bias, const uint16_t* __restrict__ res,
                                                      const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
                                                      int relu) {
-  constexpr int CB = CIN / 16;
-  constexpr int MTALL = COUT / 32;           // 32-channel output tiles in total
-  constexpr int MT = 2;                      // ... handled two at a time (64 output channels per pass over the staged tile)
-  constexpr int NT = 4;                      // rows per wave
-  constexpr int TH = 4 * NT;                 // rows per workgroup
-  constexpr int HW_ = 34;                    // halo tile width
-  constexpr int NSLAB = CIN / 64;            // 64-channel input slabs (LDS holds them all: 78 KiB each -> CIN 64 only; else one at a time)
-  __shared__ uint4 s_in[(TH + 2) * HW_ * 8];
+  constexpr int CIN = 64;
+  constexpr int TH = LDS_TH, HW_ = LDS_HW;
+  constexpr int SBATCH = 10;  // loads in flight per thread while staging (2 batches cover the tile)
+  static_assert(2 * SBATCH * 256 >= LDS_NSTAGE, "staging batches");
+  static_assert(!HAS_RES || COUT == 64, "the residual is folded into the accumulators of a single 64-channel pass");
+  __shared__ uint4 s_in[LDS_NSTAGE];
+  __shared__ uint32_t s_rowmask[TH];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int px = lane & 31, kb = lane >> 5;
   const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
   const int64_t n_tiles = (int64_t)B * tiles_y * tiles_x;
+  CT_DECL
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int tx = (int)(tile % tiles_x);
     const int ty = (int)((tile / tiles_x) % tiles_y);
     const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
     const int x0 = tx * 32, y0 = ty * TH;
-    const int ox = x0 + px, oy0 = y0 + wv * NT;
-    bool act[NT], any_row[NT];
-    bool any = false;
+    const int ox = x0 + px;
+    CT_TOCK(7)
+    // ---- active sites: one 32-bit column mask per row of the tile
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-      const int oy = oy0 + j;
-      const bool in = ox < W && oy < H;
-      act[j] = in && (mask == nullptr || mask[((int64_t)b * H + oy) * W + ox] != 0);
-      any_row[j] = __ballot(act[j]) != 0;
-      any = any || any_row[j];
+    for (int j = 0; j < 4; j++) {
+      const int oy = y0 + wv * 4 + j;
+      const bool a = ox < W && oy < H && (mask == nullptr || mask[((int64_t)b * H + oy) * W + ox] != 0);
+      const uint32_t bal = (uint32_t)__ballot(a);
+      if (lane == 0) s_rowmask[wv * 4 + j] = bal;
     }
-    const bool wg_any = __syncthreads_or(any ? 1 : 0) != 0;  // also: everybody is done with the previous tile's LDS
-
-    for (int mg = 0; mg < MTALL; mg += MT) {  // 64 output channels per pass
-      v16f acc[NT][MT];
+    __syncthreads();  // row masks visible; everybody is done reading the previous tile's s_in
+    CT_TOCK(0)
+    const uint32_t my_rm = s_rowmask[lane & 15];
+    const uint32_t am = (uint32_t)__ballot(my_rm != 0) & 0xffffu;  // rows with an active site (wave-uniform, same in all waves)
+    // ---- rows without any active site: zero-fill (natural rows of this wave)
 #pragma unroll
-      for (int j = 0; j < NT; j++)
-#pragma unroll
-        for (int m = 0; m < MT; m++)
-#pragma unroll
-          for (int i = 0; i < 16; i++) acc[j][m][i] = 0.f;
-      if (wg_any) {
-        for (int slab = 0; slab < NSLAB; slab++) {
-          const int ch0 = slab * 64;
-          if (NSLAB > 1 || mg == 0) {  // with a single slab the staged tile serves every output-channel pass
-            if (slab > 0 || mg > 0) __syncthreads();
-#pragma unroll 5
-            for (int idx = threadIdx.x; idx < (TH + 2) * HW_ * 8; idx += 256) {
-              const int chunk = idx & 7, pix = idx >> 3;
-              const int r = pix / HW_, c = pix - r * HW_;
-              const int iy = y0 - 1 + r, ix = x0 - 1 + c;
-              uint4 q = make_uint4(0, 0, 0, 0);
-              if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                q = *reinterpret_cast<const uint4*>(x + (((int64_t)b * H + iy) * W + ix) * CIN + ch0 + chunk * 8);
-              s_in[pix * 8 + (chunk ^ (c & 7))] = q;
-            }
-            __syncthreads();
-          }
-          if (any) {
-            // weight fragments of one tap (4 k-steps x 2 channel tiles) are fetched one tap ahead of their MFMAs
-            uint4 wn[4][MT];
-#pragma unroll
-            for (int cbl = 0; cbl < 4; cbl++)
-#pragma unroll
-              for (int m = 0; m < MT; m++) wn[cbl][m] = wfrag[((0 * CB + (ch0 >> 4) + cbl) * MTALL + mg + m) * 64 + lane];
-            for (int tap = 0; tap < 9; tap++) {  // not unrolled: a full unroll spills (measured: 484 B scratch, 25 % slower)
-              const int dy = tap / 3, dx = tap % 3;  // halo coordinates: +1 already included
-              const int c = px + dx;
-              uint4 wc[4][MT];
-#pragma unroll
-              for (int cbl = 0; cbl < 4; cbl++)
-#pragma unroll
-                for (int m = 0; m < MT; m++) wc[cbl][m] = wn[cbl][m];
-              if (tap < 8) {
-#pragma unroll
-                for (int cbl = 0; cbl < 4; cbl++)
-#pragma unroll
-                  for (int m = 0; m < MT; m++) wn[cbl][m] = wfrag[(((tap + 1) * CB + (ch0 >> 4) + cbl) * MTALL + mg + m) * 64 + lane];
-              }
-#pragma unroll
-              for (int cbl = 0; cbl < 4; cbl++) {
-#pragma unroll
-                for (int j = 0; j < NT; j++) {
-                  if (!any_row[j]) continue;  // wave-uniform
-                  const uint4 q = s_in[((wv * NT + j + dy) * HW_ + c) * 8 + ((cbl * 2 + kb) ^ (c & 7))];
-                  const bf16x8 bfr = __builtin_bit_cast(bf16x8, q);
-#pragma unroll
-                  for (int m = 0; m < MT; m++)
-                    acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wc[cbl][m]), bfr, acc[j][m], 0, 0, 0);
-                }
-              }
-            }
-          }
-        }
+    for (int j = 0; j < 4; j++) {
+      const int rr = wv * 4 + j, oy = y0 + rr;
+      if (((am >> rr) & 1u) == 0 && oy < H && ox < W) {
+        uint4* dst = reinterpret_cast<uint4*>(y + (((int64_t)b * H + oy) * W + ox) * COUT);
+#pragma unroll 1
+        for (int ch = kb; ch < COUT / 8; ch += 2) dst[ch] = make_uint4(0, 0, 0, 0);
       }
+    }
+    if (am == 0) continue;  // uniform over the workgroup
+    // ---- the active rows, dealt round-robin to the waves (wave wv takes the active rows number wv, wv+4, ...)
+    int nr = 0;
+    int rbase[4], rrow[4];
+    {
+      uint32_t rest = am;
+      for (int k = 0; k < wv && rest; k++) rest &= rest - 1;
 #pragma unroll
-      for (int j = 0; j < NT; j++) {
-        const int oy = oy0 + j;
-        if (!(ox < W && oy < H)) continue;
-        const int64_t o = (((int64_t)b * H + oy) * W + ox) * COUT;
+      for (int j = 0; j < 4; j++) {
+        const bool has = rest != 0;
+        rrow[j] = has ? __builtin_ctz(rest) : 0;  // dummy rows point at row 0
+        nr += has ? 1 : 0;
+        for (int k = 0; k < 4 && rest; k++) rest &= rest - 1;
+      }
+    }
+    nr = __builtin_amdgcn_readfirstlane(nr);
+    uint32_t rmask[4];
+    uint16_t* yrow[4];
 #pragma unroll
-        for (int m = 0; m < MT; m++) {
+    for (int j = 0; j < 4; j++) {
+      rrow[j] = __builtin_amdgcn_readfirstlane(rrow[j]);
+      rbase[j] = rrow[j] * HW_ * 8;
+      rmask[j] = j < nr ? __builtin_amdgcn_readfirstlane(s_rowmask[rrow[j]]) : 0u;
+      yrow[j] = y + (((int64_t)b * H + (y0 + rrow[j])) * W + x0) * COUT;
+    }
+    const uint32_t need = am | (am << 1) | (am << 2);  // halo rows some active row reads
+    CT_TOCK(1)
+    // ---- residual lines: requested before the tile is staged, consumed after
+    uint4 rq[4][2][2];
+    if (HAS_RES) {
 #pragma unroll
-          for (int gq = 0; gq < 4; gq++) {
-            const int c0 = (mg + m) * 32 + 8 * gq + 4 * kb;
-            uint2 p = make_uint2(0, 0);
-            if (act[j]) {
-              const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
-              float v0 = acc[j][m][4 * gq + 0] + bv.x, v1 = acc[j][m][4 * gq + 1] + bv.y;
-              float v2 = acc[j][m][4 * gq + 2] + bv.z, v3 = acc[j][m][4 * gq + 3] + bv.w;
-              if (res != nullptr) {
-                const uint2 r = *reinterpret_cast<const uint2*>(res + o + c0);
-                v0 += bf2f_lo(r.x);
-                v1 += bf2f_hi(r.x);
-                v2 += bf2f_lo(r.y);
-                v3 += bf2f_hi(r.y);
-              }
-              if (relu) {
-                v0 = fmaxf(v0, 0.f);
-                v1 = fmaxf(v1, 0.f);
-                v2 = fmaxf(v2, 0.f);
-                v3 = fmaxf(v3, 0.f);
-              }
-              p.x = f2bf_rne(v0) | (f2bf_rne(v1) << 16);
-              p.y = f2bf_rne(v2) | (f2bf_rne(v3) << 16);
-            }
-            *reinterpret_cast<uint2*>(y + o + c0) = p;
-          }
+      for (int j = 0; j < 4; j++)
+        load_residual(rq[j], res + (((int64_t)b * H + (y0 + rrow[j])) * W + (ox < W ? ox : 0)) * COUT, (rmask[j] >> px) & 1u, kb);
+    }
+    // ---- stage the halo tile: 256 threads = 32 pixels x 8 chunks per step, all loads of a batch in flight before the first write
+    {
+      const uint16_t* xt = x + (((int64_t)b * H + (y0 - 1)) * W + (x0 - 1)) * CIN;  // element (0, 0) of the halo tile
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));  // opaque: keeps the 20 per-thread staging addresses from being hoisted out of the tile loop (and spilled)
+      const int chunk = tid & 7;
+      const uint32_t rows_ok = need & ~(y0 == 0 ? 1u : 0u);  // halo row 0 of the first tile row lies above the image
+#pragma unroll
+      for (int part = 0; part < 2; part++) {
+        uint4 q[SBATCH];
+#pragma unroll
+        for (int i = 0; i < SBATCH; i++) {
+          const int pix = (part * SBATCH + i) * 32 + (tid >> 3);
+          const int r = (pix * 1928) >> 16, c = pix - r * HW_;  // pix / 34 for pix < 640
+          q[i] = make_uint4(0, 0, 0, 0);
+          if (pix < (TH + 2) * HW_ && ((rows_ok >> r) & 1u) && y0 - 1 + r < H && (unsigned)(x0 - 1 + c) < (unsigned)W)
+            q[i] = *reinterpret_cast<const uint4*>(xt + (r * W + c) * CIN + chunk * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < SBATCH; i++) {
+          const int pix = (part * SBATCH + i) * 32 + (tid >> 3);
+          const int r = (pix * 1928) >> 16, c = pix - r * HW_;
+          if (pix < (TH + 2) * HW_) s_in[pix * 8 + (chunk ^ lds_swz(c))] = q[i];
         }
       }
     }
+    CT_TOCK(2)
+    __syncthreads();
+    CT_TOCK(3)
+    const int n_valid = W - x0;
+    switch (nr) {  // wave-uniform
+      case 1: conv_rows<1, COUT, HAS_RES>(s_in, wfrag, bias, rq, rbase, rmask, yrow, n_valid, relu, px, kb, lane); break;
+      case 2: conv_rows<2, COUT, HAS_RES>(s_in, wfrag, bias, rq, rbase, rmask, yrow, n_valid, relu, px, kb, lane); break;
+      case 3: conv_rows<3, COUT, HAS_RES>(s_in, wfrag, bias, rq, rbase, rmask, yrow, n_valid, relu, px, kb, lane); break;
+      case 4: conv_rows<4, COUT, HAS_RES>(s_in, wfrag, bias, rq, rbase, rmask, yrow, n_valid, relu, px, kb, lane); break;
+      default: break;
+    }
+    CT_TOCK(4)
   }
+  CT_FLUSH
 }
 
-template <int CIN, int COUT>
+template <int COUT>
 int launch_lds(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
                hipStream_t st) {
-  constexpr int TH = 16;
+  constexpr int TH = LDS_TH;
   const int64_t n_tiles = (int64_t)B * ((H + TH - 1) / TH) * ((W + 31) / 32);
   int64_t nb = n_tiles;
-  const int64_t cap = 256 * 2;  // resident workgroups (LDS: 78 KiB per workgroup)
+  const int64_t cap = 256 * 2;  // resident workgroups (LDS: 76.5 KiB per workgroup)
   if (nb > cap) nb = cap;
-  k_conv3x3_lds<CIN, COUT><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B,
-                                                        H, W, relu);
+  if constexpr (COUT == 64) {
+    if (res != nullptr) {
+      k_conv3x3_lds<COUT, true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B,
+                                                             H, W, relu);
+      PNX_LAUNCH_CHECK();
+      return PNX_OK;
+    }
+  } else {
+    PNX_REQUIRE(res == nullptr, PNX_ERR_UNSUPPORTED, "residual with %d output channels", COUT);
+  }
+  k_conv3x3_lds<COUT, false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -325,6 +569,16 @@ int launch(const void* x, const void* wfrag, const float* bias, const void* res,
 
 extern "C" {
 
+#ifdef PNX_CONV_TIMERS
+int pnx_debug_conv_timers(unsigned long long* out) {  // sums over waves of s_memtime ticks per section; resets the counters
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  PNX_CHECK_HIP(hipDeviceSynchronize());
+  PNX_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_T), sizeof(z)));
+  PNX_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_T), z, sizeof(z)));
+  return PNX_OK;
+}
+#endif
+
 int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, pnx_stream_t stream) {
   PNX_REQUIRE(x && wfrag && bias && y && batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "bad arguments");
@@ -334,11 +588,10 @@ int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const 
   const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1 && getenv("PNX_CONV_DIRECT") == nullptr) {
-    if (cin == 64 && cout == 64) return launch_lds<64, 64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
-    if (cin == 128 && cout == 128) return launch_lds<128, 128>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
-    if (cin == 64 && cout == 384) return launch_lds<64, 384>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
-    if (cin == 64 && cout == 320) return launch_lds<64, 320>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
-    if (cin == 64 && cout == 448) return launch_lds<64, 448>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
+    if (cin == 64 && cout == 64) return launch_lds<64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
+    if (cin == 64 && cout == 384) return launch_lds<384>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
+    if (cin == 64 && cout == 320) return launch_lds<320>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
+    if (cin == 64 && cout == 448) return launch_lds<448>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
   }
 #define PNX_CONV_CASE(CI, CO)                                                                                          \
   if (cin == CI && cout == CO) {                                                                                       \
