@@ -304,6 +304,38 @@ constexpr int LDS_NSTAGE = (LDS_TH + 2) * LDS_HW * 8;  // uint4 per staged tile 
 
 __device__ __forceinline__ int lds_swz(int c) { return (c & 7) ^ ((c >> 3) & 1); }
 
+// Stage the (TH+2) x 34 halo tile of 64 input channels [ch0, ch0+64) of image b at tile origin (y0, x0): 256 threads = 32 pixels
+// x 8 chunks per step, all loads of a batch in flight before the first ds_write.  `need` = halo rows to load (bit r).
+template <int CSTRIDE>
+__device__ __forceinline__ void stage_tile64(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, int b, int H, int W, int ch0, int y0, int x0,
+                                             uint32_t need) {
+  constexpr int SBATCH = 10;  // loads in flight per thread (2 batches cover the tile)
+  static_assert(2 * SBATCH * 256 >= LDS_NSTAGE, "staging batches");
+  const uint16_t* xt = x + (((int64_t)b * H + (y0 - 1)) * W + (x0 - 1)) * CSTRIDE + ch0;  // element (0, 0) of the halo tile
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // opaque: keeps the 20 per-thread staging addresses from being hoisted out of the tile loop (and spilled)
+  const int chunk = tid & 7;
+  const uint32_t rows_ok = need & ~(y0 == 0 ? 1u : 0u);  // halo row 0 of the first tile row lies above the image
+#pragma unroll
+  for (int part = 0; part < 2; part++) {
+    uint4 q[SBATCH];
+#pragma unroll
+    for (int i = 0; i < SBATCH; i++) {
+      const int pix = (part * SBATCH + i) * 32 + (tid >> 3);
+      const int r = (pix * 1928) >> 16, c = pix - r * LDS_HW;  // pix / 34 for pix < 640
+      q[i] = make_uint4(0, 0, 0, 0);
+      if (pix < (LDS_TH + 2) * LDS_HW && ((rows_ok >> r) & 1u) && y0 - 1 + r < H && (unsigned)(x0 - 1 + c) < (unsigned)W)
+        q[i] = *reinterpret_cast<const uint4*>(xt + (r * W + c) * CSTRIDE + chunk * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < SBATCH; i++) {
+      const int pix = (part * SBATCH + i) * 32 + (tid >> 3);
+      const int r = (pix * 1928) >> 16, c = pix - r * LDS_HW;
+      if (pix < (LDS_TH + 2) * LDS_HW) s_in[pix * 8 + (chunk ^ lds_swz(c))] = q[i];
+    }
+  }
+}
+
 // One 64-output-channel pass of a wave over its NR rows: 9 taps x 4 k-steps, software-pipelined in registers -- B fragments one
 // k-step ahead (LDS), weight fragments one tap ahead (L1/L2; each register pair is refilled for the next tap right after its
 // last MFMA of this tap).
@@ -404,8 +436,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
                                                      int relu) {
   constexpr int CIN = 64;
   constexpr int TH = LDS_TH, HW_ = LDS_HW;
-  constexpr int SBATCH = 10;  // loads in flight per thread while staging (2 batches cover the tile)
-  static_assert(2 * SBATCH * 256 >= LDS_NSTAGE, "staging batches");
   static_assert(!HAS_RES || COUT == 64, "the residual is folded into the accumulators of a single 64-channel pass");
   __shared__ uint4 s_in[LDS_NSTAGE];
   __shared__ uint32_t s_rowmask[TH];
@@ -477,32 +507,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
       for (int j = 0; j < 4; j++)
         load_residual(rq[j], res + (((int64_t)b * H + (y0 + rrow[j])) * W + (ox < W ? ox : 0)) * COUT, (rmask[j] >> px) & 1u, kb);
     }
-    // ---- stage the halo tile: 256 threads = 32 pixels x 8 chunks per step, all loads of a batch in flight before the first write
-    {
-      const uint16_t* xt = x + (((int64_t)b * H + (y0 - 1)) * W + (x0 - 1)) * CIN;  // element (0, 0) of the halo tile
-      int tid = threadIdx.x;
-      asm volatile("" : "+v"(tid));  // opaque: keeps the 20 per-thread staging addresses from being hoisted out of the tile loop (and spilled)
-      const int chunk = tid & 7;
-      const uint32_t rows_ok = need & ~(y0 == 0 ? 1u : 0u);  // halo row 0 of the first tile row lies above the image
-#pragma unroll
-      for (int part = 0; part < 2; part++) {
-        uint4 q[SBATCH];
-#pragma unroll
-        for (int i = 0; i < SBATCH; i++) {
-          const int pix = (part * SBATCH + i) * 32 + (tid >> 3);
-          const int r = (pix * 1928) >> 16, c = pix - r * HW_;  // pix / 34 for pix < 640
-          q[i] = make_uint4(0, 0, 0, 0);
-          if (pix < (TH + 2) * HW_ && ((rows_ok >> r) & 1u) && y0 - 1 + r < H && (unsigned)(x0 - 1 + c) < (unsigned)W)
-            q[i] = *reinterpret_cast<const uint4*>(xt + (r * W + c) * CIN + chunk * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < SBATCH; i++) {
-          const int pix = (part * SBATCH + i) * 32 + (tid >> 3);
-          const int r = (pix * 1928) >> 16, c = pix - r * HW_;
-          if (pix < (TH + 2) * HW_) s_in[pix * 8 + (chunk ^ lds_swz(c))] = q[i];
-        }
-      }
-    }
+    stage_tile64<CIN>(s_in, x, b, H, W, 0, y0, x0, need);
     CT_TOCK(2)
     __syncthreads();
     CT_TOCK(3)
@@ -517,6 +522,89 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
     CT_TOCK(4)
   }
   CT_FLUSH
+}
+
+// ---- final convolution of the merged SepHead branches (det3d/models/dense_heads/centerpoint.py:30-60: Conv2d(64, k_j, 3) of every
+// branch j of a task).  The first (merged) convolution leaves NBR x 64 channels per pixel; branch j reads only its own 64, so
+// the stacked weight (sum k_j <= 16 outputs x NBR*64 inputs) is block diagonal.  HBM-bound by its input (768 B per pixel at
+// NBR = 6 against 32 B of output): the 64-channel slabs are staged through LDS one after the other (each pixel is read from
+// HBM/L2 once instead of 9 times) and accumulated on v_mfma_f32_16x16x32_bf16 with M = the 16 output channels, N = 16 pixels;
+// the D fragment (lane = pixel n + 16 q: channels 4q..4q+3) stores 8 bytes per lane, 512 contiguous bytes per instruction.
+// wfrag: [branch][tap][kc][lane = q*16 + o][8]: W[o][branch*64 + kc*32 + q*8 + e][ky][kx] (ops.py::sephead_pack_weights).
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int NBR>
+__global__ __launch_bounds__(256, 2) void k_sephead_out(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                     uint16_t* __restrict__ y, int B, int H, int W) {
+  constexpr int CIN = NBR * 64, TH = LDS_TH, HW_ = LDS_HW;
+  __shared__ uint4 s_in[LDS_NSTAGE];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * q);
+  const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
+  const int64_t n_tiles = (int64_t)B * tiles_y * tiles_x;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int tx = (int)(tile % tiles_x);
+    const int ty = (int)((tile / tiles_x) % tiles_y);
+    const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
+    const int x0 = tx * 32, y0 = ty * TH;
+    v4f acc[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) acc[r][h] = v4f{bq.x, bq.y, bq.z, bq.w};
+#pragma unroll 1
+    for (int j = 0; j < NBR; j++) {
+      __syncthreads();  // everybody is done reading the previous slab
+      stage_tile64<CIN>(s_in, x, b, H, W, j * 64, y0, x0, 0x3ffffu);
+      __syncthreads();
+      const uint4* wj = wfrag + (size_t)j * 18 * 64 + lane;
+      uint4 wn[2] = {wj[0], wj[64]};
+#pragma unroll 1
+      for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3, dx = tap - 3 * dy;  // halo coordinates: +1 already included
+        const uint4 wc[2] = {wn[0], wn[1]};
+        if (tap < 8) wn[0] = wj[(tap + 1) * 128], wn[1] = wj[(tap + 1) * 128 + 64];
+#pragma unroll
+        for (int kc = 0; kc < 2; kc++) {
+          uint4 bf[4][2];
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const int c = 16 * h + n + dx;
+              bf[r][h] = s_in[((wv * 4 + r + dy) * HW_ + c) * 8 + ((kc * 4 + q) ^ lds_swz(c))];
+            }
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+              acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[kc]), __builtin_bit_cast(bf16x8, bf[r][h]), acc[r][h], 0,
+                                                                  0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int oy = y0 + wv * 4 + r, ox = x0 + 16 * h + n;
+        if (oy < H && ox < W) {
+          uint2 p;
+          p.x = pack_bf16(acc[r][h][0], acc[r][h][1]);
+          p.y = pack_bf16(acc[r][h][2], acc[r][h][3]);
+          *reinterpret_cast<uint2*>(y + (((int64_t)b * H + oy) * W + ox) * 16 + 4 * q) = p;
+        }
+      }
+  }
+}
+
+template <int NBR>
+int launch_sephead(const void* x, const void* wfrag, const float* bias, void* y, int B, int H, int W, hipStream_t st) {
+  int64_t nb = (int64_t)B * ((H + LDS_TH - 1) / LDS_TH) * ((W + 31) / 32);
+  if (nb > 512) nb = 512;  // resident workgroups (LDS: 76.5 KiB per workgroup)
+  k_sephead_out<NBR><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (uint16_t*)y, B, H, W);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
 }
 
 template <int COUT>
@@ -578,6 +666,21 @@ int pnx_debug_conv_timers(unsigned long long* out) {  // sums over waves of s_me
   return PNX_OK;
 }
 #endif
+
+int pnx_sephead_out_bf16(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t n_branch,
+                         pnx_stream_t stream) {
+  PNX_REQUIRE(x && wfrag && bias && y && batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "bad arguments");
+  PNX_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)wfrag | (uintptr_t)bias) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
+  hipStream_t st = (hipStream_t)stream;
+  switch (n_branch) {
+    case 5: return launch_sephead<5>(x, wfrag, bias, y, batch, h, w, st);
+    case 6: return launch_sephead<6>(x, wfrag, bias, y, batch, h, w, st);
+    case 7: return launch_sephead<7>(x, wfrag, bias, y, batch, h, w, st);
+    default: break;
+  }
+  pnx_set_error("pnx_sephead_out_bf16: no kernel for %d branches", n_branch);
+  return PNX_ERR_UNSUPPORTED;
+}
 
 int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, pnx_stream_t stream) {

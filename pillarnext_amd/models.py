@@ -514,6 +514,19 @@ class _HipConv3x3(nn.Module):
         return ops.conv3x3_masked(x, self.wfrag, self.bias, self.cout, self.stride, mask, residual, True)
 
 
+class _HipSepHeadOut(nn.Module):
+    """Last 3x3 conv of all SepHead branches of a task as ONE HIP kernel over the block-diagonal weight (csrc/conv3x3.hip::k_sephead_out)."""
+
+    def __init__(self, weight, bias):
+        super().__init__()
+        self.cout = weight.shape[0]
+        self.register_buffer("wfrag", ops.sephead_pack_weights(weight))
+        self.register_buffer("bias", bias.float().contiguous())
+
+    def forward(self, x, mask=None, residual=None):
+        return ops.sephead_out(x, self.wfrag, self.bias)
+
+
 def _backbone_conv(weight, bias, stride, padding, dtype, hip_conv):
     co, ci, kh, kw = weight.shape
     if hip_conv and dtype == torch.bfloat16 and (kh, kw) == (3, 3) and padding == 1 and (ci, co) in ops.CONV3X3_SHAPES and stride in (1, 2):
@@ -566,6 +579,7 @@ class FusedPillarNeXt(nn.Module):
         self.task_conv1 = nn.ModuleList()
         self.task_conv2 = nn.ModuleList()
         self.task_split = []
+        self.task_chans = []
         for task in hd.tasks:
             db = task.deblock
             w, b = _fold_bn(db.conv.conv.weight, db.norm, transposed=True)
@@ -585,6 +599,9 @@ class FusedPillarNeXt(nn.Module):
             W1 = torch.cat(w1s, 0)                                   # (nh*hc, 64, 3, 3)
             tot = sum(outs)
             tot_p = (tot + 7) // 8 * 8                               # epilogue kernel wants channels % 8 == 0
+            hip_out = hip_conv and dtype == torch.bfloat16 and hc == 64 and tot <= 16 and len(names) in (5, 6, 7)
+            if hip_out:
+                tot_p = 16                                           # k_sephead_out: 16 output channels (one MFMA M tile)
             W2 = torch.zeros((tot_p, hc * len(names), 3, 3), dtype=torch.float32, device=W1.device)
             B2 = torch.zeros((tot_p,), dtype=torch.float32, device=W1.device)
             o = 0
@@ -596,7 +613,8 @@ class FusedPillarNeXt(nn.Module):
                 self.task_conv1.append(_HipConv3x3(W1, torch.cat(b1s), 1))   # input tile staged once, reused for all 64-channel passes
             else:
                 self.task_conv1.append(_FusedConv(W1, torch.cat(b1s), 1, 1, dtype=dtype))
-            self.task_conv2.append(_FusedConv(W2, B2, 1, 1, relu=False, dtype=dtype))
+            self.task_conv2.append(_HipSepHeadOut(W2, B2) if hip_out else _FusedConv(W2, B2, 1, 1, relu=False, dtype=dtype))
+            self.task_chans.append(tot_p)
             self.task_split.append((names, outs))
 
     @torch.no_grad()
@@ -648,7 +666,7 @@ class FusedPillarNeXt(nn.Module):
             from .decode import PackedDecoder
 
             hd = self.head_ref
-            chans = [c2.weight.shape[0] for c2 in self.task_conv2]
+            chans = list(self.task_chans)
             self._decoder = PackedDecoder(hd.num_classes, hd.rectifier, self.post_processing, hd.with_iou, chans)
         return self._decoder
 

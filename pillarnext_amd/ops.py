@@ -216,6 +216,26 @@ def conv3x3_pack_weights(w):
     return v.reshape(-1).to(torch.bfloat16).contiguous()
 
 
+def sephead_pack_weights(w2):
+    """Block-diagonal (16, nb*64, 3, 3) -> bf16 fragment order [branch][tap][kc][lane = q*16 + o][8]  (csrc/conv3x3.hip::k_sephead_out)."""
+    co, ci = w2.shape[:2]
+    if co != 16 or ci % 64:
+        raise PnxError("sephead_pack_weights wants a (16, nb*64, 3, 3) weight")
+    v = w2.detach().float().reshape(16, ci // 64, 2, 4, 8, 3, 3)                # (o, j, kc, q, e, ky, kx)
+    v = v.permute(1, 5, 6, 2, 3, 0, 4).contiguous()                               # (j, ky, kx, kc, q, o, e)
+    return v.reshape(-1).to(torch.bfloat16).contiguous()
+
+
+def sephead_out(x, wfrag, bias):
+    """x (B, nb*64, H, W) channels_last bf16 -> (B, 16, H, W) channels_last bf16: the last 3x3 conv of every SepHead branch of a task."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise PnxError("sephead_out needs a channels_last bf16 CUDA tensor")
+    B, ci, H, W = x.shape
+    y = torch.empty((B, 16, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    check(lib().pnx_sephead_out_bf16(ptr(x), ptr(wfrag), ptr(bias), ptr(y), B, H, W, ci // 64, stream_ptr()), "pnx_sephead_out_bf16")
+    return y
+
+
 def conv3x3_masked(x, wfrag, bias, cout, stride=1, mask=None, residual=None, relu=True):
     """x (B,Cin,H,W) channels_last bf16 -> (B,Cout,Ho,Wo) channels_last bf16; mask uint8 (B,Ho,Wo) of the OUTPUT sites."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):

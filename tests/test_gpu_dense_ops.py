@@ -84,3 +84,52 @@ def test_conv3x3_masked_matches_torch(cin, cout, stride, residual):
     got2 = ops.conv3x3_masked(x, ops.conv3x3_pack_weights(w), bias, cout, stride, None, None, False).float()
     ref2 = torch.nn.functional.conv2d(x.float(), w.float(), None, stride, 1) + bias.view(1, -1, 1, 1)
     torch.testing.assert_close(got2, ref2, rtol=1.6e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("cout,residual", [(64, False), (64, True), (384, False)])
+def test_conv3x3_sparse_rows(cout, residual):
+    """Few active rows per 16-row tile: the per-row-count (NR = 1..3) paths, dummy rows and zero-filled rows of the LDS kernel."""
+    from pillarnext_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(7 + cout)
+    B, H, W, cin = 2, 83, 101, 64
+    mask = torch.zeros((B, H, W), dtype=torch.uint8, device="cuda")
+    for r in (0, 3, 17, 18, 19, 40, 41, 42, 43, 44, 45, 46, 63, 82):      # 1, 1+3, 7 (-> waves with 2 and 1 rows), 1, last row
+        mask[0, r] = (torch.rand((W,), device="cuda", generator=g) > 0.5).to(torch.uint8)
+    mask[1] = (torch.rand((H, W), device="cuda", generator=g) > 0.97).to(torch.uint8)
+    x = (torch.randn((B, cin, H, W), device="cuda", generator=g) * mask.unsqueeze(1)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((cout, cin, 3, 3), device="cuda", generator=g) / 24).to(torch.bfloat16)
+    bias = torch.randn((cout,), device="cuda", generator=g)
+    res = torch.randn((B, cout, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if residual else None
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), None, 1, 1) + bias.view(1, -1, 1, 1)
+    if residual:
+        ref = ref + res.float()
+    ref = torch.relu(ref) * mask.unsqueeze(1).float()
+    y = torch.full((B, cout, H, W), 7.0, dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last)  # noqa: F841 (poison)
+    got = ops.conv3x3_masked(x, ops.conv3x3_pack_weights(w), bias, cout, 1, mask, res, True).float()
+    assert bool((got[(mask == 0).unsqueeze(1).expand_as(got)] == 0).all())
+    torch.testing.assert_close(got, ref, rtol=1.6e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("nb", [5, 6, 7])
+def test_sephead_out_matches_torch(nb):
+    """k_sephead_out vs the dense conv over the block-diagonal weight (what the merged SepHead's last convolutions compute)."""
+    from pillarnext_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(nb)
+    B, H, W = 2, 45, 70
+    outs = [2, 1, 3, 2, 2, 1, 2][:nb]
+    x = torch.relu(torch.randn((B, nb * 64, H, W), device="cuda", generator=g)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    W2 = torch.zeros((16, nb * 64, 3, 3), device="cuda")
+    o = 0
+    for j, k in enumerate(outs):
+        W2[o:o + k, j * 64:(j + 1) * 64] = torch.randn((k, 64, 3, 3), device="cuda", generator=g) / 24
+        o += k
+    W2 = W2.to(torch.bfloat16)
+    bias = torch.zeros((16,), device="cuda")
+    bias[:o] = torch.randn((o,), device="cuda", generator=g)
+    ref = torch.nn.functional.conv2d(x.float(), W2.float(), None, 1, 1) + bias.view(1, -1, 1, 1)
+    got = ops.sephead_out(x, ops.sephead_pack_weights(W2), bias).float()
+    assert got.shape == ref.shape
+    assert bool((got[:, o:] == 0).all())
+    torch.testing.assert_close(got, ref, rtol=1.6e-2, atol=2e-2)
