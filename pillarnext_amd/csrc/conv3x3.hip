@@ -306,11 +306,12 @@ __device__ __forceinline__ int lds_swz(int c) { return (c & 7) ^ ((c >> 3) & 1);
 
 // Stage the (TH+2) x 34 halo tile of 64 input channels [ch0, ch0+64) of image b at tile origin (y0, x0): 256 threads = 32 pixels
 // x 8 chunks per step, all loads of a batch in flight before the first ds_write.  `need` = halo rows to load (bit r).
-template <int CSTRIDE>
+template <int CSTRIDE, int TH = LDS_TH>
 __device__ __forceinline__ void stage_tile64(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, int b, int H, int W, int ch0, int y0, int x0,
                                              uint32_t need) {
-  constexpr int SBATCH = 10;  // loads in flight per thread (2 batches cover the tile)
-  static_assert(2 * SBATCH * 256 >= LDS_NSTAGE, "staging batches");
+  constexpr int NPIX = (TH + 2) * LDS_HW;
+  constexpr int SBATCH = (NPIX * 8 + 511) / 512;  // loads in flight per thread (2 batches cover the tile): 10 at TH = 16, 6 at TH = 8
+  static_assert(NPIX <= 640, "pix / 34 by multiplication");
   const uint16_t* xt = x + (((int64_t)b * H + (y0 - 1)) * W + (x0 - 1)) * CSTRIDE + ch0;  // element (0, 0) of the halo tile
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));  // opaque: keeps the 20 per-thread staging addresses from being hoisted out of the tile loop (and spilled)
@@ -324,14 +325,14 @@ __device__ __forceinline__ void stage_tile64(uint4* __restrict__ s_in, const uin
       const int pix = (part * SBATCH + i) * 32 + (tid >> 3);
       const int r = (pix * 1928) >> 16, c = pix - r * LDS_HW;  // pix / 34 for pix < 640
       q[i] = make_uint4(0, 0, 0, 0);
-      if (pix < (LDS_TH + 2) * LDS_HW && ((rows_ok >> r) & 1u) && y0 - 1 + r < H && (unsigned)(x0 - 1 + c) < (unsigned)W)
+      if (pix < NPIX && ((rows_ok >> r) & 1u) && y0 - 1 + r < H && (unsigned)(x0 - 1 + c) < (unsigned)W)
         q[i] = *reinterpret_cast<const uint4*>(xt + (r * W + c) * CSTRIDE + chunk * 8);
     }
 #pragma unroll
     for (int i = 0; i < SBATCH; i++) {
       const int pix = (part * SBATCH + i) * 32 + (tid >> 3);
       const int r = (pix * 1928) >> 16, c = pix - r * LDS_HW;
-      if (pix < (LDS_TH + 2) * LDS_HW) s_in[pix * 8 + (chunk ^ lds_swz(c))] = q[i];
+      if (pix < NPIX) s_in[pix * 8 + (chunk ^ lds_swz(c))] = q[i];
     }
   }
 }
@@ -339,15 +340,14 @@ __device__ __forceinline__ void stage_tile64(uint4* __restrict__ s_in, const uin
 // One 64-output-channel pass of a wave over its NR rows: 9 taps x 4 k-steps, software-pipelined in registers -- B fragments one
 // k-step ahead (LDS), weight fragments one tap ahead (L1/L2; each register pair is refilled for the next tap right after its
 // last MFMA of this tap).
-template <int NR, int MTALL>
+template <int NR, int MTALL, int CB = 4>
 __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __restrict__ s_in, const uint4* __restrict__ wfrag, const int (&rbase)[4],
-                                          int mg, int px, int kb, int lane) {
-  constexpr int CB = 4;
+                                          int mg, int px, int kb, int lane, int kstep0 = 0) {
   uint4 w[4][2];
 #pragma unroll
   for (int cbl = 0; cbl < 4; cbl++)
 #pragma unroll
-    for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[(cbl * MTALL + mg + m) * 64 + lane];
+    for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[((kstep0 + cbl) * MTALL + mg + m) * 64 + lane];
   uint4 qn[NR];
   {
     const int sw = lds_swz(px);
@@ -385,7 +385,7 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __res
       }
       if (tap < 8) {
 #pragma unroll
-        for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[((tn * CB + cbl) * MTALL + mg + m) * 64 + lane];
+        for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[((tn * CB + kstep0 + cbl) * MTALL + mg + m) * 64 + lane];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -522,6 +522,151 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
     CT_TOCK(4)
   }
   CT_FLUSH
+}
+
+// ---- 128 -> 128 channels, stride 1 (stage 1 of the backbone).  Same machinery on an 8 x 32 pixel tile: the 4 waves are 2 row
+// groups x 2 output-channel halves (4 rows x 64 channels of accumulators each, as above), the two 64-channel input slabs pass
+// through the same 43.5 KiB LDS buffer one after the other (accumulators stay in registers across the re-staging), so 2
+// workgroups share a CU.  Barriers sit inside the per-row-count switch: every wave of the workgroup executes the same number
+// of them whatever its NR (s_barrier counts arrivals, not program counters).
+constexpr int L128_TH = 8;
+constexpr int L128_NSTAGE = (L128_TH + 2) * LDS_HW * 8;
+
+template <int NR, bool HAS_RES>
+__device__ __forceinline__ void conv_rows128(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
+                                             const float* __restrict__ bias, const uint4 (&rq)[4][2][2], const int (&rbase)[4], const uint32_t (&rmask)[4],
+                                             uint16_t* const (&yrow)[4], int b, int H, int W, int y0, int x0, uint32_t need, int mg, int relu, int px,
+                                             int kb, int lane) {
+  v16f acc[NR > 0 ? NR : 1][2];
+  if (NR > 0) {
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      const v16f bq = bias_tile(bias, (mg + m) * 32, kb);
+#pragma unroll
+      for (int j = 0; j < NR; j++) acc[j][m] = bq;
+    }
+    if (HAS_RES) {
+#pragma unroll
+      for (int j = 0; j < NR; j++) add_residual(acc[j], rq[j]);
+    }
+    conv_taps<(NR > 0 ? NR : 1), 4, 8>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 0);
+  }
+  __syncthreads();  // slab 0 consumed
+  stage_tile64<128, L128_TH>(s_in, x, b, H, W, 64, y0, x0, need);
+  __syncthreads();
+  if (NR > 0) {
+    conv_taps<(NR > 0 ? NR : 1), 4, 8>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 4);
+    const int n_valid = W - x0;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+      const bool act = (rmask[j] >> px) & 1u;
+      uint4 D[4];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        uint4 pk[2];
+        pack_tile(acc[j][m], act, relu, pk);
+        D[2 * m] = pk[0], D[2 * m + 1] = pk[1];
+      }
+      transpose_row64(D, lane);
+      store_row64<128>(D, yrow[j] + mg * 32, n_valid, lane);
+    }
+  }
+}
+
+template <bool HAS_RES>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
+                                                        const float* __restrict__ bias, const uint16_t* __restrict__ res,
+                                                        const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
+                                                        int relu) {
+  constexpr int CIN = 128, COUT = 128, TH = L128_TH, HW_ = LDS_HW;
+  __shared__ uint4 s_in[L128_NSTAGE];
+  __shared__ uint32_t s_rowmask[TH];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int px = lane & 31, kb = lane >> 5;
+  const int rg = wv & 1, mg = 2 * (wv >> 1);  // row group, first 32-channel output tile of this wave
+  const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
+  const int64_t n_tiles = (int64_t)B * tiles_y * tiles_x;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int tx = (int)(tile % tiles_x);
+    const int ty = (int)((tile / tiles_x) % tiles_y);
+    const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
+    const int x0 = tx * 32, y0 = ty * TH;
+    const int ox = x0 + px;
+    // ---- active sites: one 32-bit column mask per row of the tile (wave wv looks at rows 2wv, 2wv+1)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int oy = y0 + wv * 2 + j;
+      const bool a = ox < W && oy < H && (mask == nullptr || mask[((int64_t)b * H + oy) * W + ox] != 0);
+      const uint32_t bal = (uint32_t)__ballot(a);
+      if (lane == 0) s_rowmask[wv * 2 + j] = bal;
+    }
+    __syncthreads();  // row masks visible; everybody is done reading the previous tile's s_in
+    const uint32_t my_rm = s_rowmask[lane & 7];
+    const uint32_t am = (uint32_t)__ballot(my_rm != 0) & 0xffu;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {  // rows without any active site: zero-fill
+      const int rr = wv * 2 + j, oy = y0 + rr;
+      if (((am >> rr) & 1u) == 0 && oy < H && ox < W) {
+        uint4* dst = reinterpret_cast<uint4*>(y + (((int64_t)b * H + oy) * W + ox) * COUT);
+#pragma unroll 1
+        for (int ch = kb; ch < COUT / 8; ch += 2) dst[ch] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    if (am == 0) continue;  // uniform over the workgroup
+    // ---- the active rows, dealt round-robin to the 2 row groups
+    int nr = 0;
+    int rbase[4], rrow[4];
+    {
+      uint32_t rest = am;
+      if (rg && rest) rest &= rest - 1;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool has = rest != 0;
+        rrow[j] = has ? __builtin_ctz(rest) : 0;  // dummy rows point at row 0
+        nr += has ? 1 : 0;
+        for (int k = 0; k < 2 && rest; k++) rest &= rest - 1;
+      }
+    }
+    nr = __builtin_amdgcn_readfirstlane(nr);
+    uint32_t rmask[4];
+    uint16_t* yrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      rrow[j] = __builtin_amdgcn_readfirstlane(rrow[j]);
+      rbase[j] = rrow[j] * HW_ * 8;
+      rmask[j] = j < nr ? __builtin_amdgcn_readfirstlane(s_rowmask[rrow[j]]) : 0u;
+      yrow[j] = y + (((int64_t)b * H + (y0 + rrow[j])) * W + x0) * COUT;
+    }
+    const uint32_t need = am | (am << 1) | (am << 2);  // halo rows some active row reads
+    uint4 rq[4][2][2];
+    if (HAS_RES) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        load_residual(rq[j], res + (((int64_t)b * H + (y0 + rrow[j])) * W + (ox < W ? ox : 0)) * COUT + mg * 32, (rmask[j] >> px) & 1u, kb);
+    }
+    stage_tile64<CIN, TH>(s_in, x, b, H, W, 0, y0, x0, need);
+    __syncthreads();
+    switch (nr) {  // wave-uniform; every case runs the same two barriers
+      case 0: conv_rows128<0, HAS_RES>(s_in, x, wfrag, bias, rq, rbase, rmask, yrow, b, H, W, y0, x0, need, mg, relu, px, kb, lane); break;
+      case 1: conv_rows128<1, HAS_RES>(s_in, x, wfrag, bias, rq, rbase, rmask, yrow, b, H, W, y0, x0, need, mg, relu, px, kb, lane); break;
+      case 2: conv_rows128<2, HAS_RES>(s_in, x, wfrag, bias, rq, rbase, rmask, yrow, b, H, W, y0, x0, need, mg, relu, px, kb, lane); break;
+      case 3: conv_rows128<3, HAS_RES>(s_in, x, wfrag, bias, rq, rbase, rmask, yrow, b, H, W, y0, x0, need, mg, relu, px, kb, lane); break;
+      default: conv_rows128<4, HAS_RES>(s_in, x, wfrag, bias, rq, rbase, rmask, yrow, b, H, W, y0, x0, need, mg, relu, px, kb, lane); break;
+    }
+  }
+}
+
+int launch_lds128(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
+                  hipStream_t st) {
+  int64_t nb = (int64_t)B * ((H + L128_TH - 1) / L128_TH) * ((W + 31) / 32);
+  if (nb > 512) nb = 512;  // resident workgroups: 2 per CU (registers)
+  if (res != nullptr)
+    k_conv3x3_lds128<true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B, H, W,
+                                                        relu);
+  else
+    k_conv3x3_lds128<false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
 }
 
 // ---- final convolution of the merged SepHead branches (det3d/models/dense_heads/centerpoint.py:30-60: Conv2d(64, k_j, 3) of every
@@ -692,6 +837,7 @@ int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const 
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1 && getenv("PNX_CONV_DIRECT") == nullptr) {
     if (cin == 64 && cout == 64) return launch_lds<64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
+    if (cin == 128 && cout == 128) return launch_lds128(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
     if (cin == 64 && cout == 384) return launch_lds<384>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
     if (cin == 64 && cout == 320) return launch_lds<320>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
     if (cin == 64 && cout == 448) return launch_lds<448>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);

@@ -86,13 +86,13 @@ def test_conv3x3_masked_matches_torch(cin, cout, stride, residual):
     torch.testing.assert_close(got2, ref2, rtol=1.6e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("cout,residual", [(64, False), (64, True), (384, False)])
-def test_conv3x3_sparse_rows(cout, residual):
+@pytest.mark.parametrize("cin,cout,residual", [(64, 64, False), (64, 64, True), (64, 384, False), (128, 128, False), (128, 128, True)])
+def test_conv3x3_sparse_rows(cin, cout, residual):
     """Few active rows per 16-row tile: the per-row-count (NR = 1..3) paths, dummy rows and zero-filled rows of the LDS kernel."""
     from pillarnext_amd import ops
 
     g = torch.Generator(device="cuda").manual_seed(7 + cout)
-    B, H, W, cin = 2, 83, 101, 64
+    B, H, W = 2, 83, 101
     mask = torch.zeros((B, H, W), dtype=torch.uint8, device="cuda")
     for r in (0, 3, 17, 18, 19, 40, 41, 42, 43, 44, 45, 46, 63, 82):      # 1, 1+3, 7 (-> waves with 2 and 1 rows), 1, last row
         mask[0, r] = (torch.rand((W,), device="cuda", generator=g) > 0.5).to(torch.uint8)
