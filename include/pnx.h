@@ -135,9 +135,13 @@ int pnx_bias_act_mask(const void* x, const void* residual, const float* bias, co
 /* Masked 3x3 convolution (pad 1, stride 1 or 2) with the same epilogue fused, bf16 NHWC, fp32 accumulation on MFMA:
  *   y = mask_out * [relu]( conv3x3(x, W) + bias [+ residual] ),  rows/tiles of the output without an active site are skipped.
  *   x (B,h,w,cin), y/residual (B,ho,wo,cout), mask uint8 (B,ho,wo) or NULL; wfrag = weights in MFMA-fragment order
- *   (pillarnext_amd/ops.py::conv3x3_pack_weights).  Built for (cin,cout) in {(64,64), (64,128), (128,128)} at stride 1|2 and {(64,320), (64,384), (64,448)} at stride 1. */
+ *   (pillarnext_amd/ops.py::conv3x3_pack_weights).  Built for (cin,cout) in {(64,64), (64,128), (128,128)} at stride 1|2 and {(64,320), (64,384), (64,448)} at stride 1.
+ *   row_dirty (optional, with a mask): uint8 (B, ho, ceil(wo/32)), one flag per 32-pixel row segment of y -- "may hold non-zero
+ *   data".  With it the kernel keeps y sparse-in-dense: segments without an active site are zero-filled only when their flag is
+ *   set (then cleared), segments with active sites are written and flagged; an all-empty segment of a PERSISTENT output buffer
+ *   costs no HBM traffic at all.  Contract: (y, row_dirty) start zeroed and y is only ever written through this function. */
 int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
-                     int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, pnx_stream_t stream);
+                     int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, uint8_t* row_dirty, pnx_stream_t stream);
 /* Final convolution of the merged SepHead branches of one task (det3d/models/dense_heads/centerpoint.py:30-60, the last
  * Conv2d(64, k_j, 3, padding=1, bias=True) of every branch j):  y[b,oy,ox,o] = bias[o] + sum_{j,ky,kx,c} x[b,oy+ky-1,ox+kx-1,64j+c] * W[o][64j+c][ky][kx]
  * with W block diagonal (output o belongs to exactly one branch).  x (B,h,w,64*n_branch) bf16, y (B,h,w,16) bf16 (sum k_j <= 16,

@@ -161,7 +161,7 @@ template <int CIN, int COUT, int STRIDE, bool W_LDS>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                  const float* __restrict__ bias, const uint16_t* __restrict__ res,
                                                  const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W, int Ho,
-                                                 int Wo, int relu) {
+                                                 int Wo, int relu, uint8_t* __restrict__ row_dirty) {
   constexpr int CB = CIN / 16, MT = COUT / 32, KSTEPS = 9 * CB;
   constexpr int NT = (MT <= 2) ? 4 : 2;  // rows of 32 pixels per wave: 8 accumulators either way
   extern __shared__ uint4 s_w[];         // KSTEPS * MT * 64 uint4 when W_LDS
@@ -189,6 +189,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const uint16_t* __restrict__
       act[j] = in && (mask == nullptr || mask[((int64_t)b * Ho + oy) * Wo + ox] != 0);
       any_row[j] = __ballot(act[j]) != 0;
       any = any || any_row[j];
+    }
+    // rows without an active site are written (as zeros) only when the row segment may hold stale data (see pnx.h: row_dirty)
+    bool row_store[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const int oy = oy0 + j;
+      row_store[j] = oy < Ho;
+      if (row_dirty != nullptr && oy < Ho) {
+        uint8_t* d = row_dirty + ((int64_t)b * Ho + oy) * tiles_x + tx;
+        const bool was = __builtin_amdgcn_readfirstlane((int)*d) != 0;
+        row_store[j] = any_row[j] || was;
+        if (lane == 0 && was != any_row[j]) *d = any_row[j] ? 1 : 0;
+      }
     }
     v16f acc[NT][MT];
 #pragma unroll
@@ -250,8 +263,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const uint16_t* __restrict__
     const int n_valid = Wo - tx * 32;  // pixels of this row segment inside the image (>= 32: all)
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-      const bool row_in = oy0 + j < Ho;  // wave-uniform
-      uint16_t* row = y + (((int64_t)b * Ho + (row_in ? oy0 + j : 0)) * Wo + tx * 32) * COUT;
+      const bool row_in = row_store[j];  // wave-uniform
+      if (!row_in) continue;
+      uint16_t* row = y + (((int64_t)b * Ho + (oy0 + j)) * Wo + tx * 32) * COUT;
 #pragma unroll
       for (int m0 = 0; m0 < MT; m0 += 2) {
         uint4 R[4];
@@ -433,7 +447,7 @@ template <int COUT, bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                      const float* __restrict__ bias, const uint16_t* __restrict__ res,
                                                      const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
-                                                     int relu) {
+                                                     int relu, uint8_t* __restrict__ row_dirty) {
   constexpr int CIN = 64;
   constexpr int TH = LDS_TH, HW_ = LDS_HW;
   static_assert(!HAS_RES || COUT == 64, "the residual is folded into the accumulators of a single 64-channel pass");
@@ -451,11 +465,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
     const int x0 = tx * 32, y0 = ty * TH;
     const int ox = x0 + px;
     CT_TOCK(7)
-    // ---- active sites: one 32-bit column mask per row of the tile
+    // ---- active sites: one 32-bit column mask per row of the tile; was[j]: the row segment may hold stale data (pnx.h: row_dirty)
+    bool was[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int oy = y0 + wv * 4 + j;
       const bool a = ox < W && oy < H && (mask == nullptr || mask[((int64_t)b * H + oy) * W + ox] != 0);
+      was[j] = true;
+      if (row_dirty != nullptr && oy < H) was[j] = __builtin_amdgcn_readfirstlane((int)row_dirty[((int64_t)b * H + oy) * tiles_x + tx]) != 0;
       const uint32_t bal = (uint32_t)__ballot(a);
       if (lane == 0) s_rowmask[wv * 4 + j] = bal;
     }
@@ -463,15 +480,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
     CT_TOCK(0)
     const uint32_t my_rm = s_rowmask[lane & 15];
     const uint32_t am = (uint32_t)__ballot(my_rm != 0) & 0xffffu;  // rows with an active site (wave-uniform, same in all waves)
-    // ---- rows without any active site: zero-fill (natural rows of this wave)
+    // ---- rows without any active site: zero-fill where needed (natural rows of this wave)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int rr = wv * 4 + j, oy = y0 + rr;
-      if (((am >> rr) & 1u) == 0 && oy < H && ox < W) {
+      const bool active = (am >> rr) & 1u;
+      if (!active && was[j] && oy < H && ox < W) {
         uint4* dst = reinterpret_cast<uint4*>(y + (((int64_t)b * H + oy) * W + ox) * COUT);
 #pragma unroll 1
         for (int ch = kb; ch < COUT / 8; ch += 2) dst[ch] = make_uint4(0, 0, 0, 0);
       }
+      if (row_dirty != nullptr && oy < H && lane == 0 && was[j] != active) row_dirty[((int64_t)b * H + oy) * tiles_x + tx] = active ? 1 : 0;
     }
     if (am == 0) continue;  // uniform over the workgroup
     // ---- the active rows, dealt round-robin to the waves (wave wv takes the active rows number wv, wv+4, ...)
@@ -577,7 +596,7 @@ template <bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                         const float* __restrict__ bias, const uint16_t* __restrict__ res,
                                                         const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
-                                                        int relu) {
+                                                        int relu, uint8_t* __restrict__ row_dirty) {
   constexpr int CIN = 128, COUT = 128, TH = L128_TH, HW_ = LDS_HW;
   __shared__ uint4 s_in[L128_NSTAGE];
   __shared__ uint32_t s_rowmask[TH];
@@ -593,10 +612,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __res
     const int x0 = tx * 32, y0 = ty * TH;
     const int ox = x0 + px;
     // ---- active sites: one 32-bit column mask per row of the tile (wave wv looks at rows 2wv, 2wv+1)
+    bool was[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int oy = y0 + wv * 2 + j;
       const bool a = ox < W && oy < H && (mask == nullptr || mask[((int64_t)b * H + oy) * W + ox] != 0);
+      was[j] = true;
+      if (row_dirty != nullptr && oy < H) was[j] = __builtin_amdgcn_readfirstlane((int)row_dirty[((int64_t)b * H + oy) * tiles_x + tx]) != 0;
       const uint32_t bal = (uint32_t)__ballot(a);
       if (lane == 0) s_rowmask[wv * 2 + j] = bal;
     }
@@ -604,13 +626,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __res
     const uint32_t my_rm = s_rowmask[lane & 7];
     const uint32_t am = (uint32_t)__ballot(my_rm != 0) & 0xffu;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {  // rows without any active site: zero-fill
+    for (int j = 0; j < 2; j++) {  // rows without any active site: zero-fill where needed
       const int rr = wv * 2 + j, oy = y0 + rr;
-      if (((am >> rr) & 1u) == 0 && oy < H && ox < W) {
+      const bool active = (am >> rr) & 1u;
+      if (!active && was[j] && oy < H && ox < W) {
         uint4* dst = reinterpret_cast<uint4*>(y + (((int64_t)b * H + oy) * W + ox) * COUT);
 #pragma unroll 1
         for (int ch = kb; ch < COUT / 8; ch += 2) dst[ch] = make_uint4(0, 0, 0, 0);
       }
+      if (row_dirty != nullptr && oy < H && lane == 0 && was[j] != active) row_dirty[((int64_t)b * H + oy) * tiles_x + tx] = active ? 1 : 0;
     }
     if (am == 0) continue;  // uniform over the workgroup
     // ---- the active rows, dealt round-robin to the 2 row groups
@@ -657,14 +681,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __res
 }
 
 int launch_lds128(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
-                  hipStream_t st) {
+                  uint8_t* row_dirty, hipStream_t st) {
   int64_t nb = (int64_t)B * ((H + L128_TH - 1) / L128_TH) * ((W + 31) / 32);
   if (nb > 512) nb = 512;  // resident workgroups: 2 per CU (registers)
   if (res != nullptr)
     k_conv3x3_lds128<true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B, H, W,
-                                                        relu);
+                                                        relu, row_dirty);
   else
-    k_conv3x3_lds128<false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu);
+    k_conv3x3_lds128<false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu,
+                                                         row_dirty);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -754,7 +779,7 @@ int launch_sephead(const void* x, const void* wfrag, const float* bias, void* y,
 
 template <int COUT>
 int launch_lds(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
-               hipStream_t st) {
+               uint8_t* row_dirty, hipStream_t st) {
   constexpr int TH = LDS_TH;
   const int64_t n_tiles = (int64_t)B * ((H + TH - 1) / TH) * ((W + 31) / 32);
   int64_t nb = n_tiles;
@@ -763,21 +788,22 @@ int launch_lds(const void* x, const void* wfrag, const float* bias, const void* 
   if constexpr (COUT == 64) {
     if (res != nullptr) {
       k_conv3x3_lds<COUT, true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B,
-                                                             H, W, relu);
+                                                             H, W, relu, row_dirty);
       PNX_LAUNCH_CHECK();
       return PNX_OK;
     }
   } else {
     PNX_REQUIRE(res == nullptr, PNX_ERR_UNSUPPORTED, "residual with %d output channels", COUT);
   }
-  k_conv3x3_lds<COUT, false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu);
+  k_conv3x3_lds<COUT, false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu,
+                                                          row_dirty);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
 
 template <int CIN, int COUT, int STRIDE>
 int launch(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int Ho,
-           int Wo, int relu, hipStream_t st) {
+           int Wo, int relu, uint8_t* row_dirty, hipStream_t st) {
   constexpr size_t wbytes = (size_t)9 * (CIN / 16) * (COUT / 32) * 64 * 16;
   constexpr bool W_LDS = wbytes <= 76 * 1024;
   constexpr int NT = (COUT / 32 <= 2) ? 4 : 2;
@@ -793,7 +819,7 @@ int launch(const void* x, const void* wfrag, const float* bias, const void* res,
     }
   }
   kern<<<(unsigned)nb, 256, W_LDS ? wbytes : 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B, H, W,
-                                                    Ho, Wo, relu);
+                                                    Ho, Wo, relu, row_dirty);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -828,24 +854,25 @@ int pnx_sephead_out_bf16(const void* x, const void* wfrag, const float* bias, vo
 }
 
 int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
-                     int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, pnx_stream_t stream) {
+                     int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, uint8_t* row_dirty, pnx_stream_t stream) {
   PNX_REQUIRE(x && wfrag && bias && y && batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "bad arguments");
   PNX_REQUIRE(stride == 1 || stride == 2, PNX_ERR_UNSUPPORTED, "stride %d", stride);
+  PNX_REQUIRE(row_dirty == nullptr || mask != nullptr, PNX_ERR_INVALID, "row_dirty needs an active-site mask");
   PNX_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)wfrag | (uintptr_t)bias | (uintptr_t)residual) & 15) == 0, PNX_ERR_INVALID,
               "16-byte alignment required");
   const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1 && getenv("PNX_CONV_DIRECT") == nullptr) {
-    if (cin == 64 && cout == 64) return launch_lds<64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
-    if (cin == 128 && cout == 128) return launch_lds128(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
-    if (cin == 64 && cout == 384) return launch_lds<384>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
-    if (cin == 64 && cout == 320) return launch_lds<320>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
-    if (cin == 64 && cout == 448) return launch_lds<448>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, st);
+    if (cin == 64 && cout == 64) return launch_lds<64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
+    if (cin == 128 && cout == 128) return launch_lds128(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
+    if (cin == 64 && cout == 384) return launch_lds<384>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
+    if (cin == 64 && cout == 320) return launch_lds<320>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
+    if (cin == 64 && cout == 448) return launch_lds<448>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
   }
 #define PNX_CONV_CASE(CI, CO)                                                                                          \
   if (cin == CI && cout == CO) {                                                                                       \
-    if (stride == 1) return launch<CI, CO, 1>(x, wfrag, bias, residual, mask, y, batch, h, w, ho, wo, relu, st);         \
-    return launch<CI, CO, 2>(x, wfrag, bias, residual, mask, y, batch, h, w, ho, wo, relu, st);                         \
+    if (stride == 1) return launch<CI, CO, 1>(x, wfrag, bias, residual, mask, y, batch, h, w, ho, wo, relu, row_dirty, st);         \
+    return launch<CI, CO, 2>(x, wfrag, bias, residual, mask, y, batch, h, w, ho, wo, relu, row_dirty, st);                         \
   }
   PNX_CONV_CASE(64, 64)
   PNX_CONV_CASE(64, 128)

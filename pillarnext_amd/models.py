@@ -510,8 +510,8 @@ class _HipConv3x3(nn.Module):
         self.register_buffer("wfrag", ops.conv3x3_pack_weights(weight))
         self.register_buffer("bias", bias.float().contiguous())
 
-    def forward(self, x, mask=None, residual=None):
-        return ops.conv3x3_masked(x, self.wfrag, self.bias, self.cout, self.stride, mask, residual, True)
+    def forward(self, x, mask=None, residual=None, out=None):
+        return ops.conv3x3_masked(x, self.wfrag, self.bias, self.cout, self.stride, mask, residual, True, out=out)
 
 
 class _HipSepHeadOut(nn.Module):
@@ -540,10 +540,12 @@ class FusedPillarNeXt(nn.Module):
 
     def __init__(self, det, dtype=torch.bfloat16, hip_conv=None):
         super().__init__()
-        if hip_conv is None:
-            import os
+        import os
 
+        if hip_conv is None:
             hip_conv = os.environ.get("PNX_HIP_CONV", "1") != "0"
+        self._ws = {}
+        self.sparse_ws = os.environ.get("PNX_SPARSE_WS", "1") != "0"
         self.reader = det.reader
         self.post_processing = det.post_processing
         self.head_ref = det.head  # predict() / rectifier / class bookkeeping
@@ -634,10 +636,19 @@ class FusedPillarNeXt(nn.Module):
         for si, (mods, (stride, subm)) in enumerate(zip(self.stages, self.stage_meta)):
             if not subm:
                 mask = ops.mask_pool3(mask, stride)
-            x = mods[0](x, mask)
+            ws, k = self._stage_workspace(si, mods, mask), 0
+
+            def run(m, inp, res=None):
+                nonlocal k
+                if ws is None:
+                    return m(inp, mask, residual=res)
+                k += 1                                  # x, y, out of a block sit in three different buffers
+                return m(inp, mask, residual=res, out=ws[(k - 1) % 3])
+
+            x = run(mods[0], x)
             for j in range(1, len(mods), 2):
-                y = mods[j](x, mask)
-                x = mods[j + 1](y, mask, residual=x)
+                y = run(mods[j], x)
+                x = run(mods[j + 1], y, x)
             mark(f"backbone.stage{si}")
         x = self.mapping(x, mask)
         # BasicBlock (utils/conv.py): act(block2(block1(x)) + x) where block2 already ends in a ReLU, so the residual is added
@@ -660,6 +671,17 @@ class FusedPillarNeXt(nn.Module):
             preds.append(d)
         mark("head")
         return preds
+
+    def _stage_workspace(self, si, mods, mask):
+        """Three persistent (activation, row_dirty) pairs per all-HIP backbone stage: the convolutions then touch only the row
+        segments that hold (or held, one frame ago) active sites -- ops.conv3x3_workspace / pnx.h row_dirty."""
+        if not self.sparse_ws or not all(isinstance(m, _HipConv3x3) for m in mods):
+            return None
+        B, H, W = mask.shape
+        key = (si, B, H, W, mask.device)
+        if key not in self._ws:
+            self._ws[key] = [ops.conv3x3_workspace(B, mods[0].cout, H, W, mask.device) for _ in range(3)]
+        return self._ws[key]
 
     def decoder(self):
         if self._decoder is None:

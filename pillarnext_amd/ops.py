@@ -236,13 +236,25 @@ def sephead_out(x, wfrag, bias):
     return y
 
 
-def conv3x3_masked(x, wfrag, bias, cout, stride=1, mask=None, residual=None, relu=True):
-    """x (B,Cin,H,W) channels_last bf16 -> (B,Cout,Ho,Wo) channels_last bf16; mask uint8 (B,Ho,Wo) of the OUTPUT sites."""
+def conv3x3_workspace(batch, cout, ho, wo, device):
+    """A persistent (output buffer, row_dirty flags) pair for conv3x3_masked(out=...): both start zeroed (pnx.h: row_dirty)."""
+    y = torch.zeros((batch, cout, ho, wo), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
+    return y, torch.zeros((batch, ho, (wo + 31) // 32), dtype=torch.uint8, device=device)
+
+
+def conv3x3_masked(x, wfrag, bias, cout, stride=1, mask=None, residual=None, relu=True, out=None):
+    """x (B,Cin,H,W) channels_last bf16 -> (B,Cout,Ho,Wo) channels_last bf16; mask uint8 (B,Ho,Wo) of the OUTPUT sites.
+    out = (y, row_dirty) from conv3x3_workspace: write into the persistent buffer, touching only row segments that are or were active."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):
         raise PnxError("conv3x3_masked needs a channels_last bf16 CUDA tensor")
     B, ci, H, W = x.shape
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
-    y = torch.empty((B, cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    if out is not None:
+        y, dirty = out
+        if mask is None or tuple(y.shape) != (B, cout, Ho, Wo) or tuple(dirty.shape) != (B, Ho, (Wo + 31) // 32):
+            raise PnxError("conv3x3_masked: out= needs a mask and a workspace of the output shape")
+    else:
+        y, dirty = torch.empty((B, cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last), None
     check(lib().pnx_conv3x3_bf16(ptr(x), ptr(wfrag), ptr(bias), ptr(residual), ptr(mask), ptr(y), B, H, W, ci, cout, stride, 1 if relu else 0,
-                                 stream_ptr()), "pnx_conv3x3_bf16")
+                                 ptr(dirty), stream_ptr()), "pnx_conv3x3_bf16")
     return y

@@ -133,3 +133,31 @@ def test_sephead_out_matches_torch(nb):
     assert got.shape == ref.shape
     assert bool((got[:, o:] == 0).all())
     torch.testing.assert_close(got, ref, rtol=1.6e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (128, 128, 1), (64, 128, 2)])
+def test_conv3x3_row_dirty_workspace(cin, cout, stride):
+    """Persistent output buffer + row_dirty flags (pnx.h): three frames with different active sets through ONE workspace must
+    equal the stateless result every time -- stale rows of an earlier frame are cleared, untouched rows stay zero."""
+    from pillarnext_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(cin + stride)
+    B, H, W = 2, 70, 99
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    w = (torch.randn((cout, cin, 3, 3), device="cuda", generator=g) / 24).to(torch.bfloat16)
+    wf = ops.conv3x3_pack_weights(w)
+    bias = torch.randn((cout,), device="cuda", generator=g)
+    ws = ops.conv3x3_workspace(B, cout, Ho, Wo, "cuda")
+    for frame in range(3):
+        mask = torch.zeros((B, Ho, Wo), dtype=torch.uint8, device="cuda")
+        rows = torch.randperm(Ho, device="cuda", generator=g)[: 6 + 5 * frame]
+        mask[0, rows] = (torch.rand((rows.numel(), Wo), device="cuda", generator=g) > 0.6).to(torch.uint8)
+        if frame != 1:
+            mask[1, 5 * frame:5 * frame + 20, 10:40] = (torch.rand((20, 30), device="cuda", generator=g) > 0.8).to(torch.uint8)
+        x = torch.randn((B, cin, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        ref = ops.conv3x3_masked(x, wf, bias, cout, stride, mask, None, True)
+        got = ops.conv3x3_masked(x, wf, bias, cout, stride, mask, None, True, out=ws)
+        assert got.data_ptr() == ws[0].data_ptr()
+        assert torch.equal(got, ref), f"frame {frame}"
+        seg_active = torch.nn.functional.max_pool1d(mask.float(), 32, 32, ceil_mode=True) > 0
+        assert torch.equal(ws[1] != 0, seg_active), "row_dirty must equal the active row segments after a call"
