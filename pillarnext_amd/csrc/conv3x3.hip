@@ -702,11 +702,11 @@ int launch_lds128(const void* x, const void* wfrag, const float* bias, const voi
 // the D fragment (lane = pixel n + 16 q: channels 4q..4q+3) stores 8 bytes per lane, 512 contiguous bytes per instruction.
 // wfrag: [branch][tap][kc][lane = q*16 + o][8]: W[o][branch*64 + kc*32 + q*8 + e][ky][kx] (ops.py::sephead_pack_weights).
 typedef float v4f __attribute__((ext_vector_type(4)));
-template <int NBR>
-__global__ __launch_bounds__(256, 2) void k_sephead_out(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+template <int NBR, int TH>
+__global__ __launch_bounds__(256) void k_sephead_out(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
                                                      uint16_t* __restrict__ y, int B, int H, int W) {
-  constexpr int CIN = NBR * 64, TH = LDS_TH, HW_ = LDS_HW;
-  __shared__ uint4 s_in[LDS_NSTAGE];
+  constexpr int CIN = NBR * 64, HW_ = LDS_HW, RW = TH / 4;  // RW rows per wave
+  __shared__ uint4 s_in[(TH + 2) * LDS_HW * 8];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
   const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * q);
@@ -717,15 +717,15 @@ __global__ __launch_bounds__(256, 2) void k_sephead_out(const uint16_t* __restri
     const int ty = (int)((tile / tiles_x) % tiles_y);
     const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
     const int x0 = tx * 32, y0 = ty * TH;
-    v4f acc[4][2];
+    v4f acc[RW][2];
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+    for (int r = 0; r < RW; r++)
 #pragma unroll
       for (int h = 0; h < 2; h++) acc[r][h] = v4f{bq.x, bq.y, bq.z, bq.w};
 #pragma unroll 1
     for (int j = 0; j < NBR; j++) {
       __syncthreads();  // everybody is done reading the previous slab
-      stage_tile64<CIN>(s_in, x, b, H, W, j * 64, y0, x0, 0x3ffffu);
+      stage_tile64<CIN, TH>(s_in, x, b, H, W, j * 64, y0, x0, (1u << (TH + 2)) - 1u);
       __syncthreads();
       const uint4* wj = wfrag + (size_t)j * 18 * 64 + lane;
       uint4 wn[2] = {wj[0], wj[64]};
@@ -736,16 +736,16 @@ __global__ __launch_bounds__(256, 2) void k_sephead_out(const uint16_t* __restri
         if (tap < 8) wn[0] = wj[(tap + 1) * 128], wn[1] = wj[(tap + 1) * 128 + 64];
 #pragma unroll
         for (int kc = 0; kc < 2; kc++) {
-          uint4 bf[4][2];
+          uint4 bf[RW][2];
 #pragma unroll
-          for (int r = 0; r < 4; r++)
+          for (int r = 0; r < RW; r++)
 #pragma unroll
             for (int h = 0; h < 2; h++) {
               const int c = 16 * h + n + dx;
-              bf[r][h] = s_in[((wv * 4 + r + dy) * HW_ + c) * 8 + ((kc * 4 + q) ^ lds_swz(c))];
+              bf[r][h] = s_in[((wv * RW + r + dy) * HW_ + c) * 8 + ((kc * 4 + q) ^ lds_swz(c))];
             }
 #pragma unroll
-          for (int r = 0; r < 4; r++)
+          for (int r = 0; r < RW; r++)
 #pragma unroll
             for (int h = 0; h < 2; h++)
               acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[kc]), __builtin_bit_cast(bf16x8, bf[r][h]), acc[r][h], 0,
@@ -754,10 +754,10 @@ __global__ __launch_bounds__(256, 2) void k_sephead_out(const uint16_t* __restri
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+    for (int r = 0; r < RW; r++)
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const int oy = y0 + wv * 4 + r, ox = x0 + 16 * h + n;
+        const int oy = y0 + wv * RW + r, ox = x0 + 16 * h + n;
         if (oy < H && ox < W) {
           uint2 p;
           p.x = pack_bf16(acc[r][h][0], acc[r][h][1]);
@@ -770,9 +770,15 @@ __global__ __launch_bounds__(256, 2) void k_sephead_out(const uint16_t* __restri
 
 template <int NBR>
 int launch_sephead(const void* x, const void* wfrag, const float* bias, void* y, int B, int H, int W, hipStream_t st) {
-  int64_t nb = (int64_t)B * ((H + LDS_TH - 1) / LDS_TH) * ((W + 31) / 32);
-  if (nb > 512) nb = 512;  // resident workgroups (LDS: 76.5 KiB per workgroup)
-  k_sephead_out<NBR><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (uint16_t*)y, B, H, W);
+  static const int th = getenv("PNX_SEPHEAD_TH") ? atoi(getenv("PNX_SEPHEAD_TH")) : 8;
+  const int TH = th == 16 ? 16 : 8;
+  int64_t nb = (int64_t)B * ((H + TH - 1) / TH) * ((W + 31) / 32);
+  const int64_t cap = TH == 16 ? 512 : 768;  // resident workgroups: 2 (76.5 KiB) or 3 (43.5 KiB) per CU
+  if (nb > cap) nb = cap;
+  if (TH == 16)
+    k_sephead_out<NBR, 16><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (uint16_t*)y, B, H, W);
+  else
+    k_sephead_out<NBR, 8><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (uint16_t*)y, B, H, W);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

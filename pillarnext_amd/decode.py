@@ -52,8 +52,9 @@ class PackedDecoder:
         return out
 
     @torch.no_grad()
-    def __call__(self, packed, tokens=None):
-        """packed: list (one per task) of (B, C_t, H, W) channels_last tensors, fp32 or bf16 (all the same dtype)."""
+    def launch(self, packed, tokens=None):
+        """packed: list (one per task) of (B, C_t, H, W) channels_last tensors, fp32 or bf16 (all the same dtype).
+        Enqueues decode + NMS + the D2H copy and returns a PendingDetections."""
         B = packed[0].shape[0]
         dev = packed[0].device
         dt = PNX_F32 if packed[0].dtype == torch.float32 else PNX_BF16
@@ -97,11 +98,31 @@ class PackedDecoder:
         out = torch.empty((S, self.post_max, 10), dtype=torch.float32, device=dev)
         check(L.pnx_gather_kept(ptr(boxes9), ptr(scores), ptr(keep), ptr(cnt), S, self.pre_max, self.post_max, ptr(out), stream_ptr()),
               "pnx_gather_kept")
-        out_c = out.cpu()            # the one device->host hand-off of the frame batch
-        cnt_c = cnt[:S].cpu().tolist()
-        tokens = tokens if tokens else [None] * B
+        # the one device->host hand-off of the frame batch: asynchronous into pinned memory; PendingDetections.result() waits
+        out_h = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        cnt_h = torch.empty((S,), dtype=cnt.dtype, pin_memory=True)
+        out_h.copy_(out, non_blocking=True)
+        cnt_h.copy_(cnt[:S], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return PendingDetections(ev, out_h, cnt_h, B, self.nc_total, tokens if tokens else [None] * B)
+
+    def __call__(self, packed, tokens=None):
+        return self.launch(packed, tokens).result()
+
+
+class PendingDetections:
+    """Detections of one frame batch on their way to the host.  Splitting launch() from result() lets a serving loop enqueue
+    the next batch's GPU work before it blocks on this one (the GPU never idles on the host's post-processing)."""
+
+    def __init__(self, event, out_h, cnt_h, batch, nc_total, tokens):
+        self.event, self.out_h, self.cnt_h, self.batch, self.nc_total, self.tokens = event, out_h, cnt_h, batch, nc_total, tokens
+
+    def result(self):
+        self.event.synchronize()
+        out_c, cnt_c = self.out_h, self.cnt_h.tolist()
         res = []
-        for b in range(B):
+        for b in range(self.batch):
             bb, ss, ll = [], [], []
             for c in range(self.nc_total):
                 k = cnt_c[b * self.nc_total + c]
@@ -109,5 +130,5 @@ class PackedDecoder:
                 bb.append(blk[:, :9])
                 ss.append(blk[:, 9])
                 ll.append(torch.full((k,), c, dtype=torch.int64))
-            res.append({"box3d_lidar": torch.cat(bb), "scores": torch.cat(ss), "label_preds": torch.cat(ll), "token": tokens[b]})
+            res.append({"box3d_lidar": torch.cat(bb), "scores": torch.cat(ss), "label_preds": torch.cat(ll), "token": self.tokens[b]})
         return res

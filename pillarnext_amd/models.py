@@ -693,12 +693,20 @@ class FusedPillarNeXt(nn.Module):
         return self._decoder
 
     @torch.no_grad()
-    def forward(self, example):
+    def forward_async(self, example):
+        """Enqueue the whole frame batch (reader -> ... -> NMS -> D2H copy) and return a decode.PendingDetections."""
         packed = []
         self.forward_preds(example["points"], example["batch_size"], packed_out=packed)
-        outputs = self.decoder()(packed, example.get("token"))
+        return self.decoder().launch(packed, example.get("token"))
+
+    @staticmethod
+    def detections(outputs):
         det = {}
         for o in outputs:
             tok = o.pop("token")
             det[tok] = o  # already on the host
         return det
+
+    @torch.no_grad()
+    def forward(self, example):
+        return self.detections(self.forward_async(example).result())
