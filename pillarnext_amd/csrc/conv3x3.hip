@@ -318,36 +318,42 @@ constexpr int LDS_NSTAGE = (LDS_TH + 2) * LDS_HW * 8;  // uint4 per staged tile 
 
 __device__ __forceinline__ int lds_swz(int c) { return (c & 7) ^ ((c >> 3) & 1); }
 
-// Stage the (TH+2) x 34 halo tile of 64 input channels [ch0, ch0+64) of image b at tile origin (y0, x0): 256 threads = 32 pixels
-// x 8 chunks per step, all loads of a batch in flight before the first ds_write.  `need` = halo rows to load (bit r).
+// Stage the (TH+2) x 34 halo tile of 64 input channels [ch0, ch0+64) of image b at tile origin (y0, x0).  Thread t owns chunk t&7
+// of halo column t>>3 (0..31) in every row -- address = wave-uniform row pointer + ONE per-thread 32-bit offset, row validity is
+// scalar -- and the two remaining columns (32, 33) are spread over the threads as 16 slots per row.  Two batches; all loads of
+// a batch are in flight before its first ds_write.  `need` = halo rows to load (bit r); the rest of LDS keeps stale data nobody
+// reads.
 template <int CSTRIDE, int TH = LDS_TH>
 __device__ __forceinline__ void stage_tile64(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, int b, int H, int W, int ch0, int y0, int x0,
                                              uint32_t need) {
-  constexpr int NPIX = (TH + 2) * LDS_HW;
-  constexpr int SBATCH = (NPIX * 8 + 511) / 512;  // loads in flight per thread (2 batches cover the tile): 10 at TH = 16, 6 at TH = 8
-  static_assert(NPIX <= 640, "pix / 34 by multiplication");
+  constexpr int NROW = TH + 2, HALF = NROW / 2, NEXTRA = NROW * 16;
+  static_assert(NROW % 2 == 0 && NEXTRA <= 512, "two batches");
   const uint16_t* xt = x + (((int64_t)b * H + (y0 - 1)) * W + (x0 - 1)) * CSTRIDE + ch0;  // element (0, 0) of the halo tile
   int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));  // opaque: keeps the 20 per-thread staging addresses from being hoisted out of the tile loop (and spilled)
-  const int chunk = tid & 7;
-  const uint32_t rows_ok = need & ~(y0 == 0 ? 1u : 0u);  // halo row 0 of the first tile row lies above the image
+  asm volatile("" : "+v"(tid));  // opaque: keeps per-thread staging addresses from being hoisted out of the tile loop (and spilled)
+  const int chunk = tid & 7, col = tid >> 3;
+  uint32_t rows_ok = need & ~(y0 == 0 ? 1u : 0u);  // halo row 0 of the first tile row lies above the image
+  if (y0 - 1 + NROW > H) rows_ok &= (1u << (H - (y0 - 1))) - 1u;  // rows below the image
+  const bool col_ok = (unsigned)(x0 - 1 + col) < (unsigned)W;
+  const uint32_t voff = (uint32_t)(col * CSTRIDE + chunk * 8) * 2u;
+  const int lds_main = col * 8 + (chunk ^ lds_swz(col));
 #pragma unroll
   for (int part = 0; part < 2; part++) {
-    uint4 q[SBATCH];
+    uint4 q[HALF], qe = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < SBATCH; i++) {
-      const int pix = (part * SBATCH + i) * 32 + (tid >> 3);
-      const int r = (pix * 1928) >> 16, c = pix - r * LDS_HW;  // pix / 34 for pix < 640
+    for (int i = 0; i < HALF; i++) {
+      const int r = part * HALF + i;
       q[i] = make_uint4(0, 0, 0, 0);
-      if (pix < NPIX && ((rows_ok >> r) & 1u) && y0 - 1 + r < H && (unsigned)(x0 - 1 + c) < (unsigned)W)
-        q[i] = *reinterpret_cast<const uint4*>(xt + (r * W + c) * CSTRIDE + chunk * 8);
+      if (((rows_ok >> r) & 1u) && col_ok)
+        q[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(xt + (int64_t)r * W * CSTRIDE) + voff);
     }
+    const int e = part * 256 + tid;  // slot of the two extra columns: row e>>4, column 32 + ((e>>3)&1), chunk e&7
+    const int re = e >> 4, ce = 32 + ((e >> 3) & 1);
+    if (e < NEXTRA && ((rows_ok >> re) & 1u) && (unsigned)(x0 - 1 + ce) < (unsigned)W)
+      qe = *reinterpret_cast<const uint4*>(xt + ((int64_t)re * W + ce) * CSTRIDE + (e & 7) * 8);
 #pragma unroll
-    for (int i = 0; i < SBATCH; i++) {
-      const int pix = (part * SBATCH + i) * 32 + (tid >> 3);
-      const int r = (pix * 1928) >> 16, c = pix - r * LDS_HW;
-      if (pix < NPIX) s_in[pix * 8 + (chunk ^ lds_swz(c))] = q[i];
-    }
+    for (int i = 0; i < HALF; i++) s_in[(part * HALF + i) * LDS_HW * 8 + lds_main] = q[i];
+    if (e < NEXTRA) s_in[(re * LDS_HW + ce) * 8 + ((e & 7) ^ lds_swz(ce))] = qe;
   }
 }
 
