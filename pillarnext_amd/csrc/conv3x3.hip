@@ -5,12 +5,16 @@
 //        y[b, oy, ox, :] = mask[b, oy, ox] * relu( sum_{ky,kx} x[b, oy*s+ky-1, ox*s+kx-1, :] . W[:, ky, kx, :] + bias [+ res] )
 //
 // Implicit GEMM on v_mfma_f32_32x32x16_bf16 with M = output channels, N = 32 consecutive output pixels of one image row,
-// K = 9 taps x CIN.  The B fragment of a lane is 8 consecutive input channels of one pixel = ONE 16-byte NHWC load (from
-// L1/L2: every input pixel is reused by 9 taps and 2-4 channel tiles), the A fragments (weights, pre-arranged on the host in
-// fragment order) sit in LDS when they fit (64->64: 72 KiB) and are streamed through L2 otherwise.  A wave owns 4 rows x 32
-// columns of output pixels (8 accumulators at COUT=64); rows/tiles without a single active site skip their MFMAs -- that is
-// where the sparsity of the BEV map pays in a dense layout -- and the epilogue (bias, residual, ReLU, mask, bf16 pack) writes
-// each output line once.  MIOpen needs a conv pass plus a separate elementwise pass for the same result.
+// K = 9 taps x CIN.  The B fragment of a lane is 8 consecutive input channels of one pixel = ONE 16-byte NHWC read, the A
+// fragments (weights) are pre-arranged on the host in fragment order.  Kernels in this file:
+//   k_conv3x3          direct: B fragments straight from L1/L2 (strided layers; every input line is re-read 9 times)
+//   k_conv3x3_lds      stride 1, 64 input channels: 18x34 halo tile staged once in LDS, 1..7 passes of 64 output channels
+//   k_conv3x3_lds128   stride 1, 128 -> 128: 10x34 tile, two input slabs through one LDS buffer under live accumulators
+//   k_sephead_out      block-diagonal 16-output convolution closing the merged SepHead branches (16x16x32 MFMA)
+// Rows/tiles without an active site skip their MFMAs (and, with row_dirty, their HBM traffic) -- that is where the sparsity of
+// the BEV map pays in a dense layout; bias and residual start the accumulators, the epilogue (ReLU, mask, bf16 pack) writes
+// complete 128-byte lines.  MIOpen needs a conv pass plus a separate elementwise pass for the same result.  DESIGN.md section 4
+// has the measurements each of these choices came from.
 #include "pnx_common.h"
 
 namespace {
@@ -20,12 +24,6 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float bf2f_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf2f_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ uint32_t f2bf_rne(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
-}
 
 // Epilogue.  The MFMA leaves lane (px, kb) with channels {8g + 4kb + i} of pixel px: four 8-byte pieces per 32-channel tile,
 // i.e. 32 scattered 8-byte stores per row of 32 pixels.  Measured, that store pattern -- not the MFMAs -- bounded the kernel

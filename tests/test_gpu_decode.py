@@ -88,6 +88,47 @@ def test_fused_inference_graph_matches_module_graph():
     assert set(d) == {"a", "b"} and d["a"]["box3d_lidar"].shape[1] == 9
 
 
+def test_fused_graph_is_stateless_across_frames():
+    """The persistent sparse-in-dense stage workspaces (row_dirty) must not leak one frame into the next: frame B after frame A
+    through ONE FusedPillarNeXt == frame B through a fresh one (same kernels, so bit-equal), also with the workspaces disabled."""
+    from pillarnext_amd import synth
+    from pillarnext_amd.models import FusedPillarNeXt, build_pillarnext_b
+
+    cfg = synth.CONFIGS["C1"]
+    torch.manual_seed(3)
+    torch.backends.cudnn.deterministic = True
+    model = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"], tasks=[["car"], ["truck", "bus"]], with_iou_head=True).cuda().eval()
+    frames = [torch.from_numpy(synth.make_batch("C1", 2, d, n=n, frame0=f)).cuda() for d, n, f in (("sweep", 30_000, 0), ("uniform", 4_000, 7),
+                                                                                                  ("sweep", 20_000, 3))]
+    seq = FusedPillarNeXt(model).cuda().eval()
+    assert seq.sparse_ws
+    outs_seq = [[p.clone() for p in _packed(seq, f)] for f in frames]
+    assert seq._ws, "stage workspaces were not used"
+    for i, f in enumerate(frames):
+        fresh = FusedPillarNeXt(model).cuda().eval()
+        for a, b in zip(outs_seq[i], _packed(fresh, f)):
+            _same(a, b, f"frame {i}: workspace state leaked into the result")
+    dense = FusedPillarNeXt(model).cuda().eval()
+    dense.sparse_ws = False
+    for a, b in zip(outs_seq[2], _packed(dense, frames[2])):
+        _same(a, b, "sparse workspaces vs freshly allocated outputs")
+
+
+def _same(a, b, what):
+    # same kernels on the same inputs: normally bit-equal; the tolerance only absorbs a different MIOpen solver pick between two
+    # module instances (a leaked row of stale activations would be an O(1) error)
+    err = (a.float() - b.float()).abs().max().item()
+    assert err <= 2e-2 * (b.float().abs().max().item() + 1.0), (what, err)
+
+
+def _packed(fused, pts):
+    packed = []
+    with torch.no_grad():
+        fused.forward_preds(pts, 2, packed_out=packed)
+    torch.cuda.synchronize()
+    return packed
+
+
 def test_packed_hip_decoder_matches_reference_golden():
     """csrc/decode.hip + one sort + one batched NMS == the reference's CenterHead.predict on the golden head outputs."""
     from pillarnext_amd.decode import PackedDecoder

@@ -40,7 +40,7 @@ if L is not None and hasattr(L, "pnx_debug_conv_timers") and not a.miopen:
     buf = (ctypes.c_ulonglong * 8)()
     L.pnx_debug_conv_timers(buf)          # reset
     run(); L.pnx_debug_conv_timers(buf)
-    names = ["rowmask+sync", "deal rows/zero rows", "stage issue+write", "stage barrier", "taps", "epilogue", "-", "tile head"]
+    names = ["rowmask+sync", "deal rows/zero rows", "residual loads + stage issue+write", "stage barrier", "taps + epilogue", "-", "-", "tile head"]
     tot = sum(buf)
     print("  section share of wave time:", ", ".join(f"{n} {100.0*v/tot:.1f}%" for n, v in zip(names, buf) if v))
 print(f"{'miopen+epilogue' if a.miopen else 'pnx_conv3x3'} {a.cin}->{a.cout} {a.hw}^2 b{a.batch} density {a.density}: {ms*1e3:.1f} us  {fl/ms/1e9:.0f} TFLOP/s (dense-equivalent)")
