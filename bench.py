@@ -31,8 +31,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PNX_BENCH_BATCH", "16")),
-                    help="frames per GPU per step (throughput: 4 -> 292, 8 -> 315, 16 -> 330 frames/s on one MI355X; 3 x 4.2 GB of stage-0 workspaces at 16)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PNX_BENCH_BATCH", "8")),
+                    help="frames per GPU per step (measured on one MI355X: 4 -> 292, 8 -> 325, 16 -> 326 frames/s)")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--dist", default="sweep", choices=["uniform", "sweep"],
                     help="sweep = ring-structured 10-sweep cloud (BASELINE configs[1]); uniform = worst case, ~1.2 points per pillar")
