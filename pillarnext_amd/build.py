@@ -33,7 +33,11 @@ def build(force=False, verbose=False):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        extra = ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + (["-DPNX_PFN_TIMERS"] if os.environ.get("PNX_PFN_TIMERS") else []) if src == "pfn_mfma.hip" else (["-fno-honor-nans"] + (["-DPNX_CONV_TIMERS"] if os.environ.get("PNX_CONV_TIMERS") else []) if src == "conv3x3.hip" else [])  # fmaxf without canonicalising v_max pairs (-inf still honoured); MFMA accumulators in VGPRs (no v_accvgpr traffic)
+        extra = []
+        if src == "pfn_mfma.hip":  # fmaxf without canonicalising v_max pairs (-inf still honoured); MFMA accumulators in VGPRs (no v_accvgpr traffic)
+            extra = ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + (["-DPNX_PFN_TIMERS"] if os.environ.get("PNX_PFN_TIMERS") else [])
+        elif src == "conv3x3.hip":
+            extra = ["-fno-honor-nans"] + (["-DPNX_CONV_TIMERS"] if os.environ.get("PNX_CONV_TIMERS") else [])
         cmd = [_hipcc()] + FLAGS + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
