@@ -291,3 +291,26 @@ def test_many_points_in_one_pillar_and_clamped_record_fields():
     canvas = net.forward_dense(tp, 1)
     c = co_a.long()
     assert torch.equal(canvas.permute(0, 2, 3, 1)[c[:, 0], c[:, 1], c[:, 2]], fm_a.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("layout", ["nhwc", "nchw"])
+@pytest.mark.parametrize("geom", [((-51.2, -51.2, -5.0, 51.2, 51.2, 3.0), (0.2, 0.2, 8.0)),      # 512 x 512: whole 32-cell tiles
+                                  ((-50.4, -50.4, -5.0, 50.4, 50.4, 3.0), (0.3, 0.3, 8.0)),      # 336 x 336: pitch % 16 == 0, edge tiles
+                                  ((-20.0, -31.0, -5.0, 20.0, 31.0, 3.0), (0.4, 0.4, 8.0))])     # 100 x 155: unaligned pitch
+def test_occupancy_output_is_the_pillar_set(geom, layout):
+    """forward_dense(occupancy=...) hands the backbone its active-site mask: exactly the cells listed in `coords`."""
+    from pillarnext_amd import synth
+
+    pc_range, voxel = geom
+    net = make_net(pc_range, voxel, synth.pfn_params())
+    B = 3
+    pts = torch.from_numpy(np.concatenate([synth.sweep_cloud(6000 + 500 * b, pc_range, 50 + b, batch_idx=b) for b in range(B)])).cuda()
+    ny, nx = (int(v) for v in net.grid_size)
+    occ = torch.full((B, ny, nx), 7, dtype=torch.uint8, device="cuda")
+    canvas = net.forward_dense(pts, B, channels_last=(layout == "nhwc"), occupancy=occ)
+    _, coords, _ = net(pts, B)
+    exp = torch.zeros((B, ny, nx), dtype=torch.uint8, device="cuda")
+    c = coords.long()
+    exp[c[:, 0], c[:, 1], c[:, 2]] = 1
+    assert torch.equal(occ, exp)
+    assert bool((canvas.float().abs().sum(1)[exp == 0] == 0).all())
