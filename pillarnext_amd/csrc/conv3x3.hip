@@ -316,6 +316,29 @@ constexpr int LDS_NSTAGE = (LDS_TH + 2) * LDS_HW * 8;  // uint4 per staged tile 
 
 __device__ __forceinline__ int lds_swz(int c) { return (c & 7) ^ ((c >> 3) & 1); }
 
+// Dynamic tile scheduling.  Tiles cost anything between "read 16 mask rows" and "4 rows x 9 taps of MFMAs per wave"; dealing
+// them to the persistent workgroups round-robin leaves the slowest workgroup 36 % above the mean on a LiDAR sweep (simulated
+// from the occupancy), a shared counter 3 %.  Thread 0 draws the NEXT tile at the top of an iteration (the
+// atomic's latency hides behind the mask loads), everybody reads it after the iteration's first barrier; the LDS word is
+// double-buffered by iteration parity because an empty tile has no second barrier.  g_tile_ctr[slot] = {next tile - gridDim.x,
+// finished workgroups}; the last workgroup to finish re-arms the slot, the host rotates 64 slots so that launches in flight
+// never share one.
+__device__ unsigned int g_tile_ctr[64][2];
+__device__ __forceinline__ void sched_draw(unsigned int* s_next, int it, int slot) {
+  if (threadIdx.x == 0) s_next[it & 1] = atomicAdd(&g_tile_ctr[slot][0], 1u);
+}
+__device__ __forceinline__ int64_t sched_next(const unsigned int* s_next, int it) { return (int64_t)s_next[it & 1] + gridDim.x; }
+__device__ __forceinline__ void sched_done(int slot) {
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&g_tile_ctr[slot][1], 1u) == gridDim.x - 1) {
+      g_tile_ctr[slot][0] = 0;
+      g_tile_ctr[slot][1] = 0;
+      __threadfence();
+    }
+  }
+}
+
 // Stage the (TH+2) x 34 halo tile of 64 input channels [ch0, ch0+64) of image b at tile origin (y0, x0).  Thread t owns chunk t&7
 // of halo column t>>3 (0..31) in every row -- address = wave-uniform row pointer + ONE per-thread 32-bit offset, row validity is
 // scalar -- and the two remaining columns (32, 33) are spread over the threads as 16 slots per row.  Two batches; all loads of
@@ -451,18 +474,22 @@ template <int COUT, bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                      const float* __restrict__ bias, const uint16_t* __restrict__ res,
                                                      const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
-                                                     int relu, uint8_t* __restrict__ row_dirty) {
+                                                     int relu, uint8_t* __restrict__ row_dirty, int slot) {
   constexpr int CIN = 64;
   constexpr int TH = LDS_TH, HW_ = LDS_HW;
   static_assert(!HAS_RES || COUT == 64, "the residual is folded into the accumulators of a single 64-channel pass");
   __shared__ uint4 s_in[LDS_NSTAGE];
   __shared__ uint32_t s_rowmask[TH];
+  __shared__ unsigned int s_next[2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int px = lane & 31, kb = lane >> 5;
   const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
   const int64_t n_tiles = (int64_t)B * tiles_y * tiles_x;
   CT_DECL
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  int64_t next = 0;
+  int it = 0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile = next, it++) {
+    sched_draw(s_next, it, slot);
     const int tx = (int)(tile % tiles_x);
     const int ty = (int)((tile / tiles_x) % tiles_y);
     const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
@@ -481,6 +508,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
       if (lane == 0) s_rowmask[wv * 4 + j] = bal;
     }
     __syncthreads();  // row masks visible; everybody is done reading the previous tile's s_in
+    next = sched_next(s_next, it);
     CT_TOCK(0)
     const uint32_t my_rm = s_rowmask[lane & 15];
     const uint32_t am = (uint32_t)__ballot(my_rm != 0) & 0xffffu;  // rows with an active site (wave-uniform, same in all waves)
@@ -544,6 +572,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
     }
     CT_TOCK(4)
   }
+  sched_done(slot);
   CT_FLUSH
 }
 
@@ -600,16 +629,20 @@ template <bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                         const float* __restrict__ bias, const uint16_t* __restrict__ res,
                                                         const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
-                                                        int relu, uint8_t* __restrict__ row_dirty) {
+                                                        int relu, uint8_t* __restrict__ row_dirty, int slot) {
   constexpr int CIN = 128, COUT = 128, TH = L128_TH, HW_ = LDS_HW;
   __shared__ uint4 s_in[L128_NSTAGE];
   __shared__ uint32_t s_rowmask[TH];
+  __shared__ unsigned int s_next[2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int px = lane & 31, kb = lane >> 5;
   const int rg = wv & 1, mg = 2 * (wv >> 1);  // row group, first 32-channel output tile of this wave
   const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
   const int64_t n_tiles = (int64_t)B * tiles_y * tiles_x;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  int64_t next = 0;
+  int it = 0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile = next, it++) {
+    sched_draw(s_next, it, slot);
     const int tx = (int)(tile % tiles_x);
     const int ty = (int)((tile / tiles_x) % tiles_y);
     const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
@@ -627,6 +660,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __res
       if (lane == 0) s_rowmask[wv * 2 + j] = bal;
     }
     __syncthreads();  // row masks visible; everybody is done reading the previous tile's s_in
+    next = sched_next(s_next, it);
     const uint32_t my_rm = s_rowmask[lane & 7];
     const uint32_t am = (uint32_t)__ballot(my_rm != 0) & 0xffu;
 #pragma unroll
@@ -682,18 +716,25 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __res
       default: conv_rows128<4, HAS_RES>(s_in, x, wfrag, bias, rq, rbase, rmask, yrow, b, H, W, y0, x0, need, mg, relu, px, kb, lane); break;
     }
   }
+  sched_done(slot);
+}
+
+int next_sched_slot() {
+  static unsigned int n = 0;  // one host thread per process drives the launches (pnx.h: not thread-safe)
+  return (int)(n++ & 63u);
 }
 
 int launch_lds128(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
                   uint8_t* row_dirty, hipStream_t st) {
+  const int slot = next_sched_slot();
   int64_t nb = (int64_t)B * ((H + L128_TH - 1) / L128_TH) * ((W + 31) / 32);
   if (nb > 512) nb = 512;  // resident workgroups: 2 per CU (registers)
   if (res != nullptr)
     k_conv3x3_lds128<true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B, H, W,
-                                                        relu, row_dirty);
+                                                        relu, row_dirty, slot);
   else
     k_conv3x3_lds128<false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu,
-                                                         row_dirty);
+                                                         row_dirty, slot);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -795,10 +836,11 @@ int launch_lds(const void* x, const void* wfrag, const float* bias, const void* 
   int64_t nb = n_tiles;
   const int64_t cap = 256 * 2;  // resident workgroups (LDS: 76.5 KiB per workgroup)
   if (nb > cap) nb = cap;
+  const int slot = next_sched_slot();
   if constexpr (COUT == 64) {
     if (res != nullptr) {
       k_conv3x3_lds<COUT, true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B,
-                                                             H, W, relu, row_dirty);
+                                                             H, W, relu, row_dirty, slot);
       PNX_LAUNCH_CHECK();
       return PNX_OK;
     }
@@ -806,7 +848,7 @@ int launch_lds(const void* x, const void* wfrag, const float* bias, const void* 
     PNX_REQUIRE(res == nullptr, PNX_ERR_UNSUPPORTED, "residual with %d output channels", COUT);
   }
   k_conv3x3_lds<COUT, false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu,
-                                                          row_dirty);
+                                                          row_dirty, slot);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
