@@ -324,12 +324,15 @@ __device__ __forceinline__ int lds_swz(int c) { return (c & 7) ^ ((c >> 3) & 1);
 // finished workgroups}; the last workgroup to finish re-arms the slot, the host rotates 64 slots so that launches in flight
 // never share one.
 __device__ unsigned int g_tile_ctr[64][2];
+// slot < 0: static round-robin (dense inputs: every tile costs the same and the ticket only adds latency).
 __device__ __forceinline__ void sched_draw(unsigned int* s_next, int it, int slot) {
-  if (threadIdx.x == 0) s_next[it & 1] = atomicAdd(&g_tile_ctr[slot][0], 1u);
+  if (slot >= 0 && threadIdx.x == 0) s_next[it & 1] = atomicAdd(&g_tile_ctr[slot][0], 1u);
 }
-__device__ __forceinline__ int64_t sched_next(const unsigned int* s_next, int it) { return (int64_t)s_next[it & 1] + gridDim.x; }
+__device__ __forceinline__ int64_t sched_next(const unsigned int* s_next, int it, int slot, int64_t tile) {
+  return slot >= 0 ? (int64_t)s_next[it & 1] + gridDim.x : tile + gridDim.x;
+}
 __device__ __forceinline__ void sched_done(int slot) {
-  if (threadIdx.x == 0) {
+  if (slot >= 0 && threadIdx.x == 0) {
     __threadfence();
     if (atomicAdd(&g_tile_ctr[slot][1], 1u) == gridDim.x - 1) {
       g_tile_ctr[slot][0] = 0;
@@ -339,42 +342,49 @@ __device__ __forceinline__ void sched_done(int slot) {
   }
 }
 
-// Stage the (TH+2) x 34 halo tile of 64 input channels [ch0, ch0+64) of image b at tile origin (y0, x0).  Thread t owns chunk t&7
-// of halo column t>>3 (0..31) in every row -- address = wave-uniform row pointer + ONE per-thread 32-bit offset, row validity is
-// scalar -- and the two remaining columns (32, 33) are spread over the threads as 16 slots per row.  Two batches; all loads of
-// a batch are in flight before its first ds_write.  `need` = halo rows to load (bit r); the rest of LDS keeps stale data nobody
-// reads.
+// Stage the (TH+2) x 34 halo tile of 64 input channels [ch0, ch0+64) of image b at tile origin (y0, x0).  Thread t owns slot t&7
+// of halo column t>>3 (0..31) in every row: a wave covers 8 pixels x 8 slots = 1 KiB of LDS that is contiguous in lane order, so
+// the rows go global -> LDS directly (global_load_lds_dwordx4: no VGPRs, no ds_write pass, ALL rows in flight at once instead of
+// two register batches); the XOR swizzle is applied on the SOURCE side -- slot k of column c receives chunk k ^ swz(c) of the
+// pixel's 128-byte line, so coalescing is unchanged.  LDS-DMA cannot write zeros: cells that are needed but lie outside the image
+// get a plain ds_write.  The two remaining columns (32, 33; 16 slots per row) keep the register path.  `need` = halo rows that
+// will be read (bit r); other rows keep stale data.  Callers follow with __syncthreads(), which drains the DMA (vmcnt(0)).
 template <int CSTRIDE, int TH = LDS_TH>
 __device__ __forceinline__ void stage_tile64(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, int b, int H, int W, int ch0, int y0, int x0,
                                              uint32_t need) {
-  constexpr int NROW = TH + 2, HALF = NROW / 2, NEXTRA = NROW * 16;
-  static_assert(NROW % 2 == 0 && NEXTRA <= 512, "two batches");
+  constexpr int NROW = TH + 2, NEXTRA = NROW * 16;
+  static_assert(NEXTRA <= 512, "two slots of the extra columns per thread");
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
   const uint16_t* xt = x + (((int64_t)b * H + (y0 - 1)) * W + (x0 - 1)) * CSTRIDE + ch0;  // element (0, 0) of the halo tile
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));  // opaque: keeps per-thread staging addresses from being hoisted out of the tile loop (and spilled)
-  const int chunk = tid & 7, col = tid >> 3;
-  uint32_t rows_ok = need & ~(y0 == 0 ? 1u : 0u);  // halo row 0 of the first tile row lies above the image
-  if (y0 - 1 + NROW > H) rows_ok &= (1u << (H - (y0 - 1))) - 1u;  // rows below the image
+  const int slot = tid & 7, col = tid >> 3, wbase = (tid >> 6) * 8;  // wbase: first column of this wave
+  uint32_t rows_in = (1u << NROW) - 1u;  // halo rows inside the image
+  if (y0 == 0) rows_in &= ~1u;
+  if (y0 - 1 + NROW > H) rows_in &= (1u << (H - (y0 - 1))) - 1u;
   const bool col_ok = (unsigned)(x0 - 1 + col) < (unsigned)W;
-  const uint32_t voff = (uint32_t)(col * CSTRIDE + chunk * 8) * 2u;
-  const int lds_main = col * 8 + (chunk ^ lds_swz(col));
+  const uint32_t voff = (uint32_t)(col * CSTRIDE + (slot ^ lds_swz(col)) * 8) * 2u;
 #pragma unroll
-  for (int part = 0; part < 2; part++) {
-    uint4 q[HALF], qe = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < HALF; i++) {
-      const int r = part * HALF + i;
-      q[i] = make_uint4(0, 0, 0, 0);
-      if (((rows_ok >> r) & 1u) && col_ok)
-        q[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(xt + (int64_t)r * W * CSTRIDE) + voff);
+  for (int r = 0; r < NROW; r++) {
+    if (!((need >> r) & 1u)) continue;  // wave-uniform
+    if (((rows_in >> r) & 1u) && col_ok) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(xt + (int64_t)r * W * CSTRIDE) + voff),
+                                       (lptr_t)(s_in + (r * LDS_HW + wbase) * 8), 16, 0, 0);
+    } else {
+      s_in[(r * LDS_HW + col) * 8 + slot] = make_uint4(0, 0, 0, 0);
     }
+  }
+#pragma unroll
+  for (int part = 0; part < (NEXTRA + 255) / 256; part++) {
     const int e = part * 256 + tid;  // slot of the two extra columns: row e>>4, column 32 + ((e>>3)&1), chunk e&7
     const int re = e >> 4, ce = 32 + ((e >> 3) & 1);
-    if (e < NEXTRA && ((rows_ok >> re) & 1u) && (unsigned)(x0 - 1 + ce) < (unsigned)W)
-      qe = *reinterpret_cast<const uint4*>(xt + ((int64_t)re * W + ce) * CSTRIDE + (e & 7) * 8);
-#pragma unroll
-    for (int i = 0; i < HALF; i++) s_in[(part * HALF + i) * LDS_HW * 8 + lds_main] = q[i];
-    if (e < NEXTRA) s_in[(re * LDS_HW + ce) * 8 + ((e & 7) ^ lds_swz(ce))] = qe;
+    if (e < NEXTRA && ((need >> re) & 1u)) {
+      uint4 qe = make_uint4(0, 0, 0, 0);
+      if (((rows_in >> re) & 1u) && (unsigned)(x0 - 1 + ce) < (unsigned)W)
+        qe = *reinterpret_cast<const uint4*>(xt + ((int64_t)re * W + ce) * CSTRIDE + (e & 7) * 8);
+      s_in[(re * LDS_HW + ce) * 8 + ((e & 7) ^ lds_swz(ce))] = qe;
+    }
   }
 }
 
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
       if (lane == 0) s_rowmask[wv * 4 + j] = bal;
     }
     __syncthreads();  // row masks visible; everybody is done reading the previous tile's s_in
-    next = sched_next(s_next, it);
+    next = sched_next(s_next, it, slot, tile);
     CT_TOCK(0)
     const uint32_t my_rm = s_rowmask[lane & 15];
     const uint32_t am = (uint32_t)__ballot(my_rm != 0) & 0xffffu;  // rows with an active site (wave-uniform, same in all waves)
@@ -660,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __res
       if (lane == 0) s_rowmask[wv * 2 + j] = bal;
     }
     __syncthreads();  // row masks visible; everybody is done reading the previous tile's s_in
-    next = sched_next(s_next, it);
+    next = sched_next(s_next, it, slot, tile);
     const uint32_t my_rm = s_rowmask[lane & 7];
     const uint32_t am = (uint32_t)__ballot(my_rm != 0) & 0xffu;
 #pragma unroll
@@ -726,7 +736,7 @@ int next_sched_slot() {
 
 int launch_lds128(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
                   uint8_t* row_dirty, hipStream_t st) {
-  const int slot = next_sched_slot();
+  const int slot = mask != nullptr ? next_sched_slot() : -1;
   int64_t nb = (int64_t)B * ((H + L128_TH - 1) / L128_TH) * ((W + 31) / 32);
   if (nb > 512) nb = 512;  // resident workgroups: 2 per CU (registers)
   if (res != nullptr)
@@ -836,7 +846,7 @@ int launch_lds(const void* x, const void* wfrag, const float* bias, const void* 
   int64_t nb = n_tiles;
   const int64_t cap = 256 * 2;  // resident workgroups (LDS: 76.5 KiB per workgroup)
   if (nb > cap) nb = cap;
-  const int slot = next_sched_slot();
+  const int slot = mask != nullptr ? next_sched_slot() : -1;
   if constexpr (COUT == 64) {
     if (res != nullptr) {
       k_conv3x3_lds<COUT, true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B,
