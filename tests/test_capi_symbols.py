@@ -54,3 +54,32 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("oracle/pnx_oracle.c's", "").lower() or f in ("iou3d.hip",), f
+
+
+def test_conv_entry_points_validate_before_launching():
+    """Argument checks of the convolution entry points need no GPU: they come before any HIP call."""
+    from pillarnext_amd import _lib
+
+    L = _lib.lib()
+    buf = (ctypes.c_char * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    rc = L.pnx_conv3x3_bf16(None, None, None, None, None, None, 1, 8, 8, 64, 64, 1, 1, None, None)
+    assert rc < 0 and b"bad arguments" in L.pnx_last_error()
+    rc = L.pnx_conv3x3_bf16(p, p, p, None, None, p, 1, 8, 8, 64, 64, 3, 1, None, None)
+    assert rc < 0 and b"stride" in L.pnx_last_error()
+    rc = L.pnx_conv3x3_bf16(p, p, p, None, None, p, 1, 8, 8, 64, 64, 1, 1, p, None)       # row_dirty without a mask
+    assert rc < 0 and b"row_dirty" in L.pnx_last_error()
+    rc = L.pnx_conv3x3_bf16(p, p, p, None, p, p, 1, 8, 8, 48, 64, 1, 1, None, None)       # no kernel for 48 input channels
+    assert rc < 0 and b"48" in L.pnx_last_error()
+    rc = L.pnx_sephead_out_bf16(p, p, p, p, 1, 8, 8, 3, None)
+    assert rc < 0 and b"branches" in L.pnx_last_error()
+    rc = L.pnx_sephead_out_bf16(None, p, p, p, 1, 8, 8, 6, None)
+    assert rc < 0 and b"bad arguments" in L.pnx_last_error()
+
+
+def test_decode_descriptor_layout_matches_the_library():
+    from pillarnext_amd import _lib
+    from pillarnext_amd.decode import pack_task
+
+    blob = pack_task(16, True, 2, 3, 360, 360, 4, (0.075, 0.075), (-54.0, -54.0), 0.1, [-61.2, -61.2, -10, 61.2, 61.2, 10], [0.5, 0.5])
+    assert len(blob) == _lib.lib().pnx_decode_task_desc_bytes() == 92
