@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
   constexpr int TH = LDS_TH, HW_ = LDS_HW;
   static_assert(!HAS_RES || COUT == 64, "the residual is folded into the accumulators of a single 64-channel pass");
   __shared__ uint4 s_in[LDS_NSTAGE];
-  __shared__ uint32_t s_rowmask[TH];
+  __shared__ uint32_t s_rowmask2[2 * TH];  // double-buffered by iteration parity: an empty tile has a single barrier (see s_next)
   __shared__ unsigned int s_next[2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int px = lane & 31, kb = lane >> 5;
@@ -500,6 +500,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
   int it = 0;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile = next, it++) {
     sched_draw(s_next, it, slot);
+    uint32_t* const s_rowmask = s_rowmask2 + (it & 1) * TH;
     const int tx = (int)(tile % tiles_x);
     const int ty = (int)((tile / tiles_x) % tiles_y);
     const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __res
                                                         int relu, uint8_t* __restrict__ row_dirty, int slot) {
   constexpr int CIN = 128, COUT = 128, TH = L128_TH, HW_ = LDS_HW;
   __shared__ uint4 s_in[L128_NSTAGE];
-  __shared__ uint32_t s_rowmask[TH];
+  __shared__ uint32_t s_rowmask2[2 * TH];  // double-buffered by iteration parity: an empty tile has a single barrier (see s_next)
   __shared__ unsigned int s_next[2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int px = lane & 31, kb = lane >> 5;
@@ -653,6 +654,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __res
   int it = 0;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile = next, it++) {
     sched_draw(s_next, it, slot);
+    uint32_t* const s_rowmask = s_rowmask2 + (it & 1) * TH;
     const int tx = (int)(tile % tiles_x);
     const int ty = (int)((tile / tiles_x) % tiles_y);
     const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
