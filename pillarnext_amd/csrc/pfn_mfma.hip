@@ -67,6 +67,53 @@ __device__ __forceinline__ void seg_max_n(float* v, int idx, int col, const Scan
   if (pl.s8) max_step<DPP_ROW_SHR8, 0xF, N>(v, idx >= 8);
   if (pl.s1) max_step<DPP_ROW_BCAST15, 0xA, N>(v, idx > (col & 15));  // pillar straddling the two 16-lane rows of a half
 }
+// The same scan for NON-NEGATIVE values (post-ReLU): 0 is then the identity of max, so a lane that must not take its neighbour
+// ANDs the shifted value with a per-step lane mask (one VGPR per step, shared by all registers) and lanes without a DPP source
+// read 0 (bound_ctrl) -- two instructions per register and step, v_and_b32_dpp + v_max_f32, where the general form above
+// compiles to five (v_mov_dpp, s_nop, v_max, v_cndmask, v_mov: 1 200 of the ~2 000 instructions of a tile).  hipcc does not form
+// the DPP operand by itself here (it turns the AND back into a select), hence inline asm, eight registers per statement: every
+// DPP read then sits >= 8 instructions behind the write of its register (the 2 wait states a VALU-write -> DPP-read needs), the
+// leading s_nop covers the first one.  row_bcast:15 runs with all rows enabled: rows 0 and 2 receive 0 / the other half's
+// lane 31, both discarded by the lane mask (idx <= column inside a tile).
+#define PNX_AND_DPP(i, CTRL) "v_and_b32_dpp %[t" #i "], %[v" #i "], %[m] " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define PNX_MAXF(i) "v_max_f32 %[v" #i "], %[v" #i "], %[t" #i "]\n"
+#define PNX_SCAN8(CTRL, v, m)                                                                                                       \
+  {                                                                                                                                 \
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;                                                                                        \
+    asm volatile("s_nop 1\n" PNX_AND_DPP(0, CTRL) PNX_AND_DPP(1, CTRL) PNX_AND_DPP(2, CTRL) PNX_AND_DPP(3, CTRL) PNX_AND_DPP(4, CTRL)  \
+                     PNX_AND_DPP(5, CTRL) PNX_AND_DPP(6, CTRL) PNX_AND_DPP(7, CTRL) PNX_MAXF(0) PNX_MAXF(1) PNX_MAXF(2) PNX_MAXF(3)   \
+                         PNX_MAXF(4) PNX_MAXF(5) PNX_MAXF(6) PNX_MAXF(7)                                                             \
+                 : [v0] "+v"((v)[0]), [v1] "+v"((v)[1]), [v2] "+v"((v)[2]), [v3] "+v"((v)[3]), [v4] "+v"((v)[4]), [v5] "+v"((v)[5]),  \
+                   [v6] "+v"((v)[6]), [v7] "+v"((v)[7]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),               \
+                   [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7)                                                     \
+                 : [m] "v"(m));                                                                                                     \
+  }
+// 16 registers, one step
+#define PNX_SCAN16(CTRL, v, m) \
+  PNX_SCAN8(CTRL, v, m)        \
+  PNX_SCAN8(CTRL, (v) + 8, m)
+__device__ __forceinline__ void seg_max_nn16(float* v, int idx, int col, const ScanPlan& pl) {
+  if (pl.s1) {
+    const uint32_t m = idx >= 1 ? 0xFFFFFFFFu : 0u;
+    PNX_SCAN16("row_shr:1", v, m)
+  }
+  if (pl.s2) {
+    const uint32_t m = idx >= 2 ? 0xFFFFFFFFu : 0u;
+    PNX_SCAN16("row_shr:2", v, m)
+  }
+  if (pl.s4) {
+    const uint32_t m = idx >= 4 ? 0xFFFFFFFFu : 0u;
+    PNX_SCAN16("row_shr:4", v, m)
+  }
+  if (pl.s8) {
+    const uint32_t m = idx >= 8 ? 0xFFFFFFFFu : 0u;
+    PNX_SCAN16("row_shr:8", v, m)
+  }
+  if (pl.s1) {  // pillar straddling the two 16-lane rows of a half
+    const uint32_t m = idx > (col & 15) ? 0xFFFFFFFFu : 0u;
+    PNX_SCAN16("row_bcast:15", v, m)
+  }
+}
 __device__ __forceinline__ double seg_sum(double v, int idx, int col, const ScanPlan& pl) {
   if (pl.s1) { const double t = dpp_d<DPP_ROW_SHR1, 0xF>(v); v += idx >= 1 ? t : 0.0; }
   if (pl.s2) { const double t = dpp_d<DPP_ROW_SHR2, 0xF>(v); v += idx >= 2 ? t : 0.0; }
@@ -317,6 +364,13 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
     w1b[i] = FP[(55 + i) * 64];
   }
   const float4* __restrict__ s1lane = reinterpret_cast<const float4*>(P + FR + 64 * 89 + l * 32);  // s1 in this lane's channel order
+  float s1a[16], s1b[16];  // folded-BN shift of layer 1 for this lane's 2 x 16 channels
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float4 sa = s1lane[j], sb = s1lane[4 + j];
+    s1a[4 * j + 0] = sa.x, s1a[4 * j + 1] = sa.y, s1a[4 * j + 2] = sa.z, s1a[4 * j + 3] = sa.w;
+    s1b[4 * j + 0] = sb.x, s1b[4 * j + 1] = sb.y, s1b[4 * j + 2] = sb.z, s1b[4 * j + 3] = sb.w;
+  }
 
   TOCK(0);
   // results of the previous tile, stored one tile late so that the record prefetch never waits behind fresh stores
@@ -328,16 +382,8 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
       const int64_t cell = out.canvas ? (int64_t)out.cell[p_rank] : 0;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const float4 sa = s1lane[j], sb = s1lane[4 + j];
-        float4 oa, ob;  // bias + ReLU after the max: relu(max(x) + s) == max(relu(x + s))
-        oa.x = fmaxf(pa[4 * j + 0] + sa.x, 0.f);
-        oa.y = fmaxf(pa[4 * j + 1] + sa.y, 0.f);
-        oa.z = fmaxf(pa[4 * j + 2] + sa.z, 0.f);
-        oa.w = fmaxf(pa[4 * j + 3] + sa.w, 0.f);
-        ob.x = fmaxf(pb[4 * j + 0] + sb.x, 0.f);
-        ob.y = fmaxf(pb[4 * j + 1] + sb.y, 0.f);
-        ob.z = fmaxf(pb[4 * j + 2] + sb.z, 0.f);
-        ob.w = fmaxf(pb[4 * j + 3] + sb.w, 0.f);
+        const float4 oa = make_float4(pa[4 * j + 0], pa[4 * j + 1], pa[4 * j + 2], pa[4 * j + 3]);
+        const float4 ob = make_float4(pb[4 * j + 0], pb[4 * j + 1], pb[4 * j + 2], pb[4 * j + 3]);
         store_piece(out, p_rank, cell, 8 * j + 4 * h, oa);
         store_piece(out, p_rank, cell, 32 + 8 * j + 4 * h, ob);
       }
@@ -431,14 +477,12 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
       // ---- "max" half of the concat: per-pillar max of layer 0, delivered to every point of the pillar
       float g0[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) g0[i] = d0[i];
+      for (int i = 0; i < 16; i++) g0[i] = fmaxf(d0[i], 0.f);  // ReLU first: max(relu(x)) == relu(max(x)), and the scan may use 0 as identity
       if (pl.s1) {
-        seg_max_n<16>(g0, idx, col, pl);
+        seg_max_nn16(g0, idx, col, pl);
 #pragma unroll
         for (int i = 0; i < 16; i++) g0[i] = from_lane(g0[i], tail_lane);
       }
-#pragma unroll
-      for (int i = 0; i < 16; i++) g0[i] = fmaxf(g0[i], 0.f);  // relu(max(x)) == max(relu(x))
       TOCK(4);
       // ---- layer 1: 64 output channels as two 32-row tiles, K in accumulator-register order
       v16f da, db;
@@ -459,14 +503,15 @@ __global__ __launch_bounds__(256) void k_pfn_mfma(const uint32_t* __restrict__ r
         db = PNX_MFMA(w1b[16 + i], g0[i], db);
       }
       TOCK(5);
-      // ---- per-pillar max of layer 1 (raw accumulators; bias/ReLU/stores happen in flush(), one tile later)
+      // ---- per-pillar max of layer 1.  Shift + ReLU first (max(relu(x + s)) == relu(max(x) + s), x -> relu(x + s) is monotone), so
+      // the scan runs on non-negative values; the stores happen in flush(), one tile later
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        pa[i] = da[i];
-        pb[i] = db[i];
+        pa[i] = fmaxf(da[i] + s1a[i], 0.f);
+        pb[i] = fmaxf(db[i] + s1b[i], 0.f);
       }
-      seg_max_n<16>(pa, idx, col, pl);
-      seg_max_n<16>(pb, idx, col, pl);
+      seg_max_nn16(pa, idx, col, pl);
+      seg_max_nn16(pb, idx, col, pl);
       p_store = act && rem == 0;
       p_rank = r;
       ts = ts_next;
