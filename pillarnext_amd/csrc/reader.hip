@@ -475,8 +475,8 @@ __global__ __launch_bounds__(kBlock) void k_canvas_fill_nhwc(const uint32_t* __r
   uint4* out = reinterpret_cast<uint4*>(canvas);
   const int rows = min(32, g.gy - y0);
   // occupancy bytes: 16 cells = one 16-byte store (a byte store per cell from every 8th lane of the loop below cost 60 us of the
-  // 400 us at 8 frames); tiles cut by the right edge or an unaligned row pitch keep the per-cell stores
-  const bool occ_wide = occ != nullptr && x0 + 32 <= g.gx && (g.gx & 15) == 0;
+  // 400 us at 8 frames); tiles cut by the right edge, an unaligned row pitch or an unaligned buffer keep the per-cell stores
+  const bool occ_wide = occ != nullptr && x0 + 32 <= g.gx && (g.gx & 15) == 0 && (reinterpret_cast<uintptr_t>(occ) & 15) == 0;
   if (occ_wide && t < rows * 2) {
     const int yl = t >> 1, half = t & 1;
     uint32_t w4[4];
