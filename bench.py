@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--dist", default="sweep", choices=["uniform", "sweep"],
                     help="sweep = ring-structured 10-sweep cloud (BASELINE configs[1]); uniform = worst case, ~1.2 points per pillar")
-    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded CPU-baseline sample (0 = skip)")
     return ap.parse_args()
 
 
