@@ -101,6 +101,7 @@ int pnx_reader_forward(const float* points, int64_t n_points, int32_t row_stride
 int pnx_profile_begin(int32_t max_samples);
 int pnx_profile_end(float* reader_us_avg_host, float* canvas_us_avg_host, int32_t* samples_host);
 float pnx_profile_last_pfn_us(void); /* average PFN-kernel microseconds of the interval closed by the last pnx_profile_end */
+float pnx_profile_last_voxelize_us(void); /* same interval: reader start -> pillar-sorted records ready (keys, scans, binning, bin sort) */
 
 /* Voxelizer alone (PillarNet.forward :78-125): indices plus the decorated (N', F+5) features
  * (rows in kept-point order; may be NULL).  Used by the training path, where Linear/BN stay in

@@ -1,0 +1,514 @@
+// pfn_v3.hip -- the PFN (pillar_encoder.py:35-50 x2, :174-182) over the pillar-sorted, pre-decorated 64-byte records that
+// reader_bins.h::k_bin_sort writes, fused with the zero-fill of the pillar-free canvas cells (pnx_fill.h).
+//
+// Same MFMA mapping as round 1 (pfn_mfma.hip): one wave = one tile of <= 32 points cut at pillar boundaries, lane = (point, h),
+// h = lane>>5 selecting the even/odd K element of v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain at the fp32 vector rate):
+//   layer 0   D0 = W0'(32ch x K) * F^T: the lane's six operand words ARE the six record words it loaded (no select, no decoration,
+//             no per-pillar mean here -- k_bin_sort did that once per point); D0 leaves 16 channels of the point in the lane,
+//             which is the B fragment of layer 1 when K is visited in accumulator-register order (no transpose)
+//   max       per-pillar max = segmented scan ACROSS LANES with DPP row shifts on the post-ReLU values (pnx_dppscan.h: two
+//             instructions per register and step, steps no pillar of the tile needs skipped by a ballot); the pillar's layer-0
+//             max reaches every point of the pillar with one ds_bpermute per register (the "max" half of the concat, pe:44,49).
+//             Measured alternatives on C2/8 frames: ds_max_u32 into per-pillar LDS rows 399 us (LDS atomics serialise), a
+//             lanes = channels running-max walk over LDS rows 374 us (a scalar-controlled 32-step loop per pass).
+//   layer 1   64 MFMAs; shift + ReLU before the max (x -> relu(x + s) is monotone); the TAIL lane of every pillar writes the
+//             finished row, in NATURAL channel order, into the wave's private LDS rows
+//   store     8 lanes per pillar read 16-byte pieces of the finished rows and store them: one store instruction writes 8 complete
+//             128-byte lines (bf16) of the NHWC canvas (round 1: 16 instructions of scattered 8-byte pieces per tile)
+// Fused fill: blocks [0, n_fill) of the SAME launch run pnx_fill_tile over the 32x32-cell tiles (HBM-write bound, almost no
+// ALU), the other blocks run the PFN (MFMA bound, little HBM) -- the two roles overlap on every CU and each canvas byte is still
+// written exactly once.  Pillars with more than 32 points go to k_pfn3_big.
+#include <vector>
+
+#include "pnx_common.h"
+#include "pnx_dppscan.h"
+#include "pnx_fill.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+#define PNX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+constexpr int kZS = 68;                 // words per LDS row (64 channels + 4: rows stay 16-byte aligned, 8 consecutive rows cover all banks)
+constexpr int kWaveLds = 32 * kZS + 64;  // per wave: 32 pillar rows + rank[32] + cell[32], in words
+
+struct Pfn3Out {
+  float* g1;  // (rows, 64) fp32 or null
+  int64_t g1_rows;
+  void* canvas;  // NHWC canvas or null
+  int dt;        // PNX_F32 / PNX_BF16 / PNX_F16
+};
+
+__device__ __forceinline__ uint32_t bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);  // inputs are finite post-ReLU values
+  return u >> 16;
+}
+__device__ __forceinline__ uint32_t f16_rne(float f) {
+  const _Float16 hv = (_Float16)f;
+  return (uint32_t)__builtin_bit_cast(unsigned short, hv);
+}
+
+// the two 16-byte quads of one half of a sorted record (reader_bins.h)
+struct Half {
+  uint4 a, b;  // a = f[h], f[2+h], f[4+h], f[6+h]   b = f[8+h], f[10+h], aux, (h ? cell : rank)
+};
+__device__ __forceinline__ Half load_half(const uint4* __restrict__ rec, uint32_t slot, int h) {
+  const uint4* p = rec + (int64_t)slot * 4 + 2 * h;
+  Half r;
+  r.a = p[0];
+  r.b = p[1];
+  return r;
+}
+
+// First slot of the pillar after the one that contains `slot`.
+__device__ __forceinline__ uint32_t pillar_end_at(const uint4* __restrict__ rec, int64_t slot, const uint32_t* __restrict__ pfirst,
+                                                  const uint32_t* __restrict__ pcnt, bool* is_head) {
+  const uint4 w = rec[slot * 4 + 1];
+  const uint32_t idx = w.z & 0xFFFFu, rem = w.z >> 16;
+  *is_head = idx == 0;
+  if (idx < 0xFFFFu && rem < 0xFFFFu) return (uint32_t)slot + rem + 1u;
+  return pfirst[w.w] + pcnt[w.w];  // 16-bit fields saturated: a pillar with >= 65535 points
+}
+
+// wave-synchronous LDS exchange: the LDS unit executes one wave's DS instructions in order; the fences only pin the compiler
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 8 consecutive channels (chan0 = 8q) of one pillar: canvas cell and/or feat_max row
+template <int DT>
+__device__ __forceinline__ void store_chunk(const Pfn3Out& o, int rank, int64_t cell, int q, const float* v) {
+  if (o.g1 != nullptr && (int64_t)rank < o.g1_rows) {
+    float4* d = reinterpret_cast<float4*>(o.g1 + (int64_t)rank * 64 + 8 * q);
+    d[0] = make_float4(v[0], v[1], v[2], v[3]);
+    d[1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+  if (o.canvas != nullptr) {
+    if (DT == PNX_F32) {
+      float4* d = reinterpret_cast<float4*>(reinterpret_cast<float*>(o.canvas) + cell * 64 + 8 * q);
+      d[0] = make_float4(v[0], v[1], v[2], v[3]);
+      d[1] = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      uint4 p;
+      if (DT == PNX_BF16) {
+        p.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
+        p.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
+        p.z = bf16_rne(v[4]) | (bf16_rne(v[5]) << 16);
+        p.w = bf16_rne(v[6]) | (bf16_rne(v[7]) << 16);
+      } else {
+        p.x = f16_rne(v[0]) | (f16_rne(v[1]) << 16);
+        p.y = f16_rne(v[2]) | (f16_rne(v[3]) << 16);
+        p.z = f16_rne(v[4]) | (f16_rne(v[5]) << 16);
+        p.w = f16_rne(v[6]) | (f16_rne(v[7]) << 16);
+      }
+      *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(o.canvas) + cell * 64 + 8 * q) = p;
+    }
+  }
+}
+
+template <int DT>
+__device__ __forceinline__ void fill_role(const uint32_t* __restrict__ bitmap, const PnxGeomDev& g, void* canvas, uint8_t* occ, int n_fill,
+                                          bool nt, uint32_t* s_word) {
+  const int tiles = ((g.gx + 31) >> 5) * (g.gyp >> 5) * g.B;
+  for (int tile = blockIdx.x; tile < tiles; tile += n_fill) {
+    if (nt)
+      pnx_fill_tile<DT, true>(bitmap, g, canvas, occ, tile, s_word, threadIdx.x, 256);
+    else
+      pnx_fill_tile<DT, false>(bitmap, g, canvas, occ, tile, s_word, threadIdx.x, 256);
+    __syncthreads();  // s_word is rewritten by the next tile
+  }
+}
+
+// Window tickets without a stall: hipcc's atomic optimizer expands atomicAdd into ballot + one atomic + an immediate
+// s_waitcnt vmcnt(0) + readfirstlane, i.e. a fabric round trip (and a drain of the record prefetch) in front of every window.
+// The asm form returns into a VGPR that nobody reads until ticket_wait(); the hardware vmcnt only ever makes hipcc's own waits
+// more conservative (MI355X guide 5.7: an uncounted asm memory op).
+__device__ __forceinline__ int ticket_issue(int32_t* counter, int lane) {
+  int ret = 0;
+  const int one = 1;
+  if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ret) : "v"(counter), "v"(one) : "memory");
+  return ret;
+}
+__device__ __forceinline__ int ticket_wait(int tk) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(tk)::"memory");
+  return __builtin_amdgcn_readfirstlane(tk);
+}
+
+// One word hands out ~88 tickets/us (MI355X guide, "dequeue"): 16 ticket words in separate 128-byte lines, word s serving the
+// windows s, s+16, ...; a wave starts on word (block & 15) and moves on when its word runs dry.  Returns the window or -1.
+constexpr int kTickShards = 16, kTickStride = 32;
+__device__ __forceinline__ int64_t next_window(int32_t* tick, int& shard, int& tried, int tk, int64_t nwin, int lane) {
+  for (;;) {
+    const int64_t w = (int64_t)tk * kTickShards + shard;
+    if (w < nwin) return w;
+    if (++tried >= kTickShards) return -1;
+    shard = (shard + 1) & (kTickShards - 1);
+    tk = ticket_wait(ticket_issue(tick + shard * kTickStride, lane));
+  }
+}
+
+// counters: [0] = P, [1] = N' (kept points = sorted records), [3] = number of big pillars appended to biglist; tick = window tickets
+template <int F, int R, int DT>
+__global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ pcnt,
+                                             int32_t* __restrict__ counters, int32_t* __restrict__ tick, int32_t* __restrict__ biglist, int bigcap,
+                                             const float* __restrict__ P, Pfn3Out out, int n_fill, const uint32_t* __restrict__ bitmap,
+                                             PnxGeomDev g, uint8_t* __restrict__ occ, int fill_nt, int dbg) {
+  constexpr int C0 = F + 5, KS = (C0 + 2) / 2;     // K = C0 features + the constant-1 column that carries the folded BN shift
+  constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;  // start of the fragment-ordered block (k_fold_bn)
+  __shared__ __align__(16) uint32_t s_lds[4 * kWaveLds];
+  if ((int)blockIdx.x < n_fill) {  // ---- fill role (block-uniform)
+    fill_role<DT>(bitmap, g, out.canvas, occ, n_fill, fill_nt != 0, s_lds);
+    return;
+  }
+  // ---- PFN role
+  const int l = threadIdx.x & 63, col = l & 31, h = l >> 5, wv = threadIdx.x >> 6;
+  uint32_t* s_out = s_lds + wv * kWaveLds;  // 32 pillar rows
+  uint32_t* s_rank = s_out + 32 * kZS;
+  uint32_t* s_cell = s_rank + 32;
+  const int n_kept = counters[1];
+
+  // weight fragments: coalesced loads, once per (persistent) wave
+  const float* __restrict__ FP = P + FR + l;
+  float w0f[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) w0f[kk] = FP[kk * 64];
+  float w1a[32], w1b[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    w1a[i] = FP[(23 + i) * 64];
+    w1b[i] = FP[(55 + i) * 64];
+  }
+  const float4* __restrict__ s1lane = reinterpret_cast<const float4*>(P + FR + 64 * 89 + l * 32);  // s1 in this lane's channel order
+  float s1a[16], s1b[16];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float4 sa = s1lane[j], sb = s1lane[4 + j];
+    s1a[4 * j + 0] = sa.x, s1a[4 * j + 1] = sa.y, s1a[4 * j + 2] = sa.z, s1a[4 * j + 3] = sa.w;
+    s1b[4 * j + 0] = sb.x, s1b[4 * j + 1] = sb.y, s1b[4 * j + 2] = sb.z, s1b[4 * j + 3] = sb.w;
+  }
+
+  // Windows of R sorted slots are handed out by ticket counters: while the fill blocks occupy their share of every CU only part of
+  // the PFN blocks is resident, and a static deal would leave the late blocks' share for after the fill.
+  // (experiment) phase offset between the two waves that share a SIMD (blocks b and b + resident/2): dbg bits 8.. = sleep units of 64 cycles
+  if ((dbg >> 8) != 0 && ((((int)blockIdx.x - n_fill) >> 8) & 1)) {
+    for (int k = 0; k < (dbg >> 8); k += 64) __builtin_amdgcn_s_sleep(64);
+  }
+  const int64_t nwin = ((int64_t)n_kept + R - 1) / R;
+  int shard = (int)(blockIdx.x & (kTickShards - 1)), tried = 0;
+  int64_t pass = next_window(tick, shard, tried, ticket_wait(ticket_issue(tick + shard * kTickStride, l)), nwin, l);
+  while (pass >= 0) {
+    const int64_t slot0 = pass * R;
+    const int64_t slot1 = (slot0 + R < n_kept) ? slot0 + R : n_kept;
+    // pillars owned by this pass = those whose first slot lies in [slot0, slot1)
+    bool head0;
+    const uint32_t e0 = pillar_end_at(rec, slot0, pfirst, pcnt, &head0);
+    const uint32_t base = head0 ? (uint32_t)slot0 : e0;
+    uint32_t end = (uint32_t)n_kept;
+    if (slot1 < n_kept) {
+      bool head1;
+      const uint32_t e1 = pillar_end_at(rec, slot1, pfirst, pcnt, &head1);
+      end = head1 ? (uint32_t)slot1 : e1;
+    }
+    uint32_t ts = base;
+    Half nxt;
+    if (base < end) nxt = load_half(rec, min(ts + (uint32_t)col, end - 1), h);
+    const int tk_next = ticket_issue(tick + shard * kTickStride, l);  // next window's ticket: issued behind this window's first record load
+    while (ts < end) {
+      const Half cur = nxt;
+      const bool in_range = ts + (uint32_t)col < end;
+      const int idx = (int)(cur.b.z & 0xFFFFu), rem = (int)(cur.b.z >> 16);
+      const bool complete = in_range && (col + rem <= 31);
+      const uint32_t V = (uint32_t)__ballot(complete && h == 0);
+      const int nv = __builtin_popcount(V);
+      if (nv == 0) {
+        // the pillar at ts has more than 32 points: hand it to k_pfn3_big and step over it
+        const int q = __builtin_amdgcn_readfirstlane((int)cur.b.w);  // lane 0 is in half 0: word = rank
+        const uint32_t c = pcnt[q];
+        if (l == 0) {
+          const int at = atomicAdd(&counters[3], 1);
+          if (at < bigcap) biglist[at] = q;
+        }
+        ts += c;
+        if (ts < end) nxt = load_half(rec, min(ts + (uint32_t)col, end - 1), h);
+        continue;
+      }
+      const uint32_t ts_next = ts + (uint32_t)nv;
+      nxt = load_half(rec, min(ts_next + (uint32_t)col, end - 1), h);  // prefetch the next tile while this one computes
+      const bool act = col < nv;
+      const uint32_t heads = (uint32_t)__ballot(act && idx == 0 && h == 0);
+      const int npil = __builtin_popcount(heads);
+      const int pid = __builtin_popcount(heads & (0xFFFFFFFFu >> (31 - col))) - 1;  // pillar of this lane inside the tile (act lanes)
+      const int tail_lane = act ? l + rem : l;                                     // same half
+      ScanPlan pl;
+      pl.s1 = __ballot(act && idx >= 1) != 0;
+      pl.s2 = __ballot(act && idx >= 2) != 0;
+      pl.s4 = __ballot(act && idx >= 4) != 0;
+      pl.s8 = __ballot(act && idx >= 8) != 0;
+
+      // ---- layer 0 (lane = point, registers = channels)
+      float ff[6] = {__uint_as_float(cur.a.x), __uint_as_float(cur.a.y), __uint_as_float(cur.a.z),
+                     __uint_as_float(cur.a.w), __uint_as_float(cur.b.x), __uint_as_float(cur.b.y)};
+      v16f d0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) d0[i] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], act ? ff[kk] : 0.f, d0);
+      // ---- "max" half of the concat (pe:43-44,49): per-pillar max of relu(layer 0), delivered to every point of the pillar
+      float g0[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) g0[i] = fmaxf(d0[i], 0.f);  // ReLU first: max(relu(x)) == relu(max(x)); 0 is then the identity
+      if (pl.s1 && !(dbg & 2)) {
+        seg_max_nn16(g0, idx, col, pl);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          g0[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(tail_lane << 2, __builtin_bit_cast(int, g0[i])));
+      }
+      // ---- layer 1: 64 output channels as two 32-row tiles, K in accumulator-register order
+      v16f da, db;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        da[i] = 0.f;
+        db[i] = 0.f;
+      }
+      if (!(dbg & 4)) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const float u = fmaxf(d0[i], 0.f);
+          da = PNX_MFMA(w1a[i], u, da);
+          db = PNX_MFMA(w1b[i], u, db);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          da = PNX_MFMA(w1a[16 + i], g0[i], da);
+          db = PNX_MFMA(w1b[16 + i], g0[i], db);
+        }
+      }
+      // ---- per-pillar max of relu(layer 1 + shift): scan on non-negative values, the result sits in the pillar's tail lane
+      float pa[16], pb[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        pa[i] = fmaxf(da[i] + s1a[i], 0.f);
+        pb[i] = fmaxf(db[i] + s1b[i], 0.f);
+      }
+      if (!(dbg & 2)) {
+        seg_max_nn16(pa, idx, col, pl);
+        seg_max_nn16(pb, idx, col, pl);
+      }
+      // The record prefetch (issued a whole tile ago) is waited for HERE, before this tile's stores go out: otherwise the next
+      // tile's first use of it waits behind those stores -- vmcnt is in-order and hipcc cannot count a data-dependent number of stores.
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      // tail lanes write the finished rows in NATURAL channel order: accumulator registers 4j..4j+3 of half h are channels
+      // 8j + 4h .. +3 (pa) / 32 + those (pb)
+      if (act && rem == 0) {
+        uint32_t* dst = s_out + pid * kZS + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          *reinterpret_cast<uint4*>(dst + 8 * j) =
+              make_uint4(__float_as_uint(pa[4 * j]), __float_as_uint(pa[4 * j + 1]), __float_as_uint(pa[4 * j + 2]), __float_as_uint(pa[4 * j + 3]));
+          *reinterpret_cast<uint4*>(dst + 32 + 8 * j) =
+              make_uint4(__float_as_uint(pb[4 * j]), __float_as_uint(pb[4 * j + 1]), __float_as_uint(pb[4 * j + 2]), __float_as_uint(pb[4 * j + 3]));
+        }
+        if (h == 0) s_rank[pid] = cur.b.w;  // where the row goes
+        else s_cell[pid] = cur.b.w;
+      }
+      wave_lds_sync();
+      // ---- stores: lane -> (pillar l>>3 + 8*it, channels 8*(l&7) .. +7)
+      {
+        const int q = l & 7;
+        for (int p = l >> 3; p < ((dbg & 1) ? 0 : npil); p += 8) {
+          const uint4* src = reinterpret_cast<const uint4*>(s_out + p * kZS + 8 * q);
+          const uint4 x0 = src[0], x1 = src[1];
+          const float v[8] = {__uint_as_float(x0.x), __uint_as_float(x0.y), __uint_as_float(x0.z), __uint_as_float(x0.w),
+                              __uint_as_float(x1.x), __uint_as_float(x1.y), __uint_as_float(x1.z), __uint_as_float(x1.w)};
+          store_chunk<DT>(out, (int)s_rank[p], (int64_t)(int32_t)s_cell[p], q, v);
+        }
+      }
+      wave_lds_sync();  // the next tile rewrites the rows
+      ts = ts_next;
+    }
+    pass = next_window(tick, shard, tried, ticket_wait(tk_next), nwin, l);
+  }
+}
+
+// Pillars with more than 32 points: one wave per pillar, two sweeps over its tiles (layer-0 max; layer 1 + max) with per-lane
+// running maxima, then one all-lane reduction per register.  Rare at PillarNeXt-B resolution, common only for coarse voxels.
+template <int F>
+__global__ __launch_bounds__(256) void k_pfn3_big(const uint4* __restrict__ rec, const uint32_t* __restrict__ pfirst,
+                                                 const uint32_t* __restrict__ pcnt, const int32_t* __restrict__ cell_of_pillar,
+                                                 const int32_t* __restrict__ counters, const int32_t* __restrict__ biglist, int bigcap,
+                                                 const float* __restrict__ P, Pfn3Out out) {
+  constexpr int C0 = F + 5, KS = (C0 + 2) / 2;
+  constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;
+  const int l = threadIdx.x & 63, col = l & 31, h = l >> 5;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  int nbig = counters[3];
+  if (nbig > bigcap) nbig = bigcap;
+  if (wave >= nbig) return;
+  const float* __restrict__ FP = P + FR + l;
+  float w0f[KS], w1a[32], w1b[32];
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) w0f[kk] = FP[kk * 64];
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    w1a[i] = FP[(23 + i) * 64];
+    w1b[i] = FP[(55 + i) * 64];
+  }
+  const float4* __restrict__ s1lane = reinterpret_cast<const float4*>(P + FR + 64 * 89 + l * 32);
+  for (int bi = wave; bi < nbig; bi += nwaves) {
+    const int r = biglist[bi];
+    const uint32_t st = pfirst[r], c = pcnt[r];
+    float g0[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) g0[i] = 0.f;  // post-ReLU maxima
+    for (uint32_t t0 = 0; t0 < c; t0 += 32) {
+      const bool act = t0 + col < c;
+      const Half cur = load_half(rec, st + min(t0 + (uint32_t)col, c - 1), h);
+      const float ff[6] = {__uint_as_float(cur.a.x), __uint_as_float(cur.a.y), __uint_as_float(cur.a.z),
+                           __uint_as_float(cur.a.w), __uint_as_float(cur.b.x), __uint_as_float(cur.b.y)};
+      v16f d0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) d0[i] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], act ? ff[kk] : 0.f, d0);
+#pragma unroll
+      for (int i = 0; i < 16; i++) g0[i] = fmaxf(g0[i], act ? fmaxf(d0[i], 0.f) : 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) g0[i] = fmaxf(g0[i], __shfl_xor(g0[i], d));  // inside each half
+    }
+    const float NI = -__builtin_inff();
+    float pa[16], pb[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      pa[i] = NI;
+      pb[i] = NI;
+    }
+    for (uint32_t t0 = 0; t0 < c; t0 += 32) {
+      const bool act = t0 + col < c;
+      const Half cur = load_half(rec, st + min(t0 + (uint32_t)col, c - 1), h);
+      const float ff[6] = {__uint_as_float(cur.a.x), __uint_as_float(cur.a.y), __uint_as_float(cur.a.z),
+                           __uint_as_float(cur.a.w), __uint_as_float(cur.b.x), __uint_as_float(cur.b.y)};
+      v16f d0, da, db;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        d0[i] = 0.f;
+        da[i] = 0.f;
+        db[i] = 0.f;
+      }
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], act ? ff[kk] : 0.f, d0);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const float u = fmaxf(d0[i], 0.f);
+        da = PNX_MFMA(w1a[i], u, da);
+        db = PNX_MFMA(w1b[i], u, db);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        da = PNX_MFMA(w1a[16 + i], g0[i], da);
+        db = PNX_MFMA(w1b[16 + i], g0[i], db);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        pa[i] = fmaxf(pa[i], act ? da[i] : NI);
+        pb[i] = fmaxf(pb[i], act ? db[i] : NI);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) {
+        pa[i] = fmaxf(pa[i], __shfl_xor(pa[i], d));
+        pb[i] = fmaxf(pb[i], __shfl_xor(pb[i], d));
+      }
+    }
+    if (col == 0) {  // one lane per half: its 2 x 16 channels as 4-channel pieces
+      const int64_t cell = (int64_t)cell_of_pillar[r];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float4 sa = s1lane[j], sb = s1lane[4 + j];
+        const float va[4] = {fmaxf(pa[4 * j] + sa.x, 0.f), fmaxf(pa[4 * j + 1] + sa.y, 0.f), fmaxf(pa[4 * j + 2] + sa.z, 0.f),
+                             fmaxf(pa[4 * j + 3] + sa.w, 0.f)};
+        const float vb[4] = {fmaxf(pb[4 * j] + sb.x, 0.f), fmaxf(pb[4 * j + 1] + sb.y, 0.f), fmaxf(pb[4 * j + 2] + sb.z, 0.f),
+                             fmaxf(pb[4 * j + 3] + sb.w, 0.f)};
+#pragma unroll
+        for (int half2 = 0; half2 < 2; half2++) {
+          const float* v = half2 ? vb : va;
+          const int chan0 = 32 * half2 + 8 * j + 4 * h;
+          if (out.g1 != nullptr && (int64_t)r < out.g1_rows)
+            *reinterpret_cast<float4*>(out.g1 + (int64_t)r * 64 + chan0) = make_float4(v[0], v[1], v[2], v[3]);
+          if (out.canvas != nullptr) {
+            if (out.dt == PNX_F32) {
+              *reinterpret_cast<float4*>(reinterpret_cast<float*>(out.canvas) + cell * 64 + chan0) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+              uint2 p;
+              if (out.dt == PNX_BF16) {
+                p.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
+                p.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
+              } else {
+                p.x = f16_rne(v[0]) | (f16_rne(v[1]) << 16);
+                p.y = f16_rne(v[2]) | (f16_rne(v[3]) << 16);
+              }
+              *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out.canvas) + cell * 64 + chan0) = p;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int F>
+int launch3(const uint4* rec, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar, int32_t* counters, int32_t* tick, int32_t* biglist,
+            int64_t bigcap, const float* folded, const Pfn3Out& out, int64_t n, int n_fill, const uint32_t* bitmap, const PnxGeomDev& g,
+            uint8_t* occ, int fill_nt, hipStream_t st) {
+  constexpr int R = 256;
+  const char* b_env = getenv("PNX_PFN_BLOCKS");
+  const int max_blocks = b_env ? atoi(b_env) : 512;  // 256 CUs x 2 blocks x 4 waves = 2 waves per SIMD
+  int64_t nb = ((n + R - 1) / R + 3) / 4;
+  if (nb > max_blocks) nb = max_blocks;
+  if (n <= 0) nb = 0;
+  const int bc = (int)(bigcap > 0x7fffffff ? 0x7fffffff : bigcap);
+  const char* d_env = getenv("PNX_PFN_DBG");  // timing ablations only (results are wrong): 1 no stores, 2 no scans, 4 no layer-1 MFMAs
+  const int dbg = d_env ? atoi(d_env) : 0;
+  if (nb + n_fill > 0) {
+    const int grid = (int)(nb + n_fill);
+    if (out.dt == PNX_F32) k_pfn3<F, R, PNX_F32><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, counters, tick, biglist, bc, folded, out, n_fill, bitmap, g, occ, fill_nt, dbg);
+    else if (out.dt == PNX_BF16) k_pfn3<F, R, PNX_BF16><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, counters, tick, biglist, bc, folded, out, n_fill, bitmap, g, occ, fill_nt, dbg);
+    else k_pfn3<F, R, PNX_F16><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, counters, tick, biglist, bc, folded, out, n_fill, bitmap, g, occ, fill_nt, dbg);
+    PNX_LAUNCH_CHECK();
+  }
+  if (n > 0) {
+    k_pfn3_big<F><<<64, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out);
+    PNX_LAUNCH_CHECK();
+  }
+  return PNX_OK;
+}
+
+}  // namespace
+
+// n_fill > 0: blocks [0, n_fill) of the launch zero-fill the pillar-free canvas cells (and write `occ`) concurrently with the PFN.
+int pnx_launch_pfn_v3(int F, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar,
+                      int32_t* counters, int32_t* tick, int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows,
+                      void* canvas, int canvas_dt, int64_t n_points, int n_fill, const uint32_t* bitmap, const PnxGeomDev& geom, uint8_t* occ,
+                      int fill_nt, hipStream_t st) {
+  Pfn3Out out;
+  out.g1 = g1;
+  out.g1_rows = g1_rows;
+  out.canvas = canvas;
+  out.dt = canvas_dt;
+  const uint4* rec = reinterpret_cast<const uint4*>(rec64);
+  switch (F) {
+    case 3: return launch3<3>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bigcap, folded, out, n_points, n_fill, bitmap, geom, occ, fill_nt, st);
+    case 4: return launch3<4>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bigcap, folded, out, n_points, n_fill, bitmap, geom, occ, fill_nt, st);
+    case 5: return launch3<5>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bigcap, folded, out, n_points, n_fill, bitmap, geom, occ, fill_nt, st);
+    case 6: return launch3<6>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bigcap, folded, out, n_points, n_fill, bitmap, geom, occ, fill_nt, st);
+  }
+  pnx_set_error("num_point_features %d not in 3..6", F);
+  return PNX_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,65 @@
+// pnx_fill.h -- zero-fill of the pillar-free cells of the dense NHWC canvas (device code shared by reader.hip's stand-alone
+// k_canvas_fill_nhwc and the fused PFN+fill launch of pfn_v3.hip).
+//
+// Direct mode of the reader (sparse_resnet.py:63-68 .dense() semantics, written BEFORE a dense backbone): the PFN kernel stores
+// every pillar's 64 features straight into its cell; this code writes the zeros of all OTHER cells and the occupancy bytes.
+// Together they write each canvas byte exactly once.  One call = one 32x32-cell tile; `s_word` is 32 words of LDS.
+#pragma once
+#include "pnx_common.h"
+
+// NT: nontemporal stores.  Measured (C2 sweep, bf16): 2 GB canvas (8 frames) 356 -> 335 us = 6.0 TB/s; 1 GB (4 frames) 171 -> 189 us,
+// where a quarter of the footprint is absorbed by the 256 MB Infinity Cache that the nontemporal hint bypasses -- the host picks.
+template <int DT, bool NT>
+__device__ __forceinline__ void pnx_fill_tile(const uint32_t* __restrict__ bitmap, const PnxGeomDev& g, void* __restrict__ canvas,
+                                              uint8_t* __restrict__ occ, int tile, uint32_t* s_word, int t, int nthreads) {
+  constexpr int ESZ = (DT == PNX_F32) ? 4 : 2;
+  constexpr int CH = 64 * ESZ / 16;  // 16-byte chunks per cell
+  const int tiles_x = (g.gx + 31) >> 5, tiles_y = g.gyp >> 5;
+  const int tx = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty = tile % tiles_y, b = tile / tiles_y;
+  const int x0 = tx << 5, y0 = ty << 5;
+  if (t < 32) {
+    const int xi = x0 + t;
+    s_word[t] = xi < g.gx ? bitmap[((b * g.gx + xi) * g.gyp + y0) >> 5] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  uint4* out = reinterpret_cast<uint4*>(canvas);
+  const int rows = min(32, g.gy - y0);
+  // occupancy bytes: 16 cells = one 16-byte store (a byte store per cell from every 8th lane of the loop below cost 60 us of the
+  // 400 us at 8 frames); tiles cut by the right edge, an unaligned row pitch or an unaligned buffer keep the per-cell stores
+  const bool occ_wide = occ != nullptr && x0 + 32 <= g.gx && (g.gx & 15) == 0 && (reinterpret_cast<uintptr_t>(occ) & 15) == 0;
+  if (occ_wide && t < rows * 2) {
+    const int yl = t >> 1, half = t & 1;
+    uint32_t w4[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) v |= ((s_word[half * 16 + k * 4 + i] >> yl) & 1u) << (8 * i);
+      w4[k] = v;
+    }
+    const int64_t cell = ((int64_t)b * g.gy + (y0 + yl)) * g.gx + x0 + half * 16;
+    *reinterpret_cast<uint4*>(occ + cell) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+  }
+  for (int idx = t; idx < rows * 32 * CH; idx += nthreads) {
+    const int q = idx % CH;
+    const int xl = (idx / CH) & 31;
+    const int yl = idx / (CH * 32);
+    const int xi = x0 + xl;
+    if (xi >= g.gx) continue;
+    const uint32_t bit = (s_word[xl] >> yl) & 1u;
+    const int64_t cell = ((int64_t)b * g.gy + (y0 + yl)) * g.gx + xi;
+    if (occ != nullptr && !occ_wide && q == 0) occ[cell] = (uint8_t)bit;
+    if (!bit) {
+      if (NT) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(u32x4{0u, 0u, 0u, 0u}, reinterpret_cast<u32x4*>(out + cell * CH + q));
+      } else {
+        out[cell * CH + q] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  }
+}
+
+static inline int pnx_fill_tiles(const PnxGeomDev& g) { return ((g.gx + 31) / 32) * (g.gyp / 32) * g.B; }

@@ -24,6 +24,7 @@
 
 #include "pnx_common.h"
 #include "pnx_scan.h"
+#include "pnx_fill.h"
 
 namespace {
 
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void k_keys(const float* __restrict__ pts, 
     //  - occupancy as one BYTE per cell: every writer stores the same value, byte-granular dirty masks merge across XCDs
     //  - owner[cell] = some point of the cell (last writer wins): that point takes slot 0 without an atomic
     bytemap[key] = 1;
-    owner[key] = (int32_t)i;
+    if (owner != nullptr) owner[key] = (int32_t)i;  // the binned path (reader_bins.h) needs no owner
   }
   key_out[i] = key;
 }
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(kBlock) void k_keys(const float* __restrict__ pts, 
 __device__ __forceinline__ uint32_t nib4(uint32_t v) { return ((v * 0x00204081u) >> 21) & 0xFu; }  // 4 bytes (0/1) -> 4 bits
 
 __global__ __launch_bounds__(kBlock) void k_pack_scan(const uint8_t* __restrict__ bytemap, int64_t nwords, uint32_t* __restrict__ bitmap,
-                                                      uint32_t* __restrict__ out_local, uint32_t* __restrict__ blk_tot) {
+                                                      uint32_t* __restrict__ out_local, uint32_t* __restrict__ blk_tot,
+                                                      uint2* __restrict__ wcomb) {
   __shared__ uint32_t s_wave[kBlock / 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t base = (int64_t)blockIdx.x * PNX_SCAN_ITEMS + (int64_t)t * 8;
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_scan(const uint8_t* __restrict_
     if (base + k < nwords) {
       bitmap[base + k] = w[k];
       out_local[base + k] = excl + pre[k];
+      if (wcomb != nullptr) wcomb[base + k] = make_uint2(w[k], excl + pre[k]);  // {bits, prefix} in one 8-byte load for the per-point rank
     }
   if (t == kBlock - 1) blk_tot[blockIdx.x] = excl + sum;
 }
@@ -103,6 +106,12 @@ __device__ __forceinline__ int32_t cell_rank(int32_t key, const uint32_t* __rest
   const int32_t w = key >> 5;
   const uint32_t bits = bitmap[w];
   return (int32_t)(wblk[w >> PNX_SCAN_SHIFT] + wpre[w] + __popc(bits & ((1u << (key & 31)) - 1u)));
+}
+
+__device__ __forceinline__ int32_t cell_rank2(int32_t key, const uint2* __restrict__ wcomb, const uint32_t* __restrict__ wblk) {
+  const int32_t w = key >> 5;
+  const uint2 c = wcomb[w];
+  return (int32_t)(wblk[w >> PNX_SCAN_SHIFT] + c.y + __popc(c.x & ((1u << (key & 31)) - 1u)));
 }
 
 // rank of every point (== unq_inv of the reference for kept points), slot inside the pillar, coords.
@@ -142,6 +151,8 @@ __global__ __launch_bounds__(kBlock) void k_rank(const int32_t* __restrict__ key
 __device__ __forceinline__ uint32_t pillar_start(int32_t r, const uint32_t* __restrict__ cpre, const uint32_t* __restrict__ cblk) {
   return cblk[r >> PNX_SCAN_SHIFT] + cpre[r];
 }
+
+#include "reader_bins.h"
 
 // CSR fill: plist[start(rank) + slot] = point id, plus a 32-byte record per slot [x, y, z, f.. (6 words), idx|rem, rank] so the PFN
 // kernel streams its input with coalesced loads instead of chasing plist -> rank -> point row.
@@ -450,64 +461,13 @@ __global__ __launch_bounds__(kBlock) void k_canvas_nhwc(const uint32_t* __restri
 }
 
 // NHWC canvas, direct-write mode: the PFN kernel stores every pillar's 64 features straight into its cell; this kernel
-// writes the zeros of all OTHER cells (and the occupancy bytes).  Together they still write each canvas byte exactly once,
-// and the (P,64) fp32 intermediate disappears from the traffic.
-// NT: nontemporal stores.  Measured (C2 sweep, bf16): 2 GB canvas (8 frames) 356 -> 335 us = 6.0 TB/s; 1 GB (4 frames) 171 -> 189 us,
-// where a quarter of the footprint is absorbed by the 256 MB Infinity Cache that the nontemporal hint bypasses -- the host picks.
+// writes the zeros of all OTHER cells (and the occupancy bytes) -- see pnx_fill.h (the fused PFN+fill launch of pfn_v3.hip
+// runs the same tile routine from its fill blocks).
 template <int DT, bool NT>
 __global__ __launch_bounds__(kBlock) void k_canvas_fill_nhwc(const uint32_t* __restrict__ bitmap, GeomDev g, void* __restrict__ canvas,
                                                              uint8_t* __restrict__ occ) {
-  constexpr int ESZ = (DT == PNX_F32) ? 4 : 2;
-  constexpr int CH = 64 * ESZ / 16;  // 16-byte chunks per cell
   __shared__ uint32_t s_word[32];
-  const int tiles_x = (g.gx + 31) >> 5, tiles_y = g.gyp >> 5;
-  int tile = blockIdx.x;
-  const int tx = tile % tiles_x;
-  tile /= tiles_x;
-  const int ty = tile % tiles_y, b = tile / tiles_y;
-  const int x0 = tx << 5, y0 = ty << 5;
-  const int t = threadIdx.x;
-  if (t < 32) {
-    const int xi = x0 + t;
-    s_word[t] = xi < g.gx ? bitmap[((b * g.gx + xi) * g.gyp + y0) >> 5] : 0xFFFFFFFFu;
-  }
-  __syncthreads();
-  uint4* out = reinterpret_cast<uint4*>(canvas);
-  const int rows = min(32, g.gy - y0);
-  // occupancy bytes: 16 cells = one 16-byte store (a byte store per cell from every 8th lane of the loop below cost 60 us of the
-  // 400 us at 8 frames); tiles cut by the right edge, an unaligned row pitch or an unaligned buffer keep the per-cell stores
-  const bool occ_wide = occ != nullptr && x0 + 32 <= g.gx && (g.gx & 15) == 0 && (reinterpret_cast<uintptr_t>(occ) & 15) == 0;
-  if (occ_wide && t < rows * 2) {
-    const int yl = t >> 1, half = t & 1;
-    uint32_t w4[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      uint32_t v = 0;
-#pragma unroll
-      for (int i = 0; i < 4; i++) v |= ((s_word[half * 16 + k * 4 + i] >> yl) & 1u) << (8 * i);
-      w4[k] = v;
-    }
-    const int64_t cell = ((int64_t)b * g.gy + (y0 + yl)) * g.gx + x0 + half * 16;
-    *reinterpret_cast<uint4*>(occ + cell) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-  }
-  for (int idx = t; idx < rows * 32 * CH; idx += kBlock) {
-    const int q = idx % CH;
-    const int xl = (idx / CH) & 31;
-    const int yl = idx / (CH * 32);
-    const int xi = x0 + xl;
-    if (xi >= g.gx) continue;
-    const uint32_t bit = (s_word[xl] >> yl) & 1u;
-    const int64_t cell = ((int64_t)b * g.gy + (y0 + yl)) * g.gx + xi;
-    if (occ != nullptr && !occ_wide && q == 0) occ[cell] = (uint8_t)bit;
-    if (!bit) {
-      if (NT) {
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(u32x4{0u, 0u, 0u, 0u}, reinterpret_cast<u32x4*>(out + cell * CH + q));
-      } else {
-        out[cell * CH + q] = make_uint4(0, 0, 0, 0);
-      }
-    }
-  }
+  pnx_fill_tile<DT, NT>(bitmap, g, canvas, occ, blockIdx.x, s_word, threadIdx.x, kBlock);
 }
 
 // NCHW canvas (what .dense() returns).  Not the performance layout; same tile scheme, one element per store.
@@ -585,17 +545,19 @@ __global__ __launch_bounds__(kBlock) void k_scatter_list(const float* __restrict
 
 // ------------------------------------------------------------------------------------------ host side
 // Optional event timing (pnx_profile_begin/end).
+constexpr int kEv = 8;
 struct Prof {
   bool on = false;
   int cap = 0, n = 0;
-  std::vector<hipEvent_t> ev;  // 6 per sample: reader start, canvas start, canvas stop, reader stop, pfn start, pfn stop
+  std::vector<hipEvent_t> ev;  // kEv per sample: reader start, canvas start, canvas stop, reader stop, pfn start, pfn stop, voxelize stop
 } g_prof;
 inline void prof_mark(int which, hipStream_t st) {
-  if (g_prof.on && g_prof.n < g_prof.cap) (void)hipEventRecord(g_prof.ev[g_prof.n * 6 + which], st);
+  if (g_prof.on && g_prof.n < g_prof.cap) (void)hipEventRecord(g_prof.ev[g_prof.n * kEv + which], st);
 }
 
 struct ReaderWs {
   int32_t* counters;  // [0]=P [1]=N'
+  int32_t* tick;      // 16 ticket words in separate lines (pfn_v3.hip), zeroed with the counters
   uint32_t *bitmap, *wpre, *wblk;
   uint8_t* bytemap;
   int32_t* owner;
@@ -612,6 +574,13 @@ struct ReaderWs {
   float* g1;
   int64_t nwords, pcap;
   int nblk_w, nblk_c, nblk_k;
+  // binned path (reader_bins.h): bins of 2^sh pillars, K1 bins, points handled in `nwg` chunks of `chunk`
+  int sh, K1, chunk, nwg, nblk_m;
+  int64_t matlen;
+  uint32_t *histmat, *hpre, *hblk;
+  uint32_t* rec64;               // pillar-sorted decorated records, 64 B per kept point
+  uint32_t *pfirst, *pcnt;       // first sorted slot / number of points of every pillar
+  uint2* wcomb;                  // {bitmap word, popcount prefix} pairs
   size_t bytes;
 };
 
@@ -632,6 +601,7 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   w.nblk_k = (int)((n + PNX_SCAN_ITEMS - 1) / PNX_SCAN_ITEMS);
   if (w.nblk_k < 1) w.nblk_k = 1;
   w.counters = c.take<int32_t>(64);
+  w.tick = c.take<int32_t>(16 * 32);
   w.count = c.take<uint32_t>(w.pcap + 8);
   w.bytemap = c.take<uint8_t>(cells + 64);
   w.zero_bytes = c.used();
@@ -653,6 +623,25 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   w.kblk = c.take<uint32_t>(w.nblk_k + 8);
   w.mean = c.take<float>(w.pcap * 3 + 8);
   w.g1 = c.take<float>(w.pcap * 64 + 8);
+  // binned path: bins small enough for k_bin_sort's LDS (<= 2048 pillars), at most ~1200 of them for the usual sizes; chunks sized so
+  // that the (bin x workgroup) matrix stays ~0.5 M entries while >= 128 workgroups share the point passes
+  w.sh = 8;
+  while (w.sh < 11 && ((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh) > 1200) w.sh++;
+  w.K1 = (int)((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh);
+  int64_t chunk = (n / 512 + 255) / 256 * 256;
+  if (chunk < 2048) chunk = 2048;
+  w.chunk = (int)chunk;
+  w.nwg = (int)((n + chunk - 1) / chunk);
+  if (w.nwg < 1) w.nwg = 1;
+  w.matlen = (int64_t)w.K1 * w.nwg;
+  w.nblk_m = (int)((w.matlen + PNX_SCAN_ITEMS - 1) / PNX_SCAN_ITEMS);
+  w.histmat = c.take<uint32_t>(w.matlen + 8);
+  w.hpre = c.take<uint32_t>(w.matlen + 8);
+  w.hblk = c.take<uint32_t>(w.nblk_m + 8);
+  w.rec64 = c.take<uint32_t>((n + 8) * 16);
+  w.pfirst = c.take<uint32_t>(w.pcap + 8);
+  w.pcnt = c.take<uint32_t>(w.pcap + 8);
+  w.wcomb = c.take<uint2>(w.nwords + 8);
   w.bytes = c.used();
   return w;
 }
@@ -690,7 +679,7 @@ int run_voxelize(const float* points, int64_t n, int32_t stride, const GeomDev& 
     k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bytemap, w.owner);
     PNX_LAUNCH_CHECK();
   }
-  k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk);
+  k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk, nullptr);
   k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
   PNX_LAUNCH_CHECK();
   if (n > 0) {
@@ -717,6 +706,58 @@ int run_voxelize(const float* points, int64_t n, int32_t stride, const GeomDev& 
   return PNX_OK;
 }
 
+// Steps 1-4 of the binned path (reader_bins.h): keys, bitmap scan, bin histogram matrix + scan, bin scatter, in-LDS bin sort.
+// Leaves counters = {P, N'}, the pillar-sorted decorated records w.rec64, w.pfirst / w.pcnt / w.cell per pillar, w.rank per point.
+template <int F>
+int launch_bin_sort(const GeomDev& gd, const ReaderWs& w, int32_t* coords, int64_t pillar_capacity, hipStream_t st) {
+  const size_t lds = bin_sort_lds(w.sh);
+  static size_t lds_set = 0;
+  if (lds > lds_set) {  // more than the 64 KiB a launch gets by default
+    PNX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_sort<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
+  }
+  const char* d_env = getenv("PNX_SORT_DBG");  // timing ablations only (results are wrong): 1 no fp64 sums
+  const int sdbg = d_env ? atoi(d_env) : 0;
+  k_bin_sort<F><<<w.K1, kSortBlock, lds, st>>>(w.rec, gd, w.sh, w.nwg, w.matlen, w.hpre, w.hblk, w.counters, w.rec64, w.pfirst, w.pcnt,
+                                               w.cell, coords, pillar_capacity, sdbg);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev& gd, const ReaderWs& w, int32_t* coords,
+                  int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, hipStream_t st) {
+  PNX_CHECK_HIP(hipMemsetAsync(w.counters, 0, w.zero_bytes, st));  // counters | count | bytemap
+  if (n > 0) {
+    k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bytemap, nullptr);
+    PNX_LAUNCH_CHECK();
+  }
+  k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk, w.wcomb);
+  k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
+  PNX_LAUNCH_CHECK();
+  if (n <= 0) return PNX_OK;
+  const size_t hl = (size_t)w.K1 * sizeof(uint32_t);
+  k_bin_count<<<w.nwg, kBlock, hl, st>>>(w.key, n, w.chunk, w.sh, w.K1, w.nwg, w.wcomb, w.wblk, w.rank, pillar_of_point, w.histmat);
+  k_scan_local<SCAN_IDENT><<<w.nblk_m, kBlock, 0, st>>>(w.histmat, w.matlen, w.hpre, w.hblk);
+  k_scan_blocks<<<1, kBlock, 0, st>>>(w.hblk, w.nblk_m, w.counters + 1);
+  k_bin_scatter<<<w.nwg, kBlock, hl, st>>>(points, stride, w.key, w.rank, n, w.chunk, w.sh, w.K1, w.nwg, w.hpre, w.hblk, w.rec);
+  PNX_LAUNCH_CHECK();
+  int rc;
+  switch (stride - 1) {
+    case 3: rc = launch_bin_sort<3>(gd, w, coords, pillar_capacity, st); break;
+    case 4: rc = launch_bin_sort<4>(gd, w, coords, pillar_capacity, st); break;
+    case 5: rc = launch_bin_sort<5>(gd, w, coords, pillar_capacity, st); break;
+    default: rc = launch_bin_sort<6>(gd, w, coords, pillar_capacity, st); break;
+  }
+  if (rc != PNX_OK) return rc;
+  if (unq_inv) {
+    k_scan_local<SCAN_KEPT><<<w.nblk_k, kBlock, 0, st>>>(reinterpret_cast<const uint32_t*>(w.key), n, w.kpre, w.kblk);
+    k_scan_blocks<<<1, kBlock, 0, st>>>(w.kblk, w.nblk_k, nullptr);
+    k_write_inv<<<nblocks(n), kBlock, 0, st>>>(w.rank, n, w.kpre, w.kblk, unq_inv);
+    PNX_LAUNCH_CHECK();
+  }
+  return PNX_OK;
+}
+
 template <int DT>
 int launch_canvas(const ReaderWs& w, const float* g1, int64_t g1_rows, const GeomDev& gd, void* canvas, uint8_t* occ, int layout, hipStream_t st) {
   const int tiles = ((gd.gx + 31) / 32) * (gd.gyp / 32) * gd.B;
@@ -734,6 +775,12 @@ int launch_canvas(const ReaderWs& w, const float* g1, int64_t g1_rows, const Geo
 int pnx_launch_pfn_mfma(int F, const uint32_t* rec, const PnxGeomDev& geom, const uint32_t* count, const uint32_t* cpre,
                         const uint32_t* cblk, int32_t* counters, int32_t* biglist, int64_t bigcap, const float* folded, float* g1,
                         int64_t g1_rows, void* canvas, const int32_t* cell_of_pillar, int canvas_dt, int64_t n_points, hipStream_t st);
+
+// implemented in pfn_v3.hip: PFN over the pillar-sorted records of the binned path, optionally fused with the canvas zero-fill
+int pnx_launch_pfn_v3(int F, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar,
+                      int32_t* counters, int32_t* tick, int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows,
+                      void* canvas, int canvas_dt, int64_t n_points, int n_fill, const uint32_t* bitmap, const PnxGeomDev& geom, uint8_t* occ,
+                      int fill_nt, hipStream_t st);
 
 extern "C" {
 
@@ -770,24 +817,36 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   const ReaderWs w = carve(workspace, n, batch, g);
   const GeomDev gd = make_geom(g, batch);
 
-  prof_mark(0, st);
-  rc = run_voxelize(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, unq_inv != nullptr, st);
-  if (rc != PNX_OK) return rc;
-
-  const char* impl_env = getenv("PNX_PFN_IMPL");  // 0 = per-pillar cross-check kernel
+  // PNX_PFN_IMPL=0: per-pillar cross-check PFN kernel.  PNX_READER_IMPL=1: round-1 pipeline (global-atomic slots, 32-byte records,
+  // DPP-scan PFN); default 2: binned pipeline (reader_bins.h) + LDS-max PFN fused with the canvas zero-fill (pfn_v3.hip).
+  const char* impl_env = getenv("PNX_PFN_IMPL");
   const int impl = impl_env ? atoi(impl_env) : 1;
+  const char* rimpl_env = getenv("PNX_READER_IMPL");
+  const bool binned = (rimpl_env ? atoi(rimpl_env) : 2) != 1 && impl != 0 && w.K1 <= 16384;
+  prof_mark(0, st);
+  if (binned) rc = run_voxelize2(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, st);
+  else rc = run_voxelize(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, unq_inv != nullptr, st);
+  if (rc != PNX_OK) return rc;
+  prof_mark(6, st);
+
   const int F = stride - 1;
-  // Direct mode (NHWC canvas, MFMA PFN): the PFN kernel stores each pillar straight into its canvas cell and a fill kernel
-  // writes the zeros of every other cell -- no (P,64) fp32 intermediate, every canvas byte still written exactly once.
+  // Direct mode (NHWC canvas, MFMA PFN): the PFN kernel stores each pillar straight into its canvas cell and fill blocks (or a fill
+  // kernel) write the zeros of every other cell -- no (P,64) fp32 intermediate, every canvas byte still written exactly once.
   const bool direct = canvas != nullptr && canvas_layout == PNX_NHWC && impl != 0;
   // feat_max doubles as the PFN output buffer when it can hold every possible pillar
   float* g1 = (feat_max && pillar_capacity >= w.pcap) ? feat_max : w.g1;
   if (direct && feat_max == nullptr) g1 = nullptr;
   const int64_t g1_rows = (g1 == feat_max) ? pillar_capacity : w.pcap;
+  const size_t canvas_bytes = (size_t)gd.B * gd.gx * gd.gy * 64 * (canvas_dtype == PNX_F32 ? 4 : 2);
+  const char* nt_env = getenv("PNX_FILL_NT");
+  const bool fill_nt = nt_env ? nt_env[0] == '1' : canvas_bytes >= ((size_t)3 << 29);  // >= 1.5 GiB: far beyond what the Infinity Cache absorbs
+  const char* fuse_env = getenv("PNX_READER_FUSE");  // 0: zero-fill as its own kernel in front of the PFN
+  const char* fb_env = getenv("PNX_FILL_BLOCKS");
+  const bool fuse = binned && direct && !(fuse_env && fuse_env[0] == '0');
 
   static hipStream_t side = nullptr;
   static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  const bool overlap = direct && getenv("PNX_READER_OVERLAP") != nullptr;  // zero-fill on a second stream, concurrent with the PFN
+  const bool overlap = direct && !binned && getenv("PNX_READER_OVERLAP") != nullptr;  // round-1 path: zero-fill on a second stream
   if (overlap && side == nullptr) {
     PNX_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -795,9 +854,7 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   }
   auto launch_fill = [&](hipStream_t fs) -> int {
     const int tiles = ((gd.gx + 31) / 32) * (gd.gyp / 32) * gd.B;
-    static const char* nt_env = getenv("PNX_FILL_NT");
-    const size_t canvas_bytes = (size_t)gd.B * gd.gx * gd.gy * 64 * (canvas_dtype == PNX_F32 ? 4 : 2);
-    const bool nt = nt_env ? nt_env[0] == '1' : canvas_bytes >= ((size_t)3 << 29);  // >= 1.5 GiB: far beyond what the Infinity Cache absorbs
+    const bool nt = fill_nt;
 #define PNX_FILL(DT)                                                                                    \
   if (nt) k_canvas_fill_nhwc<DT, true><<<tiles, kBlock, 0, fs>>>(w.bitmap, gd, canvas, occupancy);      \
   else k_canvas_fill_nhwc<DT, false><<<tiles, kBlock, 0, fs>>>(w.bitmap, gd, canvas, occupancy)
@@ -812,7 +869,7 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
     PNX_LAUNCH_CHECK();
     return PNX_OK;
   };
-  if (direct) {
+  if (direct && !fuse) {
     if (overlap) {
       PNX_CHECK_HIP(hipEventRecord(ev_fork, st));
       PNX_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
@@ -826,7 +883,17 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
       prof_mark(2, st);
     }
   }
-  if (n > 0) {
+  if (binned) {
+    // fill blocks: enough resident 256-thread blocks to keep ~2 TB/s x 3 of stores in flight next to the PFN blocks (measured)
+    const int n_fill = fuse ? (fb_env ? atoi(fb_env) : 256) : 0;
+    prof_mark(4, st);
+    if (fuse) prof_mark(1, st);
+    rc = pnx_launch_pfn_v3(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.tick, w.biglist, w.bigcap, pfn_folded, g1, g1_rows,
+                           direct ? canvas : nullptr, canvas_dtype, n, n_fill, w.bitmap, gd, occupancy, fill_nt ? 1 : 0, st);
+    if (rc != PNX_OK) return rc;
+    prof_mark(5, st);
+    if (fuse) prof_mark(2, st);
+  } else if (n > 0) {
     if (impl == 0) {
       const int nb = nblocks(w.pcap);
       switch (F) {
@@ -873,7 +940,7 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
 
 int pnx_profile_begin(int32_t max_samples) {
   PNX_REQUIRE(max_samples > 0 && max_samples <= 65536, PNX_ERR_INVALID, "max_samples out of range");
-  while ((int)g_prof.ev.size() < max_samples * 6) {
+  while ((int)g_prof.ev.size() < max_samples * kEv) {
     hipEvent_t e;
     PNX_CHECK_HIP(hipEventCreate(&e));
     g_prof.ev.push_back(e);
@@ -884,24 +951,27 @@ int pnx_profile_begin(int32_t max_samples) {
   return PNX_OK;
 }
 
-static float g_last_pfn_us = 0.f;
+static float g_last_pfn_us = 0.f, g_last_vox_us = 0.f;
 float pnx_profile_last_pfn_us(void) { return g_last_pfn_us; }
+float pnx_profile_last_voxelize_us(void) { return g_last_vox_us; }
 
 int pnx_profile_end(float* reader_us, float* canvas_us, int32_t* samples) {
   g_prof.on = false;
-  double r = 0, c = 0, f = 0;
+  double r = 0, c = 0, f = 0, v = 0;
   for (int i = 0; i < g_prof.n; i++) {
     float ms = 0;
-    PNX_CHECK_HIP(hipEventSynchronize(g_prof.ev[i * 6 + 3]));
-    PNX_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[i * 6 + 0], g_prof.ev[i * 6 + 3]));
+    PNX_CHECK_HIP(hipEventSynchronize(g_prof.ev[i * kEv + 3]));
+    PNX_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[i * kEv + 0], g_prof.ev[i * kEv + 3]));
     r += ms;
-    PNX_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[i * 6 + 1], g_prof.ev[i * 6 + 2]));
+    PNX_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[i * kEv + 1], g_prof.ev[i * kEv + 2]));
     c += ms;
-    if (hipEventElapsedTime(&ms, g_prof.ev[i * 6 + 4], g_prof.ev[i * 6 + 5]) == hipSuccess) f += ms;
+    if (hipEventElapsedTime(&ms, g_prof.ev[i * kEv + 4], g_prof.ev[i * kEv + 5]) == hipSuccess) f += ms;
+    if (hipEventElapsedTime(&ms, g_prof.ev[i * kEv + 0], g_prof.ev[i * kEv + 6]) == hipSuccess) v += ms;
   }
   if (getenv("PNX_DEBUG") && g_prof.n) fprintf(stderr, "[pnx] profile: pfn kernel %.2f us avg over %d calls\n", f * 1e3 / g_prof.n, g_prof.n);
   const int n = g_prof.n;
   g_last_pfn_us = n ? (float)(f * 1e3 / n) : 0.f;
+  g_last_vox_us = n ? (float)(v * 1e3 / n) : 0.f;
   if (reader_us) *reader_us = n ? (float)(r * 1e3 / n) : 0.f;
   if (canvas_us) *canvas_us = n ? (float)(c * 1e3 / n) : 0.f;
   if (samples) *samples = n;

@@ -27,9 +27,13 @@ def make_net(pc_range, voxel_size, layers, F=5, num_filters=(64, 64)):
     return net.eval()
 
 
-@pytest.fixture(params=["mfma", "pillar"])
+@pytest.fixture(params=["binned", "binned_unfused", "round1", "pillar"])
 def pfn_impl(request, monkeypatch):
-    monkeypatch.setenv("PNX_PFN_IMPL", "1" if request.param == "mfma" else "0")
+    """binned = default pipeline (reader_bins.h + pfn_v3.hip, zero-fill fused into the PFN launch); binned_unfused = the same with
+    the fill as its own kernel; round1 = global-atomic slots + DPP-scan PFN; pillar = thread-per-pillar cross-check kernel."""
+    monkeypatch.setenv("PNX_PFN_IMPL", "0" if request.param == "pillar" else "1")
+    monkeypatch.setenv("PNX_READER_IMPL", "1" if request.param == "round1" else "2")
+    monkeypatch.setenv("PNX_READER_FUSE", "0" if request.param == "binned_unfused" else "1")
     return request.param
 
 

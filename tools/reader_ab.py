@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""A/B timing of the reader's pipelines on one GPU (points resident -> bf16 NHWC canvas + occupancy), HIP events from libpnx_hip.so.
+
+Variants are environment settings read by pnx_reader_forward on every call:
+  PNX_READER_IMPL=1            round-1 pipeline (global-atomic slots, 32-byte records, DPP-scan PFN, separate fill kernel)
+  PNX_READER_IMPL=2            binned pipeline (reader_bins.h) + LDS-max PFN (pfn_v3.hip)
+    PNX_READER_FUSE=0|1        zero-fill as its own kernel | as blocks of the PFN launch
+    PNX_FILL_BLOCKS, PNX_PFN_BLOCKS   block counts of the two roles
+Every variant's canvas must equal the first variant's bit for bit.
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pillarnext_amd import _lib, synth  # noqa: E402
+from pillarnext_amd.reader import PillarFeatureNet  # noqa: E402
+
+VARIANTS = [
+    ("round1", {"PNX_READER_IMPL": "1"}),
+    ("binned unfused", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "0"}),
+    ("binned fused f128", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "1", "PNX_FILL_BLOCKS": "128"}),
+    ("binned fused f256", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "1", "PNX_FILL_BLOCKS": "256"}),
+    ("binned fused f384", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "1", "PNX_FILL_BLOCKS": "384"}),
+    ("binned fused f512", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "1", "PNX_FILL_BLOCKS": "512"}),
+    ("binned fused f256 p256", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "1", "PNX_FILL_BLOCKS": "256", "PNX_PFN_BLOCKS": "256"}),
+    ("binned fused f256 p768", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "1", "PNX_FILL_BLOCKS": "256", "PNX_PFN_BLOCKS": "768"}),
+]
+KEYS = ["PNX_READER_IMPL", "PNX_READER_FUSE", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--dist", default="sweep")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    cfg = synth.CONFIGS[a.config]
+    net = PillarFeatureNet(5, [64, 64], list(cfg["voxel_size"]), list(cfg["pc_range"])).cuda().eval()
+    # four different batches rotate through the loop, as in bench.py
+    batches = [torch.from_numpy(synth.make_batch(a.config, a.batch, a.dist, frame0=k * a.batch)).cuda() for k in range(4)]
+    ny, nx = (int(v) for v in net.grid_size)
+    out = torch.empty((a.batch, 64, ny, nx), dtype=torch.bfloat16, device="cuda", memory_format=torch.channels_last)
+    occ = torch.empty((a.batch, ny, nx), dtype=torch.uint8, device="cuda")
+    counts = torch.zeros(2, dtype=torch.int32, device="cuda")
+    L = _lib.lib()
+    ref = None
+    alg = 24 * batches[0].shape[0] + out.numel() * 2
+    print(f"# {a.config} {a.dist} B={a.batch}: algorithmic {alg/1e6:.1f} MB per launch (24*N + canvas)")
+    for name, env in VARIANTS:
+        if a.only and a.only not in name:
+            continue
+        for k in KEYS:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        for i in range(a.warmup):
+            net.forward_dense(batches[i % 4], a.batch, out=out, counts=counts, occupancy=occ)
+        net.forward_dense(batches[0], a.batch, out=out, counts=counts, occupancy=occ)
+        torch.cuda.synchronize()
+        chk = (out.view(torch.int16).to(torch.int64).sum().item(), occ.to(torch.int64).sum().item())
+        if ref is None:
+            ref_canvas, ref_occ = out.clone(), occ.clone()
+            ref = chk
+        same = torch.equal(out, ref_canvas) and torch.equal(occ, ref_occ)
+        L.pnx_profile_begin(a.iters)
+        for i in range(a.iters):
+            net.forward_dense(batches[i % 4], a.batch, out=out, counts=counts, occupancy=occ)
+        torch.cuda.synchronize()
+        r_us, c_us, ns = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
+        L.pnx_profile_end(ctypes.byref(r_us), ctypes.byref(c_us), ctypes.byref(ns))
+        P, m = counts.tolist()
+        print(f"{name:26s} reader {r_us.value:8.1f} us  voxelize {L.pnx_profile_last_voxelize_us():7.1f}  pfn {L.pnx_profile_last_pfn_us():7.1f}  "
+              f"canvas {c_us.value:7.1f}  -> {alg / r_us.value / 1e6:5.2f} TB/s ({alg / r_us.value / 1e6 / 8 * 100:4.1f}% of 8)  P={P} N'={m}  "
+              f"{'== first variant' if same else 'MISMATCH vs first variant'}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
