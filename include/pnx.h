@@ -62,10 +62,11 @@ int pnx_geom_init(const double* pc_range6_host, const double* voxel_size3_host, 
  * floats: [W0' (32 x (F+5)) | s0 (32) | W1' (64 x 64) | s1 (64)] with a = gamma / sqrt(running_var + eps),
  * W'[c,:] = a[c] * W[c,:] and s = beta - running_mean * a   (BatchNorm1d eval folded into the Linear, :32-33,37-38;
  * SURVEY.md H8 measured this fold at 1.4e-6 abs from the reference), followed by the same numbers re-ordered as
- * MFMA fragments (64 lanes x 121 registers) so that the PFN kernel loads them with coalesced reads.
+ * MFMA fragments (64 lanes x 121 registers, then 64 x 71 for the fp16x3 form of layer 1) so that the PFN kernels load them with
+ * coalesced reads.
  * Only num_filters = [64, 64] (every PillarNeXt config) and 3 <= F <= 6 are built.
  */
-#define PNX_PFN_FOLDED_FLOATS(F) (32 * ((F) + 5) + 32 + 64 * 64 + 64 + 64 * 121)
+#define PNX_PFN_FOLDED_FLOATS(F) (32 * ((F) + 5) + 32 + 64 * 64 + 64 + 64 * 121 + 64 * 71)
 
 int pnx_pfn_fold_bn(int32_t num_point_features, /* F */
                     const float* w0, const float* gamma0, const float* beta0, const float* mean0, const float* var0,

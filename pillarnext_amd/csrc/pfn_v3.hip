@@ -11,7 +11,14 @@
 //             max reaches every point of the pillar with one ds_bpermute per register (the "max" half of the concat, pe:44,49).
 //             Measured alternatives on C2/8 frames: ds_max_u32 into per-pillar LDS rows 399 us (LDS atomics serialise), a
 //             lanes = channels running-max walk over LDS rows 374 us (a scalar-controlled 32-step loop per pass).
-//   layer 1   64 MFMAs; shift + ReLU before the max (x -> relu(x + s) is monotone); the TAIL lane of every pillar writes the
+//   layer 1   fp16x3 (default): layer 0 leaves h0 pre-scaled by 2^SU, every value is split into fp16 hi (round-toward-zero) + lo
+//             (the exact remainder, rounded toward zero): 22 significant bits; W1' * 2^SW is split the same way at fold time, and
+//             hi*hi + hi*lo + lo*hi runs as 24 v_mfma_f32_32x32x16_f16 (fp32 accumulation) instead of 64 fp32 MFMAs of twice the
+//             duration: 768 instead of 4 096 matrix-pipe cycles per tile, error ~1e-6 relative (on the order of the fp32 chain's own
+//             rounding; tools/study_f16x3.py).  K is a contraction index, so the only layout requirement is that A and B put a
+//             channel into the same K slot: slot (step s, lane half kg, element e) = the channel lane-half kg already holds as its
+//             value 8s + e -- no transpose.  A tile whose pillar maximum would overflow fp16 (h0 >= 937) hands its pillars to
+//             k_pfn3_big (fp32 MFMA).  PNX_PFN_F16X3=0 selects the plain fp32 form: 64 MFMAs; shift + ReLU before the max (x -> relu(x + s) is monotone); the TAIL lane of every pillar writes the
 //             finished row, in NATURAL channel order, into the wave's private LDS rows
 //   store     8 lanes per pillar read 16-byte pieces of the finished rows and store them: one store instruction writes 8 complete
 //             128-byte lines (bf16) of the NHWC canvas (round 1: 16 instructions of scattered 8-byte pieces per tile)
@@ -28,8 +35,24 @@ namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 #define PNX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+#define PNX_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ v8h as_v8h(const uint32_t* w) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 t = {w[0], w[1], w[2], w[3]};
+  return __builtin_bit_cast(v8h, t);
+}
+// two non-negative fp32 values -> packed fp16 hi (round toward zero) and lo = fp16(x - hi) (x - hi is exact in fp32)
+__device__ __forceinline__ void split2_f16(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  const auto hv = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  const float r0 = __fsub_rn(x0, (float)hv[0]), r1 = __fsub_rn(x1, (float)hv[1]);
+  const auto lv = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+  hi = __builtin_bit_cast(uint32_t, hv);
+  lo = __builtin_bit_cast(uint32_t, lv);
+}
 
 constexpr int kZS = 68;                 // words per LDS row (64 channels + 4: rows stay 16-byte aligned, 8 consecutive rows cover all banks)
+constexpr int kZSP = 36;                // the same for rows of 64 16-bit values (128 bytes + 16)
 constexpr int kWaveLds = 32 * kZS + 64;  // per wave: 32 pillar rows + rank[32] + cell[32], in words
 
 struct Pfn3Out {
@@ -78,6 +101,15 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// two fp32 -> two 16-bit floats of the canvas dtype, round-to-nearest-even, low half = first argument
+template <int DT>
+__device__ __forceinline__ uint32_t cvt_pk16(float a, float b) {
+  uint32_t r;
+  if (DT == PNX_BF16) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  else asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // 8 consecutive channels (chan0 = 8q) of one pillar: canvas cell and/or feat_max row
 template <int DT>
 __device__ __forceinline__ void store_chunk(const Pfn3Out& o, int rank, int64_t cell, int q, const float* v) {
@@ -106,19 +138,6 @@ __device__ __forceinline__ void store_chunk(const Pfn3Out& o, int rank, int64_t 
       }
       *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(o.canvas) + cell * 64 + 8 * q) = p;
     }
-  }
-}
-
-template <int DT>
-__device__ __forceinline__ void fill_role(const uint32_t* __restrict__ bitmap, const PnxGeomDev& g, void* canvas, uint8_t* occ, int n_fill,
-                                          bool nt, uint32_t* s_word) {
-  const int tiles = ((g.gx + 31) >> 5) * (g.gyp >> 5) * g.B;
-  for (int tile = blockIdx.x; tile < tiles; tile += n_fill) {
-    if (nt)
-      pnx_fill_tile<DT, true>(bitmap, g, canvas, occ, tile, s_word, threadIdx.x, 256);
-    else
-      pnx_fill_tile<DT, false>(bitmap, g, canvas, occ, tile, s_word, threadIdx.x, 256);
-    __syncthreads();  // s_word is rewritten by the next tile
   }
 }
 
@@ -151,16 +170,15 @@ __device__ __forceinline__ int64_t next_window(int32_t* tick, int& shard, int& t
 }
 
 // counters: [0] = P, [1] = N' (kept points = sorted records), [3] = number of big pillars appended to biglist; tick = window tickets
-template <int F, int R, int DT>
+template <int F, int R, int DT, bool PACK, bool H16>
 __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ pcnt,
                                              int32_t* __restrict__ counters, int32_t* __restrict__ tick, int32_t* __restrict__ biglist, int bigcap,
-                                             const float* __restrict__ P, Pfn3Out out, int n_fill, const uint32_t* __restrict__ bitmap,
-                                             PnxGeomDev g, uint8_t* __restrict__ occ, int fill_nt, int dbg) {
+                                             const float* __restrict__ P, Pfn3Out out, int n_fill, PnxGeomDev g, PnxFillJob fj, int dbg) {
   constexpr int C0 = F + 5, KS = (C0 + 2) / 2;     // K = C0 features + the constant-1 column that carries the folded BN shift
   constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;  // start of the fragment-ordered block (k_fold_bn)
   __shared__ __align__(16) uint32_t s_lds[4 * kWaveLds];
-  if ((int)blockIdx.x < n_fill) {  // ---- fill role (block-uniform)
-    fill_role<DT>(bitmap, g, out.canvas, occ, n_fill, fill_nt != 0, s_lds);
+  if ((int)blockIdx.x < n_fill) {  // ---- fill role (block-uniform): this launch's share of the zero-fill tiles
+    pnx_fill_share_dt<DT>(fj, g, s_lds, threadIdx.x, 256);
     return;
   }
   // ---- PFN role
@@ -172,14 +190,23 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
 
   // weight fragments: coalesced loads, once per (persistent) wave
   const float* __restrict__ FP = P + FR + l;
+  const float* __restrict__ FP2 = FP + 64 * 121;  // fp16x3 block (k_fold_bn)
   float w0f[KS];
 #pragma unroll
-  for (int kk = 0; kk < KS; kk++) w0f[kk] = FP[kk * 64];
+  for (int kk = 0; kk < KS; kk++) w0f[kk] = H16 ? FP2[kk * 64] : FP[kk * 64];
+  // fp32 form: w1a/w1b = rows 0..31 / 32..63 of W1' for the lane's K elements; fp16x3 form: the same 64 registers hold the hi
+  // (wq[0..31]) and lo (wq[32..63]) fragments, index ((mt*4 + s)*4 + tq)
   float w1a[32], w1b[32];
+  uint32_t wq[64];
+  if (H16) {
 #pragma unroll
-  for (int i = 0; i < 32; i++) {
-    w1a[i] = FP[(23 + i) * 64];
-    w1b[i] = FP[(55 + i) * 64];
+    for (int i = 0; i < 64; i++) wq[i] = __float_as_uint(FP2[(7 + i) * 64]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      w1a[i] = FP[(23 + i) * 64];
+      w1b[i] = FP[(55 + i) * 64];
+    }
   }
   const float4* __restrict__ s1lane = reinterpret_cast<const float4*>(P + FR + 64 * 89 + l * 32);  // s1 in this lane's channel order
   float s1a[16], s1b[16];
@@ -247,6 +274,8 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
       pl.s2 = __ballot(act && idx >= 2) != 0;
       pl.s4 = __ballot(act && idx >= 4) != 0;
       pl.s8 = __ballot(act && idx >= 8) != 0;
+      uint32_t sm[5];
+      scan_masks(sm, act ? idx : 0, col);
 
       // ---- layer 0 (lane = point, registers = channels)
       float ff[6] = {__uint_as_float(cur.a.x), __uint_as_float(cur.a.y), __uint_as_float(cur.a.z),
@@ -256,74 +285,177 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
       for (int i = 0; i < 16; i++) d0[i] = 0.f;
 #pragma unroll
       for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], act ? ff[kk] : 0.f, d0);
-      // ---- "max" half of the concat (pe:43-44,49): per-pillar max of relu(layer 0), delivered to every point of the pillar
-      float g0[16];
+      // ---- "max" half of the concat (pe:43-44,49): per-pillar max of relu(layer 0), delivered to every point of the pillar.
+      // ReLU first: max(relu(x)) == relu(max(x)), and 0 is then the identity of the masked scan.  The scan's 5 x 16 register-steps
+      // are dealt, five at a time, into the gaps of the 32 layer-1 MFMAs that only need the point's own h0 (each fp32 32x32x2 MFMA
+      // keeps the matrix pipe busy for 64 cycles): one in-order wave then overlaps its own VALU with its own MFMAs -- two waves of a
+      // SIMD were measured NOT to overlap each other's phases (512 vs 256 blocks: 347 vs 398 us).
+      float u[16], g0[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) g0[i] = fmaxf(d0[i], 0.f);  // ReLU first: max(relu(x)) == relu(max(x)); 0 is then the identity
-      if (pl.s1 && !(dbg & 2)) {
-        seg_max_nn16(g0, idx, col, pl);
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-          g0[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(tail_lane << 2, __builtin_bit_cast(int, g0[i])));
+      for (int i = 0; i < 16; i++) {
+        u[i] = fmaxf(d0[i], 0.f);
+        g0[i] = u[i];
       }
-      // ---- layer 1: 64 output channels as two 32-row tiles, K in accumulator-register order
+      scan_fence16(g0);
       v16f da, db;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         da[i] = 0.f;
         db[i] = 0.f;
       }
-      if (!(dbg & 4)) {
+#define PNX_G0_PAIR(Pq)                                                             \
+  {                                                                                 \
+    constexpr int st_ = (Pq) / 16, rg_ = (Pq) % 16;                                 \
+    scan_pair_f32<st_>(g0[rg_], sm);                                                \
+  }
+      bool ovf = false;
+      if (H16) {
+        // B operands of K steps 0, 1: the point's own (pre-scaled) h0
+        uint32_t bh[16], bl[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const float u = fmaxf(d0[i], 0.f);
-          da = PNX_MFMA(w1a[i], u, da);
-          db = PNX_MFMA(w1b[i], u, db);
+        for (int tq = 0; tq < 8; tq++) split2_f16(u[2 * tq], u[2 * tq + 1], bh[tq], bl[tq]);
+#define PNX_L1H(S, PROD, I0, N)                                                                                         \
+  if (!(dbg & 4)) {                                                                                                     \
+    da = PNX_MFMA16(as_v8h(&wq[((PROD) == 2 ? 32 : 0) + (0 * 4 + (S)) * 4]), as_v8h((PROD) == 1 ? &bl[4 * ((S) & 1)] : &bh[4 * ((S) & 1)]), da); \
+    db = PNX_MFMA16(as_v8h(&wq[((PROD) == 2 ? 32 : 0) + (1 * 4 + (S)) * 4]), as_v8h((PROD) == 1 ? &bl[4 * ((S) & 1)] : &bh[4 * ((S) & 1)]), db); \
+  }                                                                                                                     \
+  __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  if (!(dbg & 2) && (N) > 0) {                                                                                          \
+    _Pragma("unroll") for (int pq_ = 0; pq_ < (N); pq_++) {                                                             \
+      switch (((I0) + pq_) / 16) {                                                                                      \
+        case 0: scan_pair_f32<0>(g0[((I0) + pq_) % 16], sm); break;                                                     \
+        case 1: scan_pair_f32<1>(g0[((I0) + pq_) % 16], sm); break;                                                     \
+        case 2: scan_pair_f32<2>(g0[((I0) + pq_) % 16], sm); break;                                                     \
+        case 3: scan_pair_f32<3>(g0[((I0) + pq_) % 16], sm); break;                                                     \
+        default: scan_pair_f32<4>(g0[((I0) + pq_) % 16], sm); break;                                                    \
+      }                                                                                                                 \
+    }                                                                                                                   \
+  }                                                                                                                     \
+  __builtin_amdgcn_sched_barrier(0);
+        // 12 MFMAs (K steps 0, 1 x {hi*hi, hi*lo, lo*hi} x 2 row tiles) with the 80 register-steps of the g0 scan in between
+        PNX_L1H(0, 0, 0, 14) PNX_L1H(0, 1, 14, 14) PNX_L1H(0, 2, 28, 14) PNX_L1H(1, 0, 42, 14) PNX_L1H(1, 1, 56, 14) PNX_L1H(1, 2, 70, 10)
+        if (pl.s1) {
+#pragma unroll
+          for (int i = 0; i < 16; i++)
+            g0[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(tail_lane << 2, __builtin_bit_cast(int, g0[i])));
         }
+        // the pillar maximum bounds every value of the pillar: one range test covers both operand halves
+        float gm = fmaxf(fmaxf(fmaxf(g0[0], g0[1]), fmaxf(g0[2], g0[3])), fmaxf(fmaxf(g0[4], g0[5]), fmaxf(g0[6], g0[7])));
+        gm = fmaxf(gm, fmaxf(fmaxf(fmaxf(g0[8], g0[9]), fmaxf(g0[10], g0[11])), fmaxf(fmaxf(g0[12], g0[13]), fmaxf(g0[14], g0[15]))));
+        ovf = __ballot(act && !(gm < 60000.f)) != 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          da = PNX_MFMA(w1a[16 + i], g0[i], da);
-          db = PNX_MFMA(w1b[16 + i], g0[i], db);
+        for (int tq = 0; tq < 8; tq++) split2_f16(g0[2 * tq], g0[2 * tq + 1], bh[tq], bl[tq]);
+        PNX_L1H(2, 0, 0, 0) PNX_L1H(2, 1, 0, 0) PNX_L1H(2, 2, 0, 0) PNX_L1H(3, 0, 0, 0) PNX_L1H(3, 1, 0, 0) PNX_L1H(3, 2, 0, 0)
+#undef PNX_L1H
+      } else {
+#define PNX_L1A(I)                                                                  \
+  if (!(dbg & 4)) {                                                                 \
+    da = PNX_MFMA(w1a[I], u[I], da);                                                \
+    db = PNX_MFMA(w1b[I], u[I], db);                                                \
+  }                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  if (!(dbg & 2)) {                                                                 \
+    PNX_G0_PAIR(5 * (I) + 0) PNX_G0_PAIR(5 * (I) + 1) PNX_G0_PAIR(5 * (I) + 2) PNX_G0_PAIR(5 * (I) + 3) PNX_G0_PAIR(5 * (I) + 4) \
+  }                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);
+        PNX_L1A(0) PNX_L1A(1) PNX_L1A(2) PNX_L1A(3) PNX_L1A(4) PNX_L1A(5) PNX_L1A(6) PNX_L1A(7)
+        PNX_L1A(8) PNX_L1A(9) PNX_L1A(10) PNX_L1A(11) PNX_L1A(12) PNX_L1A(13) PNX_L1A(14) PNX_L1A(15)
+#undef PNX_L1A
+        if (pl.s1) {
+#pragma unroll
+          for (int i = 0; i < 16; i++)
+            g0[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(tail_lane << 2, __builtin_bit_cast(int, g0[i])));
+        }
+        if (!(dbg & 4)) {
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            da = PNX_MFMA(w1a[16 + i], g0[i], da);
+            db = PNX_MFMA(w1b[16 + i], g0[i], db);
+          }
         }
       }
-      // ---- per-pillar max of relu(layer 1 + shift): scan on non-negative values, the result sits in the pillar's tail lane
-      float pa[16], pb[16];
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        pa[i] = fmaxf(da[i] + s1a[i], 0.f);
-        pb[i] = fmaxf(db[i] + s1b[i], 0.f);
+#undef PNX_G0_PAIR
+      if (ovf) {
+        // outside the fp16 range: every pillar of the tile goes to k_pfn3_big (fp32 MFMA, unscaled weights)
+        if (act && idx == 0 && h == 0) {
+          const int at = atomicAdd(&counters[3], 1);
+          if (at < bigcap) biglist[at] = (int)cur.b.w;
+        }
+        ts = ts_next;
+        continue;
       }
-      if (!(dbg & 2)) {
-        seg_max_nn16(pa, idx, col, pl);
-        seg_max_nn16(pb, idx, col, pl);
-      }
-      // The record prefetch (issued a whole tile ago) is waited for HERE, before this tile's stores go out: otherwise the next
-      // tile's first use of it waits behind those stores -- vmcnt is in-order and hipcc cannot count a data-dependent number of stores.
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-      // tail lanes write the finished rows in NATURAL channel order: accumulator registers 4j..4j+3 of half h are channels
-      // 8j + 4h .. +3 (pa) / 32 + those (pb)
-      if (act && rem == 0) {
-        uint32_t* dst = s_out + pid * kZS + 4 * h;
+      // fp16x3: the accumulators carry the scale 2^(SU+SW); an exact power of two, folded into the shift's fma
+      constexpr float kDs = H16 ? 1.0f / (float)(1 << (PNX_PFN_SU + PNX_PFN_SW)) : 1.0f;
+      // ---- per-pillar max of relu(layer 1 + shift): scan on non-negative values, the result sits in the pillar's tail lane.
+      // The tail lanes then write the finished rows in NATURAL channel order: accumulator registers 4j..4j+3 of half h are channels
+      // 8j + 4h .. +3 (da) / 32 + those (db).
+      if (PACK) {
+        // 16-bit canvas and no fp32 feat_max output: round FIRST (round-to-nearest-even is monotone, so the max of the rounded values
+        // is the rounded max, bit for bit) and scan two channels per register with v_pk_max_u16
+        uint32_t q[16];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          *reinterpret_cast<uint4*>(dst + 8 * j) =
-              make_uint4(__float_as_uint(pa[4 * j]), __float_as_uint(pa[4 * j + 1]), __float_as_uint(pa[4 * j + 2]), __float_as_uint(pa[4 * j + 3]));
-          *reinterpret_cast<uint4*>(dst + 32 + 8 * j) =
-              make_uint4(__float_as_uint(pb[4 * j]), __float_as_uint(pb[4 * j + 1]), __float_as_uint(pb[4 * j + 2]), __float_as_uint(pb[4 * j + 3]));
+          const float a0 = fmaxf(__builtin_fmaf(da[4 * j], kDs, s1a[4 * j]), 0.f), a1 = fmaxf(__builtin_fmaf(da[4 * j + 1], kDs, s1a[4 * j + 1]), 0.f);
+          const float a2 = fmaxf(__builtin_fmaf(da[4 * j + 2], kDs, s1a[4 * j + 2]), 0.f), a3 = fmaxf(__builtin_fmaf(da[4 * j + 3], kDs, s1a[4 * j + 3]), 0.f);
+          const float b0 = fmaxf(__builtin_fmaf(db[4 * j], kDs, s1b[4 * j]), 0.f), b1 = fmaxf(__builtin_fmaf(db[4 * j + 1], kDs, s1b[4 * j + 1]), 0.f);
+          const float b2 = fmaxf(__builtin_fmaf(db[4 * j + 2], kDs, s1b[4 * j + 2]), 0.f), b3 = fmaxf(__builtin_fmaf(db[4 * j + 3], kDs, s1b[4 * j + 3]), 0.f);
+          q[2 * j] = cvt_pk16<DT>(a0, a1), q[2 * j + 1] = cvt_pk16<DT>(a2, a3);
+          q[8 + 2 * j] = cvt_pk16<DT>(b0, b1), q[8 + 2 * j + 1] = cvt_pk16<DT>(b2, b3);
         }
-        if (h == 0) s_rank[pid] = cur.b.w;  // where the row goes
-        else s_cell[pid] = cur.b.w;
-      }
-      wave_lds_sync();
-      // ---- stores: lane -> (pillar l>>3 + 8*it, channels 8*(l&7) .. +7)
-      {
-        const int q = l & 7;
+        if (!(dbg & 2)) seg_max_pk16(q, sm, pl);
+        // The record prefetch (issued a whole tile ago) is waited for HERE, before this tile's stores go out: otherwise the next
+        // tile's first use of it waits behind those stores -- vmcnt is in-order and hipcc cannot count a data-dependent number of stores.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        if (act && rem == 0) {
+          uint32_t* dst = s_out + pid * kZSP + 2 * h;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            *reinterpret_cast<uint2*>(dst + 4 * j) = make_uint2(q[2 * j], q[2 * j + 1]);
+            *reinterpret_cast<uint2*>(dst + 16 + 4 * j) = make_uint2(q[8 + 2 * j], q[8 + 2 * j + 1]);
+          }
+          if (h == 0) s_rank[pid] = cur.b.w;  // where the row goes
+          else s_cell[pid] = cur.b.w;
+        }
+        wave_lds_sync();
+        // ---- stores: lane -> (pillar l>>3 + 8*it, 16 bytes = channels 8*(l&7) .. +7): one instruction writes 8 complete 128-byte lines
+        const int qq = l & 7;
         for (int p = l >> 3; p < ((dbg & 1) ? 0 : npil); p += 8) {
-          const uint4* src = reinterpret_cast<const uint4*>(s_out + p * kZS + 8 * q);
+          const uint4 x = *reinterpret_cast<const uint4*>(s_out + p * kZSP + 4 * qq);
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(out.canvas) + (int64_t)(int32_t)s_cell[p] * 64 + 8 * qq) = x;
+        }
+      } else {
+        float pa[16], pb[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          pa[i] = fmaxf(__builtin_fmaf(da[i], kDs, s1a[i]), 0.f);
+          pb[i] = fmaxf(__builtin_fmaf(db[i], kDs, s1b[i]), 0.f);
+        }
+        if (!(dbg & 2)) {
+          seg_max_nn16(pa, idx, col, pl);
+          seg_max_nn16(pb, idx, col, pl);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see above
+        if (act && rem == 0) {
+          uint32_t* dst = s_out + pid * kZS + 4 * h;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            *reinterpret_cast<uint4*>(dst + 8 * j) =
+                make_uint4(__float_as_uint(pa[4 * j]), __float_as_uint(pa[4 * j + 1]), __float_as_uint(pa[4 * j + 2]), __float_as_uint(pa[4 * j + 3]));
+            *reinterpret_cast<uint4*>(dst + 32 + 8 * j) =
+                make_uint4(__float_as_uint(pb[4 * j]), __float_as_uint(pb[4 * j + 1]), __float_as_uint(pb[4 * j + 2]), __float_as_uint(pb[4 * j + 3]));
+          }
+          if (h == 0) s_rank[pid] = cur.b.w;  // where the row goes
+          else s_cell[pid] = cur.b.w;
+        }
+        wave_lds_sync();
+        // ---- stores: lane -> (pillar l>>3 + 8*it, channels 8*(l&7) .. +7)
+        const int qq = l & 7;
+        for (int p = l >> 3; p < ((dbg & 1) ? 0 : npil); p += 8) {
+          const uint4* src = reinterpret_cast<const uint4*>(s_out + p * kZS + 8 * qq);
           const uint4 x0 = src[0], x1 = src[1];
           const float v[8] = {__uint_as_float(x0.x), __uint_as_float(x0.y), __uint_as_float(x0.z), __uint_as_float(x0.w),
                               __uint_as_float(x1.x), __uint_as_float(x1.y), __uint_as_float(x1.z), __uint_as_float(x1.w)};
-          store_chunk<DT>(out, (int)s_rank[p], (int64_t)(int32_t)s_cell[p], q, v);
+          store_chunk<DT>(out, (int)s_rank[p], (int64_t)(int32_t)s_cell[p], qq, v);
         }
       }
       wave_lds_sync();  // the next tile rewrites the rows
@@ -465,8 +597,7 @@ __global__ __launch_bounds__(256) void k_pfn3_big(const uint4* __restrict__ rec,
 
 template <int F>
 int launch3(const uint4* rec, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar, int32_t* counters, int32_t* tick, int32_t* biglist,
-            int64_t bigcap, const float* folded, const Pfn3Out& out, int64_t n, int n_fill, const uint32_t* bitmap, const PnxGeomDev& g,
-            uint8_t* occ, int fill_nt, hipStream_t st) {
+            int64_t bigcap, const float* folded, const Pfn3Out& out, int64_t n, int n_fill, const PnxGeomDev& g, const PnxFillJob& fj, hipStream_t st) {
   constexpr int R = 256;
   const char* b_env = getenv("PNX_PFN_BLOCKS");
   const int max_blocks = b_env ? atoi(b_env) : 512;  // 256 CUs x 2 blocks x 4 waves = 2 waves per SIMD
@@ -478,9 +609,22 @@ int launch3(const uint4* rec, const uint32_t* pfirst, const uint32_t* pcnt, cons
   const int dbg = d_env ? atoi(d_env) : 0;
   if (nb + n_fill > 0) {
     const int grid = (int)(nb + n_fill);
-    if (out.dt == PNX_F32) k_pfn3<F, R, PNX_F32><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, counters, tick, biglist, bc, folded, out, n_fill, bitmap, g, occ, fill_nt, dbg);
-    else if (out.dt == PNX_BF16) k_pfn3<F, R, PNX_BF16><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, counters, tick, biglist, bc, folded, out, n_fill, bitmap, g, occ, fill_nt, dbg);
-    else k_pfn3<F, R, PNX_F16><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, counters, tick, biglist, bc, folded, out, n_fill, bitmap, g, occ, fill_nt, dbg);
+    const bool pack = out.g1 == nullptr && out.canvas != nullptr && out.dt != PNX_F32;
+    const char* h_env = getenv("PNX_PFN_F16X3");  // 0: plain fp32 MFMA layer 1
+    const bool h16 = !(h_env && h_env[0] == '0');
+#define PNX_GO(DT_, PACK_)                                                                                                                        \
+  {                                                                                                                                               \
+    if (h16) k_pfn3<F, R, DT_, PACK_, true><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, counters, tick, biglist, bc, folded, out, n_fill, g, fj, dbg); \
+    else k_pfn3<F, R, DT_, PACK_, false><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, counters, tick, biglist, bc, folded, out, n_fill, g, fj, dbg);    \
+  }
+    if (out.dt == PNX_F32) {
+      PNX_GO(PNX_F32, false)
+    } else if (out.dt == PNX_BF16) {
+      if (pack) PNX_GO(PNX_BF16, true) else PNX_GO(PNX_BF16, false)
+    } else {
+      if (pack) PNX_GO(PNX_F16, true) else PNX_GO(PNX_F16, false)
+    }
+#undef PNX_GO
     PNX_LAUNCH_CHECK();
   }
   if (n > 0) {
@@ -492,11 +636,10 @@ int launch3(const uint4* rec, const uint32_t* pfirst, const uint32_t* pcnt, cons
 
 }  // namespace
 
-// n_fill > 0: blocks [0, n_fill) of the launch zero-fill the pillar-free canvas cells (and write `occ`) concurrently with the PFN.
+// n_fill > 0: blocks [0, n_fill) of the launch take the zero-fill tiles of `fj` (pnx_fill.h) concurrently with the PFN.
 int pnx_launch_pfn_v3(int F, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar,
                       int32_t* counters, int32_t* tick, int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows,
-                      void* canvas, int canvas_dt, int64_t n_points, int n_fill, const uint32_t* bitmap, const PnxGeomDev& geom, uint8_t* occ,
-                      int fill_nt, hipStream_t st) {
+                      void* canvas, int canvas_dt, int64_t n_points, int n_fill, const PnxGeomDev& geom, const PnxFillJob& fj, hipStream_t st) {
   Pfn3Out out;
   out.g1 = g1;
   out.g1_rows = g1_rows;
@@ -504,10 +647,10 @@ int pnx_launch_pfn_v3(int F, const uint32_t* rec64, const uint32_t* pfirst, cons
   out.dt = canvas_dt;
   const uint4* rec = reinterpret_cast<const uint4*>(rec64);
   switch (F) {
-    case 3: return launch3<3>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bigcap, folded, out, n_points, n_fill, bitmap, geom, occ, fill_nt, st);
-    case 4: return launch3<4>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bigcap, folded, out, n_points, n_fill, bitmap, geom, occ, fill_nt, st);
-    case 5: return launch3<5>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bigcap, folded, out, n_points, n_fill, bitmap, geom, occ, fill_nt, st);
-    case 6: return launch3<6>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bigcap, folded, out, n_points, n_fill, bitmap, geom, occ, fill_nt, st);
+    case 3: return launch3<3>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bigcap, folded, out, n_points, n_fill, geom, fj, st);
+    case 4: return launch3<4>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bigcap, folded, out, n_points, n_fill, geom, fj, st);
+    case 5: return launch3<5>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bigcap, folded, out, n_points, n_fill, geom, fj, st);
+    case 6: return launch3<6>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bigcap, folded, out, n_points, n_fill, geom, fj, st);
   }
   pnx_set_error("num_point_features %d not in 3..6", F);
   return PNX_ERR_UNSUPPORTED;

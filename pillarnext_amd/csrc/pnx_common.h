@@ -61,3 +61,8 @@ struct PnxGeomDev {
 // Two-level exclusive scan granularity: one 256-thread block scans 2048 items.
 #define PNX_SCAN_ITEMS 2048
 #define PNX_SCAN_SHIFT 11
+
+// fp16x3 layer 1 of pfn_v3.hip: power-of-two pre-scales of the layer-0 output (2^SU) and of W1' (2^SW) that keep the fp16 hi/lo
+// parts in the normal range; the product scale 2^-(SU+SW) is applied (exactly) in the epilogue.
+#define PNX_PFN_SU 6
+#define PNX_PFN_SW 8

@@ -91,4 +91,60 @@ __device__ __forceinline__ void seg_max_nn16(float* v, int idx, int col, const S
   }
 }
 
+// ---- single-register forms, for streams that interleave the scan with MFMAs (pfn_v3.hip).  STEP 0..4 = row_shr:1,2,4,8, row_bcast:15;
+// m[STEP] = the step's lane mask.  No s_nop inside: the caller guarantees >= 2 issued instructions between a VALU write of `v`
+// and the pair (the 2 wait states a VALU-write -> DPP-read needs), e.g. with scan_fence16 below.
+#define PNX_PAIR_ASM(OP, CTRL, v, mm)                                                                              \
+  {                                                                                                                \
+    uint32_t t_;                                                                                                   \
+    asm volatile("v_and_b32_dpp %1, %0, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" OP " %0, %0, %1"    \
+                 : "+v"(v), "=&v"(t_)                                                                              \
+                 : "v"(mm));                                                                                       \
+  }
+template <int STEP>
+__device__ __forceinline__ void scan_pair_f32(float& v, const uint32_t* m) {
+  if (STEP == 0) PNX_PAIR_ASM("v_max_f32", "row_shr:1", v, m[0])
+  if (STEP == 1) PNX_PAIR_ASM("v_max_f32", "row_shr:2", v, m[1])
+  if (STEP == 2) PNX_PAIR_ASM("v_max_f32", "row_shr:4", v, m[2])
+  if (STEP == 3) PNX_PAIR_ASM("v_max_f32", "row_shr:8", v, m[3])
+  if (STEP == 4) PNX_PAIR_ASM("v_max_f32", "row_bcast:15", v, m[4])
+}
+// two non-negative 16-bit floats (bf16 or fp16) per register: they order like unsigned integers
+template <int STEP>
+__device__ __forceinline__ void scan_pair_pk16(uint32_t& v, const uint32_t* m) {
+  if (STEP == 0) PNX_PAIR_ASM("v_pk_max_u16", "row_shr:1", v, m[0])
+  if (STEP == 1) PNX_PAIR_ASM("v_pk_max_u16", "row_shr:2", v, m[1])
+  if (STEP == 2) PNX_PAIR_ASM("v_pk_max_u16", "row_shr:4", v, m[2])
+  if (STEP == 3) PNX_PAIR_ASM("v_pk_max_u16", "row_shr:8", v, m[3])
+  if (STEP == 4) PNX_PAIR_ASM("v_pk_max_u16", "row_bcast:15", v, m[4])
+}
+// all 16 registers are final before this point and nothing that writes them may sink below it; covers the DPP wait states
+template <typename T>
+__device__ __forceinline__ void scan_fence16(T* v) {
+  asm volatile("s_nop 1"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                 "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+}
+__device__ __forceinline__ void scan_masks(uint32_t* m, int idx, int col) {
+  m[0] = idx >= 1 ? 0xFFFFFFFFu : 0u;
+  m[1] = idx >= 2 ? 0xFFFFFFFFu : 0u;
+  m[2] = idx >= 4 ? 0xFFFFFFFFu : 0u;
+  m[3] = idx >= 8 ? 0xFFFFFFFFu : 0u;
+  m[4] = idx > (col & 15) ? 0xFFFFFFFFu : 0u;  // pillar straddling the two 16-lane rows of a half
+}
+// 16 packed registers, the steps the tile needs
+template <int STEP>
+__device__ __forceinline__ void scan_step16_pk16(uint32_t* v, const uint32_t* m) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) scan_pair_pk16<STEP>(v[i], m);
+}
+__device__ __forceinline__ void seg_max_pk16(uint32_t* v, const uint32_t* m, const ScanPlan& pl) {
+  scan_fence16(v);
+  if (pl.s1) scan_step16_pk16<0>(v, m);
+  if (pl.s2) scan_step16_pk16<1>(v, m);
+  if (pl.s4) scan_step16_pk16<2>(v, m);
+  if (pl.s8) scan_step16_pk16<3>(v, m);
+  if (pl.s1) scan_step16_pk16<4>(v, m);
+}
+
 }  // namespace

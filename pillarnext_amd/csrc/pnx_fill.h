@@ -63,3 +63,35 @@ __device__ __forceinline__ void pnx_fill_tile(const uint32_t* __restrict__ bitma
 }
 
 static inline int pnx_fill_tiles(const PnxGeomDev& g) { return ((g.gx + 31) / 32) * (g.gyp / 32) * g.B; }
+
+// A share of the zero-fill carried by extra blocks of another launch.  The fill is HBM-write bound and needs next to no ALU; the
+// reader's grouping kernels are latency bound and leave HBM idle, the PFN is MFMA bound -- so blocks [n_main, gridDim) of those
+// launches take the tiles [base, base + quota) one by one from `counter` (zeroed with the reader's other counters) while the
+// launch's own blocks do their work.  Every tile belongs to exactly one launch: each canvas byte is still written exactly once.
+struct PnxFillJob {
+  const uint32_t* bitmap;
+  void* canvas;
+  uint8_t* occ;
+  int32_t* counter;
+  int base, quota;  // tiles [base, base + quota)
+  int dt, nt;       // canvas dtype, nontemporal stores
+  int n_main;       // first fill block of the launch (quota == 0: no fill blocks)
+};
+
+template <int DT>
+__device__ __forceinline__ void pnx_fill_share_dt(const PnxFillJob& j, const PnxGeomDev& g, uint32_t* s_word /* 33 words */, int t, int nthreads) {
+  for (;;) {
+    if (t == 0) s_word[32] = (uint32_t)atomicAdd(j.counter, 1);
+    __syncthreads();
+    const int k = (int)s_word[32];
+    if (k >= j.quota) break;  // block-uniform
+    if (j.nt) pnx_fill_tile<DT, true>(j.bitmap, g, j.canvas, j.occ, j.base + k, s_word, t, nthreads);
+    else pnx_fill_tile<DT, false>(j.bitmap, g, j.canvas, j.occ, j.base + k, s_word, t, nthreads);
+    __syncthreads();  // s_word is rewritten by the next tile
+  }
+}
+__device__ __forceinline__ void pnx_fill_share(const PnxFillJob& j, const PnxGeomDev& g, uint32_t* s_word, int t, int nthreads) {
+  if (j.dt == PNX_F32) pnx_fill_share_dt<PNX_F32>(j, g, s_word, t, nthreads);
+  else if (j.dt == PNX_BF16) pnx_fill_share_dt<PNX_BF16>(j, g, s_word, t, nthreads);
+  else pnx_fill_share_dt<PNX_F16>(j, g, s_word, t, nthreads);
+}

@@ -284,7 +284,44 @@ __global__ void k_fold_bn(int C0, const float* w0, const float* g0, const float*
   //   j 55..86 W1'[32+col][k(i,h)]
   //   j 87, 88 s1[col], s1[32+col]
   //   then 64 x 32: s1[ch(i,h)] (i<16) | s1[32+ch(i-16,h)], contiguous per lane (tail-lane epilogue of k_pfn_mfma)
+  // Second fragment block (pfn_v3.hip, fp16x3 layer 1), register j of lane l at FR + 64*121 + j*64 + l:
+  //   j 0..6   layer-0 fragments as j 0..6 above, times 2^PNX_PFN_SU (layer 0 then leaves h0 pre-scaled for the fp16 split)
+  //   j 7..70  W1' * 2^PNX_PFN_SW as fp16 hi/lo pairs in the operand order of v_mfma_f32_32x32x16_f16:
+  //            j = 7 + ((part*2 + mt)*4 + s)*4 + tq, part 0 = hi (RNE), 1 = lo = fp16(x - hi); row = 32*mt + (l&31); the word packs the
+  //            K slots e = 2tq (low half), 2tq+1 of K group kg = l>>5 at K step s, slot (s, kg, e) = the input channel that lane-half kg
+  //            holds as its value 8s + e: ch(8s+e, kg) for s < 2 (h0), 32 + ch(8(s-2)+e, kg) for s >= 2 (pillar max)
   const int FR = S1 + 64;
+  for (int idx = t; idx < 64 * 71; idx += gridDim.x * blockDim.x) {
+    const int j = idx >> 6, l = idx & 63;
+    const int col = l & 31, h = l >> 5;
+    auto fold0 = [&](int c, int k) { return __fmul_rn(w0[c * C0 + k], __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v0[c], eps))), g0[c])); };
+    auto fold1 = [&](int c, int k) { return __fmul_rn(w1[c * 64 + k], __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v1[c], eps))), g1[c])); };
+    auto shift0 = [&](int c) { return __fsub_rn(b0[c], __fmul_rn(m0[c], __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v0[c], eps))), g0[c]))); };
+    uint32_t word;
+    if (j < 7) {
+      float v;
+      if (j < 6) {
+        const int k = 2 * j + h;
+        v = k < C0 ? fold0(col, k) : (k == C0 ? shift0(col) : 0.f);
+      } else {
+        v = shift0(col);
+      }
+      word = __float_as_uint(__fmul_rn(v, (float)(1 << PNX_PFN_SU)));
+    } else {
+      const int q = j - 7, tq = q & 3, st = (q >> 2) & 3, mt = (q >> 4) & 1, part = q >> 5;
+      uint32_t hw[2];
+      for (int e2 = 0; e2 < 2; e2++) {
+        const int e = 2 * tq + e2, i8 = 8 * (st & 1) + e;
+        const int k = (st < 2 ? 0 : 32) + (i8 & 3) + 8 * (i8 >> 2) + 4 * h;
+        const float x = __fmul_rn(fold1(32 * mt + col, k), (float)(1 << PNX_PFN_SW));
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)__fsub_rn(x, (float)hi);
+        hw[e2] = (uint32_t)__builtin_bit_cast(unsigned short, part ? lo : hi);
+      }
+      word = hw[0] | (hw[1] << 16);
+    }
+    out[FR + 64 * 121 + idx] = __uint_as_float(word);
+  }
   for (int idx = t; idx < 64 * 121; idx += gridDim.x * blockDim.x) {
     int j = idx >> 6, l = idx & 63;
     if (idx >= 64 * 89) {  // rows 89..120: s1 in each lane's own channel order, 32 contiguous floats per lane
@@ -601,13 +638,13 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   w.nblk_k = (int)((n + PNX_SCAN_ITEMS - 1) / PNX_SCAN_ITEMS);
   if (w.nblk_k < 1) w.nblk_k = 1;
   w.counters = c.take<int32_t>(64);
-  w.tick = c.take<int32_t>(16 * 32);
+  w.tick = c.take<int32_t>(20 * 32);  // 16 window-ticket words + 4 fill-share counters, one 128-byte line each
   w.count = c.take<uint32_t>(w.pcap + 8);
   w.bytemap = c.take<uint8_t>(cells + 64);
   w.zero_bytes = c.used();
   w.owner = c.take<int32_t>(cells + 8);
   w.rec = c.take<uint32_t>((n + 8) * 8);
-  w.bigcap = n / 33 + 8;
+  w.bigcap = w.pcap + 8;  // pillars of > 32 points and every pillar of a tile that leaves the fp16x3 range (pfn_v3.hip)
   w.biglist = c.take<int32_t>(w.bigcap);
   w.cell = c.take<int32_t>((w.pcap > 0 ? w.pcap : 1) + 8);
   w.bitmap = c.take<uint32_t>(w.nwords + 8);
@@ -626,7 +663,10 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   // binned path: bins small enough for k_bin_sort's LDS (<= 2048 pillars), at most ~1200 of them for the usual sizes; chunks sized so
   // that the (bin x workgroup) matrix stays ~0.5 M entries while >= 128 workgroups share the point passes
   w.sh = 8;
-  while (w.sh < 11 && ((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh) > 1200) w.sh++;
+  static const char* sh_env = getenv("PNX_BIN_SH");  // experiment: bins of 2^sh pillars
+  static const int k1max = getenv("PNX_BIN_K1MAX") ? atoi(getenv("PNX_BIN_K1MAX")) : 2400;
+  while (w.sh < 11 && ((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh) > k1max) w.sh++;
+  if (sh_env) w.sh = atoi(sh_env);
   w.K1 = (int)((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh);
   int64_t chunk = (n / 512 + 255) / 256 * 256;
   if (chunk < 2048) chunk = 2048;
@@ -709,7 +749,7 @@ int run_voxelize(const float* points, int64_t n, int32_t stride, const GeomDev& 
 // Steps 1-4 of the binned path (reader_bins.h): keys, bitmap scan, bin histogram matrix + scan, bin scatter, in-LDS bin sort.
 // Leaves counters = {P, N'}, the pillar-sorted decorated records w.rec64, w.pfirst / w.pcnt / w.cell per pillar, w.rank per point.
 template <int F>
-int launch_bin_sort(const GeomDev& gd, const ReaderWs& w, int32_t* coords, int64_t pillar_capacity, hipStream_t st) {
+int launch_bin_sort(const GeomDev& gd, const ReaderWs& w, int32_t* coords, int64_t pillar_capacity, const PnxFillJob& fj, int fill_blocks, hipStream_t st) {
   const size_t lds = bin_sort_lds(w.sh);
   static size_t lds_set = 0;
   if (lds > lds_set) {  // more than the 64 KiB a launch gets by default
@@ -718,14 +758,15 @@ int launch_bin_sort(const GeomDev& gd, const ReaderWs& w, int32_t* coords, int64
   }
   const char* d_env = getenv("PNX_SORT_DBG");  // timing ablations only (results are wrong): 1 no fp64 sums
   const int sdbg = d_env ? atoi(d_env) : 0;
-  k_bin_sort<F><<<w.K1, kSortBlock, lds, st>>>(w.rec, gd, w.sh, w.nwg, w.matlen, w.hpre, w.hblk, w.counters, w.rec64, w.pfirst, w.pcnt,
-                                               w.cell, coords, pillar_capacity, sdbg);
+  k_bin_sort<F><<<w.K1 + (fj.quota > 0 ? fill_blocks : 0), kSortBlock, lds, st>>>(w.rec, gd, w.sh, w.nwg, w.matlen, w.hpre, w.hblk, w.counters, w.rec64,
+                                                                                 w.pfirst, w.pcnt, w.cell, coords, pillar_capacity, sdbg, fj);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
 
+// fill[0..2]: shares of the canvas zero-fill carried by extra blocks of k_bin_count / k_bin_scatter / k_bin_sort (quota 0 = none)
 int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev& gd, const ReaderWs& w, int32_t* coords,
-                  int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, hipStream_t st) {
+                  int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, const PnxFillJob* fill, int fill_blocks, hipStream_t st) {
   PNX_CHECK_HIP(hipMemsetAsync(w.counters, 0, w.zero_bytes, st));  // counters | count | bytemap
   if (n > 0) {
     k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bytemap, nullptr);
@@ -735,18 +776,22 @@ int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev&
   k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
   PNX_LAUNCH_CHECK();
   if (n <= 0) return PNX_OK;
-  const size_t hl = (size_t)w.K1 * sizeof(uint32_t);
-  k_bin_count<<<w.nwg, kBlock, hl, st>>>(w.key, n, w.chunk, w.sh, w.K1, w.nwg, w.wcomb, w.wblk, w.rank, pillar_of_point, w.histmat);
+  const size_t hl = (size_t)(w.K1 > 64 ? w.K1 : 64) * sizeof(uint32_t);
+  PnxFillJob f0 = fill[0], f1 = fill[1], f2 = fill[2];
+  f0.n_main = w.nwg, f1.n_main = w.nwg, f2.n_main = w.K1;
+  k_bin_count<<<w.nwg + (f0.quota > 0 ? fill_blocks : 0), kBlock, hl, st>>>(w.key, n, w.chunk, w.sh, w.K1, w.nwg, w.wcomb, w.wblk, w.rank, pillar_of_point,
+                                                                           w.histmat, gd, f0);
   k_scan_local<SCAN_IDENT><<<w.nblk_m, kBlock, 0, st>>>(w.histmat, w.matlen, w.hpre, w.hblk);
   k_scan_blocks<<<1, kBlock, 0, st>>>(w.hblk, w.nblk_m, w.counters + 1);
-  k_bin_scatter<<<w.nwg, kBlock, hl, st>>>(points, stride, w.key, w.rank, n, w.chunk, w.sh, w.K1, w.nwg, w.hpre, w.hblk, w.rec);
+  k_bin_scatter<<<w.nwg + (f1.quota > 0 ? fill_blocks : 0), kBlock, hl, st>>>(points, stride, w.key, w.rank, n, w.chunk, w.sh, w.K1, w.nwg, w.hpre, w.hblk,
+                                                                             w.rec, gd, f1);
   PNX_LAUNCH_CHECK();
   int rc;
   switch (stride - 1) {
-    case 3: rc = launch_bin_sort<3>(gd, w, coords, pillar_capacity, st); break;
-    case 4: rc = launch_bin_sort<4>(gd, w, coords, pillar_capacity, st); break;
-    case 5: rc = launch_bin_sort<5>(gd, w, coords, pillar_capacity, st); break;
-    default: rc = launch_bin_sort<6>(gd, w, coords, pillar_capacity, st); break;
+    case 3: rc = launch_bin_sort<3>(gd, w, coords, pillar_capacity, f2, fill_blocks / 2, st); break;
+    case 4: rc = launch_bin_sort<4>(gd, w, coords, pillar_capacity, f2, fill_blocks / 2, st); break;
+    case 5: rc = launch_bin_sort<5>(gd, w, coords, pillar_capacity, f2, fill_blocks / 2, st); break;
+    default: rc = launch_bin_sort<6>(gd, w, coords, pillar_capacity, f2, fill_blocks / 2, st); break;
   }
   if (rc != PNX_OK) return rc;
   if (unq_inv) {
@@ -779,8 +824,7 @@ int pnx_launch_pfn_mfma(int F, const uint32_t* rec, const PnxGeomDev& geom, cons
 // implemented in pfn_v3.hip: PFN over the pillar-sorted records of the binned path, optionally fused with the canvas zero-fill
 int pnx_launch_pfn_v3(int F, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar,
                       int32_t* counters, int32_t* tick, int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows,
-                      void* canvas, int canvas_dt, int64_t n_points, int n_fill, const uint32_t* bitmap, const PnxGeomDev& geom, uint8_t* occ,
-                      int fill_nt, hipStream_t st);
+                      void* canvas, int canvas_dt, int64_t n_points, int n_fill, const PnxGeomDev& geom, const PnxFillJob& fj, hipStream_t st);
 
 extern "C" {
 
@@ -795,7 +839,7 @@ int pnx_pfn_fold_bn(int32_t F, const float* w0, const float* gamma0, const float
   PNX_REQUIRE(F >= 3 && F <= 6, PNX_ERR_UNSUPPORTED, "num_point_features %d not in 3..6", F);
   PNX_REQUIRE(w0 && gamma0 && beta0 && mean0 && var0 && w1 && gamma1 && beta1 && mean1 && var1 && folded_out, PNX_ERR_INVALID,
               "null parameter pointer");
-  k_fold_bn<<<16, 256, 0, (hipStream_t)stream>>>(F + 5, w0, gamma0, beta0, mean0, var0, w1, gamma1, beta1, mean1, var1, eps, folded_out);
+  k_fold_bn<<<32, 256, 0, (hipStream_t)stream>>>(F + 5, w0, gamma0, beta0, mean0, var0, w1, gamma1, beta1, mean1, var1, eps, folded_out);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -823,12 +867,6 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   const int impl = impl_env ? atoi(impl_env) : 1;
   const char* rimpl_env = getenv("PNX_READER_IMPL");
   const bool binned = (rimpl_env ? atoi(rimpl_env) : 2) != 1 && impl != 0 && w.K1 <= 16384;
-  prof_mark(0, st);
-  if (binned) rc = run_voxelize2(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, st);
-  else rc = run_voxelize(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, unq_inv != nullptr, st);
-  if (rc != PNX_OK) return rc;
-  prof_mark(6, st);
-
   const int F = stride - 1;
   // Direct mode (NHWC canvas, MFMA PFN): the PFN kernel stores each pillar straight into its canvas cell and fill blocks (or a fill
   // kernel) write the zeros of every other cell -- no (P,64) fp32 intermediate, every canvas byte still written exactly once.
@@ -843,6 +881,30 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   const char* fuse_env = getenv("PNX_READER_FUSE");  // 0: zero-fill as its own kernel in front of the PFN
   const char* fb_env = getenv("PNX_FILL_BLOCKS");
   const bool fuse = binned && direct && !(fuse_env && fuse_env[0] == '0');
+  // The zero-fill's 32x32-cell tiles are dealt to four launches: extra blocks of k_bin_count / k_bin_scatter / k_bin_sort (latency-bound
+  // kernels that leave HBM idle) take `split` percent each, the PFN launch the rest (pnx_fill.h).  PNX_FILL_SPLIT="a,b,c".
+  PnxFillJob fjob[4];
+  {
+    int split[3] = {5, 9, 24};
+    const char* sp_env = getenv("PNX_FILL_SPLIT");
+    if (sp_env) sscanf(sp_env, "%d,%d,%d", &split[0], &split[1], &split[2]);
+    const int tiles = pnx_fill_tiles(gd);
+    int base = 0;
+    for (int k = 0; k < 4; k++) {
+      int q = k < 3 ? (int)((int64_t)tiles * split[k] / 100) : tiles - base;
+      if (!fuse || n <= 0) q = k < 3 ? 0 : (fuse ? tiles : 0);
+      if (q > tiles - base) q = tiles - base;
+      fjob[k].bitmap = w.bitmap, fjob[k].canvas = canvas, fjob[k].occ = occupancy, fjob[k].counter = w.tick + (16 + k) * 32;
+      fjob[k].base = base, fjob[k].quota = q, fjob[k].dt = canvas_dtype, fjob[k].nt = fill_nt ? 1 : 0, fjob[k].n_main = 0;
+      base += q;
+    }
+  }
+  const int fill_blocks = fb_env ? atoi(fb_env) : 256;
+  prof_mark(0, st);
+  if (binned) rc = run_voxelize2(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, fjob, fill_blocks, st);
+  else rc = run_voxelize(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, unq_inv != nullptr, st);
+  if (rc != PNX_OK) return rc;
+  prof_mark(6, st);
 
   static hipStream_t side = nullptr;
   static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -884,12 +946,11 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
     }
   }
   if (binned) {
-    // fill blocks: enough resident 256-thread blocks to keep ~2 TB/s x 3 of stores in flight next to the PFN blocks (measured)
-    const int n_fill = fuse ? (fb_env ? atoi(fb_env) : 256) : 0;
+    const int n_fill = fuse ? fill_blocks : 0;
     prof_mark(4, st);
     if (fuse) prof_mark(1, st);
     rc = pnx_launch_pfn_v3(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.tick, w.biglist, w.bigcap, pfn_folded, g1, g1_rows,
-                           direct ? canvas : nullptr, canvas_dtype, n, n_fill, w.bitmap, gd, occupancy, fill_nt ? 1 : 0, st);
+                           direct ? canvas : nullptr, canvas_dtype, n, n_fill, gd, fjob[3], st);
     if (rc != PNX_OK) return rc;
     prof_mark(5, st);
     if (fuse) prof_mark(2, st);

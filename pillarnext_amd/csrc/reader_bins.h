@@ -26,9 +26,14 @@
 __global__ __launch_bounds__(kBlock) void k_bin_count(const int32_t* __restrict__ key, int64_t n, int chunk, int sh, int K1, int nwg,
                                                       const uint2* __restrict__ wcomb, const uint32_t* __restrict__ wblk,
                                                       int32_t* __restrict__ rank_out,
-                                                      int32_t* __restrict__ pillar_of_point, uint32_t* __restrict__ histmat) {
+                                                      int32_t* __restrict__ pillar_of_point, uint32_t* __restrict__ histmat, PnxGeomDev g,
+                                                      PnxFillJob fj) {
   extern __shared__ uint32_t s_hist[];
   const int t = threadIdx.x;
+  if (fj.quota > 0 && (int)blockIdx.x >= fj.n_main) {  // fill share (pnx_fill.h)
+    pnx_fill_share(fj, g, s_hist, t, kBlock);
+    return;
+  }
   for (int b = t; b < K1; b += kBlock) s_hist[b] = 0u;
   __syncthreads();
   const int64_t i0 = (int64_t)blockIdx.x * chunk;
@@ -55,9 +60,13 @@ __device__ __forceinline__ uint32_t mat_prefix(int64_t v, const uint32_t* __rest
 __global__ __launch_bounds__(kBlock) void k_bin_scatter(const float* __restrict__ pts, int stride, const int32_t* __restrict__ key,
                                                         const int32_t* __restrict__ rank, int64_t n, int chunk, int sh, int K1, int nwg,
                                                         const uint32_t* __restrict__ hpre, const uint32_t* __restrict__ hblk,
-                                                        uint32_t* __restrict__ binbuf) {
+                                                        uint32_t* __restrict__ binbuf, PnxGeomDev g, PnxFillJob fj) {
   extern __shared__ uint32_t s_cur[];
   const int t = threadIdx.x;
+  if (fj.quota > 0 && (int)blockIdx.x >= fj.n_main) {  // fill share (pnx_fill.h)
+    pnx_fill_share(fj, g, s_cur, t, kBlock);
+    return;
+  }
   for (int b = t; b < K1; b += kBlock) s_cur[b] = mat_prefix((int64_t)b * nwg + blockIdx.x, hpre, hblk);
   __syncthreads();
   const int64_t i0 = (int64_t)blockIdx.x * chunk;
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_sort(const uint32_t* __restr
                                                          const int32_t* __restrict__ counters, uint32_t* __restrict__ rec64,
                                                          uint32_t* __restrict__ pillar_first, uint32_t* __restrict__ pillar_cnt,
                                                          int32_t* __restrict__ cell_of_pillar, int32_t* __restrict__ coords,
-                                                         int64_t pillar_capacity, int dbg) {
+                                                         int64_t pillar_capacity, int dbg, PnxFillJob fj) {
   constexpr int C0 = F + 5;
   extern __shared__ __align__(16) unsigned char s_raw[];
   const int S = 1 << sh;
@@ -123,6 +132,10 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_sort(const uint32_t* __restr
   __shared__ uint32_t s_wave[kSortBlock / 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int b = blockIdx.x;
+  if (fj.quota > 0 && b >= fj.n_main) {  // fill share (pnx_fill.h)
+    pnx_fill_share(fj, g, reinterpret_cast<uint32_t*>(s_raw), t, kSortBlock);
+    return;
+  }
   const int64_t P = counters[0];
   const int64_t r0 = (int64_t)b << sh;
   if (r0 >= P) return;  // block-uniform

@@ -32,7 +32,7 @@ class Workspace:
 # --------------------------------------------------------------------------------------------- reader
 def fold_bn(F, w0, bn0, w1, bn1, eps, out=None):
     """bn = (gamma, beta, running_mean, running_var) fp32 CUDA tensors -> folded parameter buffer."""
-    n = 32 * (F + 5) + 32 + 64 * 64 + 64 + 64 * 121  # PNX_PFN_FOLDED_FLOATS(F)
+    n = 32 * (F + 5) + 32 + 64 * 64 + 64 + 64 * 121 + 64 * 71  # PNX_PFN_FOLDED_FLOATS(F)
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=w0.device)
     ts = [w0, *bn0, w1, *bn1]

@@ -21,15 +21,15 @@ from pillarnext_amd.reader import PillarFeatureNet  # noqa: E402
 
 VARIANTS = [
     ("round1", {"PNX_READER_IMPL": "1"}),
+    ("binned unfused fp32-L1", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "0", "PNX_PFN_F16X3": "0"}),
     ("binned unfused", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "0"}),
-    ("binned fused f128", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "1", "PNX_FILL_BLOCKS": "128"}),
-    ("binned fused f256", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "1", "PNX_FILL_BLOCKS": "256"}),
-    ("binned fused f384", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "1", "PNX_FILL_BLOCKS": "384"}),
-    ("binned fused f512", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "1", "PNX_FILL_BLOCKS": "512"}),
-    ("binned fused f256 p256", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "1", "PNX_FILL_BLOCKS": "256", "PNX_PFN_BLOCKS": "256"}),
-    ("binned fused f256 p768", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "1", "PNX_FILL_BLOCKS": "256", "PNX_PFN_BLOCKS": "768"}),
+    ("binned fused pfn-only", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,0"}),
+    ("binned fused 5,9,24", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "5,9,24"}),
+    ("binned fused 10,15,35", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "10,15,35"}),
+    ("binned fused 0,0,0 f384", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,0", "PNX_FILL_BLOCKS": "384"}),
+    ("binned fused 5,9,24 fp32-L1", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "5,9,24", "PNX_PFN_F16X3": "0"}),
 ]
-KEYS = ["PNX_READER_IMPL", "PNX_READER_FUSE", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS"]
+KEYS = ["PNX_READER_IMPL", "PNX_READER_FUSE", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS", "PNX_FILL_SPLIT", "PNX_PFN_F16X3"]
 
 
 def main():
