@@ -1,29 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- PillarNeXt-B inference frames/s on synthetic nuScenes-shaped clouds (BASELINE.json metric).
 
+    python bench.py --gpus N --steps K --warmup W
+
 A step = one batch of `--batch` frames through the whole path with inputs already resident in HBM:
-  HIP reader (voxelize + PFN + dense bf16 canvas)  ->  dense masked ResNet-18 + ASPP + CenterHead (PyTorch-ROCm,
-  bf16, channels_last, MIOpen)  ->  decode + batched rotated NMS (HIP).
-Rank 0 prints ONE JSON line (see the driver contract).  Extra objects:
-  roofline      the reader's dominant kernel (dense-canvas writer), HBM-bound; algorithmic bytes per launch =
-                (24*N + nx*ny*64*2) * frames per launch, duration from HIP events recorded on the
-                kernel's own stream inside libpnx_hip.so (pnx_profile_begin/end) during the timed steps
-  cpu_baseline  the CPU oracle ("port", one core) on a bounded sample of the same frames, hot path only
+  HIP reader (voxelize + PFN + dense bf16 canvas)  ->  dense masked ResNet-18 + ASPP + CenterHead (PyTorch-ROCm + HIP conv kernels,
+  bf16, channels_last)  ->  decode + batched rotated NMS (HIP).  FOUR different frame batches rotate through the loop.
+`--gpus N` without WORLD_SIZE in the environment re-launches itself under torch.distributed.run with N ranks (one per GPU, RCCL);
+under a launcher (RANK/LOCAL_RANK/WORLD_SIZE set) it is one rank.  Frames are sharded by rank, there is no collective on the path
+("replicas only"); time = max over ranks between barriers.  Rank 0 prints ONE JSON line.  Extra objects:
+  roofline        the READER (all of its kernels): algorithmic bytes (24*N + nx*ny*64*2) * frames per launch over the time
+                  from the reader's first to its last kernel, HIP events recorded on the reader's own stream inside libpnx_hip.so
+  roofline_fill   its dominant launch (PFN + canvas zero-fill fused, HBM-write bound) with the canvas bytes it writes
+  roofline_pfn    the same launch read as MFMA work (8 832 FLOP per kept point)
+  value_uniform   frames/s on the worst-case uniform cloud (~1.2 points per pillar)
+  sections_us     reader / backbone / neck / head / decode+NMS per step (torch.cuda events, separate short pass)
+  nms_us          stand-alone batched rotated NMS on SURVEY 8d's box sets
+  cpu_baseline    the CPU oracle ("port") on a bounded sample of the same frames, hot path only: all cores (threads over frames)
+                  as `value`, one thread and an own PyTorch-CPU statement of the op sequence beside it
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ROTATE = 4             # distinct frame batches in the timed loop
 
 
 def parse():
@@ -36,112 +44,295 @@ def parse():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--dist", default="sweep", choices=["uniform", "sweep"],
                     help="sweep = ring-structured 10-sweep cloud (BASELINE configs[1]); uniform = worst case, ~1.2 points per pillar")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded one-thread CPU-baseline sample (0 = skip all CPU legs)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch/rendezvous/timing/JSON plumbing only, no GPU work (CPU test of the --gpus path, backend gloo)")
+    ap.add_argument("--include-h2d", action="store_true", help="also time the loop with the frames uploaded from pinned host memory each step")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_uniform / sections / NMS / CPU legs (profiling runs)")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, config, dist_name, frames):
-    """CPU oracle (plain-C port of the reference algorithm, single thread) on `frames` frames: voxelize+PFN+scatter."""
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def respawn(a):
+    """`python bench.py --gpus N` on its own: become N ranks (tools/test.py:26-31 relies on torchrun for the same)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines (rank 0, N = 1)
+def cpu_baselines(cfg, config, dist_name, frames_1t):
+    """Bounded samples (~10-30 s of CPU work in total) of voxelize + PFN + scatter to the fp32 canvas on the host:
+    the plain-C oracle on one thread and on all cores (threads over frames; ctypes releases the GIL), and an own PyTorch-CPU
+    statement of the same op sequence (oracle/torch_cpu_reader.py) with 1 and all threads."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+
     from oracle import oracle as O
+    from oracle import torch_cpu_reader as T
     from pillarnext_amd import synth
 
     layers = synth.pfn_params()
-    t_total = 0.0
-    for f in range(frames):
-        pts = synth.make_batch(config, 1, dist_name, frame0=f)
+    ncore = os.cpu_count() or 1
+    pool = [synth.make_batch(config, 1, dist_name, frame0=f) for f in range(min(frames_1t, 8))]
+
+    def one(i):
+        O.reader_forward(pool[i % len(pool)], cfg["pc_range"], cfg["voxel_size"], [64, 64], layers, B=1, want_canvas=True)
+
+    O.lib()
+    t0 = time.perf_counter()
+    for i in range(frames_1t):
+        one(i)
+    t1 = time.perf_counter() - t0
+    # all cores: the canvas alone is 0.53 GB fp32 per frame in flight, so the thread count is capped at 32
+    nthr = min(ncore, 32)
+    n_all = nthr * 2
+    with ThreadPoolExecutor(nthr) as ex:
+        list(ex.map(one, range(nthr)))  # warm
         t0 = time.perf_counter()
-        O.reader_forward(pts, cfg["pc_range"], cfg["voxel_size"], [64, 64], layers, B=1, want_canvas=True)
-        t_total += time.perf_counter() - t0
-    return {"value": round(frames / t_total, 3), "unit": "frames/s (voxelize+PFN+scatter only, fp32 canvas)", "cores": 1, "kind": "port",
-            "sample": f"{frames} frames of {config}/{dist_name}, oracle/pnx_oracle.c orc_reader_forward, 1 thread, host {os.cpu_count()} cores"}
+        list(ex.map(one, range(n_all)))
+        tall = time.perf_counter() - t0
+    res = {"value": round(n_all / tall, 3), "unit": "frames/s (voxelize+PFN+scatter only, fp32 canvas)", "cores": nthr, "kind": "port",
+           "sample": f"{n_all} frames of {config}/{dist_name} over {nthr} threads (one frame per call), oracle/pnx_oracle.c orc_reader_forward; "
+                     f"host {ncore} logical cores, {cpu_model()}",
+           "value_1thread": round(frames_1t / t1, 3), "sample_1thread": f"{frames_1t} frames, 1 thread"}
+    # own PyTorch-CPU statement of the op sequence (sort-unique + scatter, like the reference's)
+    tc = {}
+    for thr, nfr in ((1, 3), (min(ncore, 32), 8)):
+        torch.set_num_threads(thr)
+        T.reader_forward(pool[0], cfg["pc_range"], cfg["voxel_size"], layers)  # warm
+        t0 = time.perf_counter()
+        for i in range(nfr):
+            T.reader_forward(pool[i % len(pool)], cfg["pc_range"], cfg["voxel_size"], layers)
+        tc[f"threads_{thr}"] = {"frames_per_s": round(nfr / (time.perf_counter() - t0), 3), "frames": nfr}
+    res["torch_cpu"] = tc
+    return res
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+# ------------------------------------------------------------------------------------------------ GPU legs
+def serving_loop(model, examples, steps, upload=None):
+    """`steps` frame batches through the fused graph; batch i+1 is enqueued before the host blocks on (and unpacks) the detections of
+    batch i, and every batch's detections are on the host, as dicts, before this returns."""
+    pending, out = None, None
+    for i in range(steps):
+        ex = examples[i % len(examples)]
+        if upload is not None:
+            ex = upload(i)
+        nxt = model.forward_async(ex)
+        if pending is not None:
+            out = model.detections(pending.result())
+        pending = nxt
+    if pending is not None:
+        out = model.detections(pending.result())
+    return out
+
+
+def nms_bench(dev):
+    """SURVEY 8d NMS inputs: n=1000 x 10 classes (thr 0.2, post 83) and n=4096 x 3 classes (thr 0.7/0.2/0.25, post 500)."""
+    import torch
+
+    from pillarnext_amd import ops, synth
+
+    res = {}
+    for name, n, nseg, thr, post in (("n1000x10_thr0.2_post83", 1000, 10, [0.2] * 10, 83), ("n4096x3_thr0.7_0.2_0.25_post500", 4096, 3, [0.7, 0.2, 0.25], 500)):
+        boxes = torch.from_numpy(__import__("numpy").concatenate([synth.clustered_boxes(n, 7 + s)[0] for s in range(nseg)])).to(dev)
+        off = (torch.arange(nseg + 1, dtype=torch.int32, device=dev) * n).contiguous()
+        th = torch.tensor(thr, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            ops.nms_batched(boxes, off, th, n, post_max=post)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            keep, cnt = ops.nms_batched(boxes, off, th, n, post_max=post)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = {"us": round(e0.elapsed_time(e1) * 1e3 / 20, 1), "kept": [int(v) for v in cnt[:nseg].tolist()]}
+    return res
+
+
+def sections(model, examples, batch):
+    """Per-section GPU time of one step (torch.cuda events between the sections; separate pass, 5 steps averaged)."""
+    import torch
+
+    acc = {}
+    for i in range(6):
+        marks = []
+        packed = []
+        model.forward_preds(examples[i % len(examples)]["points"], batch, marks=marks, packed_out=packed)
+        pend = model.decoder().launch(packed, None)
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(("decode+nms", e))
+        pend.result()
+        torch.cuda.synchronize()
+        if i == 0:
+            continue
+        for (_, a), (n1, b) in zip(marks[:-1], marks[1:]):
+            acc[n1] = acc.get(n1, 0.0) + a.elapsed_time(b) * 1e3 / 5
+    return {k: round(v, 1) for k, v in acc.items()}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn(a))
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="env://")
+        dist.init_process_group("gloo" if a.dry_run else a.backend, init_method="env://")
+
+    if a.dry_run:
+        # plumbing only: spawn, rendezvous, barrier-bracketed timing, max over ranks, one JSON line from rank 0
+        def barrier():
+            if world > 1:
+                dist.barrier()
+        for _ in range(a.warmup):
+            time.sleep(0.001)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            time.sleep(0.001)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (no GPU work)", "value": round(a.batch * world * a.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
+                              "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none", "dry_run": True,
+                              "config": {"workload": "launcher plumbing only", "global_batch": a.batch * world,
+                                         "parallelism": f"frame-sharded replicas x{world}"}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    import ctypes
+
     torch.cuda.set_device(local)
     if not os.environ.get("PNX_NO_MIOPEN_BENCH"):
         torch.backends.cudnn.benchmark = True  # MIOpen times its applicable solvers once per conv shape (during warm-up)
     dev = torch.device("cuda", local)
 
     from pillarnext_amd import _lib, synth
-    from pillarnext_amd.models import build_pillarnext_b
+    from pillarnext_amd.models import FusedPillarNeXt, build_pillarnext_b
 
     cfg = synth.CONFIGS[a.config]
     torch.manual_seed(0)
     model = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"]).to(dev).eval()
-    if os.environ.get("PNX_BENCH_UNFUSED"):
-        for m in (model.backbone, model.neck, model.head):
-            m.to(memory_format=torch.channels_last, dtype=torch.bfloat16)
-    else:
-        from pillarnext_amd.models import FusedPillarNeXt
+    model = FusedPillarNeXt(model).to(dev).eval()  # same network: eval-BN folded, HIP epilogues, merged head branches
 
-        model = FusedPillarNeXt(model).to(dev).eval()  # same network: eval-BN folded, HIP epilogues, merged head branches
-    # frames are sharded across ranks: rank r gets frames r*B .. r*B+B-1 (replicas only, no collective on the path)
-    pts = torch.from_numpy(synth.make_batch(a.config, a.batch, a.dist, frame0=rank * a.batch)).to(dev)
-    example = {"points": pts, "token": [f"r{rank}f{i}" for i in range(a.batch)], "batch_size": a.batch}
+    def make_examples(dist_name):
+        # frames are sharded across ranks: rank r owns frames [r*ROTATE*B, (r+1)*ROTATE*B) (replicas only, no collective on the path)
+        exs = []
+        for k in range(ROTATE):
+            pts = torch.from_numpy(synth.make_batch(a.config, a.batch, dist_name, frame0=(rank * ROTATE + k) * a.batch)).to(dev)
+            exs.append({"points": pts, "token": [f"r{rank}b{k}f{i}" for i in range(a.batch)], "batch_size": a.batch})
+        return exs
+
+    examples = make_examples(a.dist)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(max(a.warmup, 1)):  # at least one untimed pass: library handles, MIOpen find mode, workspace allocation
-            model(example)
+    def timed(exs, steps, upload=None):
         barrier()
-        L = _lib.lib()
-        _lib.check(L.pnx_profile_begin(max(a.steps, 1)), "pnx_profile_begin")
         t0 = time.perf_counter()
-        if hasattr(model, "forward_async") and not os.environ.get("PNX_BENCH_SYNC"):
-            # serving loop: batch i+1 is enqueued before the host blocks on (and unpacks) the detections of batch i; every
-            # batch's detections are on the host, as dicts, before the timed region ends
-            pending = None
-            for _ in range(a.steps):
-                nxt = model.forward_async(example)
-                if pending is not None:
-                    out = model.detections(pending.result())
-                pending = nxt
-            if pending is not None:
-                out = model.detections(pending.result())
-        else:
-            for _ in range(a.steps):
-                out = model(example)
+        out = serving_loop(model, exs, steps, upload)
         barrier()
         dt = time.perf_counter() - t0
-    import ctypes
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
 
-    r_us, c_us, ns = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
-    _lib.check(L.pnx_profile_end(ctypes.byref(r_us), ctypes.byref(c_us), ctypes.byref(ns)), "pnx_profile_end")
+    L = _lib.lib()
+    with torch.no_grad():
+        for i in range(max(a.warmup, ROTATE)):  # at least one untimed pass per batch: library handles, MIOpen find mode, workspaces
+            model(examples[i % ROTATE])
+        _lib.check(L.pnx_profile_begin(max(a.steps, 1)), "pnx_profile_begin")
+        dt, out = timed(examples, a.steps)
+        r_us, c_us, ns = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
+        _lib.check(L.pnx_profile_end(ctypes.byref(r_us), ctypes.byref(c_us), ctypes.byref(ns)), "pnx_profile_end")
+        pfn_us, vox_us = float(L.pnx_profile_last_pfn_us()), float(L.pnx_profile_last_voxelize_us())
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        extras = {}
+        if not a.no_extras:
+            other = "uniform" if a.dist == "sweep" else "sweep"
+            ex2 = make_examples(other)
+            for i in range(ROTATE):
+                model(ex2[i])
+            dt2, _ = timed(ex2, max(a.steps // 2, 4))
+            extras[f"value_{other}"] = round(a.batch * world * max(a.steps // 2, 4) / dt2, 2)
+            if a.include_h2d:
+                from pillarnext_amd.io import PointUploader
+
+                up = PointUploader(max(e["points"].shape[0] for e in examples), 5, dev)
+                host = [[e["points"][e["points"][:, 0] == b][:, 1:].cpu().numpy() for b in range(a.batch)] for e in examples]
+
+                def upload(i):
+                    pts, B = up.upload(host[i % ROTATE])
+                    return {"points": pts, "token": examples[i % ROTATE]["token"], "batch_size": B}
+
+                for i in range(ROTATE):
+                    model(upload(i))
+                dt3, _ = timed(examples, a.steps, upload)
+                extras["value_with_h2d"] = round(a.batch * world * a.steps / dt3, 2)
+            if rank == 0:
+                extras["sections_us"] = sections(model, examples, a.batch)
+                extras["nms_us"] = nms_bench(dev)
+            for i in range(ROTATE):  # leave the persistent workspaces in the main distribution's state
+                model(examples[i])
+
     frames = a.batch * world * a.steps
     nx, ny = model.reader._geom.gx, model.reader._geom.gy
-    pfn_us = float(L.pnx_profile_last_pfn_us())
+    n_pts = examples[0]["points"].shape[0]
     canvas_bytes = a.batch * nx * ny * 64 * 2
-    frame_alg_bytes = 24 * pts.shape[0] + canvas_bytes           # SURVEY 8d: 24*N + nx*ny*64*e per frame, x frames per launch
+    reader_bytes = 24 * n_pts + canvas_bytes                     # SURVEY 8d: (24*N + nx*ny*64*e) per frame, x frames per launch
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
-    model.reader.forward_dense(pts, a.batch, counts=counts)
+    model.reader.forward_dense(examples[0]["points"], a.batch, counts=counts)
     P, n_kept = (int(v) for v in counts.tolist())
-    # the HBM-bound kernel of the reader is the canvas zero-fill (k_canvas_fill_nhwc): it writes every cell that holds no pillar;
-    # the P occupied cells (128 B each) are written by the PFN kernel's epilogue.  Its own algorithmic bytes per launch:
-    fill_bytes = canvas_bytes - P * 128
-    achieved = fill_bytes / (c_us.value * 1e-6) / 1e9 if c_us.value > 0 else None
-    pfn_flops = 2.0 * n_kept * (10 * 32 + 64 * 64)              # 8 832 FLOP per kept point (SURVEY 8a)
+    reader_gbs = reader_bytes / (r_us.value * 1e-6) / 1e9 if r_us.value > 0 else None
+    split = (ctypes.c_int32 * 3)()
+    L.pnx_reader_fill_split(split)
+    # the PFN launch writes the P pillar cells and its share of the pillar-free tiles; the rest of the zero-fill rides on the grouping kernels
+    launch_bytes = int(P * 128 + (canvas_bytes - P * 128) * (100 - sum(split)) / 100)
+    fill_gbs = launch_bytes / (c_us.value * 1e-6) / 1e9 if c_us.value > 0 else None
+    pfn_flops = 2.0 * n_kept * (10 * 32 + 64 * 64)               # 8 832 FLOP per kept point (SURVEY 8a)
     pfn_tf = pfn_flops / (pfn_us * 1e-6) / 1e12 if pfn_us > 0 else None
-    traffic = None
+    traffic, tsrc = None, None
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tj):
         try:
             traffic = json.load(open(tj)).get(f"{a.config}_b{a.batch}_{a.dist}", {}).get("hbm_bytes_per_launch")
+            tsrc = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc_traffic.py, not measured in this run)"
         except Exception:
             traffic = None
     res = {
@@ -149,22 +340,27 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{a.config}: PillarNeXt-B nuScenes inference, {cfg['n']} pts/frame, voxel {cfg['voxel_size'][0]} m, BEV {nx}x{ny}, "
-                               f"6 tasks/10 classes, cloud={a.dist}, random-init weights", "frames_per_gpu_per_step": a.batch,
-                   "global_batch": a.batch * world, "parallelism": f"frame-sharded replicas x{world}", "reader_dtype": "fp32 MFMA PFN -> bf16 canvas",
-                   "pillars_per_launch": P, "kept_points_per_launch": n_kept},
-        "roofline": {"bound": "hbm", "kernel": "k_canvas_fill_nhwc<bf16> (writes every pillar-free cell of the dense BEV canvas; occupied cells "
-                                               "come from the PFN epilogue)", "achieved": round(achieved, 1) if achieved else None,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": fill_bytes, "kernel_us": round(c_us.value, 2), "samples": ns.value,
-                     "reader_all_kernels_us": round(r_us.value, 2), "reader_algorithmic_bytes_per_launch": frame_alg_bytes,
-                     "frac_all_reader_kernels": round(frame_alg_bytes / (r_us.value * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if r_us.value > 0 else None},
-        "roofline_pfn": {"bound": "mfma", "kernel": "k_pfn_mfma<5,64> (+ k_pfn_big): fp32 v_mfma_f32_32x32x2_f32", "achieved": round(pfn_tf, 2) if pfn_tf else None,
-                         "peak": 157.3, "unit": "TFLOP/s", "frac": round(pfn_tf / 157.3, 4) if pfn_tf else None, "kernel_us": round(pfn_us, 2),
-                         "algorithmic_flops_per_launch": pfn_flops},
+                               f"6 tasks/10 classes, cloud={a.dist}, random-init weights, {ROTATE} distinct frame batches rotating",
+                   "frames_per_gpu_per_step": a.batch, "global_batch": a.batch * world, "parallelism": f"frame-sharded replicas x{world}",
+                   "reader_dtype": "fp32 layer 0 + fp16x3 (22-bit) layer 1 on MFMA -> bf16 canvas", "pillars_per_launch": P,
+                   "kept_points_per_launch": n_kept},
+        "roofline": {"bound": "hbm", "kernel": "reader, ALL of its kernels (keys, bitmap scan, binning, bin sort, PFN + canvas zero-fill)",
+                     "achieved": round(reader_gbs, 1) if reader_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(reader_gbs / HBM_PEAK_GBS, 4) if reader_gbs else None, "traffic": traffic, "traffic_source": tsrc,
+                     "algorithmic_bytes_per_launch": reader_bytes, "kernel_us": round(r_us.value, 2), "samples": ns.value,
+                     "voxelize_us": round(vox_us, 2)},
+        "roofline_fill": {"bound": "hbm", "kernel": "k_pfn3 (PFN blocks + zero-fill blocks in one launch: the pillar cells and this launch's share of the pillar-free tiles)",
+                          "achieved": round(fill_gbs, 1) if fill_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(fill_gbs / HBM_PEAK_GBS, 4) if fill_gbs else None, "algorithmic_bytes_per_launch": launch_bytes,
+                          "kernel_us": round(c_us.value, 2), "zero_fill_percent_carried_by_grouping_kernels": [int(v) for v in split]},
+        "roofline_pfn": {"bound": "mfma", "kernel": "k_pfn3 (same launch): fp32 v_mfma_f32_32x32x2_f32 layer 0 + 3 x v_mfma_f32_32x32x16_f16 layer 1",
+                         "achieved": round(pfn_tf, 2) if pfn_tf else None, "peak": 157.3, "unit": "TFLOP/s (reference fp32 FLOPs)",
+                         "frac": round(pfn_tf / 157.3, 4) if pfn_tf else None, "kernel_us": round(pfn_us, 2), "algorithmic_flops_per_launch": pfn_flops},
     }
+    res.update(extras)
     if rank == 0:
-        if world == 1 and a.cpu_frames > 0:
-            res["cpu_baseline"] = cpu_baseline(cfg, a.config, a.dist, a.cpu_frames)
+        if world == 1 and a.cpu_frames > 0 and not a.no_extras:
+            res["cpu_baseline"] = cpu_baselines(cfg, a.config, a.dist, a.cpu_frames)
         else:
             res["cpu_baseline"] = None
         res["detections_last_step"] = int(sum(len(v["scores"]) for v in out.values()))

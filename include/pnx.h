@@ -96,6 +96,10 @@ int pnx_reader_forward(const float* points, int64_t n_points, int32_t row_stride
                        float* feat_max, int32_t* coords, int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point,
                        int32_t* counts, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
 
+/* Percent of the canvas zero-fill tiles that the fused reader hands to extra blocks of its three grouping kernels (the PFN launch
+ * takes the rest); PNX_FILL_SPLIT="a,b,c" overrides the built-in split.  For reports only. */
+void pnx_reader_fill_split(int32_t* percent3_host);
+
 /* Measurement hooks for bench.py (no effect on results): between begin and end every pnx_reader_forward records
  * HIP events on ITS stream around (a) the whole reader, (b) the canvas writer (HBM-bound) and (c) the PFN kernel (MFMA-bound).
  * pnx_profile_end synchronises those events and returns average microseconds per call. */

@@ -33,6 +33,7 @@ PROTOTYPES = {
     "pnx_reader_workspace_bytes": (_sz, [_i64, _i32, ctypes.POINTER(PnxGeom)]),
     "pnx_reader_forward": (ctypes.c_int, [_vp, _i64, _i32, _i32, ctypes.POINTER(PnxGeom), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp,
                                           _vp, _vp, _sz, _vp]),
+    "pnx_reader_fill_split": (None, [ctypes.POINTER(ctypes.c_int32)]),
     "pnx_profile_begin": (ctypes.c_int, [_i32]),
     "pnx_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]),
     "pnx_profile_last_pfn_us": (ctypes.c_float, []),

@@ -885,9 +885,8 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   // kernels that leave HBM idle) take `split` percent each, the PFN launch the rest (pnx_fill.h).  PNX_FILL_SPLIT="a,b,c".
   PnxFillJob fjob[4];
   {
-    int split[3] = {5, 9, 24};
-    const char* sp_env = getenv("PNX_FILL_SPLIT");
-    if (sp_env) sscanf(sp_env, "%d,%d,%d", &split[0], &split[1], &split[2]);
+    int split[3];
+    pnx_reader_fill_split(split);
     const int tiles = pnx_fill_tiles(gd);
     int base = 0;
     for (int k = 0; k < 4; k++) {
@@ -997,6 +996,13 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   prof_mark(3, st);
   if (g_prof.on && g_prof.n < g_prof.cap) g_prof.n++;
   return PNX_OK;
+}
+
+void pnx_reader_fill_split(int32_t* percent3) {
+  percent3[0] = 5, percent3[1] = 9, percent3[2] = 24;  // measured on C2 / 8 frames (tools/reader_ab.py)
+  const char* sp_env = getenv("PNX_FILL_SPLIT");
+  if (sp_env) sscanf(sp_env, "%d,%d,%d", &percent3[0], &percent3[1], &percent3[2]);
+  for (int k = 0; k < 3; k++) percent3[k] = percent3[k] < 0 ? 0 : (percent3[k] > 100 ? 100 : percent3[k]);
 }
 
 int pnx_profile_begin(int32_t max_samples) {

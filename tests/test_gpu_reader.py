@@ -318,3 +318,32 @@ def test_occupancy_output_is_the_pillar_set(geom, layout):
     exp[c[:, 0], c[:, 1], c[:, 2]] = 1
     assert torch.equal(occ, exp)
     assert bool((canvas.float().abs().sum(1)[exp == 0] == 0).all())
+
+
+def test_fp16x3_range_fallback_and_agreement(oracle):
+    """Layer 1 of the default PFN kernel runs as fp16 hi/lo splits (pfn_v3.hip).  (a) it agrees with the plain fp32-MFMA form and with
+    the oracle at the usual tolerance; (b) pillars whose layer-0 activations leave the fp16 range (here: intensities of 1e4) take
+    the fp32 fallback and still match the oracle."""
+    from pillarnext_amd import synth
+
+    cfg = synth.CONFIGS["C1"]
+    layers = synth.pfn_params()
+    net = make_net(cfg["pc_range"], cfg["voxel_size"], layers)
+    pts = synth.make_batch("C1", 2, "sweep", n=20_000)
+    hot = pts.copy()
+    hot[::7, 4] = 1.0e4   # every 7th point: h0 far above 937 -> its tile's pillars go to the fp32 kernel
+    for p in (pts, hot):
+        o = oracle.reader_forward(p, cfg["pc_range"], cfg["voxel_size"], [64, 64], layers, B=2)
+        tp = torch.from_numpy(p).cuda()
+        fm, coords, _ = net(tp, 2)
+        assert np.array_equal(coords.cpu().numpy(), o["coords"])
+        np.testing.assert_allclose(fm.cpu().numpy(), o["feat_max"], rtol=RTOL, atol=ATOL)
+        os.environ["PNX_PFN_F16X3"] = "0"
+        try:
+            fm32, _, _ = net(tp, 2)
+        finally:
+            del os.environ["PNX_PFN_F16X3"]
+        torch.testing.assert_close(fm, fm32, rtol=2e-5, atol=2e-5)
+        canvas = net.forward_dense(tp, 2)
+        c = coords.long()
+        assert torch.equal(canvas.permute(0, 2, 3, 1)[c[:, 0], c[:, 1], c[:, 2]], fm.to(torch.bfloat16))
