@@ -1,0 +1,39 @@
+"""Checkpoint wire format of the reference trainer (trainer/utils/checkpoint.py:8-44 load, :62-89 save): a torch.save'd dict
+{"meta", "state_dict"[, "optimizer", "scheduler"]} whose keys may carry DistributedDataParallel's "module." prefix; spconv weight
+layouts are mapped onto the dense stand-in by the modules' own _load_from_state_dict (models._SpConv2d)."""
+from collections import OrderedDict
+
+import torch
+
+
+def extract_state_dict(checkpoint):
+    if isinstance(checkpoint, OrderedDict):
+        sd = checkpoint
+    elif isinstance(checkpoint, dict) and "state_dict" in checkpoint:
+        sd = checkpoint["state_dict"]
+    elif isinstance(checkpoint, dict) and "model" in checkpoint:
+        sd = checkpoint["model"]
+    else:
+        raise RuntimeError("no state_dict in the checkpoint")
+    if len(sd) and next(iter(sd)).startswith("module."):
+        sd = OrderedDict((k[7:], v) for k, v in sd.items())
+    return sd
+
+
+def load_checkpoint(model, filename, map_location=None, strict=False):
+    checkpoint = torch.load(filename, map_location=map_location, weights_only=False)
+    target = model.module if hasattr(model, "module") else model
+    missing, unexpected = target.load_state_dict(extract_state_dict(checkpoint), strict=strict)
+    return checkpoint, missing, unexpected
+
+
+def save_checkpoint(model, filename, optimizer=None, scheduler=None, meta=None):
+    if meta is not None and not isinstance(meta, dict):
+        raise TypeError("meta must be a dict or None")
+    target = model.module if hasattr(model, "module") else model
+    ck = {"meta": meta or {}, "state_dict": OrderedDict((k, v.cpu()) for k, v in target.state_dict().items())}
+    if optimizer is not None:
+        ck["optimizer"] = optimizer.state_dict()
+    if scheduler is not None:
+        ck["scheduler"] = scheduler.state_dict()
+    torch.save(ck, filename)

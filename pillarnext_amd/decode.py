@@ -40,6 +40,8 @@ class PackedDecoder:
         self.thr = [float(v) for t in _get(nms, "nms_iou_threshold") for v in t]
         self.cfg = test_cfg
         self._dev = {}
+        self._tptr = {}
+        self._pin = {}
 
     def _descs(self, shapes):
         cfg = self.cfg
@@ -76,18 +78,29 @@ class PackedDecoder:
         skeys, order = torch.sort(keys ^ (-0x8000000000000000), stable=True)
         skeys = skeys ^ (-0x8000000000000000)
         S = B * self.nc_total
-        bounds = (torch.arange(S + 1, device=dev, dtype=torch.int64) << 32) ^ (-0x8000000000000000)
-        seg_start = torch.searchsorted(skeys ^ (-0x8000000000000000), bounds)
-        seg_len = torch.clamp(seg_start[1:] - seg_start[:-1], max=self.pre_max).to(torch.int32)
-        ck = (B, T, dt, tuple(shapes))
+        ck = (B, T, dt, tuple(shapes), dev)
         if ck not in self._dev:
             tdesc = torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev)
             koff = torch.tensor(offs, dtype=torch.int64, device=dev)
             seg_off = (torch.arange(S + 1, dtype=torch.int32, device=dev) * self.pre_max).contiguous()
             thr = torch.tensor(self.thr, dtype=torch.float32, device=dev).repeat(B)
-            self._dev[ck] = (tdesc, koff, seg_off, thr)
-        tdesc, koff, seg_off, thr = self._dev[ck]
-        tptr = torch.tensor([p.data_ptr() for p in packed], dtype=torch.int64, device=dev)
+            bounds = (torch.arange(S + 1, device=dev, dtype=torch.int64) << 32) ^ (-0x8000000000000000)
+            self._dev[ck] = (tdesc, koff, seg_off, thr, bounds)
+        tdesc, koff, seg_off, thr, bounds = self._dev[ck]
+        seg_start = torch.searchsorted(skeys ^ (-0x8000000000000000), bounds)
+        seg_len = torch.clamp(seg_start[1:] - seg_start[:-1], max=self.pre_max).to(torch.int32)
+        # pointer table of the task tensors: a torch.tensor(list, device=...) is a blocking copy from pageable memory (it would make
+        # the host wait for the whole network before it could enqueue the sort/NMS); cached per pointer tuple, else a pinned async copy
+        pk = tuple(p.data_ptr() for p in packed)
+        tptr = self._tptr.get(pk)
+        if tptr is None:
+            hp = torch.tensor(pk, dtype=torch.int64).pin_memory()
+            tptr = torch.empty((T,), dtype=torch.int64, device=dev)
+            tptr.copy_(hp, non_blocking=True)
+            if len(self._tptr) > 64:
+                self._tptr.clear()
+            self._tptr[pk] = tptr
+            self._tptr_host = hp  # keep the pinned source alive until the copy ran
         n_rows = S * self.pre_max
         boxes9 = torch.empty((n_rows, 9), dtype=torch.float32, device=dev)
         boxes7 = torch.zeros((n_rows, 7), dtype=torch.float32, device=dev)
@@ -99,8 +112,15 @@ class PackedDecoder:
         check(L.pnx_gather_kept(ptr(boxes9), ptr(scores), ptr(keep), ptr(cnt), S, self.pre_max, self.post_max, ptr(out), stream_ptr()),
               "pnx_gather_kept")
         # the one device->host hand-off of the frame batch: asynchronous into pinned memory; PendingDetections.result() waits
-        out_h = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
-        cnt_h = torch.empty((S,), dtype=cnt.dtype, pin_memory=True)
+        # three rotating pinned result buffers per shape (a serving loop has at most two batches in flight: bench.py / forward_async)
+        pk2 = (tuple(out.shape), S)
+        ring = self._pin.setdefault(pk2, {"k": 0, "bufs": []})
+        if len(ring["bufs"]) < 3:
+            ring["bufs"].append((torch.empty(out.shape, dtype=out.dtype, pin_memory=True), torch.empty((S,), dtype=cnt.dtype, pin_memory=True)))
+            out_h, cnt_h = ring["bufs"][-1]
+        else:
+            ring["k"] = (ring["k"] + 1) % 3
+            out_h, cnt_h = ring["bufs"][ring["k"]]
         out_h.copy_(out, non_blocking=True)
         cnt_h.copy_(cnt[:S], non_blocking=True)
         ev = torch.cuda.Event()

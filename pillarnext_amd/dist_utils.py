@@ -34,11 +34,13 @@ def max_over_ranks(seconds, device="cpu"):
 
 
 def wrap_ddp(model, device_ids=None, sync_batchnorm=True):
-    """tools/train.py:55-60: convert every BatchNorm to SyncBatchNorm, then DDP (bucketed grad all-reduce overlapped with backward)."""
+    """tools/train.py:55-60: convert every BatchNorm to its synchronised form, then DDP (bucketed grad all-reduce overlapped with backward)."""
     if not (dist.is_available() and dist.is_initialized()):
         return model
-    if sync_batchnorm and next(model.parameters()).is_cuda:
-        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    if sync_batchnorm:
+        from .models import convert_sync_batchnorm
+
+        model = convert_sync_batchnorm(model)  # masked BN -> global active-site statistics; plain BN -> SyncBatchNorm (CUDA)
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=device_ids, find_unused_parameters=False)
 
 

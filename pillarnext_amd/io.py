@@ -30,16 +30,28 @@ class PointUploader:
         self.stream = torch.cuda.Stream(device=self.device)
         self.host = [torch.empty((max_points, 1 + num_features), dtype=torch.float32).pin_memory() for _ in range(depth)]
         self.dev = [torch.empty((max_points, 1 + num_features), dtype=torch.float32, device=self.device) for _ in range(depth)]
-        self.done = [torch.cuda.Event() for _ in range(depth)]
+        self.done = [torch.cuda.Event() for _ in range(depth)]      # slot's H2D copy finished (host buffer reusable)
+        self.marks = [None] * (depth + 1)                           # compute-stream events of the last depth+1 calls
         self.k = 0
 
     def upload(self, clouds):
         """Returns (device tensor view (N,1+F), batch size); the copy is ordered before later work on the CURRENT stream."""
         i = self.k % len(self.host)
         self.k += 1
-        self.done[i].synchronize()                      # the slot's previous upload must have been consumed
+        self.done[i].synchronize()                      # the pinned staging buffer of this slot is free again (its copy ran)
         n = sum(len(c) for c in clouds)
         collate_points(clouds, self.host[i].numpy())
+        # The DEVICE buffer of the slot may still be read by reader kernels of the batch that used it `depth` uploads ago.  Every call
+        # records an event on the compute stream first: the event of call j covers the consumers of batches < j, so the consumers of
+        # batch j - depth are covered by the event of call j - depth + 1 -- waiting for THAT one (not for "now") keeps the copy of
+        # batch j overlapped with the compute of batch j - 1.
+        j = self.k - 1
+        mark = torch.cuda.Event()
+        mark.record(torch.cuda.current_stream(self.device))
+        self.marks[j % len(self.marks)] = mark
+        need = j - len(self.host) + 1
+        if need >= 0 and self.marks[need % len(self.marks)] is not None:
+            self.stream.wait_event(self.marks[need % len(self.marks)])
         with torch.cuda.stream(self.stream):
             self.dev[i][:n].copy_(self.host[i][:n], non_blocking=True)
             ev = torch.cuda.Event()

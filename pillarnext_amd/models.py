@@ -49,16 +49,37 @@ class _SpConv2d(nn.Conv2d):
 
 class MaskedBatchNorm(nn.BatchNorm2d):
     """BatchNorm1d over ACTIVE sites of a dense map (keys/shapes identical to the reference's BatchNorm1d).
-    eval: affine with running stats.  train: statistics over mask==1 positions only."""
+    eval: affine with running stats.  train: statistics over mask==1 positions only -- of the GLOBAL batch once
+    enable_sync() was called (the masked counterpart of SyncBatchNorm, tools/train.py:56): per channel [sum, count] and then
+    [sum of squared deviations] are all-reduced with the differentiable collective, so the backward all-reduces the matching
+    gradient sums by itself.  torch's own SyncBatchNorm cannot stand in: it takes (input) only and would average over every
+    dense cell instead of the active sites."""
+
+    sync_group = None
+    sync = False
+
+    def enable_sync(self, process_group=None):
+        self.sync, self.sync_group = True, process_group
+        return self
+
+    def _all_reduce(self, t):
+        import torch.distributed as dist
+
+        if not (self.sync and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.sync_group) > 1):
+            return t
+        from torch.distributed.nn.functional import all_reduce
+
+        return all_reduce(t, group=self.sync_group)
 
     def forward(self, x, mask=None):
         if not self.training or mask is None:
             return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, self.eps)
         m = mask.to(torch.float32)
         xf = x.float()
-        cnt = m.sum().clamp(min=1.0)
-        mean = (xf * m).sum(dim=(0, 2, 3)) / cnt
-        var = (((xf - mean.view(1, -1, 1, 1)) ** 2) * m).sum(dim=(0, 2, 3)) / cnt
+        s1 = self._all_reduce(torch.cat([(xf * m).sum(dim=(0, 2, 3)), m.sum().view(1)]))
+        cnt = s1[-1].detach().clamp(min=1.0)
+        mean = s1[:-1] / cnt
+        var = self._all_reduce((((xf - mean.view(1, -1, 1, 1)) ** 2) * m).sum(dim=(0, 2, 3))) / cnt
         with torch.no_grad():
             mom = self.momentum
             self.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
@@ -66,6 +87,20 @@ class MaskedBatchNorm(nn.BatchNorm2d):
             self.num_batches_tracked += 1
         y = (xf - mean.view(1, -1, 1, 1)) * torch.rsqrt(var + self.eps).view(1, -1, 1, 1)
         return (y * self.weight.view(1, -1, 1, 1) + self.bias.view(1, -1, 1, 1)).to(x.dtype)
+
+
+def convert_sync_batchnorm(module, process_group=None):
+    """tools/train.py:56 for this model: MaskedBatchNorm layers switch to global active-site statistics in place, every other
+    BatchNorm becomes torch.nn.SyncBatchNorm (CUDA only -- torch's SyncBatchNorm has no CPU forward)."""
+    for name, child in list(module.named_children()):
+        if isinstance(child, MaskedBatchNorm):
+            child.enable_sync(process_group)
+        elif isinstance(child, nn.modules.batchnorm._BatchNorm):
+            if next(child.parameters()).is_cuda:
+                setattr(module, name, nn.SyncBatchNorm.convert_sync_batchnorm(child, process_group))
+        else:
+            convert_sync_batchnorm(child, process_group)
+    return module
 
 
 class SparseConvBlock(nn.Module):
@@ -409,7 +444,9 @@ class SingleStageDetector(nn.Module):
         if hasattr(self.reader, "forward_dense") and hasattr(self.backbone, "forward_dense"):
             if batch_size is None:
                 batch_size = int(points[:, 0].max().item()) + 1
-            dt = self.compute_dtype if not self.training else torch.float32
+            # eval: the canvas takes the dtype of the dense part (fp32 modules as built / loaded from a reference checkpoint, bf16
+            # after .to(torch.bfloat16)); compute_dtype only matters to FusedPillarNeXt, which casts its own folded weights
+            dt = next(self.backbone.parameters()).dtype if not self.training else torch.float32
             ny, nx = (int(v) for v in self.reader.grid_size)
             occ = torch.empty((batch_size, ny, nx), dtype=torch.uint8, device=points.device)
             canvas = self.reader.forward_dense(points, batch_size, dtype=dt, occupancy=occ)
@@ -620,7 +657,7 @@ class FusedPillarNeXt(nn.Module):
             self.task_split.append((names, outs))
 
     @torch.no_grad()
-    def forward_preds(self, points, batch_size, marks=None, packed_out=None):
+    def forward_preds(self, points, batch_size, marks=None, packed_out=None, taps=None):
         def mark(name):
             if marks is not None:
                 e = torch.cuda.Event(enable_timing=True)
@@ -650,6 +687,8 @@ class FusedPillarNeXt(nn.Module):
                 y = run(mods[j], x)
                 x = run(mods[j + 1], y, x)
             mark(f"backbone.stage{si}")
+            if taps is not None:
+                taps[f"stage{si}"] = x
         x = self.mapping(x, mask)
         # BasicBlock (utils/conv.py): act(block2(block1(x)) + x) where block2 already ends in a ReLU, so the residual is added
         # AFTER that ReLU; both terms are >= 0, which makes the trailing act() the identity.
@@ -657,6 +696,8 @@ class FusedPillarNeXt(nn.Module):
         outs = [x, F.conv2d(x, self.aspp_1x1)] + [F.conv2d(x, self.aspp_w, None, 1, d, d) for d in (1, 6, 12, 18)]
         x = self.post(torch.cat(outs, dim=1))
         mark("mapping+neck")
+        if taps is not None:
+            taps["neck"] = x
         x = self.shared(x)
         preds = []
         for db, c1, c2, (names, outs_n) in zip(self.task_deblock, self.task_conv1, self.task_conv2, self.task_split):
@@ -689,6 +730,14 @@ class FusedPillarNeXt(nn.Module):
 
             hd = self.head_ref
             chans = list(self.task_chans)
+            # decode.hip reads the packed channels as reg(2) height(1) dim(3) rot(2) vel(2) [iou(1)] hm(ncls): the order of the
+            # YAML's common_heads dict decides the packing, so check it instead of decoding the wrong channels silently
+            want = ["reg", "height", "dim", "rot", "vel"] + (["iou"] if hd.with_iou else []) + ["hm"]
+            sizes = {"reg": 2, "height": 1, "dim": 3, "rot": 2, "vel": 2, "iou": 1}
+            for (names, outs), ncls in zip(self.task_split, hd.num_classes):
+                if list(names) != want or any(o != sizes.get(n, ncls) for n, o in zip(names, outs)) or ncls > 4:
+                    raise ops.PnxError(f"fused decoder needs head branches {want} with sizes 2,1,3,2,2[,1],ncls<=4; got {list(zip(names, outs))} -- "
+                                       "use SingleStageDetector (CenterHead.predict) for this head layout")
             self._decoder = PackedDecoder(hd.num_classes, hd.rectifier, self.post_processing, hd.with_iou, chans)
         return self._decoder
 

@@ -1,0 +1,65 @@
+"""CPU: B1 surface beyond import paths --
+ * an own-written YAML with the reference's key structure (configs/pillarnext_b_nusc.yaml) resolves `${...}` interpolations and
+   instantiates through `_target_` into the MI355X modules, with the parameter names of the published checkpoints;
+ * a checkpoint shaped like the reference trainer's (dict with "state_dict", DDP "module." prefix, spconv weight layouts,
+   num_batches_tracked) round-trips through pillarnext_amd.checkpoint."""
+import os
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build():
+    from pillarnext_amd import config
+
+    cfg = config.load(os.path.join(ROOT, "configs", "pillarnext_b_nusc.yaml"))
+    assert cfg["model"]["backbone"]["num_input_features"] == 64                      # ${model.reader.num_filters[1]}
+    assert cfg["model"]["head"]["tasks"][1] == ["truck", "construction_vehicle"]     # ${_tasks}
+    assert cfg["model"]["post_processing"]["pc_range"] == cfg["model"]["reader"]["pc_range"]
+    return cfg, config.instantiate(cfg["model"])
+
+
+def test_yaml_instantiates_the_detector():
+    from pillarnext_amd import models, reader
+
+    cfg, det = build()
+    assert isinstance(det, models.SingleStageDetector) and isinstance(det.reader, reader.PillarFeatureNet)
+    assert isinstance(det.backbone, models.SparseResNet) and isinstance(det.neck, models.ASPPNeck) and isinstance(det.head, models.CenterHead)
+    assert list(det.reader.grid_size) == [1344, 1344] and len(det.head.tasks) == 6
+    assert det.post_processing["nms"]["nms_post_max_size"] == 83                      # plain dict, as hydra hands it over
+    keys = set(det.state_dict())
+    for k in ("reader.pfn_layers.0.linear.weight", "reader.pfn_layers.1.norm.num_batches_tracked", "backbone.blocks.0.0.conv.weight",
+              "backbone.blocks.3.2.norm2.running_var", "backbone.mapping.1.weight", "neck.pre_conv.block1.conv.conv.weight", "neck.weight",
+              "head.shared_conv.0.weight", "head.tasks.5.hm.3.bias", "head.tasks.0.deblock.conv.conv.weight"):
+        assert k in keys, k
+    assert sum(p.numel() for p in det.parameters()) > 10_000_000                       # PillarNeXt-B is ~10.4 M parameters
+
+
+def test_reference_shaped_checkpoint_round_trip(tmp_path):
+    from pillarnext_amd import checkpoint
+
+    _, det = build()
+    sd = det.state_dict()
+    torch.manual_seed(1)
+    ck = {}
+    for k, v in sd.items():
+        w = torch.randn_like(v) if v.is_floating_point() else v + 7
+        if k.startswith("backbone.") and k.endswith("conv.weight") and w.dim() == 4 or k == "backbone.mapping.0.weight" or k.endswith("conv2.weight") and k.startswith("backbone."):
+            w = w.permute(0, 2, 3, 1).contiguous()                                     # spconv >= 2.2 layout (Cout, kH, kW, Cin)
+        ck["module." + k] = w                                                          # saved from a DDP-wrapped model
+    path = os.path.join(tmp_path, "epoch_20.pth")
+    torch.save({"meta": {"epoch": 20}, "state_dict": ck, "optimizer": {}}, path)
+    _, det2 = build()
+    loaded, missing, unexpected = checkpoint.load_checkpoint(det2, path, map_location="cpu", strict=True)
+    assert loaded["meta"]["epoch"] == 20 and not missing and not unexpected
+    sd2 = det2.state_dict()
+    assert torch.equal(sd2["reader.pfn_layers.1.norm.num_batches_tracked"], sd["reader.pfn_layers.1.norm.num_batches_tracked"] + 7)
+    assert torch.equal(sd2["backbone.blocks.1.0.conv.weight"], ck["module.backbone.blocks.1.0.conv.weight"].permute(0, 3, 1, 2))
+    assert torch.equal(sd2["head.tasks.2.hm.3.weight"], ck["module.head.tasks.2.hm.3.weight"])
+    # and back out in the reference's format
+    out = os.path.join(tmp_path, "resaved.pth")
+    checkpoint.save_checkpoint(torch.nn.DataParallel(det2) if False else det2, out, meta={"epoch": 21})
+    again = torch.load(out, weights_only=False)
+    assert set(again) == {"meta", "state_dict"} and list(again["state_dict"]) == list(sd2)
+    assert all(not v.is_cuda for v in again["state_dict"].values())

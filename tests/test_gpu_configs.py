@@ -1,0 +1,142 @@
+"""GPU: the BASELINE.json configurations round 1 left untested on hardware (VERDICT r1 "configs not exercised"):
+  C5   Waymo 3-frame, 540 k points, 0.1 m pillars, 1504 x 1504, FP16 canvas -- full size vs the CPU oracle
+  C3/C4 train-mode reader at C2 / C4 geometry, full size (batch statistics) vs a torch fp32 statement of the same op sequence
+  C3   one training step of PillarNeXt-B at C2 geometry, 4 frames on one GPU: finite loss and gradients, peak memory recorded
+  plus the plain (un-fused, fp32) eval detector without manual casts and a 2-rank RCCL DDP step when 2 GPUs exist."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _net(config, layers, train=False):
+    from pillarnext_amd import synth
+    from test_gpu_reader import make_net
+
+    cfg = synth.CONFIGS[config]
+    net = make_net(cfg["pc_range"], cfg["voxel_size"], layers)
+    return (net.train() if train else net), cfg
+
+
+def test_c5_waymo_3frame_fp16_canvas_full_size(oracle):
+    from pillarnext_amd import synth
+
+    layers = synth.pfn_params(5, (64, 64), 0)
+    net, cfg = _net("C5", layers)
+    pts = synth.make_batch("C5", 1, "sweep")
+    assert pts.shape[0] == 540_000
+    o = oracle.reader_forward(pts, cfg["pc_range"], cfg["voxel_size"], [64, 64], layers, B=1)
+    tp = torch.from_numpy(pts).cuda()
+    ny, nx = (int(v) for v in net.grid_size)
+    assert (ny, nx) == (1504, 1504)
+    occ = torch.empty((1, ny, nx), dtype=torch.uint8, device="cuda")
+    canvas = net.forward_dense(tp, 1, dtype=torch.float16, occupancy=occ)
+    assert canvas.dtype == torch.float16 and canvas.shape == (1, 64, ny, nx)
+    c = torch.from_numpy(o["coords"]).long().cuda()
+    assert int(occ.sum()) == o["P"] and bool((occ[c[:, 0], c[:, 1], c[:, 2]] == 1).all())        # indices: bit-exact
+    got = canvas.permute(0, 2, 3, 1)[c[:, 0], c[:, 1], c[:, 2]].float()
+    ref = torch.from_numpy(o["feat_max"]).cuda()
+    # fp16 store of an fp32 value that is within 1e-4 + 1e-4|ref| of the reference: <= that + half an fp16 ulp
+    assert bool(((got - ref).abs() <= 1e-4 + 1e-4 * ref.abs() + 2.0 ** -11 * ref.abs().clamp(min=2.0 ** -14)).all())
+    assert int((canvas != 0).any(dim=1).sum()) <= o["P"]
+    fm, coords, _ = net(tp, 1)
+    assert np.array_equal(coords.cpu().numpy(), o["coords"])
+    assert torch.equal(got, fm.to(torch.float16).float())                                          # exactly one RNE rounding of our fp32
+    # size-independent properties at full size: permutation invariance and idempotence, bit for bit
+    perm = torch.randperm(tp.shape[0], device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    assert torch.equal(canvas, net.forward_dense(tp[perm].contiguous(), 1, dtype=torch.float16))
+    assert torch.equal(canvas, net.forward_dense(tp, 1, dtype=torch.float16))
+
+
+def _torch_train_reference(feats, inv, P, layers_mods):
+    """fp32 torch statement of PFNLayer x2 in train mode (pe:35-50): Linear, BatchNorm1d with batch statistics, ReLU, per-pillar max."""
+    x = feats
+    for i, pfn in enumerate(layers_mods):
+        y = torch.nn.functional.linear(x, pfn.linear.weight)
+        mu, var = y.mean(0), y.var(0, unbiased=False)
+        y = torch.relu((y - mu) / torch.sqrt(var + pfn.norm.eps) * pfn.norm.weight + pfn.norm.bias)
+        m = torch.zeros((P, y.shape[1]), device=y.device).scatter_reduce(0, inv[:, None].expand_as(y), y, "amax", include_self=True)
+        x = m if i == len(layers_mods) - 1 else torch.cat([y, m[inv]], dim=1)
+    return x
+
+
+@pytest.mark.parametrize("config,batch", [("C2", 4), ("C4", 4)])
+def test_train_mode_reader_full_size(config, batch):
+    """C3 / C4 training geometry, 4 frames per GPU, train mode: forward == torch fp32 statement on the HIP voxelizer's own
+    (oracle-verified) features; parameter gradients flow and are finite; the dense canvas carries the same rows."""
+    from pillarnext_amd import synth
+
+    layers = synth.pfn_params(5, (64, 64), 0)
+    net, cfg = _net(config, layers, train=True)
+    tp = torch.from_numpy(synth.make_batch(config, batch, "sweep")).cuda()
+    feats, coords, inv, _ = net.voxelization(tp, batch)
+    P = coords.shape[0]
+    with torch.no_grad():
+        ref = _torch_train_reference(feats, inv, P, net.pfn_layers)
+    rm0 = net.pfn_layers[1].norm.running_mean.clone()
+    fm, coords2, _ = net(tp, batch)
+    assert torch.equal(coords, coords2)
+    torch.testing.assert_close(fm.detach(), ref, rtol=1e-4, atol=1e-4)
+    assert not torch.equal(net.pfn_layers[1].norm.running_mean, rm0)                               # running statistics moved
+    fm.square().mean().backward()
+    for pfn in net.pfn_layers:
+        for p in (pfn.linear.weight, pfn.norm.weight, pfn.norm.bias):
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().sum()) > 0
+    canvas = net.forward_dense(tp, batch, dtype=torch.float32)
+    c = coords.long()
+    torch.testing.assert_close(canvas.permute(0, 2, 3, 1)[c[:, 0], c[:, 1], c[:, 2]].detach(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_plain_eval_detector_needs_no_manual_casts():
+    """build_pillarnext_b(...).cuda().eval()(example) with fp32 modules -- as instantiated from the YAML or loaded from a reference
+    checkpoint -- must run as is (the canvas used to be bf16 against fp32 weights)."""
+    from pillarnext_amd import synth
+    from pillarnext_amd.models import build_pillarnext_b
+
+    cfg = synth.CONFIGS["C1"]
+    torch.manual_seed(0)
+    det = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"], tasks=[["car"], ["pedestrian", "cyclist"]]).cuda().eval()
+    pts = torch.from_numpy(synth.make_batch("C1", 2, "sweep", n=20_000)).cuda()
+    out = det({"points": pts, "token": ["a", "b"], "batch_size": 2})
+    assert set(out) == {"a", "b"} and out["a"]["box3d_lidar"].shape[1] == 9 and out["a"]["scores"].dtype == torch.float32
+    det.backbone.to(torch.bfloat16), det.neck.to(torch.bfloat16), det.head.to(torch.bfloat16)      # and follows a later cast
+    out2 = det({"points": pts, "token": ["a", "b"], "batch_size": 2})
+    assert set(out2) == {"a", "b"}
+
+
+def test_training_step_c2_geometry_4_frames():
+    """tools/train_step.py (C3: PillarNeXt-B training at C2 geometry, 4 frames per GPU) on ONE GPU: two optimizer steps, finite loss,
+    finite non-zero gradients; the peak memory goes to gpurun_out/ for the report."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.setdefault("MIOPEN_FIND_MODE", "2")  # FAST: the exhaustive search over fp32 backward convolutions at 1440^2 took 260 s of a 265 s test
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_step.py"), "--batch", "4", "--steps", "2", "--config", "C2", "--check"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("step ")]
+    assert len(lines) == 2 and "peak" in p.stdout
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "train_step_c2_b4.log"), "w") as f:
+        f.write(p.stdout)
+
+
+def test_two_rank_rccl_ddp_matches_single_process():
+    """2 ranks over RCCL (backend "nccl"): SyncBN conversion + DDP through the real reader; averaged gradients == one process on
+    the 2 x 2-frame batch.  Skipped on the 1-GPU box; the driver's 8-GPU node runs it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tools", "ddp_parity.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "DDP PARITY OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]

@@ -68,22 +68,40 @@ def test_fused_inference_graph_matches_module_graph():
                 m.weight.uniform_(0.6, 1.4)
                 m.bias.uniform_(-0.2, 0.2)
     fused = FusedPillarNeXt(model).cuda().eval()
-    for mm in (model.backbone, model.neck, model.head):
-        mm.to(memory_format=torch.channels_last, dtype=torch.bfloat16)
     pts = torch.from_numpy(synth.make_batch("C1", 2, "sweep", n=30_000)).cuda()
+    # reference side: the module-by-module graph in FP32 (no oracle exists for the spconv backbone, SURVEY 8c: the masked-dense
+    # modules in full precision are the statement the fused bf16 graph is held against), stage by stage
+    taps, ref_taps = {}, {}
     with torch.no_grad():
-        ref = model._forward({"points": pts, "batch_size": 2})
-        got = fused.forward_preds(pts, 2)
+        ny, nx = (int(v) for v in model.reader.grid_size)
+        occ = torch.empty((2, ny, nx), dtype=torch.uint8, device="cuda")
+        canvas = model.reader.forward_dense(pts, 2, dtype=torch.float32, occupancy=occ)
+        x, mask = canvas, occ.unsqueeze(1).float()
+        for si, blk in enumerate(model.backbone.blocks):
+            x, mask = blk(x, mask)
+            ref_taps[f"stage{si}"] = x
+        x = torch.relu(model.backbone.mapping[1](model.backbone.mapping[0](x), mask)) * mask
+        ref_taps["neck"] = model.neck(x)
+        ref = model.head(ref_taps["neck"])
+        got = fused.forward_preds(pts, 2, taps=taps)
+    # bf16 storage between ~30 layers: the relative error grows with depth; bounds = 2x what one MI355X run measured (printed on failure)
+    bound = {"stage0": 0.02, "stage1": 0.03, "stage2": 0.04, "stage3": 0.05, "neck": 0.06}
+    for k, tol in bound.items():
+        a, b = ref_taps[k].float(), taps[k].float()
+        rel = ((a - b).norm() / (a.norm() + 1e-6)).item()
+        assert rel <= tol, (k, rel)
+        assert bool(((a == 0) == (b == 0))[..., ::1].float().mean() > 0.97), k  # the same active-site pattern (exact zeros elsewhere)
     assert len(ref) == len(got) == 2
     for r, g in zip(ref, got):
         assert set(r) == set(g)
         for k in r:
             a, b = r[k].float(), g[k].float()
             assert a.shape == b.shape
+            rel = ((a - b).norm() / (a.norm() + 1e-6)).item()
             err = (a - b).abs().max().item()
             scale = a.abs().max().item() + 1e-3
-            assert err <= 0.08 * scale + 0.05, (k, err, scale)  # two bf16 graphs with different rounding points
-            assert torch.corrcoef(torch.stack([a.flatten(), b.flatten()]))[0, 1] > 0.995, k
+            assert rel <= 0.08 and err <= 0.06 * scale + 0.03, (k, rel, err, scale)
+            assert torch.corrcoef(torch.stack([a.flatten(), b.flatten()]))[0, 1] > 0.997, k
     d = fused({"points": pts, "token": ["a", "b"], "batch_size": 2})
     assert set(d) == {"a", "b"} and d["a"]["box3d_lidar"].shape[1] == 9
 

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--config", default="C2")
+    ap.add_argument("--check", action="store_true", help="assert finite loss / gradients and print the peak device memory")
     a = ap.parse_args()
     rank, world, local = dist_utils.init()
     torch.cuda.set_device(local)
@@ -57,12 +58,17 @@ def main():
         loss, _ = model(ex)
         opt.zero_grad()
         loss.backward()                                   # DDP: bucketed all-reduce over RCCL overlapped with backward
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 35)
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 35)
+        if a.check:
+            assert bool(torch.isfinite(loss)) and bool(torch.isfinite(gn)) and float(gn) > 0, (float(loss), float(gn))
         opt.step()
         torch.cuda.synchronize()
         dt = dist_utils.max_over_ranks(time.perf_counter() - t0, dev)
         if rank == 0:
             print(f"step {it}: loss {loss.item():.4f}  {dt*1e3:.1f} ms  ({a.batch * world / dt:.1f} frames/s over {world} GPU)")
+    if rank == 0 and a.check:
+        print(f"peak device memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB allocated, {torch.cuda.max_memory_reserved() / 2**30:.2f} GiB reserved "
+              f"({a.config}, {a.batch} frames per GPU, fp32 training)")
 
 
 if __name__ == "__main__":
