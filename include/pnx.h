@@ -108,6 +108,30 @@ int pnx_profile_end(float* reader_us_avg_host, float* canvas_us_avg_host, int32_
 float pnx_profile_last_pfn_us(void); /* average PFN-kernel microseconds of the interval closed by the last pnx_profile_end */
 float pnx_profile_last_voxelize_us(void); /* same interval: reader start -> pillar-sorted records ready (keys, scans, binning, bin sort) */
 
+/* ------------------------------------------------------------------------------------------------
+ * Reader, TRAINING mode (BatchNorm1d with batch statistics, pillar_encoder.py:33,38) and its backward, fused: no (N',32/64)
+ * activation or gradient tensor is ever materialised, every pass recomputes the per-point chain from the pillar-sorted records that
+ * pass 0 leaves in `workspace` (csrc/pfn_train.hip).  The passes return small per-block / per-wave partial sums; between two
+ * passes the caller reduces them (fp64) and -- under SyncBatchNorm, tools/train.py:56 -- all-reduces the statistics (the 65- and
+ * 129-float vectors torch's SyncBatchNorm exchanges forward, 2x64 and 2x32 backward) before it builds the next parameter block.
+ * The host side of this protocol, including the BatchNorm algebra for dW0/dW1, is pillarnext_amd/pfn_train.py.
+ *   params    pnx_pfn_train_param_floats(F) floats: W1 (64x64) | mu1 invstd1 gamma1 beta1 m1 m2 (6 x 64) | mu0 invstd0 gamma0 beta0
+ *             (4 x 32) | W0 (32 x (F+5));  m1 = sum(dz1)/N, m2 = sum(dz1*xhat1)/N (backward pass 1 only)
+ *   partials  pnx_pfn_train_partial_floats(F, which) floats, which = 0,1 (forward pass 0,1), 3,4 (backward pass 0,1)
+ * pnx_pfn_forward_train: pass 0 groups the points (coords, pillar_of_point, counts = {P, N'} as in pnx_reader_forward) and returns the
+ *   Gram sums of the decorated features; pass 1 (params with mu0/invstd0) the Gram sums of u = [h0, max h0]; pass 2 (mu1/invstd1 too)
+ *   writes feat_max (P,64) fp32.
+ * pnx_pfn_backward: pass 0: grad_feat_max routed through the pillar maxima and the ReLU -> sum dz1, sum dz1*xhat1, sum dz1^T u;
+ *   pass 1 (params with m1, m2): -> sum dz0, sum dz0*xhat0, sum dz0^T f.  No gradient flows to the points (:91-123 is index math). */
+size_t pnx_pfn_train_param_floats(int32_t num_point_features);
+size_t pnx_pfn_train_partial_floats(int32_t num_point_features, int32_t which);
+int pnx_pfn_forward_train(int32_t pass, const float* points, int64_t n_points, int32_t row_stride, int32_t batch, const pnx_geom* geom_host,
+                          const float* params, float* partials, float* feat_max, int64_t pillar_capacity, int32_t* coords,
+                          int32_t* pillar_of_point, int32_t* counts, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
+int pnx_pfn_backward(int32_t pass, int64_t n_points, int32_t row_stride, int32_t batch, const pnx_geom* geom_host, const float* params,
+                     const float* grad_feat_max, const float* feat_max, float* partials, void* workspace, size_t workspace_bytes,
+                     pnx_stream_t stream);
+
 /* Voxelizer alone (PillarNet.forward :78-125): indices plus the decorated (N', F+5) features
  * (rows in kept-point order; may be NULL).  Used by the training path, where Linear/BN stay in
  * PyTorch so that SyncBatchNorm semantics are the reference's. */

@@ -196,6 +196,32 @@ def gen_reader():
     reader_case("reader_single_point", pr, vs, [one])
 
 
+def gen_reader_train():
+    """Round 2: two more TRAIN-mode fixtures for the fused training PFN (forward with batch statistics, running statistics,
+    gradients of both Linear weights and both BatchNorm affines for a fixed upstream gradient)."""
+    rng = np.random.default_rng(43)
+    pr, vs = synth.CONFIGS["C1"]["pc_range"], synth.CONFIGS["C1"]["voxel_size"]
+    # (6) C1 geometry (0.2 m pillars), one sample, a pillar with 90 points (> 64: beyond one wave's lanes) and a few of 33..40
+    a = synth.sweep_cloud(2500, pr, 1010, 0)
+    fat = np.zeros((90, 6), np.float32)
+    fat[:, 1] = 12.0 + rng.uniform(0, 0.19, 90)
+    fat[:, 2] = 4.0 + rng.uniform(0, 0.19, 90)
+    fat[:, 3] = rng.uniform(-3, 1, 90)
+    fat[:, 4:6] = rng.uniform(0, 1, (90, 2))
+    mid = np.zeros((110, 6), np.float32)
+    mid[:, 1] = -20.0 + 0.2 * rng.integers(0, 3, 110) + rng.uniform(0, 0.19, 110)
+    mid[:, 2] = 8.0 + rng.uniform(0, 0.19, 110)
+    mid[:, 3] = rng.uniform(-3, 1, 110)
+    mid[:, 4:6] = rng.uniform(0, 1, (110, 2))
+    pts = np.concatenate([a, fat, mid])
+    reader_case("reader_c1_train_fat", pr, vs, [pts[rng.permutation(len(pts))]], train=True, seed=1)
+    # (7) B = 3 with an EMPTY middle sample (b = 1 absent), train mode
+    e = synth.sweep_cloud(1800, pr, 1011, 0)
+    f = synth.uniform_cloud(1200, pr, 1012, 2)
+    pts = np.concatenate([e, f, edge_rows(pr, vs, 2)])
+    reader_case("reader_c1_b3_gap_train", pr, vs, [pts[rng.permutation(len(pts))]], train=True, seed=2)
+
+
 # --------------------------------------------------------------------------- IoU / NMS fixtures
 def special_boxes():
     b = [
@@ -386,9 +412,11 @@ def main():
     install_numba_identity()
     install_iou3d_nms()
     sys.path.insert(0, REF)
-    what = sys.argv[1:] or ["reader", "iou", "decode", "loss"]
+    what = sys.argv[1:] or ["reader", "train", "iou", "decode", "loss"]
     if "reader" in what:
         gen_reader()
+    if "train" in what:
+        gen_reader_train()
     if "iou" in what:
         gen_iou_nms()
     if "decode" in what:

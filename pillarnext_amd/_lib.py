@@ -38,6 +38,10 @@ PROTOTYPES = {
     "pnx_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]),
     "pnx_profile_last_pfn_us": (ctypes.c_float, []),
     "pnx_profile_last_voxelize_us": (ctypes.c_float, []),
+    "pnx_pfn_train_param_floats": (_sz, [_i32]),
+    "pnx_pfn_train_partial_floats": (_sz, [_i32, _i32]),
+    "pnx_pfn_forward_train": (ctypes.c_int, [_i32, _vp, _i64, _i32, _i32, ctypes.POINTER(PnxGeom), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pnx_pfn_backward": (ctypes.c_int, [_i32, _i64, _i32, _i32, ctypes.POINTER(PnxGeom), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pnx_voxelize": (ctypes.c_int, [_vp, _i64, _i32, _i32, ctypes.POINTER(PnxGeom), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pnx_scatter_max_workspace_bytes": (_sz, [_i64, _i64]),
     "pnx_scatter_max": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),

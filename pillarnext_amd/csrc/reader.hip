@@ -826,6 +826,11 @@ int pnx_launch_pfn_v3(int F, const uint32_t* rec64, const uint32_t* pfirst, cons
                       int32_t* counters, int32_t* tick, int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows,
                       void* canvas, int canvas_dt, int64_t n_points, int n_fill, const PnxGeomDev& geom, const PnxFillJob& fj, hipStream_t st);
 
+// implemented in pfn_train.hip
+int pnx_launch_pfn_train(int F, int pass, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* counters,
+                         const float* prm, float* part, const float* G, const float* out_saved, float* out, int64_t out_rows, hipStream_t st);
+int pnx_pfn_train_blocks(void);
+
 extern "C" {
 
 size_t pnx_reader_workspace_bytes(int64_t n_points, int32_t batch, const pnx_geom* g) {
@@ -996,6 +1001,53 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   prof_mark(3, st);
   if (g_prof.on && g_prof.n < g_prof.cap) g_prof.n++;
   return PNX_OK;
+}
+
+// ---- training-mode PFN (pfn_train.hip).  Parameter block: W1 (4096) | mu1 is1 gamma1 beta1 m1 m2 (6 x 64) | mu0 is0 gamma0 beta0
+// (4 x 32) | W0 (32 x (F+5)).
+size_t pnx_pfn_train_param_floats(int32_t F) { return 4096 + 6 * 64 + 4 * 32 + 32 * (size_t)(F + 5); }
+size_t pnx_pfn_train_partial_floats(int32_t F, int32_t which) {
+  const size_t C0 = (size_t)F + 5, nb = (size_t)pnx_pfn_train_blocks();
+  switch (which) {
+    case 0: return nb * (C0 + C0 * C0);         // forward pass 0: per block  [F1 | F2]
+    case 1: return nb * 4 * 64 * 65;            // forward pass 1: per wave   [64][U2 row | U1]
+    case 3: return nb * 4 * 64 * 66;            // backward pass 0: per wave  [64][A row | D1 | D2]
+    case 4: return nb * 4 * 32 * (C0 + 2);      // backward pass 1: per wave  [32][B0 row | E1 | E2]
+  }
+  return 0;
+}
+
+int pnx_pfn_forward_train(int32_t pass, const float* points, int64_t n, int32_t stride, int32_t batch, const pnx_geom* g, const float* params,
+                          float* partials, float* feat_max, int64_t pillar_capacity, int32_t* coords, int32_t* pillar_of_point, int32_t* counts,
+                          void* workspace, size_t workspace_bytes, pnx_stream_t stream) {
+  int rc = check_common(points, n, stride, batch, g, workspace, workspace_bytes);
+  if (rc != PNX_OK) return rc;
+  PNX_REQUIRE(pass >= 0 && pass <= 2, PNX_ERR_INVALID, "pass %d not in 0..2", pass);
+  PNX_REQUIRE(pass == 2 || partials != nullptr, PNX_ERR_INVALID, "partials is NULL");
+  PNX_REQUIRE(pass == 0 || params != nullptr, PNX_ERR_INVALID, "params is NULL");
+  PNX_REQUIRE(pass != 2 || (feat_max != nullptr && pillar_capacity > 0), PNX_ERR_INVALID, "pass 2 needs feat_max");
+  hipStream_t st = (hipStream_t)stream;
+  const ReaderWs w = carve(workspace, n, batch, g);
+  PNX_REQUIRE(w.K1 <= 16384, PNX_ERR_UNSUPPORTED, "too many points for the binned grouping");
+  const GeomDev gd = make_geom(g, batch);
+  if (pass == 0) {
+    PnxFillJob nofill[3] = {};
+    rc = run_voxelize2(points, n, stride, gd, w, coords, pillar_capacity, nullptr, pillar_of_point, nofill, 0, st);
+    if (rc != PNX_OK) return rc;
+    if (counts) PNX_CHECK_HIP(hipMemcpyAsync(counts, w.counters, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  }
+  return pnx_launch_pfn_train(stride - 1, pass, w.rec64, w.pfirst, w.pcnt, w.counters, params, partials, nullptr, nullptr, feat_max, pillar_capacity, st);
+}
+
+int pnx_pfn_backward(int32_t pass, int64_t n, int32_t stride, int32_t batch, const pnx_geom* g, const float* params, const float* grad_feat_max,
+                     const float* feat_max, float* partials, void* workspace, size_t workspace_bytes, pnx_stream_t stream) {
+  PNX_REQUIRE(g != nullptr && workspace != nullptr && params && grad_feat_max && feat_max && partials, PNX_ERR_INVALID, "null pointer");
+  PNX_REQUIRE(pass == 0 || pass == 1, PNX_ERR_INVALID, "pass %d not in 0..1", pass);
+  PNX_REQUIRE(stride >= 4 && stride <= 7, PNX_ERR_UNSUPPORTED, "row_stride %d", stride);
+  PNX_REQUIRE(workspace_bytes >= pnx_reader_workspace_bytes(n, batch, g), PNX_ERR_WORKSPACE, "workspace too small");
+  const ReaderWs w = carve(workspace, n, batch, g);  // the records written by pnx_pfn_forward_train(pass 0) on the same workspace
+  return pnx_launch_pfn_train(stride - 1, pass == 0 ? 3 : 4, w.rec64, w.pfirst, w.pcnt, w.counters, params, partials, grad_feat_max, feat_max, nullptr, 0,
+                              (hipStream_t)stream);
 }
 
 void pnx_reader_fill_split(int32_t* percent3) {

@@ -92,8 +92,12 @@ class MaskedBatchNorm(nn.BatchNorm2d):
 def convert_sync_batchnorm(module, process_group=None):
     """tools/train.py:56 for this model: MaskedBatchNorm layers switch to global active-site statistics in place, every other
     BatchNorm becomes torch.nn.SyncBatchNorm (CUDA only -- torch's SyncBatchNorm has no CPU forward)."""
+    from .reader import PillarFeatureNet
+
     for name, child in list(module.named_children()):
-        if isinstance(child, MaskedBatchNorm):
+        if isinstance(child, PillarFeatureNet) and child._fused_supported():
+            child.enable_sync(process_group)  # its fused training passes exchange the statistics themselves (pfn_train.py)
+        elif isinstance(child, MaskedBatchNorm):
             child.enable_sync(process_group)
         elif isinstance(child, nn.modules.batchnorm._BatchNorm):
             if next(child.parameters()).is_cuda:

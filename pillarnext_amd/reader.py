@@ -7,8 +7,10 @@ Same class names, constructor arguments, parameter names (``pfn_layers.{i}.linea
     forward(points (N, 1+F) fp32 [b,x,y,z,..]) -> (feat_max (P,64), coords (P,3) int32 [b,y,x], grid_size [ny,nx])  # :174-182
 
 * eval mode: one fused call (voxelize + PFN with BatchNorm folded + max) -- ``pnx_reader_forward``.
-* train mode: HIP voxelizer/decoration + HIP scatter-max with autograd; Linear/BatchNorm1d stay torch
-  modules so ``SyncBatchNorm.convert_sync_batchnorm`` (tools/train.py:56) keeps the reference's semantics.
+* train mode: the fused training passes of csrc/pfn_train.hip behind ONE autograd.Function (pfn_train.py): batch statistics,
+  running-stat updates, argmax-routed backward, SyncBatchNorm semantics via enable_sync() -- no (N',64) tensor in memory.
+  PNX_TRAIN_FUSED=0 (or num_filters other than [64,64]) takes the round-1 path: HIP voxelizer + torch Linear/BatchNorm1d + HIP
+  scatter-max with autograd.
 * ``forward_dense`` is the MI355X path the detector uses: it writes the dense channels-last BEV canvas
   directly (what SparseConvTensor(...).dense() would give, sparse_resnet.py:63-68) with no host sync.
 """
@@ -93,6 +95,7 @@ class PillarFeatureNet(nn.Module):
         self._ws = ops.Workspace()
         self._folded = None
         self._folded_key = None
+        self.sync, self.sync_group = False, None  # SyncBatchNorm mode of the fused training path (enable_sync)
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -102,6 +105,12 @@ class PillarFeatureNet(nn.Module):
     def _fused_supported(self):
         return (len(self.pfn_layers) == 2 and self.pfn_layers[0].units == 32 and self.pfn_layers[1].units == 64
                 and 3 <= self.num_point_features <= 6 and all(isinstance(l.norm, nn.BatchNorm1d) for l in self.pfn_layers))
+
+    @staticmethod
+    def _unfused_training():
+        import os
+
+        return os.environ.get("PNX_TRAIN_FUSED", "1") == "0"  # the round-1 path: torch Linear/BatchNorm1d + HIP scatter-max
 
     def folded_params(self):
         """BN-folded parameter buffer, re-folded whenever a parameter/buffer changed (tensor version counters)."""
@@ -115,8 +124,22 @@ class PillarFeatureNet(nn.Module):
             self._folded_key = key
         return self._folded
 
+    def enable_sync(self, process_group=None):
+        """SyncBatchNorm semantics for the fused training path: batch statistics (and the BatchNorm backward sums) are all-reduced
+        over `process_group` by pfn_train.py; the norm modules stay BatchNorm1d (their parameters/buffers are what gets trained)."""
+        self.sync, self.sync_group = True, process_group
+        return self
+
     # ------------------------------------------------------------------ reference API
     def forward(self, points, batch_size=None):
+        if self.training and self._fused_supported() and points.is_cuda and not self._unfused_training():
+            from .pfn_train import fused_pfn_train
+
+            points = points.contiguous().float()
+            if batch_size is None:
+                batch_size = int(points[:, 0].max().item()) + 1 if points.shape[0] > 0 else 1
+            feat_max, coords = fused_pfn_train(self, points, batch_size)
+            return feat_max, coords, self.grid_size
         if self.training or not self._fused_supported():
             return self._forward_unfused(points, batch_size)
         points = points.contiguous().float()
@@ -149,7 +172,7 @@ class PillarFeatureNet(nn.Module):
         ny, nx = int(self._geom.gy), int(self._geom.gx)
         dev = points.device
         if self.training or not self._fused_supported():
-            feat_max, coords, _ = self._forward_unfused(points, batch_size)
+            feat_max, coords, _ = self.forward(points, batch_size) if self.training else self._forward_unfused(points, batch_size)
             canvas = torch.zeros((batch_size, ny, nx, 64), dtype=feat_max.dtype, device=dev)
             c = coords.long()
             canvas[c[:, 0], c[:, 1], c[:, 2]] = feat_max
