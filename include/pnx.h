@@ -172,7 +172,7 @@ int pnx_bias_act_mask(const void* x, const void* residual, const float* bias, co
  *   costs no HBM traffic at all.  Contract: (y, row_dirty) start zeroed and y is only ever written through this function. */
 int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, uint8_t* row_dirty, pnx_stream_t stream);
-/* Final convolution of the merged SepHead branches of one task (det3d/models/dense_heads/centerpoint.py:30-60, the last
+/* Final convolution of the merged SepHead branches of one task (det3d/models/heads/centerhead.py:12-59, the last
  * Conv2d(64, k_j, 3, padding=1, bias=True) of every branch j):  y[b,oy,ox,o] = bias[o] + sum_{j,ky,kx,c} x[b,oy+ky-1,ox+kx-1,64j+c] * W[o][64j+c][ky][kx]
  * with W block diagonal (output o belongs to exactly one branch).  x (B,h,w,64*n_branch) bf16, y (B,h,w,16) bf16 (sum k_j <= 16,
  * unused outputs have zero weights), bias fp32[16], wfrag from pillarnext_amd/ops.py::sephead_pack_weights; n_branch in 5..7. */

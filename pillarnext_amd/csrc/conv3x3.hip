@@ -751,7 +751,7 @@ int launch_lds128(const void* x, const void* wfrag, const float* bias, const voi
   return PNX_OK;
 }
 
-// ---- final convolution of the merged SepHead branches (det3d/models/dense_heads/centerpoint.py:30-60: Conv2d(64, k_j, 3) of every
+// ---- final convolution of the merged SepHead branches (det3d/models/heads/centerhead.py:12-59: Conv2d(64, k_j, 3) of every
 // branch j of a task).  The first (merged) convolution leaves NBR x 64 channels per pixel; branch j reads only its own 64, so
 // the stacked weight (sum k_j <= 16 outputs x NBR*64 inputs) is block diagonal.  HBM-bound by its input (768 B per pixel at
 // NBR = 6 against 32 B of output): the 64-channel slabs are staged through LDS one after the other (each pixel is read from

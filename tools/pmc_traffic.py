@@ -1,27 +1,42 @@
 #!/usr/bin/env python3
-"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; CSV output) into profiles/pmc_traffic.json.
-HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB for the kernel named on the command line: FETCH_SIZE is doubled as
-MI355X_MICROARCH.md (HBM section) prescribes for wide coalesced reads on gfx950; WRITE_SIZE is taken as reported."""
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; CSV output) of a reader run into profiles/pmc_traffic.json.
+
+HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide
+coalesced reads on gfx950; WRITE_SIZE is taken as reported.  Two kinds of entries:
+  <key>            the WHOLE reader: every dispatch of every reader kernel (and the workspace memset) summed, divided by the number of
+                   reader calls (= dispatches of k_keys) -- what bench.py's `roofline.traffic` quotes
+  <key>:<kernel>   one kernel, average per dispatch
+usage: pmc_traffic.py fetch.csv write.csv <key> <out.json>"""
 import csv
 import json
 import sys
 
+READER = ["k_keys", "k_pack_scan", "k_scan_blocks", "k_scan_local", "k_bin_count", "k_bin_scatter", "k_bin_sort", "k_pfn3", "k_canvas_fill",
+          "k_rank", "k_fill", "k_pfn_mfma", "k_pfn_big", "fillBufferAligned"]
 
-def avg(path, kernel, counter):
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
-    return sum(vals) / max(len(vals), 1), len(vals)
+
+def rows(path, counter):
+    return [(r["Kernel_Name"], float(r["Counter_Value"])) for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
 
 
 def main():
-    fetch_csv, write_csv, kernel, key, out = sys.argv[1:6]
-    f, nf = avg(fetch_csv, kernel, "FETCH_SIZE")
-    w, nw = avg(write_csv, kernel, "WRITE_SIZE")
+    fetch_csv, write_csv, key, out = sys.argv[1:5]
+    f, w = rows(fetch_csv, "FETCH_SIZE"), rows(write_csv, "WRITE_SIZE")
     try:
         d = json.load(open(out))
     except Exception:
         d = {}
-    d[key] = {"kernel": kernel, "fetch_size_kib_raw": f, "write_size_kib": w, "dispatches": [nf, nw],
-              "hbm_bytes_per_launch": int((2 * f + w) * 1024), "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as reported"}
+    calls = max(sum(1 for n, _ in f if "k_keys" in n), 1)
+    tot_f = sum(v for n, v in f if any(k in n for k in READER))
+    tot_w = sum(v for n, v in w if any(k in n for k in READER))
+    d[key] = {"kernel": "all reader kernels", "reader_calls": calls, "fetch_size_kib_raw_per_call": tot_f / calls, "write_size_kib_per_call": tot_w / calls,
+              "hbm_bytes_per_launch": int((2 * tot_f + tot_w) / calls * 1024), "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as reported"}
+    for k in READER:
+        fv = [v for n, v in f if k in n]
+        wv = [v for n, v in w if k in n]
+        if fv or wv:
+            fa, wa = sum(fv) / max(len(fv), 1), sum(wv) / max(len(wv), 1)
+            d[f"{key}:{k}"] = {"dispatches": [len(fv), len(wv)], "fetch_size_kib_raw": fa, "write_size_kib": wa, "hbm_bytes_per_dispatch": int((2 * fa + wa) * 1024)}
     json.dump(d, open(out, "w"), indent=1)
     print(json.dumps(d[key]))
 

@@ -3,10 +3,12 @@
 
 Variants are environment settings read by pnx_reader_forward on every call:
   PNX_READER_IMPL=1            round-1 pipeline (global-atomic slots, 32-byte records, DPP-scan PFN, separate fill kernel)
-  PNX_READER_IMPL=2            binned pipeline (reader_bins.h) + LDS-max PFN (pfn_v3.hip)
-    PNX_READER_FUSE=0|1        zero-fill as its own kernel | as blocks of the PFN launch
+  PNX_READER_IMPL=2            binned pipeline (reader_bins.h) + PFN v3 (pfn_v3.hip)
+    PNX_READER_FUSE=0|1        zero-fill as its own kernel | as extra blocks of the PFN launch and of the grouping kernels
+    PNX_FILL_SPLIT=a,b,c       percent of the fill tiles carried by k_bin_count / k_bin_scatter / k_bin_sort
+    PNX_PFN_F16X3=0|1          layer 1 as fp32 MFMA | fp16 hi/lo splits
     PNX_FILL_BLOCKS, PNX_PFN_BLOCKS   block counts of the two roles
-Every variant's canvas must equal the first variant's bit for bit.
+Variants with the same arithmetic must equal the first variant's canvas bit for bit (fp16x3 vs fp32 layer 1 differ in the last bits).
 """
 import argparse
 import ctypes
@@ -39,7 +41,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--only", default="")
+    ap.add_argument("--only", default="", help="run the variants whose name contains this string")
+    ap.add_argument("--exact", default="", help="run exactly this variant")
     a = ap.parse_args()
     cfg = synth.CONFIGS[a.config]
     net = PillarFeatureNet(5, [64, 64], list(cfg["voxel_size"]), list(cfg["pc_range"])).cuda().eval()
@@ -54,7 +57,7 @@ def main():
     alg = 24 * batches[0].shape[0] + out.numel() * 2
     print(f"# {a.config} {a.dist} B={a.batch}: algorithmic {alg/1e6:.1f} MB per launch (24*N + canvas)")
     for name, env in VARIANTS:
-        if a.only and a.only not in name:
+        if (a.only and a.only not in name) or (a.exact and a.exact != name):
             continue
         for k in KEYS:
             os.environ.pop(k, None)
