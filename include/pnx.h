@@ -155,6 +155,22 @@ int pnx_scatter_canvas(const float* feat_max, const int32_t* coords, const int32
                        pnx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Input contract: multi-sweep merge + collation on the device.
+ * det3d/datasets/nuscenes/nusc.py:76-121 (read_sweep, remove_close, load_pointcloud), det3d/datasets/waymo/waymo.py:49-67 and
+ * det3d/datasets/loader/collate.py:15-22 as one stable compaction over raw sweeps resident in HBM.
+ *   raw        (n_raw, raw_stride) fp32 rows [x, y, z, c3, ...]; segment s = rows [begin, end) = one sweep of one sample
+ *   seg_descs  n_segments descriptors of pnx_merge_sweeps_desc_bytes() bytes each, in row order (device memory; layout:
+ *              pillarnext_amd/io.py::pack_segments): 3x4 fp64 transform (applied in fp64, stored as fp32 -- numpy's
+ *              `T.dot(vstack(p, 1))[:3]` assigned into a float32 array), has_transform, close-point radius (0: keep every point; the
+ *              reference removes |x| < 1 AND |y| < 1 from PAST sweeps only), time value (time_lag / timestamp), batch index
+ *   out        (n_raw, n_copy + 2) fp32 rows [b, x', y', z', c3 .. c(n_copy-1), time]; the first *n_out rows are valid, in input order
+ */
+size_t pnx_merge_sweeps_desc_bytes(void);
+size_t pnx_merge_sweeps_workspace_bytes(int64_t n_raw);
+int pnx_merge_sweeps(const float* raw, int64_t n_raw, int32_t raw_stride, int32_t n_copy, const void* seg_descs_dev, int32_t n_segments, float* out,
+                     int32_t* n_out_dev, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Epilogue of the masked-dense backbone (the dense stand-in for det3d/models/utils/sparse_conv.py:16-63 with BatchNorm
  * folded into the conv):  out = [relu]( x + bias[c] [+ residual] ) * mask[site]   in one pass, bf16 NHWC.
  *   x, residual, out  (sites, channels) bf16 (residual may be NULL; out may alias x)

@@ -273,3 +273,26 @@ def reader_forward(points, pc_range, voxel_size, num_filters, layers, eps=1e-3, 
     if want_canvas:
         res["canvas"] = canvas
     return res
+
+
+# ----------------------------------------------------------------------------- multi-sweep merge (numpy restatement)
+def merge_sweeps(sweeps, n_copy=4):
+    """Restates det3d/datasets/nuscenes/nusc.py:76-121 (read_sweep: fp64 `transform.dot(vstack(xyz, 1))[:3]` stored back into the
+    float32 array, remove_close :91-99 on past sweeps only, time-lag column), det3d/datasets/waymo/waymo.py:49-67 (same with
+    `xyz1 @ rel_pose.T`, timestamp column, no close-point filter) and collate.py:15-22 (batch index column).  The reference's dataset
+    modules import the nuscenes / waymo devkits at module level (absent here), so this restatement is pinned by reading only.
+    sweeps: list of dicts {points (n, C) fp32, batch, time, radius, transform (4x4 fp64 or None)} in concatenation order."""
+    rows = []
+    for s in sweeps:
+        p = np.array(s["points"][:, :n_copy], dtype=np.float32).T.copy()          # (C, n) as read_sweep holds it
+        T = s.get("transform")
+        if T is not None:
+            p[:3, :] = np.asarray(T, np.float64).dot(np.vstack((p[:3, :], np.ones(p.shape[1]))))[:3, :]
+        r = float(s.get("radius", 0.0))
+        if r > 0:
+            close = np.logical_and(np.abs(p[0, :]) < r, np.abs(p[1, :]) < r)
+            p = p[:, np.logical_not(close)]
+        t = (float(s["time"]) * np.ones((1, p.shape[1]))).astype(np.float32)
+        b = np.full((1, p.shape[1]), float(s["batch"]), np.float32)
+        rows.append(np.vstack((b, p, t)).T)
+    return np.concatenate(rows, axis=0).astype(np.float32)

@@ -59,3 +59,44 @@ class PointUploader:
         torch.cuda.current_stream(self.device).wait_event(ev)
         self.done[i] = ev
         return self.dev[i][:n], len(clouds)
+
+
+# --------------------------------------------------------------------------------------------- multi-sweep merge on the device
+def pack_segments(segments):
+    """segments: list of dicts {begin, end, batch, time, radius=0.0, transform=None (4x4 or 3x4 array)} in row order ->
+    bytes matching `struct SegDesc` of csrc/merge.hip."""
+    import struct
+
+    blob = b""
+    for s in segments:
+        T = s.get("transform")
+        t12 = [0.0] * 12 if T is None else [float(v) for v in np.asarray(T, np.float64)[:3, :4].reshape(-1)]
+        blob += struct.pack("12d2q2f2i", *t12, int(s["begin"]), int(s["end"]), float(s.get("radius", 0.0)), float(s["time"]), int(s["batch"]),
+                            0 if T is None else 1)
+    return blob
+
+
+class SweepMerger:
+    """nusc.py:76-121 / waymo.py:49-67 + collate.py:15-22 on the GPU: raw sweeps (already uploaded, one (M, C) fp32 tensor) ->
+    the collated (N, 2+n_copy) point buffer of the reader, in one stable compaction (csrc/merge.hip)."""
+
+    def __init__(self):
+        self._ws = None
+
+    def __call__(self, raw, segments, n_copy=4):
+        from . import _lib
+
+        L = _lib.lib()
+        assert raw.is_cuda and raw.dtype == torch.float32 and raw.is_contiguous()
+        n, stride = raw.shape
+        blob = pack_segments(segments)
+        assert len(blob) == len(segments) * L.pnx_merge_sweeps_desc_bytes(), "SegDesc layout drifted"
+        desc = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(raw.device)
+        need = int(L.pnx_merge_sweeps_workspace_bytes(n)) + 256
+        if self._ws is None or self._ws.numel() < need or self._ws.device != raw.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=raw.device)
+        out = torch.empty((n, n_copy + 2), dtype=torch.float32, device=raw.device)
+        n_out = torch.zeros(1, dtype=torch.int32, device=raw.device)
+        _lib.check(L.pnx_merge_sweeps(_lib.ptr(raw), n, stride, n_copy, _lib.ptr(desc), len(segments), _lib.ptr(out), _lib.ptr(n_out), _lib.ptr(self._ws),
+                                      self._ws.numel(), _lib.stream_ptr()), "pnx_merge_sweeps")
+        return out, n_out
