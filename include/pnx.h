@@ -243,6 +243,13 @@ int pnx_nms_normal_batched(const float* boxes, const int32_t* seg_offsets, const
  *   pnx_gather_kept   out[s][j] = [box9 | score] of the j-th kept candidate (j < min(keep_count[s], post_max)), else zeros
  */
 size_t pnx_decode_task_desc_bytes(void);
+/* Segmented top-k over the keys of all tasks (box_torch_ops.py:13-15 for every (sample, class) list at once): the first pre_max
+ * candidates of each segment in descending-score order, ties in ascending key index (= what a stable sort of `keys` would give), without
+ * sorting the whole key array: per-segment score histogram -> threshold bin -> collect -> sort in LDS.  Outputs are laid out as
+ * pnx_decode_boxes expects them: row s*pre_max + j = j-th candidate of segment s, seg_start[s] = s*pre_max, seg_len[s] <= pre_max. */
+size_t pnx_decode_topk_workspace_bytes(int64_t n_keys, int32_t num_segments);
+int pnx_decode_topk(const uint64_t* keys, int64_t n_keys, int32_t num_segments, int32_t pre_max, uint64_t* sorted_keys, int64_t* order,
+                    int64_t* seg_start, int32_t* seg_len, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
 int pnx_decode_keys(const void* packed, int32_t dtype, int32_t batch, int32_t n_classes_total, const void* task_desc_host, uint64_t* keys,
                     pnx_stream_t stream);
 int pnx_decode_boxes(const void* const* task_ptrs_dev, const void* task_descs_dev, const int64_t* task_key_off_dev, int32_t n_tasks,

@@ -55,6 +55,8 @@ PROTOTYPES = {
     "pnx_conv3x3_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pnx_mask_pool3": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pnx_decode_task_desc_bytes": (_sz, []),
+    "pnx_decode_topk_workspace_bytes": (_sz, [_i64, _i32]),
+    "pnx_decode_topk": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pnx_decode_keys": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pnx_decode_boxes": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pnx_gather_kept": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),

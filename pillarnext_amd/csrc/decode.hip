@@ -137,9 +137,208 @@ __global__ __launch_bounds__(256) void k_gather_kept(const float* __restrict__ b
   o[9] = scores[src];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Segmented top-k: the first pre_max candidates of every (sample, class) segment in descending-score order (box_torch_ops.py:13-15:
+// scores.sort(descending) + [:pre_maxsize]), ties in ascending cell order (what a stable sort of the key array gives) -- WITHOUT
+// sorting the 6 M keys of a frame batch, of which a few percent are valid: a 4096-bin score histogram per segment finds the score
+// bin that the pre_max-th candidate falls into, the candidates at or above that bin (pre_max + at most one bin's population) are
+// collected per segment and sorted in LDS.
+constexpr int kBins = 4096, kSortCap = 8192;
+
+__device__ __forceinline__ int score_bin(uint32_t low32) {
+  const uint32_t bits = 0xFFFFFFFFu - low32;  // fp32 bits of a score in (0, 1]
+  const uint32_t base = 0x3D800000u;          // 2^-4; everything below shares bin 0 (monotone clamp)
+  const uint32_t d = bits > base ? (bits - base) >> 13 : 0u;
+  return (int)(d < (uint32_t)kBins ? d : (uint32_t)kBins - 1u);
+}
+
+// Wave-aggregated counter update: lanes that hit the same counter are served by ONE device atomic (same-address atomics serialise at
+// ~13 ns each: a freshly initialised head puts half of all cells into the same score bin -- 3 M atomics on one word = 39 ms).
+// Returns the lane's position (old value + its rank among the lanes of its group); inactive lanes get 0.
+__device__ __forceinline__ uint32_t wave_agg_add(uint32_t* __restrict__ counters, uint32_t index, bool active) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(active);
+  uint32_t pos = 0;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t v = (uint32_t)__shfl((int)index, leader);
+    const unsigned long long grp = __ballot(active && index == v) & todo;
+    uint32_t old = 0;
+    if (lane == leader) old = atomicAdd(&counters[v], (uint32_t)__popcll(grp));
+    old = (uint32_t)__shfl((int)old, leader);
+    if ((grp >> lane) & 1ull) pos = old + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
+    todo &= ~grp;
+  }
+  return pos;
+}
+
+__global__ __launch_bounds__(256) void k_topk_hist(const unsigned long long* __restrict__ keys, int64_t n, uint32_t* __restrict__ hist) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long k = i < n ? keys[i] : ~0ULL;
+  const bool ok = k != ~0ULL;
+  wave_agg_add(hist, ok ? (uint32_t)(k >> 32) * kBins + (uint32_t)score_bin((uint32_t)k) : 0u, ok);
+}
+
+// one block per segment: threshold bin tb[s] = the highest bin b with count(bins >= b) >= pre_max (0 if the segment has fewer
+// candidates), need[s] = count(bins >= tb[s])
+__global__ __launch_bounds__(256) void k_topk_select(const uint32_t* __restrict__ hist, int pre_max, int32_t* __restrict__ tb, uint32_t* __restrict__ need) {
+  __shared__ uint32_t s_sum[256];
+  __shared__ int s_tb;
+  const int s = blockIdx.x, t = threadIdx.x;
+  const uint32_t* h = hist + (size_t)s * kBins;
+  uint32_t loc[16], tot = 0;  // thread t owns bins [16t, 16t+16)
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    loc[k] = h[16 * t + k];
+    tot += loc[k];
+  }
+  s_sum[t] = tot;
+  if (t == 0) s_tb = 0;
+  __syncthreads();
+  uint32_t above = 0;  // candidates in the bins of higher threads
+  for (int q = t + 1; q < 256; q++) above += s_sum[q];
+  __syncthreads();
+  // walking down from the top, the first bin where the running count reaches pre_max lies in exactly one thread's range
+  if (above < (uint32_t)pre_max && above + tot >= (uint32_t)pre_max) {
+    uint32_t run = above;
+    for (int k = 15; k >= 0; k--) {
+      run += loc[k];
+      if (run >= (uint32_t)pre_max) {
+        s_tb = 16 * t + k;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  const int b = s_tb;
+  uint32_t part = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    if (16 * t + k >= b) part += loc[k];
+  __syncthreads();
+  s_sum[t] = part;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t n = 0;
+    for (int q = 0; q < 256; q++) n += s_sum[q];
+    tb[s] = b;
+    need[s] = n;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_topk_offsets(const uint32_t* __restrict__ need, int S, uint32_t* __restrict__ base, uint32_t* __restrict__ cursor) {
+  if (threadIdx.x == 0) {  // S is a few hundred at most
+    uint32_t run = 0;
+    for (int s = 0; s < S; s++) {
+      base[s] = run;
+      cursor[s] = 0;
+      run += need[s];
+    }
+    base[S] = run;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_topk_collect(const unsigned long long* __restrict__ keys, int64_t n, const int32_t* __restrict__ tb,
+                                                      const uint32_t* __restrict__ base, uint32_t* __restrict__ cursor,
+                                                      unsigned long long* __restrict__ list) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long k = i < n ? keys[i] : ~0ULL;
+  const uint32_t seg = (uint32_t)(k >> 32), low = (uint32_t)k;
+  const bool ok = k != ~0ULL && score_bin(low) >= tb[seg];
+  const uint32_t pos = wave_agg_add(cursor, ok ? seg : 0u, ok);
+  if (ok) list[base[seg] + pos] = ((unsigned long long)low << 32) | (uint32_t)i;  // ascending = score descending, then key index ascending
+}
+
+__device__ __forceinline__ void bitonic_lds(unsigned long long* a, int n2, int t) {  // n2: power of two, 256 threads
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < n2; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long x = a[i], y = a[l];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            a[i] = y;
+            a[l] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+// one block per segment: sort the collected candidates and emit the first pre_max
+__global__ __launch_bounds__(256) void k_topk_sort(const unsigned long long* __restrict__ list, const uint32_t* __restrict__ base,
+                                                   const uint32_t* __restrict__ need, int pre_max, unsigned long long* __restrict__ sorted_keys,
+                                                   int64_t* __restrict__ order, int64_t* __restrict__ seg_start, int32_t* __restrict__ seg_len) {
+  __shared__ unsigned long long s_a[kSortCap];
+  const int s = blockIdx.x, t = threadIdx.x;
+  const uint32_t n = need[s];
+  const unsigned long long* src = list + base[s];
+  const int keepn = (int)min(n, (uint32_t)pre_max);
+  // chunks of at most kSortCap - (what is kept so far): sort, keep the first pre_max, merge the next chunk
+  int have = 0;
+  uint32_t done = 0;
+  while (done < n || have == 0) {
+    const int room = kSortCap - have;
+    const int take = (int)min((uint32_t)room, n - done);
+    for (int i = t; i < take; i += 256) s_a[have + i] = src[done + i];
+    const int cnt = have + take;
+    int n2 = 1;
+    while (n2 < cnt) n2 <<= 1;
+    for (int i = cnt + t; i < n2; i += 256) s_a[i] = ~0ULL;
+    __syncthreads();
+    bitonic_lds(s_a, n2, t);
+    done += (uint32_t)take;
+    have = min(cnt, pre_max);
+    if (n == 0) break;
+  }
+  const unsigned long long segbits = (unsigned long long)(uint32_t)s << 32;
+  for (int j = t; j < keepn; j += 256) {
+    const unsigned long long v = s_a[j];
+    sorted_keys[(int64_t)s * pre_max + j] = segbits | (v >> 32);
+    order[(int64_t)s * pre_max + j] = (int64_t)(uint32_t)v;
+  }
+  if (t == 0) {
+    seg_start[s] = (int64_t)s * pre_max;
+    seg_len[s] = keepn;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t pnx_decode_topk_workspace_bytes(int64_t n_keys, int32_t num_segments) {
+  if (n_keys < 0 || num_segments < 1) return 0;
+  return pnx_align_up((size_t)num_segments * kBins * 4, 256) + 4 * pnx_align_up((size_t)(num_segments + 8) * 4, 256) + pnx_align_up((size_t)(n_keys + 8) * 8, 256);
+}
+
+// keys = the concatenated outputs of pnx_decode_keys for all tasks; outputs in the layout pnx_decode_boxes consumes
+int pnx_decode_topk(const uint64_t* keys, int64_t n_keys, int32_t num_segments, int32_t pre_max, uint64_t* sorted_keys, int64_t* order, int64_t* seg_start,
+                    int32_t* seg_len, void* workspace, size_t workspace_bytes, pnx_stream_t stream) {
+  PNX_REQUIRE(keys && sorted_keys && order && seg_start && seg_len && workspace, PNX_ERR_INVALID, "null pointer");
+  PNX_REQUIRE(n_keys >= 0 && n_keys < ((int64_t)1 << 32) && num_segments >= 1 && pre_max >= 1 && pre_max <= kSortCap / 2, PNX_ERR_INVALID,
+              "bad sizes (pre_max <= %d)", kSortCap / 2);
+  PNX_REQUIRE(workspace_bytes >= pnx_decode_topk_workspace_bytes(n_keys, num_segments), PNX_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  PnxCarver c(workspace);
+  uint32_t* hist = c.take<uint32_t>((size_t)num_segments * kBins);
+  int32_t* tb = c.take<int32_t>(num_segments + 8);
+  uint32_t* need = c.take<uint32_t>(num_segments + 8);
+  uint32_t* base = c.take<uint32_t>(num_segments + 8);
+  uint32_t* cursor = c.take<uint32_t>(num_segments + 8);
+  unsigned long long* list = c.take<unsigned long long>(n_keys + 8);
+  PNX_CHECK_HIP(hipMemsetAsync(hist, 0, (size_t)num_segments * kBins * 4, st));
+  const unsigned nb = (unsigned)((n_keys + 255) / 256);
+  if (nb > 0) k_topk_hist<<<nb, 256, 0, st>>>((const unsigned long long*)keys, n_keys, hist);
+  k_topk_select<<<num_segments, 256, 0, st>>>(hist, pre_max, tb, need);
+  k_topk_offsets<<<1, 256, 0, st>>>(need, num_segments, base, cursor);
+  if (nb > 0) k_topk_collect<<<nb, 256, 0, st>>>((const unsigned long long*)keys, n_keys, tb, base, cursor, list);
+  k_topk_sort<<<num_segments, 256, 0, st>>>(list, base, need, pre_max, (unsigned long long*)sorted_keys, order, seg_start, seg_len);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
 
 // task_desc_host: 32 floats/ints per task, see pillarnext_amd/decode.py::pack_task (copied into a DecodeTask)
 int pnx_decode_keys(const void* packed, int32_t dtype, int32_t batch, int32_t n_classes_total, const void* task_desc_host,

@@ -766,13 +766,15 @@ int launch_bin_sort(const GeomDev& gd, const ReaderWs& w, int32_t* coords, int64
 
 // fill[0..2]: shares of the canvas zero-fill carried by extra blocks of k_bin_count / k_bin_scatter / k_bin_sort (quota 0 = none)
 int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev& gd, const ReaderWs& w, int32_t* coords,
-                  int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, const PnxFillJob* fill, int fill_blocks, hipStream_t st) {
+                  int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, const PnxFillJob* fill, int fill_blocks, hipStream_t st,
+                  hipEvent_t bitmap_ready = nullptr) {
   PNX_CHECK_HIP(hipMemsetAsync(w.counters, 0, w.zero_bytes, st));  // counters | count | bytemap
   if (n > 0) {
     k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bytemap, nullptr);
     PNX_LAUNCH_CHECK();
   }
   k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk, w.wcomb);
+  if (bitmap_ready != nullptr) PNX_CHECK_HIP(hipEventRecord(bitmap_ready, st));  // the zero-fill only needs the bitmap
   k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
   PNX_LAUNCH_CHECK();
   if (n <= 0) return PNX_OK;
@@ -885,7 +887,8 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   const bool fill_nt = nt_env ? nt_env[0] == '1' : canvas_bytes >= ((size_t)3 << 29);  // >= 1.5 GiB: far beyond what the Infinity Cache absorbs
   const char* fuse_env = getenv("PNX_READER_FUSE");  // 0: zero-fill as its own kernel in front of the PFN
   const char* fb_env = getenv("PNX_FILL_BLOCKS");
-  const bool fuse = binned && direct && !(fuse_env && fuse_env[0] == '0');
+  const bool side_fill = binned && direct && fuse_env && fuse_env[0] == '2';  // experiment: stand-alone fill kernel on a second stream
+  const bool fuse = binned && direct && !(fuse_env && (fuse_env[0] == '0' || fuse_env[0] == '2'));
   // The zero-fill's 32x32-cell tiles are dealt to four launches: extra blocks of k_bin_count / k_bin_scatter / k_bin_sort (latency-bound
   // kernels that leave HBM idle) take `split` percent each, the PFN launch the rest (pnx_fill.h).  PNX_FILL_SPLIT="a,b,c".
   PnxFillJob fjob[4];
@@ -905,7 +908,14 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   }
   const int fill_blocks = fb_env ? atoi(fb_env) : 256;
   prof_mark(0, st);
-  if (binned) rc = run_voxelize2(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, fjob, fill_blocks, st);
+  static hipStream_t side2 = nullptr;
+  static hipEvent_t ev_bitmap = nullptr, ev_filled = nullptr;
+  if (side_fill && side2 == nullptr) {
+    PNX_CHECK_HIP(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
+    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_bitmap, hipEventDisableTiming));
+    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_filled, hipEventDisableTiming));
+  }
+  if (binned) rc = run_voxelize2(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, fjob, fill_blocks, st, side_fill ? ev_bitmap : nullptr);
   else rc = run_voxelize(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, unq_inv != nullptr, st);
   if (rc != PNX_OK) return rc;
   prof_mark(6, st);
@@ -935,7 +945,12 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
     PNX_LAUNCH_CHECK();
     return PNX_OK;
   };
-  if (direct && !fuse) {
+  if (side_fill) {
+    PNX_CHECK_HIP(hipStreamWaitEvent(side2, ev_bitmap, 0));
+    rc = launch_fill(side2);
+    if (rc != PNX_OK) return rc;
+    PNX_CHECK_HIP(hipEventRecord(ev_filled, side2));
+  } else if (direct && !fuse) {
     if (overlap) {
       PNX_CHECK_HIP(hipEventRecord(ev_fork, st));
       PNX_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
@@ -997,6 +1012,11 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
     }
     prof_mark(2, st);
   }
+  if (side_fill) {
+    PNX_CHECK_HIP(hipStreamWaitEvent(st, ev_filled, 0));
+    prof_mark(1, st);
+    prof_mark(2, st);
+  }
   if (counts) PNX_CHECK_HIP(hipMemcpyAsync(counts, w.counters, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   prof_mark(3, st);
   if (g_prof.on && g_prof.n < g_prof.cap) g_prof.n++;
@@ -1051,7 +1071,7 @@ int pnx_pfn_backward(int32_t pass, int64_t n, int32_t stride, int32_t batch, con
 }
 
 void pnx_reader_fill_split(int32_t* percent3) {
-  percent3[0] = 5, percent3[1] = 9, percent3[2] = 24;  // measured on C2 / 8 frames (tools/reader_ab.py)
+  percent3[0] = 0, percent3[1] = 0, percent3[2] = 24;  // measured on C2 / 8 frames (tools/reader_ab.py): only k_bin_sort's share pays
   const char* sp_env = getenv("PNX_FILL_SPLIT");
   if (sp_env) sscanf(sp_env, "%d,%d,%d", &percent3[0], &percent3[1], &percent3[2]);
   for (int k = 0; k < 3; k++) percent3[k] = percent3[k] < 0 ? 0 : (percent3[k] > 100 ? 100 : percent3[k]);

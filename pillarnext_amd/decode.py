@@ -40,6 +40,14 @@ class PackedDecoder:
         self.thr = [float(v) for t in _get(nms, "nms_iou_threshold") for v in t]
         self.cfg = test_cfg
         self._dev = {}
+        self._topk_ws = None
+        import os
+
+        # PNX_DECODE_TOPK=1: segmented top-k in HIP (pnx_decode_topk) instead of one stable device sort of all keys.  Exactly the same
+        # selection (tests/test_gpu_decode.py), but OFF by default: with a freshly initialised head half of all cells pass the score
+        # threshold and tens of thousands of them tie at one quantised score, so every segment sorts ~40 k candidates in LDS chunks --
+        # measured 6.4 ms per 8-frame step against 1.06 ms for the sort; it pays once candidates are a few percent of the cells.
+        self.use_topk = os.environ.get("PNX_DECODE_TOPK", "0") == "1"
         self._tptr = {}
         self._pin = {}
 
@@ -74,9 +82,6 @@ class PackedDecoder:
         for t, p in enumerate(packed):
             kp = ctypes.c_void_p(keys.data_ptr() + 8 * offs[t])
             check(L.pnx_decode_keys(ptr(p), dt, B, self.nc_total, descs[t], kp, stream_ptr()), "pnx_decode_keys")
-        # keys are non-negative when valid ... as int64 the all-ones key is -1: sort as unsigned by flipping the sign bit
-        skeys, order = torch.sort(keys ^ (-0x8000000000000000), stable=True)
-        skeys = skeys ^ (-0x8000000000000000)
         S = B * self.nc_total
         ck = (B, T, dt, tuple(shapes), dev)
         if ck not in self._dev:
@@ -87,8 +92,25 @@ class PackedDecoder:
             bounds = (torch.arange(S + 1, device=dev, dtype=torch.int64) << 32) ^ (-0x8000000000000000)
             self._dev[ck] = (tdesc, koff, seg_off, thr, bounds)
         tdesc, koff, seg_off, thr, bounds = self._dev[ck]
-        seg_start = torch.searchsorted(skeys ^ (-0x8000000000000000), bounds)
-        seg_len = torch.clamp(seg_start[1:] - seg_start[:-1], max=self.pre_max).to(torch.int32)
+        if self.use_topk and self.pre_max <= 4096:
+            # segmented top-k in HIP (csrc/decode.hip): per-segment score histogram -> threshold bin -> collect -> LDS sort; the
+            # 6 M-key device sort (rocprim onesweep, ~0.5 ms per 8 frames) is gone
+            n_rows0 = S * self.pre_max
+            skeys = torch.empty((n_rows0,), dtype=torch.int64, device=dev)
+            order = torch.empty((n_rows0,), dtype=torch.int64, device=dev)
+            seg_start = torch.empty((S,), dtype=torch.int64, device=dev)
+            seg_len = torch.empty((S,), dtype=torch.int32, device=dev)
+            wsb = int(L.pnx_decode_topk_workspace_bytes(offs[-1], S)) + 256
+            if self._topk_ws is None or self._topk_ws.numel() < wsb or self._topk_ws.device != dev:
+                self._topk_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            check(L.pnx_decode_topk(ptr(keys), offs[-1], S, self.pre_max, ptr(skeys), ptr(order), ptr(seg_start), ptr(seg_len), ptr(self._topk_ws),
+                                    self._topk_ws.numel(), stream_ptr()), "pnx_decode_topk")
+        else:
+            # keys are non-negative when valid ... as int64 the all-ones key is -1: sort as unsigned by flipping the sign bit
+            skeys, order = torch.sort(keys ^ (-0x8000000000000000), stable=True)
+            skeys = skeys ^ (-0x8000000000000000)
+            seg_start = torch.searchsorted(skeys ^ (-0x8000000000000000), bounds)
+            seg_len = torch.clamp(seg_start[1:] - seg_start[:-1], max=self.pre_max).to(torch.int32)
         # pointer table of the task tensors: a torch.tensor(list, device=...) is a blocking copy from pageable memory (it would make
         # the host wait for the whole network before it could enqueue the sort/NMS); cached per pointer tuple, else a pinned async copy
         pk = tuple(p.data_ptr() for p in packed)

@@ -231,3 +231,45 @@ def test_training_step_end_to_end():
     opt.step()
     loss2, _ = model(ex)
     assert torch.isfinite(loss2)
+
+
+def test_segmented_topk_equals_the_full_stable_sort():
+    """pnx_decode_topk (score histogram -> threshold bin -> collect -> LDS sort) must select and order exactly what one stable sort of
+    all keys + the [:pre_max] cut gives, including ties (bf16 head outputs quantise the scores) and segments with fewer / far more
+    candidates than pre_max."""
+    import ctypes
+
+    from pillarnext_amd._lib import check, lib, ptr, stream_ptr
+
+    L = lib()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    S, pre_max, n = 23, 1000, 900_000
+    seg = torch.randint(0, S, (n,), device="cuda", generator=g)
+    seg[seg == 5] = 6                                                        # an empty segment
+    sc = torch.rand((n,), device="cuda", generator=g) * 0.9 + 0.1
+    sc = sc.to(torch.bfloat16).float()                                       # heavy ties
+    sc[seg == 7] = 0.5                                                       # one segment: ALL scores equal (tens of thousands of ties)
+    few = (seg == 9).nonzero().flatten()
+    valid = torch.rand((n,), device="cuda", generator=g) < 0.08
+    valid[few[40:]] = False                                                  # a segment with fewer candidates than pre_max
+    low = (0xFFFFFFFF - sc.view(torch.int32).to(torch.int64))
+    keys = torch.where(valid, (seg.to(torch.int64) << 32) | low, torch.full_like(low, -1))
+    # reference: stable sort as unsigned
+    skeys, order = torch.sort(keys ^ (-0x8000000000000000), stable=True)
+    skeys = skeys ^ (-0x8000000000000000)
+    bounds = (torch.arange(S + 1, device="cuda", dtype=torch.int64) << 32) ^ (-0x8000000000000000)
+    st = torch.searchsorted(skeys ^ (-0x8000000000000000), bounds)
+    ln = torch.clamp(st[1:] - st[:-1], max=pre_max)
+    out_k = torch.empty((S * pre_max,), dtype=torch.int64, device="cuda")
+    out_o = torch.empty((S * pre_max,), dtype=torch.int64, device="cuda")
+    out_s = torch.empty((S,), dtype=torch.int64, device="cuda")
+    out_l = torch.empty((S,), dtype=torch.int32, device="cuda")
+    ws = torch.empty(int(L.pnx_decode_topk_workspace_bytes(n, S)) + 256, dtype=torch.uint8, device="cuda")
+    check(L.pnx_decode_topk(ptr(keys), n, S, pre_max, ptr(out_k), ptr(out_o), ptr(out_s), ptr(out_l), ptr(ws), ws.numel(), stream_ptr()), "pnx_decode_topk")
+    assert torch.equal(out_l.long(), ln) and int(ln[5]) == 0 and int(ln[9]) <= 40
+    for s in range(S):
+        k = int(ln[s])
+        a0 = int(st[s])
+        assert torch.equal(out_o[s * pre_max: s * pre_max + k], order[a0: a0 + k]), s
+        assert torch.equal(out_k[s * pre_max: s * pre_max + k], skeys[a0: a0 + k]), s
+        assert int(out_s[s]) == s * pre_max

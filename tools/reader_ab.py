@@ -25,11 +25,16 @@ VARIANTS = [
     ("round1", {"PNX_READER_IMPL": "1"}),
     ("binned unfused fp32-L1", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "0", "PNX_PFN_F16X3": "0"}),
     ("binned unfused", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "0"}),
+    ("binned side-stream fill", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "2"}),
     ("binned fused pfn-only", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,0"}),
     ("binned fused 5,9,24", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "5,9,24"}),
-    ("binned fused 10,15,35", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "10,15,35"}),
-    ("binned fused 0,0,0 f384", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,0", "PNX_FILL_BLOCKS": "384"}),
-    ("binned fused 5,9,24 fp32-L1", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "5,9,24", "PNX_PFN_F16X3": "0"}),
+    ("binned fused 0,0,24", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,24"}),
+    ("binned fused 0,0,35", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,35"}),
+    ("binned fused 0,0,45", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,45"}),
+    ("binned fused 0,5,40", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,5,40"}),
+    ("binned fused 3,5,35", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "3,5,35"}),
+    ("binned fused 0,0,35 f384", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,35", "PNX_FILL_BLOCKS": "384"}),
+    ("binned fused 0,0,35 f192", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,35", "PNX_FILL_BLOCKS": "192"}),
 ]
 KEYS = ["PNX_READER_IMPL", "PNX_READER_FUSE", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS", "PNX_FILL_SPLIT", "PNX_PFN_F16X3"]
 
@@ -43,6 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--only", default="", help="run the variants whose name contains this string")
     ap.add_argument("--exact", default="", help="run exactly this variant")
+    ap.add_argument("--no-occ", action="store_true", help="do not ask for the occupancy output")
     a = ap.parse_args()
     cfg = synth.CONFIGS[a.config]
     net = PillarFeatureNet(5, [64, 64], list(cfg["voxel_size"]), list(cfg["pc_range"])).cuda().eval()
@@ -50,7 +56,7 @@ def main():
     batches = [torch.from_numpy(synth.make_batch(a.config, a.batch, a.dist, frame0=k * a.batch)).cuda() for k in range(4)]
     ny, nx = (int(v) for v in net.grid_size)
     out = torch.empty((a.batch, 64, ny, nx), dtype=torch.bfloat16, device="cuda", memory_format=torch.channels_last)
-    occ = torch.empty((a.batch, ny, nx), dtype=torch.uint8, device="cuda")
+    occ = None if a.no_occ else torch.empty((a.batch, ny, nx), dtype=torch.uint8, device="cuda")
     counts = torch.zeros(2, dtype=torch.int32, device="cuda")
     L = _lib.lib()
     ref = None
@@ -66,11 +72,10 @@ def main():
             net.forward_dense(batches[i % 4], a.batch, out=out, counts=counts, occupancy=occ)
         net.forward_dense(batches[0], a.batch, out=out, counts=counts, occupancy=occ)
         torch.cuda.synchronize()
-        chk = (out.view(torch.int16).to(torch.int64).sum().item(), occ.to(torch.int64).sum().item())
         if ref is None:
-            ref_canvas, ref_occ = out.clone(), occ.clone()
-            ref = chk
-        same = torch.equal(out, ref_canvas) and torch.equal(occ, ref_occ)
+            ref_canvas, ref_occ = out.clone(), (occ.clone() if occ is not None else None)
+            ref = True
+        same = torch.equal(out, ref_canvas) and (occ is None or torch.equal(occ, ref_occ))
         L.pnx_profile_begin(a.iters)
         for i in range(a.iters):
             net.forward_dense(batches[i % 4], a.batch, out=out, counts=counts, occupancy=occ)
