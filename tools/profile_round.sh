@@ -9,9 +9,9 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/bench_trace -o p -- python $R/bench.py --steps 6 --warmup 4 --no-extras > $O/bench_trace.json 2> $O/bench_trace.err
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/reader_trace -o p -- python $R/tools/reader_ab.py --exact "binned fused 5,9,24" --iters 20 > $O/reader_trace.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python $R/tools/reader_ab.py --exact "binned fused 5,9,24" --iters 10 > $O/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python $R/tools/reader_ab.py --exact "binned fused 5,9,24" --iters 10 > $O/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/reader_trace -o p -- python $R/tools/reader_ab.py --exact "binned default" --iters 20 > $O/reader_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python $R/tools/reader_ab.py --exact "binned default" --iters 10 > $O/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python $R/tools/reader_ab.py --exact "binned default" --iters 10 > $O/pmc_write.log 2>&1
 cd $R
 python tools/steady_trace.py $O/bench_trace 3 45 > $O/bench_steady_trace.md 2>&1
 python tools/prof_summary.py $(find $O/reader_trace -name "*.db" | head -1) 30 > $O/reader_kernels.md 2>&1

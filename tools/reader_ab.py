@@ -25,6 +25,7 @@ VARIANTS = [
     ("round1", {"PNX_READER_IMPL": "1"}),
     ("binned unfused fp32-L1", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "0", "PNX_PFN_F16X3": "0"}),
     ("binned unfused", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "0"}),
+    ("binned default", {"PNX_READER_IMPL": "2"}),
     ("binned side-stream fill", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "2"}),
     ("binned fused pfn-only", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,0"}),
     ("binned fused 5,9,24", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "5,9,24"}),
