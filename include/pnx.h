@@ -178,6 +178,11 @@ int pnx_merge_sweeps(const float* raw, int64_t n_raw, int32_t raw_stride, int32_
  */
 int pnx_bias_act_mask(const void* x, const void* residual, const float* bias, const uint8_t* mask, void* out, int64_t sites,
                       int32_t channels, int32_t dtype, int32_t relu, pnx_stream_t stream);
+/* ASPP neck with the 1x1 post_conv folded into the branches (det3d/models/necks/aspp.py:19-32: post_conv(cat(x, conv1x1(x),
+ * conv_d(x, W) for d in 1,6,12,18)) == sum of six convolutions of x with post-multiplied weights): the partial results are summed
+ * in fp32 in one pass,  out = [relu]( sum_k src_k + bias[c] ), bf16 NHWC.  srcs = HOST array of n_src (1..8) device pointers. */
+int pnx_sum_bias_act(const void* const* srcs, int32_t n_src, const float* bias, void* out, int64_t sites, int32_t channels, int32_t relu,
+                     pnx_stream_t stream);
 /* Masked 3x3 convolution (pad 1, stride 1 or 2) with the same epilogue fused, bf16 NHWC, fp32 accumulation on MFMA:
  *   y = mask_out * [relu]( conv3x3(x, W) + bias [+ residual] ),  rows/tiles of the output without an active site are skipped.
  *   x (B,h,w,cin), y/residual (B,ho,wo,cout), mask uint8 (B,ho,wo) or NULL; wfrag = weights in MFMA-fragment order

@@ -55,6 +55,44 @@ __global__ __launch_bounds__(256) void k_bias_act_mask_bf16(const uint4* __restr
   }
 }
 
+// out = [relu](sum_k src_k + bias): the five partial results of the folded ASPP neck (models.py) summed in fp32 in ONE pass
+// instead of four bf16 read-modify-write adds + an epilogue.  bf16 NHWC, one thread = 8 channels.
+struct SumSrcs {
+  const uint4* p[8];
+};
+template <int N, bool RELU>
+__global__ __launch_bounds__(256) void k_sum_bias_act_bf16(SumSrcs srcs, const float* __restrict__ bias, uint4* __restrict__ out, int64_t n_vec,
+                                                           int cvec) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * 256) {
+    const int c0 = (int)(i % cvec) * 8;
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + c0), b1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
+    float a[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    uint4 v[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = srcs.p[k][i];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        a[2 * q] += bf2f(w[q] & 0xffffu);
+        a[2 * q + 1] += bf2f(w[q] >> 16);
+      }
+    }
+    uint32_t ow[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      float lo = a[2 * q], hi = a[2 * q + 1];
+      if (RELU) {
+        lo = fmaxf(lo, 0.f);
+        hi = fmaxf(hi, 0.f);
+      }
+      ow[q] = f2bf(lo) | (f2bf(hi) << 16);
+    }
+    out[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  }
+}
+
 // 3x3 / stride-s / pad-1 max-pool of the occupancy mask (the active-site rule of a strided sparse conv).
 __global__ __launch_bounds__(256) void k_mask_pool(const uint8_t* __restrict__ in, int B, int H, int W, int stride, uint8_t* __restrict__ out,
                                                    int Ho, int Wo) {
@@ -112,6 +150,34 @@ int pnx_mask_pool3(const uint8_t* mask_in, int32_t batch, int32_t h, int32_t w, 
   const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
   const int64_t n = (int64_t)batch * ho * wo;
   k_mask_pool<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(mask_in, batch, h, w, stride, mask_out, ho, wo);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+int pnx_sum_bias_act(const void* const* srcs, int32_t n_src, const float* bias, void* out, int64_t sites, int32_t channels, int32_t relu,
+                     pnx_stream_t stream) {
+  PNX_REQUIRE(srcs && bias && out && sites > 0, PNX_ERR_INVALID, "bad arguments");
+  PNX_REQUIRE(n_src >= 1 && n_src <= 8, PNX_ERR_UNSUPPORTED, "%d summands (1..8)", n_src);
+  PNX_REQUIRE(channels > 0 && channels % 8 == 0, PNX_ERR_UNSUPPORTED, "channels %d not a multiple of 8", channels);
+  SumSrcs ss;
+  for (int k = 0; k < 8; k++) {
+    ss.p[k] = k < n_src ? (const uint4*)srcs[k] : nullptr;
+    PNX_REQUIRE(k >= n_src || (srcs[k] && ((uintptr_t)srcs[k] & 15) == 0), PNX_ERR_INVALID, "summand %d: null or not 16-byte aligned", k);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int cvec = channels / 8;
+  const int64_t n_vec = sites * cvec;
+  int64_t nb = (n_vec + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+#define PNX_SUM_CASE(N_)                                                                                      \
+  case N_:                                                                                                    \
+    if (relu) k_sum_bias_act_bf16<N_, true><<<(unsigned)nb, 256, 0, st>>>(ss, bias, (uint4*)out, n_vec, cvec); \
+    else k_sum_bias_act_bf16<N_, false><<<(unsigned)nb, 256, 0, st>>>(ss, bias, (uint4*)out, n_vec, cvec);     \
+    break;
+  switch (n_src) {
+    PNX_SUM_CASE(1) PNX_SUM_CASE(2) PNX_SUM_CASE(3) PNX_SUM_CASE(4) PNX_SUM_CASE(5) PNX_SUM_CASE(6) PNX_SUM_CASE(7) PNX_SUM_CASE(8)
+  }
+#undef PNX_SUM_CASE
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

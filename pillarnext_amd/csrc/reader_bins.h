@@ -151,10 +151,11 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_sort(const uint32_t* __restr
     s_sum[3 * p + 2] = 0.0;
   }
   __syncthreads();
-  // pass 1: points per pillar, exact coordinate sums (scatter_mean numerator, pe:113), the pillar's cell key
-  for (uint32_t j = bs + t; j < be; j += kSortBlock) {
-    const uint4* q = reinterpret_cast<const uint4*>(binbuf + (int64_t)j * 8);
-    const uint4 a = q[0], c = q[1];
+  // pass 1: points per pillar, exact coordinate sums (scatter_mean numerator, pe:113), the pillar's cell key.  The raw records of the
+  // first kKeep rounds stay in registers for pass 2 (a bin holds ~3 rounds of points on the nuScenes grid): one read of binbuf, not two.
+  constexpr int kKeep = 4;
+  uint4 ka[kKeep], kc[kKeep];
+  auto tally = [&](const uint4& a, const uint4& c) {
     const uint32_t rl = c.w;
     atomicAdd(&s_start[rl], 1u);
     s_key[rl] = c.z;  // every point of the pillar stores the same key
@@ -163,6 +164,22 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_sort(const uint32_t* __restr
       atomicAdd(&s_sum[3 * rl + 1], (double)__uint_as_float(a.y));
       atomicAdd(&s_sum[3 * rl + 2], (double)__uint_as_float(a.z));
     }
+  };
+#pragma unroll
+  for (int it = 0; it < kKeep; it++) {
+    const uint32_t j = bs + it * kSortBlock + t;
+    ka[it] = make_uint4(0u, 0u, 0u, 0u);
+    kc[it] = make_uint4(0u, 0u, 0u, 0u);
+    if (j < be) {
+      const uint4* q = reinterpret_cast<const uint4*>(binbuf + (int64_t)j * 8);
+      ka[it] = q[0];
+      kc[it] = q[1];
+      tally(ka[it], kc[it]);
+    }
+  }
+  for (uint32_t j = bs + kKeep * kSortBlock + t; j < be; j += kSortBlock) {
+    const uint4* q = reinterpret_cast<const uint4*>(binbuf + (int64_t)j * 8);
+    tally(q[0], q[1]);
   }
   __syncthreads();
   // exclusive scan of the S counts (S <= 2 * kSortBlock): thread t owns entries 2t, 2t+1
@@ -230,15 +247,12 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_sort(const uint32_t* __restr
   // store ONE record per instruction, 16 bytes each, so that an instruction writes 16 complete lines: a 4x4 transpose of the
   // 16-byte quads across the quad's lanes (two DPP butterfly steps) leaves lane i holding quad i of all four records.
   const int lq = t & 3;
-  for (uint32_t jb = bs; jb < be; jb += kSortBlock) {  // every lane stays in the loop (DPP reads the quad's lanes)
-    const uint32_t j = jb + t;
+  auto emit = [&](const bool live, const uint4& a, const uint4& c) {  // every lane takes part (DPP reads the quad's lanes)
     uint32_t W[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) W[k] = 0u;
     uint32_t dst = 0xFFFFFFFFu;
-    if (j < be) {
-      const uint4* q = reinterpret_cast<const uint4*>(binbuf + (int64_t)j * 8);
-      const uint4 a = q[0], c = q[1];
+    if (live) {
       const uint32_t rl = c.w;
       const uint32_t pos = atomicAdd(&s_cur[rl], 1u);
       const uint32_t st = s_start[rl], cnt = s_start[rl + 1] - st;
@@ -277,8 +291,24 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_sort(const uint32_t* __restr
     PNX_QUAD_ROUND(2)
     PNX_QUAD_ROUND(3)
 #undef PNX_QUAD_ROUND
+  };
+#pragma unroll
+  for (int it = 0; it < kKeep; it++) {
+    const uint32_t jb = bs + it * kSortBlock;
+    if (jb < be) emit(jb + t < be, ka[it], kc[it]);  // block-uniform condition
+  }
+  for (uint32_t jb = bs + kKeep * kSortBlock; jb < be; jb += kSortBlock) {
+    const uint32_t j = jb + t;
+    uint4 a = make_uint4(0u, 0u, 0u, 0u), c = a;
+    if (j < be) {
+      const uint4* q = reinterpret_cast<const uint4*>(binbuf + (int64_t)j * 8);
+      a = q[0];
+      c = q[1];
+    }
+    emit(j < be, a, c);
   }
 }
+
 
 // LDS bytes of k_bin_sort for bins of 2^sh pillars
 static inline size_t bin_sort_lds(int sh) {

@@ -523,6 +523,19 @@ def _fold_bn(weight, bn, conv_bias=None, transposed=False):
     return w * a.view(shape), (b0 - bn.running_mean.detach().float()) * a + bn.bias.detach().float()
 
 
+def fold_aspp(nk):
+    """ASPPNeck (eval) after pre_conv as ONE sum of convolutions of x: returns (w_1x1 (O,C,1,1), [w_d (O,C,3,3) for d in 1,6,12,18], shift (O,))
+    with  relu(conv1x1(x, w_1x1) + sum_d conv_d(x, w_d) + shift) == post_conv(cat(x, conv1x1(x), conv_d(x, W)...))  (aspp.py:19-32)."""
+    wp, bp = _fold_bn(nk.post_conv.conv.conv.weight, nk.post_conv.norm)
+    C = nk.weight.shape[0]
+    P = wp.detach().float().reshape(wp.shape[0], 6, C)                       # (out, branch, mid): column blocks of the post weight
+    w1 = nk.conv1x1.weight.detach().float().reshape(C, C)
+    wa = (P[:, 0] + P[:, 1] @ w1).reshape(wp.shape[0], C, 1, 1)
+    ws = nk.weight.detach().float()
+    wds = [torch.einsum("om,mikl->oikl", P[:, 2 + k], ws) for k in range(4)]
+    return wa, wds, bp.float()
+
+
 class _FusedConv(nn.Module):
     """conv (BN folded, no bias inside MIOpen) + ONE HIP epilogue pass: [relu](y + b [+ res]) * mask."""
 
@@ -612,10 +625,16 @@ class FusedPillarNeXt(nn.Module):
         nk = det.neck
         self.pre1 = _FusedConv(*_fold_bn(nk.pre_conv.block1.conv.conv.weight, nk.pre_conv.block1.norm), 1, 1, dtype=dtype)
         self.pre2 = _FusedConv(*_fold_bn(nk.pre_conv.block2.conv.conv.weight, nk.pre_conv.block2.norm), 1, 1, dtype=dtype)
-        # ASPP: the 1x1 branch and the four dilated branches have no BN/activation of their own; post_conv is 1x1 over the concat
-        self.register_buffer("aspp_1x1", nk.conv1x1.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last))
-        self.register_buffer("aspp_w", nk.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last))
-        self.post = _FusedConv(*_fold_bn(nk.post_conv.conv.conv.weight, nk.post_conv.norm), 1, 0, dtype=dtype)
+        # ASPP (aspp.py:19-32): the identity, the 1x1 branch and the four dilated branches have no BN/activation of their own and
+        # post_conv is a 1x1 over their concat, so it distributes over the branches:
+        #     post(cat(x, conv1x1(x), conv_d(x, Ws)...)) = conv1x1(x, P0 + P1.W1) + sum_d conv_d(x, P_d.Ws)
+        # (P_k = the k-th 256-column block of the BN-folded post weight).  The 1536-channel concat and the 1536 -> 256 GEMM disappear;
+        # the five partial results are summed in fp32 by one pass (pnx_sum_bias_act) that also applies the folded-BN shift + ReLU.
+        wa, wds, bp = fold_aspp(nk)
+        self.register_buffer("aspp_1x1", wa.to(dtype).contiguous(memory_format=torch.channels_last))
+        for k, wd in enumerate(wds):
+            self.register_buffer(f"aspp_w{k}", wd.to(dtype).contiguous(memory_format=torch.channels_last))
+        self.register_buffer("aspp_bias", bp.float().contiguous())
         hd = det.head
         self.shared = _FusedConv(*_fold_bn(hd.shared_conv[0].weight, hd.shared_conv[1], hd.shared_conv[0].bias), 1, 1, dtype=dtype)
         self.task_deblock = nn.ModuleList()
@@ -697,8 +716,9 @@ class FusedPillarNeXt(nn.Module):
         # BasicBlock (utils/conv.py): act(block2(block1(x)) + x) where block2 already ends in a ReLU, so the residual is added
         # AFTER that ReLU; both terms are >= 0, which makes the trailing act() the identity.
         x = self.pre2(self.pre1(x)) + x
-        outs = [x, F.conv2d(x, self.aspp_1x1)] + [F.conv2d(x, self.aspp_w, None, 1, d, d) for d in (1, 6, 12, 18)]
-        x = self.post(torch.cat(outs, dim=1))
+        parts = [F.conv2d(x, self.aspp_1x1)] + [F.conv2d(x, getattr(self, f"aspp_w{k}"), None, 1, d, d) for k, d in enumerate((1, 6, 12, 18))]
+        parts = [p if p.is_contiguous(memory_format=torch.channels_last) else p.contiguous(memory_format=torch.channels_last) for p in parts]
+        x = ops.sum_bias_act(parts, self.aspp_bias, relu=True)
         mark("mapping+neck")
         if taps is not None:
             taps["neck"] = x

@@ -195,6 +195,19 @@ def bias_act_mask_(x, bias, mask=None, residual=None, relu=True):
     return x
 
 
+def sum_bias_act(parts, bias, relu=True):
+    """[relu](sum(parts) + bias[c]) for channels_last bf16 (B,C,H,W) tensors of one shape, summed in fp32 in one pass."""
+    x = parts[0]
+    for t in parts:
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.shape == x.shape and t.is_contiguous(memory_format=torch.channels_last)):
+            raise PnxError("sum_bias_act needs channels_last bf16 CUDA tensors of one shape")
+    B, C, H, W = x.shape
+    out = torch.empty_like(x, memory_format=torch.channels_last)
+    arr = (ctypes.c_void_p * len(parts))(*[t.data_ptr() for t in parts])
+    check(lib().pnx_sum_bias_act(arr, len(parts), ptr(bias), ptr(out), B * H * W, C, 1 if relu else 0, stream_ptr()), "pnx_sum_bias_act")
+    return out
+
+
 def mask_pool3(mask, stride):
     """uint8 (B,H,W) occupancy -> occupancy after a 3x3/stride/pad-1 sparse conv."""
     B, H, W = mask.shape

@@ -81,3 +81,32 @@ def test_merged_sephead_weights_are_block_diagonal():
             torch.testing.assert_close(B2[o:o + k], fc[3].bias.detach().float())
             o += k
         assert float(W2[o:].abs().max()) == 0.0 and float(B2[o:].abs().max()) == 0.0
+
+
+def test_aspp_fold_equals_the_module():
+    """post_conv distributed over the six ASPP branches (models.fold_aspp) against ASPPNeck itself (aspp.py:19-32), fp64 on the CPU."""
+    import torch.nn.functional as F
+
+    from pillarnext_amd.models import ASPPNeck, fold_aspp
+
+    torch.manual_seed(3)
+    nk = ASPPNeck(16).eval()
+    with torch.no_grad():
+        for m in nk.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.6, 1.4)
+                m.bias.uniform_(-0.2, 0.2)
+        nk.weight.mul_(0.1)
+    nk = nk.double()
+    x = torch.randn(2, 16, 40, 44, dtype=torch.float64)
+    with torch.no_grad():
+        want = nk(x)
+        xin = nk.pre_conv(x)
+        wa, wds, shift = fold_aspp(nk)
+        got = F.conv2d(xin, wa.double())
+        for wd, d in zip(wds, (1, 6, 12, 18)):
+            got = got + F.conv2d(xin, wd.double(), None, 1, d, d)
+        got = torch.relu(got + shift.double().view(1, -1, 1, 1))
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)   # the fold itself is computed in fp32

@@ -161,3 +161,19 @@ def test_conv3x3_row_dirty_workspace(cin, cout, stride):
         assert torch.equal(got, ref), f"frame {frame}"
         seg_active = torch.nn.functional.max_pool1d(mask.float(), 32, 32, ceil_mode=True) > 0
         assert torch.equal(ws[1] != 0, seg_active), "row_dirty must equal the active row segments after a call"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,relu", [(1, True), (5, True), (5, False), (8, True)])
+def test_sum_bias_act_matches_torch(n, relu):
+    from pillarnext_amd import ops
+
+    torch.manual_seed(n)
+    parts = [torch.randn(2, 32, 19, 23, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(n)]
+    bias = torch.randn(32, device="cuda")
+    got = ops.sum_bias_act(parts, bias, relu)
+    want = sum(p.float() for p in parts) + bias.view(1, -1, 1, 1)
+    if relu:
+        want = torch.relu(want)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(got.float(), want.to(torch.bfloat16).float(), rtol=0, atol=0)   # fp32 sum in the same order, one rounding

@@ -262,7 +262,9 @@ def test_fused_training_equals_unfused_autograd_full_size(monkeypatch):
         torch.testing.assert_close(a.float(), b.float(), rtol=1e-5, atol=1e-6)
     n = tp.shape[0]
     assert res["0"][2] > 6 * n * 64 * 4        # autograd keeps several (N',64) fp32 tensors alive
-    assert res["1"][2] < 0.5 * res["0"][2]     # the fused passes keep the sorted records (64 B per point) and the partial sums
+    # the fused passes keep the sorted records (64 B per point) and the per-workgroup partial sums instead: at least four of those
+    # (N',64) fp32 tensors less (the canvas itself, ~1 GB at this grid, is in both numbers)
+    assert res["1"][2] < res["0"][2] - 4 * n * 64 * 4
     print(f"peak extra memory: fused {res['1'][2] / 2**20:.0f} MiB, autograd {res['0'][2] / 2**20:.0f} MiB for {n} points")
 
 
