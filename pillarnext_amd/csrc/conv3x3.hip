@@ -9,7 +9,8 @@
 // fragments (weights) are pre-arranged on the host in fragment order.  Kernels in this file:
 //   k_conv3x3          direct: B fragments straight from L1/L2 (strided layers; every input line is re-read 9 times)
 //   k_conv3x3_lds      stride 1, 64 input channels: 18x34 halo tile staged once in LDS, 1..7 passes of 64 output channels
-//   k_conv3x3_lds128   stride 1, 128 -> 128: 10x34 tile, two input slabs through one LDS buffer under live accumulators
+//   k_conv3x3_ldsx     stride 1, 128 -> 128 and 256 -> 256: 10x34 tile, 64-channel input slabs through one LDS buffer under live
+//                      accumulators, 128 output channels per pass
 //   k_sephead_out      block-diagonal 16-output convolution closing the merged SepHead branches (16x16x32 MFMA)
 // Rows/tiles without an active site skip their MFMAs (and, with row_dirty, their HBM traffic) -- that is where the sparsity of
 // the BEV map pays in a dense layout; bias and residual start the accumulators, the epilogue (ReLU, mask, bf16 pack) writes
@@ -587,67 +588,90 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
   CT_FLUSH
 }
 
-// ---- 128 -> 128 channels, stride 1 (stage 1 of the backbone).  Same machinery on an 8 x 32 pixel tile: the 4 waves are 2 row
-// groups x 2 output-channel halves (4 rows x 64 channels of accumulators each, as above), the two 64-channel input slabs pass
-// through the same 43.5 KiB LDS buffer one after the other (accumulators stay in registers across the re-staging), so 2
-// workgroups share a CU.  Barriers sit inside the per-row-count switch: every wave of the workgroup executes the same number
-// of them whatever its NR (s_barrier counts arrivals, not program counters).
+// ---- CIN -> COUT channels in multiples of 64 / 128, stride 1: 8 x 32 pixel tiles, 64-channel input slabs through one LDS buffer
 constexpr int L128_TH = 8;
 constexpr int L128_NSTAGE = (L128_TH + 2) * LDS_HW * 8;
 
-template <int NR, bool HAS_RES>
-__device__ __forceinline__ void conv_rows128(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
-                                             const float* __restrict__ bias, const uint4 (&rq)[4][2][2], const int (&rbase)[4], const uint32_t (&rmask)[4],
-                                             uint16_t* const (&yrow)[4], int b, int H, int W, int y0, int x0, uint32_t need, int mg, int relu, int px,
-                                             int kb, int lane) {
-  v16f acc[NR > 0 ? NR : 1][2];
-  if (NR > 0) {
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-      const v16f bq = bias_tile(bias, (mg + m) * 32, kb);
-#pragma unroll
-      for (int j = 0; j < NR; j++) acc[j][m] = bq;
-    }
-    if (HAS_RES) {
-#pragma unroll
-      for (int j = 0; j < NR; j++) add_residual(acc[j], rq[j]);
-    }
-    conv_taps<(NR > 0 ? NR : 1), 4, 8>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 0);
-  }
-  __syncthreads();  // slab 0 consumed
-  stage_tile64<128, L128_TH>(s_in, x, b, H, W, 64, y0, x0, need);
-  __syncthreads();
-  if (NR > 0) {
-    conv_taps<(NR > 0 ? NR : 1), 4, 8>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 4);
-    const int n_valid = W - x0;
-#pragma unroll
-    for (int j = 0; j < NR; j++) {
-      const bool act = (rmask[j] >> px) & 1u;
-      uint4 D[4];
+int next_sched_slot() {
+  static unsigned int n = 0;  // one host thread per process drives the launches (pnx.h: not thread-safe)
+  return (int)(n++ & 63u);
+}
+
+// 128 -> 128 (stage 1) and 256 -> 256 (stages 2 and 3 of the backbone, sparse_resnet.py:50-68).  Per tile, COUT/128 passes (the 4
+// waves = 2 row groups x 2 groups of 64 output channels, 4 rows x 64 channels of accumulators each) over CIN/64 input slabs that
+// go through the one 43.5 KiB LDS buffer under live accumulators, so 2 workgroups share a CU.  Every (pass, slab) step is
+// bracketed by the same two barriers in every wave, whatever its row count (s_barrier counts arrivals, not program counters).
+// The residual of a pass is loaded right before it is added: holding the lines from the top of the tile (as the 64-channel
+// kernel does) cost 64-128 VGPRs and ~90 spilled registers here -- measured on the stage-1 LiDAR mask, 128 -> 128 with residual:
+// 653 us with early loads, 567 us with late ones.
+template <int NR, int CIN, int COUT, bool HAS_RES>
+__device__ __forceinline__ void conv_rows_x(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
+                                            const float* __restrict__ bias, const uint16_t* __restrict__ res, const int (&rrow)[4],
+                                            const int (&rbase)[4], const uint32_t (&rmask)[4], uint16_t* const (&yrow)[4], int b, int H, int W,
+                                            int y0, int x0, uint32_t need, int mg0, int relu, int px, int kb, int lane) {
+  constexpr int NH = COUT / 128, NS = CIN / 64, NRA = NR > 0 ? NR : 1;
+  const int ox = x0 + px;
+#pragma unroll 1
+  for (int h = 0; h < NH; h++) {
+    const int mg = mg0 + 4 * h;
+    v16f acc[NRA][2];
+    if (NR > 0) {
 #pragma unroll
       for (int m = 0; m < 2; m++) {
-        uint4 pk[2];
-        pack_tile(acc[j][m], act, relu, pk);
-        D[2 * m] = pk[0], D[2 * m + 1] = pk[1];
+        const v16f bq = bias_tile(bias, (mg + m) * 32, kb);
+#pragma unroll
+        for (int j = 0; j < NR; j++) acc[j][m] = bq;
       }
-      transpose_row64(D, lane);
-      store_row64<128>(D, yrow[j] + mg * 32, n_valid, lane);
+      if (HAS_RES) {
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+          uint4 rq[2][2];
+          load_residual(rq, res + (((int64_t)b * H + (y0 + rrow[j])) * W + (ox < W ? ox : 0)) * COUT + mg * 32, (rmask[j] >> px) & 1u, kb);
+          add_residual(acc[j], rq);
+        }
+      }
+    }
+#pragma unroll 1
+    for (int sl = 0; sl < NS; sl++) {
+      if (h | sl) {
+        __syncthreads();  // previous slab consumed
+        stage_tile64<CIN, L128_TH>(s_in, x, b, H, W, 64 * sl, y0, x0, need);
+        __syncthreads();
+      }
+      if (NR > 0) conv_taps<NRA, COUT / 32, CIN / 16>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 4 * sl);
+    }
+    if (NR > 0) {
+      const int n_valid = W - x0;
+#pragma unroll
+      for (int j = 0; j < NR; j++) {
+        const bool act = (rmask[j] >> px) & 1u;
+        uint4 D[4];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          uint4 pk[2];
+          pack_tile(acc[j][m], act, relu, pk);
+          D[2 * m] = pk[0], D[2 * m + 1] = pk[1];
+        }
+        transpose_row64(D, lane);
+        store_row64<COUT>(D, yrow[j] + mg * 32, n_valid, lane);
+      }
     }
   }
 }
 
-template <bool HAS_RES>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
-                                                        const float* __restrict__ bias, const uint16_t* __restrict__ res,
-                                                        const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
-                                                        int relu, uint8_t* __restrict__ row_dirty, int slot) {
-  constexpr int CIN = 128, COUT = 128, TH = L128_TH, HW_ = LDS_HW;
+template <int CIN, int COUT, bool HAS_RES>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
+                                                      const float* __restrict__ bias, const uint16_t* __restrict__ res,
+                                                      const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
+                                                      int relu, uint8_t* __restrict__ row_dirty, int slot) {
+  static_assert(CIN % 64 == 0 && COUT % 128 == 0, "64-channel input slabs, 128-channel output passes");
+  constexpr int TH = L128_TH, HW_ = LDS_HW;
   __shared__ uint4 s_in[L128_NSTAGE];
-  __shared__ uint32_t s_rowmask2[2 * TH];  // double-buffered by iteration parity: an empty tile has a single barrier (see s_next)
+  __shared__ uint32_t s_rowmask2[2 * TH];  // double-buffered by iteration parity (an empty tile has a single barrier)
   __shared__ unsigned int s_next[2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int px = lane & 31, kb = lane >> 5;
-  const int rg = wv & 1, mg = 2 * (wv >> 1);  // row group, first 32-channel output tile of this wave
+  const int rg = wv & 1, mg0 = 2 * (wv >> 1);  // row group, first 32-channel output tile of this wave within a pass
   const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
   const int64_t n_tiles = (int64_t)B * tiles_y * tiles_x;
   int64_t next = 0;
@@ -660,10 +684,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __res
     const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
     const int x0 = tx * 32, y0 = ty * TH;
     const int ox = x0 + px;
-    // ---- active sites: one 32-bit column mask per row of the tile (wave wv looks at rows 2wv, 2wv+1)
     bool was[2];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < 2; j++) {  // active sites: one 32-bit column mask per row of the tile (wave wv looks at rows 2wv, 2wv+1)
       const int oy = y0 + wv * 2 + j;
       const bool a = ox < W && oy < H && (mask == nullptr || mask[((int64_t)b * H + oy) * W + ox] != 0);
       was[j] = true;
@@ -687,10 +710,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __res
       if (row_dirty != nullptr && oy < H && lane == 0 && was[j] != active) row_dirty[((int64_t)b * H + oy) * tiles_x + tx] = active ? 1 : 0;
     }
     if (am == 0) continue;  // uniform over the workgroup
-    // ---- the active rows, dealt round-robin to the 2 row groups
     int nr = 0;
     int rbase[4], rrow[4];
-    {
+    {  // the active rows, dealt round-robin to the 2 row groups
       uint32_t rest = am;
       if (rg && rest) rest &= rest - 1;
 #pragma unroll
@@ -712,41 +734,33 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds128(const uint16_t* __res
       yrow[j] = y + (((int64_t)b * H + (y0 + rrow[j])) * W + x0) * COUT;
     }
     const uint32_t need = am | (am << 1) | (am << 2);  // halo rows some active row reads
-    uint4 rq[4][2][2];
-    if (HAS_RES) {
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        load_residual(rq[j], res + (((int64_t)b * H + (y0 + rrow[j])) * W + (ox < W ? ox : 0)) * COUT + mg * 32, (rmask[j] >> px) & 1u, kb);
-    }
     stage_tile64<CIN, TH>(s_in, x, b, H, W, 0, y0, x0, need);
     __syncthreads();
-    switch (nr) {  // wave-uniform; every case runs the same two barriers
-      case 0: conv_rows128<0, HAS_RES>(s_in, x, wfrag, bias, rq, rbase, rmask, yrow, b, H, W, y0, x0, need, mg, relu, px, kb, lane); break;
-      case 1: conv_rows128<1, HAS_RES>(s_in, x, wfrag, bias, rq, rbase, rmask, yrow, b, H, W, y0, x0, need, mg, relu, px, kb, lane); break;
-      case 2: conv_rows128<2, HAS_RES>(s_in, x, wfrag, bias, rq, rbase, rmask, yrow, b, H, W, y0, x0, need, mg, relu, px, kb, lane); break;
-      case 3: conv_rows128<3, HAS_RES>(s_in, x, wfrag, bias, rq, rbase, rmask, yrow, b, H, W, y0, x0, need, mg, relu, px, kb, lane); break;
-      default: conv_rows128<4, HAS_RES>(s_in, x, wfrag, bias, rq, rbase, rmask, yrow, b, H, W, y0, x0, need, mg, relu, px, kb, lane); break;
+#define PNX_ROWS_X(N_) conv_rows_x<N_, CIN, COUT, HAS_RES>(s_in, x, wfrag, bias, res, rrow, rbase, rmask, yrow, b, H, W, y0, x0, need, mg0, relu, px, kb, lane)
+    switch (nr) {  // wave-uniform; every case runs the same barriers
+      case 0: PNX_ROWS_X(0); break;
+      case 1: PNX_ROWS_X(1); break;
+      case 2: PNX_ROWS_X(2); break;
+      case 3: PNX_ROWS_X(3); break;
+      default: PNX_ROWS_X(4); break;
     }
+#undef PNX_ROWS_X
   }
   sched_done(slot);
 }
 
-int next_sched_slot() {
-  static unsigned int n = 0;  // one host thread per process drives the launches (pnx.h: not thread-safe)
-  return (int)(n++ & 63u);
-}
-
-int launch_lds128(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
-                  uint8_t* row_dirty, hipStream_t st) {
+template <int CIN, int COUT>
+int launch_ldsx(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
+                uint8_t* row_dirty, hipStream_t st) {
   const int slot = mask != nullptr ? next_sched_slot() : -1;
   int64_t nb = (int64_t)B * ((H + L128_TH - 1) / L128_TH) * ((W + 31) / 32);
   if (nb > 512) nb = 512;  // resident workgroups: 2 per CU (registers)
   if (res != nullptr)
-    k_conv3x3_lds128<true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B, H, W,
-                                                        relu, row_dirty, slot);
+    k_conv3x3_ldsx<CIN, COUT, true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y,
+                                                                 B, H, W, relu, row_dirty, slot);
   else
-    k_conv3x3_lds128<false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu,
-                                                         row_dirty, slot);
+    k_conv3x3_ldsx<CIN, COUT, false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W,
+                                                                  relu, row_dirty, slot);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -928,7 +942,8 @@ int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const 
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1 && getenv("PNX_CONV_DIRECT") == nullptr) {
     if (cin == 64 && cout == 64) return launch_lds<64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
-    if (cin == 128 && cout == 128) return launch_lds128(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
+    if (cin == 128 && cout == 128) return launch_ldsx<128, 128>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
+    if (cin == 256 && cout == 256) return launch_ldsx<256, 256>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
     if (cin == 64 && cout == 384) return launch_lds<384>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
     if (cin == 64 && cout == 320) return launch_lds<320>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
     if (cin == 64 && cout == 448) return launch_lds<448>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);

@@ -583,7 +583,8 @@ class _HipSepHeadOut(nn.Module):
 
 def _backbone_conv(weight, bias, stride, padding, dtype, hip_conv):
     co, ci, kh, kw = weight.shape
-    if hip_conv and dtype == torch.bfloat16 and (kh, kw) == (3, 3) and padding == 1 and (ci, co) in ops.CONV3X3_SHAPES and stride in (1, 2):
+    shapes = ops.CONV3X3_SHAPES_S1 if stride == 1 else ops.CONV3X3_SHAPES
+    if hip_conv and dtype == torch.bfloat16 and (kh, kw) == (3, 3) and padding == 1 and (ci, co) in shapes and stride in (1, 2):
         return _HipConv3x3(weight, bias, stride)
     return _FusedConv(weight, bias, stride, padding, dtype=dtype)
 
@@ -700,7 +701,7 @@ class FusedPillarNeXt(nn.Module):
 
             def run(m, inp, res=None):
                 nonlocal k
-                if ws is None:
+                if ws is None or not isinstance(m, _HipConv3x3):   # the strided entry conv of a 256-channel stage is MIOpen + epilogue
                     return m(inp, mask, residual=res)
                 k += 1                                  # x, y, out of a block sit in three different buffers
                 return m(inp, mask, residual=res, out=ws[(k - 1) % 3])
@@ -738,14 +739,15 @@ class FusedPillarNeXt(nn.Module):
         return preds
 
     def _stage_workspace(self, si, mods, mask):
-        """Three persistent (activation, row_dirty) pairs per all-HIP backbone stage: the convolutions then touch only the row
+        """Three persistent (activation, row_dirty) pairs per backbone stage for its HIP convolutions: they then touch only the row
         segments that hold (or held, one frame ago) active sites -- ops.conv3x3_workspace / pnx.h row_dirty."""
-        if not self.sparse_ws or not all(isinstance(m, _HipConv3x3) for m in mods):
+        if not self.sparse_ws or not any(isinstance(m, _HipConv3x3) for m in mods):
             return None
         B, H, W = mask.shape
         key = (si, B, H, W, mask.device)
         if key not in self._ws:
-            self._ws[key] = [ops.conv3x3_workspace(B, mods[0].cout, H, W, mask.device) for _ in range(3)]
+            cout = next(m.cout for m in mods if isinstance(m, _HipConv3x3))
+            self._ws[key] = [ops.conv3x3_workspace(B, cout, H, W, mask.device) for _ in range(3)]
         return self._ws[key]
 
     def decoder(self):

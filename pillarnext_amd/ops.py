@@ -218,7 +218,8 @@ def mask_pool3(mask, stride):
 
 
 CONV3X3_SHAPES = {(64, 64), (64, 128), (128, 128)}           # backbone (stride 1 or 2)
-CONV3X3_SHAPES_S1 = CONV3X3_SHAPES | {(64, 320), (64, 384), (64, 448)}  # + merged SepHead branches (5/6/7 x 64), stride 1 only
+# stride 1 only: + merged SepHead branches (5/6/7 x 64) and the 256-channel blocks of backbone stages 2-3
+CONV3X3_SHAPES_S1 = CONV3X3_SHAPES | {(64, 320), (64, 384), (64, 448), (256, 256)}
 
 
 def conv3x3_pack_weights(w):

@@ -28,13 +28,15 @@ def test_kernel_routing_and_workspace_policy():
     fused = models.FusedPillarNeXt(_detector(), hip_conv=True)
     kinds = [[type(m).__name__ for m in st] for st in fused.stages]
     assert all(k == "_HipConv3x3" for k in kinds[0] + kinds[1]), kinds          # 64- and 128-channel stages: HIP kernels
-    assert all(k == "_FusedConv" for k in kinds[2] + kinds[3]), kinds           # 256-channel stages: MIOpen + HIP epilogue
+    for st in (2, 3):   # 256-channel stages: the strided entry conv is MIOpen + HIP epilogue, the four block convs are HIP kernels
+        assert kinds[st] == ["_FusedConv"] + ["_HipConv3x3"] * 4, kinds
     assert [type(m).__name__ for m in fused.task_conv1] == ["_HipConv3x3"] * 2   # merged SepHead conv 64 -> 64 * branches
     assert [type(m).__name__ for m in fused.task_conv2] == ["_HipSepHeadOut"] * 2
     assert fused.task_chans == [16, 16]
     # sparse workspaces only for all-HIP stages, and only when enabled
     mask = torch.zeros((2, 8, 8), dtype=torch.uint8)
-    assert fused._stage_workspace(2, fused.stages[2], mask) is None
+    ws2 = fused._stage_workspace(2, fused.stages[2], mask)
+    assert len(ws2) == 3 and tuple(ws2[0][0].shape) == (2, 256, 8, 8)           # for the four HIP convs of the stage
     fused.sparse_ws = False
     assert fused._stage_workspace(0, fused.stages[0], mask) is None
     off = models.FusedPillarNeXt(_detector(), hip_conv=False)
