@@ -392,9 +392,19 @@ __device__ __forceinline__ void stage_tile64(uint4* __restrict__ s_in, const uin
 // One 64-output-channel pass of a wave over its NR rows: 9 taps x 4 k-steps, software-pipelined in registers -- B fragments one
 // k-step ahead (LDS), weight fragments one tap ahead (L1/L2; each register pair is refilled for the next tap right after its
 // last MFMA of this tap).
-template <int NR, int MTALL, int CB = 4>
+// STRIDE 2 (stage_tile64_s2): a halo row is [even input columns 0..31 | odd input columns 32..64] and has S2_RS slots, so that the 32
+// lanes of a tap still read 32 consecutive slots: tap column dx of output pixel px is input column 2 px + dx - 1 (relative to the
+// tile), i.e. slot px of the even plane for dx = 1 and slot px + dx/2 of the odd plane otherwise; row dy of output row r is halo
+// row 2 r + dy (the caller folds 2 r into rbase).
+constexpr int S2_RS = 65;
+template <int STRIDE>
+__device__ __forceinline__ int tap_slot(int px, int dx) {
+  return STRIDE == 1 ? px + dx : (dx == 1 ? px : 32 + px + (dx >> 1));
+}
+template <int NR, int MTALL, int CB = 4, int STRIDE = 1>
 __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __restrict__ s_in, const uint4* __restrict__ wfrag, const int (&rbase)[4],
                                           int mg, int px, int kb, int lane, int kstep0 = 0) {
+  constexpr int RS = STRIDE == 1 ? LDS_HW : S2_RS;
   uint4 w[4][2];
 #pragma unroll
   for (int cbl = 0; cbl < 4; cbl++)
@@ -402,18 +412,18 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __res
     for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[((kstep0 + cbl) * MTALL + mg + m) * 64 + lane];
   uint4 qn[NR];
   {
-    const int sw = lds_swz(px);
+    const int c0 = tap_slot<STRIDE>(px, 0), sw = lds_swz(c0);
 #pragma unroll
-    for (int j = 0; j < NR; j++) qn[j] = s_in[rbase[j] + px * 8 + (kb ^ sw)];
+    for (int j = 0; j < NR; j++) qn[j] = s_in[rbase[j] + c0 * 8 + (kb ^ sw)];
   }
 #pragma unroll 1
   for (int tap = 0; tap < 9; tap++) {  // not unrolled: a full unroll spills
     const int tn = tap + 1;
     const int dyn = tn / 3, dxn = tn - 3 * dyn;  // next tap (halo coordinates: +1 already included)
     const int dy = tap / 3, dx = tap - 3 * dy;
-    const int c = px + dx, cn = px + dxn;
+    const int c = tap_slot<STRIDE>(px, dx), cn = tap_slot<STRIDE>(px, dxn);
     const int sw = lds_swz(c), swn = lds_swz(cn);
-    const int cbase = (dy * LDS_HW + c) * 8, cbasen = (dyn * LDS_HW + cn) * 8;
+    const int cbase = (dy * RS + c) * 8, cbasen = (dyn * RS + cn) * 8;
 #pragma unroll
     for (int cbl = 0; cbl < 4; cbl++) {
       uint4 qc[NR];
@@ -765,6 +775,205 @@ int launch_ldsx(const void* x, const void* wfrag, const float* bias, const void*
   return PNX_OK;
 }
 
+// ---- stride 2 (the entry convolution of backbone stages 1-3: 64 -> 128, 128 -> 256, 256 -> 256; sparse_resnet.py:50-68, SparseConv2d).
+// Output tile 4 rows x 32 pixels; its 9 x 65 input halo of one 64-channel slab is staged de-interleaved (even columns, then odd
+// columns) so that the tap loop above reads consecutive slots.  74.9 KB of LDS: 2 workgroups per CU.
+constexpr int S2_TH = 4;
+constexpr int S2_ROWS = 2 * S2_TH + 1;
+constexpr int S2_NSTAGE = S2_ROWS * S2_RS * 8;
+
+// Halo rows iy0 + r (r = 0..8, `need` bit r), input columns ix0 + c (c = 0..64) of channels [ch0, ch0 + 64): slot c/2 of the even
+// plane for odd c (= even input column 2 x0 + ...: ix0 = 2 x0 - 1 is odd), slot 32 + c/2 of the odd plane for even c.  Thread t
+// owns 16-byte chunk t & 7 of plane slot t >> 3; as in stage_tile64 the rows go global -> LDS directly and the XOR swizzle is
+// applied on the source side.  Slot 64 (c = 64) keeps the register path.
+template <int CSTRIDE>
+__device__ __forceinline__ void stage_tile64_s2(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, int b, int H, int W, int ch0, int iy0,
+                                                int ix0, uint32_t need) {
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // opaque: keeps the per-thread staging addresses out of the tile loop's live ranges
+  const int slot = tid & 7, col = tid >> 3, wbase = (tid >> 6) * 8;
+  const uint16_t* xb = x + (int64_t)b * H * W * CSTRIDE + ch0;
+#pragma unroll
+  for (int pl = 0; pl < 2; pl++) {        // pl 0: even plane (c = 2 col + 1), pl 1: odd plane (c = 2 col)
+    const int ls = pl * 32 + col;         // LDS slot of this thread's column
+    const int ix = ix0 + 2 * col + (1 - pl);
+    const bool col_ok = (unsigned)ix < (unsigned)W;
+    const int chunk = slot ^ lds_swz(ls);
+#pragma unroll
+    for (int r = 0; r < S2_ROWS; r++) {
+      if (!((need >> r) & 1u)) continue;  // wave-uniform
+      const int iy = iy0 + r;
+      if ((unsigned)iy < (unsigned)H && col_ok) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(xb + ((int64_t)iy * W + ix) * CSTRIDE + chunk * 8),
+                                         (lptr_t)(s_in + (r * S2_RS + pl * 32 + wbase) * 8), 16, 0, 0);
+      } else {
+        s_in[(r * S2_RS + ls) * 8 + slot] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  }
+  if (tid < S2_ROWS * 8) {  // slot 64: input column ix0 + 64
+    const int re = tid >> 3, ce = tid & 7;
+    if ((need >> re) & 1u) {
+      const int iy = iy0 + re, ix = ix0 + 64;
+      uint4 qe = make_uint4(0, 0, 0, 0);
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) qe = *reinterpret_cast<const uint4*>(xb + ((int64_t)iy * W + ix) * CSTRIDE + ce * 8);
+      s_in[(re * S2_RS + 64) * 8 + (ce ^ lds_swz(64))] = qe;
+    }
+  }
+}
+
+template <int NR, int CIN, int COUT>
+__device__ __forceinline__ void conv_rows_s2(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
+                                             const float* __restrict__ bias, const int (&rbase)[4], const uint32_t (&rmask)[4],
+                                             uint16_t* const (&yrow)[4], int b, int H, int W, int iy0, int ix0, int n_valid, uint32_t need, int mg,
+                                             int relu, int px, int kb, int lane) {
+  constexpr int NS = CIN / 64, NRA = NR > 0 ? NR : 1;
+  v16f acc[NRA][2];
+  if (NR > 0) {
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      const v16f bq = bias_tile(bias, (mg + m) * 32, kb);
+#pragma unroll
+      for (int j = 0; j < NR; j++) acc[j][m] = bq;
+    }
+  }
+#pragma unroll 1
+  for (int sl = 0; sl < NS; sl++) {
+    if (sl) {
+      __syncthreads();  // previous slab consumed
+      stage_tile64_s2<CIN>(s_in, x, b, H, W, 64 * sl, iy0, ix0, need);
+      __syncthreads();
+    }
+    if (NR > 0) conv_taps<NRA, COUT / 32, CIN / 16, 2>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 4 * sl);
+  }
+  if (NR > 0) {
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+      const bool act = (rmask[j] >> px) & 1u;
+      uint4 D[4];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        uint4 pk[2];
+        pack_tile(acc[j][m], act, relu, pk);
+        D[2 * m] = pk[0], D[2 * m + 1] = pk[1];
+      }
+      transpose_row64(D, lane);
+      store_row64<COUT>(D, yrow[j] + mg * 32, n_valid, lane);
+    }
+  }
+}
+
+// H, W: input; Ho, Wo: output.  The 4 waves are COUT/64 groups of 64 output channels x 4/(COUT/64) row groups.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_s2(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                    const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W, int Ho, int Wo,
+                                                    int relu, uint8_t* __restrict__ row_dirty, int slot) {
+  static_assert(CIN % 64 == 0 && (COUT == 128 || COUT == 256), "64-channel input slabs; 2 or 4 groups of 64 output channels");
+  constexpr int TH = S2_TH, NCG = COUT / 64, NRG = 4 / NCG, NRMAX = TH / NRG;
+  extern __shared__ uint4 s_in[];  // S2_NSTAGE
+  __shared__ uint32_t s_rowmask2[2 * TH];
+  __shared__ unsigned int s_next[2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int px = lane & 31, kb = lane >> 5;
+  const int rg = wv % NRG, mg = 2 * (wv / NRG);
+  const int tiles_x = (Wo + 31) >> 5, tiles_y = (Ho + TH - 1) / TH;
+  const int64_t n_tiles = (int64_t)B * tiles_y * tiles_x;
+  int64_t next = 0;
+  int it = 0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile = next, it++) {
+    sched_draw(s_next, it, slot);
+    uint32_t* const s_rowmask = s_rowmask2 + (it & 1) * TH;
+    const int tx = (int)(tile % tiles_x);
+    const int ty = (int)((tile / tiles_x) % tiles_y);
+    const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
+    const int x0 = tx * 32, y0 = ty * TH;
+    const int ox = x0 + px;
+    bool was = true;
+    {  // active sites: wave wv looks at output row wv of the tile
+      const int oy = y0 + wv;
+      const bool a = ox < Wo && oy < Ho && (mask == nullptr || mask[((int64_t)b * Ho + oy) * Wo + ox] != 0);
+      if (row_dirty != nullptr && oy < Ho) was = __builtin_amdgcn_readfirstlane((int)row_dirty[((int64_t)b * Ho + oy) * tiles_x + tx]) != 0;
+      const uint32_t bal = (uint32_t)__ballot(a);
+      if (lane == 0) s_rowmask[wv] = bal;
+    }
+    __syncthreads();  // row masks visible; everybody is done reading the previous tile's s_in
+    next = sched_next(s_next, it, slot, tile);
+    const uint32_t my_rm = s_rowmask[lane & 3];
+    const uint32_t am = (uint32_t)__ballot(my_rm != 0) & 0xfu;
+    {  // a row without any active site: zero-fill where needed
+      const int oy = y0 + wv;
+      const bool active = (am >> wv) & 1u;
+      if (!active && was && oy < Ho && ox < Wo) {
+        uint4* dst = reinterpret_cast<uint4*>(y + (((int64_t)b * Ho + oy) * Wo + ox) * COUT);
+#pragma unroll 1
+        for (int ch = kb; ch < COUT / 8; ch += 2) dst[ch] = make_uint4(0, 0, 0, 0);
+      }
+      if (row_dirty != nullptr && oy < Ho && lane == 0 && was != active) row_dirty[((int64_t)b * Ho + oy) * tiles_x + tx] = active ? 1 : 0;
+    }
+    if (am == 0) continue;  // uniform over the workgroup
+    int nr = 0;
+    int rbase[4], rrow[4];
+    {  // the active rows, dealt round-robin to the row groups
+      uint32_t rest = am;
+      for (int k = 0; k < rg && rest; k++) rest &= rest - 1;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool has = j < NRMAX && rest != 0;
+        rrow[j] = has ? __builtin_ctz(rest) : 0;  // dummy rows point at row 0
+        nr += has ? 1 : 0;
+        for (int k = 0; k < NRG && rest; k++) rest &= rest - 1;
+      }
+    }
+    nr = __builtin_amdgcn_readfirstlane(nr);
+    uint32_t rmask[4];
+    uint16_t* yrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      rrow[j] = __builtin_amdgcn_readfirstlane(rrow[j]);
+      rbase[j] = 2 * rrow[j] * S2_RS * 8;
+      rmask[j] = j < nr ? __builtin_amdgcn_readfirstlane(s_rowmask[rrow[j]]) : 0u;
+      yrow[j] = y + (((int64_t)b * Ho + (y0 + rrow[j])) * Wo + x0) * COUT;
+    }
+    uint32_t need = 0;  // halo rows some active output row reads: rows 2r, 2r+1, 2r+2
+#pragma unroll
+    for (int r = 0; r < TH; r++)
+      if ((am >> r) & 1u) need |= 7u << (2 * r);
+    const int iy0 = 2 * y0 - 1, ix0 = 2 * x0 - 1;
+    stage_tile64_s2<CIN>(s_in, x, b, H, W, 0, iy0, ix0, need);
+    __syncthreads();
+#define PNX_ROWS_S2(N_) conv_rows_s2<(N_ <= NRMAX ? N_ : NRMAX), CIN, COUT>(s_in, x, wfrag, bias, rbase, rmask, yrow, b, H, W, iy0, ix0, Wo - x0, need, mg, relu, px, kb, lane)
+    switch (nr) {  // wave-uniform; every case runs the same barriers
+      case 0: PNX_ROWS_S2(0); break;
+      case 1: PNX_ROWS_S2(1); break;
+      case 2: PNX_ROWS_S2(2); break;
+      case 3: PNX_ROWS_S2(3); break;
+      default: PNX_ROWS_S2(4); break;
+    }
+#undef PNX_ROWS_S2
+  }
+  sched_done(slot);
+}
+
+template <int CIN, int COUT>
+int launch_s2(const void* x, const void* wfrag, const float* bias, const uint8_t* mask, void* y, int B, int H, int W, int Ho, int Wo, int relu,
+              uint8_t* row_dirty, hipStream_t st) {
+  const int slot = mask != nullptr ? next_sched_slot() : -1;
+  int64_t nb = (int64_t)B * ((Ho + S2_TH - 1) / S2_TH) * ((Wo + 31) / 32);
+  if (nb > 512) nb = 512;  // resident workgroups: 2 per CU (LDS and registers)
+  auto kern = k_conv3x3_s2<CIN, COUT>;
+  constexpr int lds = S2_NSTAGE * 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PNX_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  kern<<<(unsigned)nb, 256, lds, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, mask, (uint16_t*)y, B, H, W, Ho, Wo, relu, row_dirty, slot);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
 // ---- final convolution of the merged SepHead branches (det3d/models/heads/centerhead.py:12-59: Conv2d(64, k_j, 3) of every
 // branch j of a task).  The first (merged) convolution leaves NBR x 64 channels per pixel; branch j reads only its own 64, so
 // the stacked weight (sum k_j <= 16 outputs x NBR*64 inputs) is block diagonal.  HBM-bound by its input (768 B per pixel at
@@ -947,6 +1156,11 @@ int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const 
     if (cin == 64 && cout == 384) return launch_lds<384>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
     if (cin == 64 && cout == 320) return launch_lds<320>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
     if (cin == 64 && cout == 448) return launch_lds<448>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
+  }
+  if (stride == 2 && residual == nullptr && getenv("PNX_CONV_DIRECT") == nullptr) {
+    if (cin == 64 && cout == 128) return launch_s2<64, 128>(x, wfrag, bias, mask, y, batch, h, w, ho, wo, relu, row_dirty, st);
+    if (cin == 128 && cout == 256) return launch_s2<128, 256>(x, wfrag, bias, mask, y, batch, h, w, ho, wo, relu, row_dirty, st);
+    if (cin == 256 && cout == 256) return launch_s2<256, 256>(x, wfrag, bias, mask, y, batch, h, w, ho, wo, relu, row_dirty, st);
   }
 #define PNX_CONV_CASE(CI, CO)                                                                                          \
   if (cin == CI && cout == CO) {                                                                                       \

@@ -583,7 +583,7 @@ class _HipSepHeadOut(nn.Module):
 
 def _backbone_conv(weight, bias, stride, padding, dtype, hip_conv):
     co, ci, kh, kw = weight.shape
-    shapes = ops.CONV3X3_SHAPES_S1 if stride == 1 else ops.CONV3X3_SHAPES
+    shapes = ops.CONV3X3_SHAPES_S1 if stride == 1 else ops.CONV3X3_SHAPES_S2
     if hip_conv and dtype == torch.bfloat16 and (kh, kw) == (3, 3) and padding == 1 and (ci, co) in shapes and stride in (1, 2):
         return _HipConv3x3(weight, bias, stride)
     return _FusedConv(weight, bias, stride, padding, dtype=dtype)

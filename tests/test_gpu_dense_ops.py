@@ -54,7 +54,8 @@ def test_point_uploader_roundtrip():
         assert np.array_equal(np.unique(ref[:, 0]), [0, 1, 2])
 
 
-@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 128, 2), (128, 128, 1), (64, 64, 2), (64, 384, 1), (64, 320, 1), (256, 256, 1)])
+@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 128, 2), (128, 128, 1), (64, 64, 2), (64, 384, 1), (64, 320, 1), (256, 256, 1), (128, 256, 2),
+                                               (256, 256, 2)])
 @pytest.mark.parametrize("residual", [False, True])
 def test_conv3x3_masked_matches_torch(cin, cout, stride, residual):
     from pillarnext_amd import ops
@@ -136,7 +137,7 @@ def test_sephead_out_matches_torch(nb):
     torch.testing.assert_close(got, ref, rtol=1.6e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (128, 128, 1), (64, 128, 2), (256, 256, 1)])
+@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (128, 128, 1), (64, 128, 2), (256, 256, 1), (128, 256, 2), (256, 256, 2)])
 def test_conv3x3_row_dirty_workspace(cin, cout, stride):
     """Persistent output buffer + row_dirty flags (pnx.h): three frames with different active sets through ONE workspace must
     equal the stateless result every time -- stale rows of an earlier frame are cleared, untouched rows stay zero."""

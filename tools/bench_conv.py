@@ -9,7 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cin", type=int, default=64); ap.add_argument("--cout", type=int, default=64)
 ap.add_argument("--hw", type=int, default=1440); ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--density", type=float, default=1.0); ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--miopen", action="store_true"); ap.add_argument("--res", action="store_true")
+ap.add_argument("--stride", type=int, default=1); ap.add_argument("--miopen", action="store_true"); ap.add_argument("--res", action="store_true")
 ap.add_argument("--lidar", type=int, default=-1, help="backbone stage (0..3): active sites = the C2 sweep occupancy pooled to that stage (sets --hw)")
 a = ap.parse_args()
 lidar_mask = None
@@ -24,19 +24,23 @@ if a.lidar >= 0:
     ok = (xi >= 0) & (xi < nx) & (yi >= 0) & (yi < ny)
     occ = torch.zeros((a.batch, ny, nx), dtype=torch.uint8, device="cuda")
     occ[bi[ok], yi[ok], xi[ok]] = 1
+    occ_in = occ
     for _ in range(a.lidar):
-        occ = ops.mask_pool3(occ, 2)
+        occ_in, occ = occ, ops.mask_pool3(occ, 2)
     lidar_mask, a.hw = occ, occ.shape[-1]
+    if a.stride == 1:
+        occ_in = occ
     seg = torch.nn.functional.max_pool1d(occ.float(), 32, 32, ceil_mode=True)
     print(f"stage {a.lidar}: {a.hw}^2, active sites {occ.float().mean().item():.3f}, active 32-px row segments {seg.mean().item():.3f}")
 g = torch.Generator(device="cuda").manual_seed(0)
-x = torch.randn((a.batch, a.cin, a.hw, a.hw), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+hw_in = a.hw * a.stride
+x = torch.randn((a.batch, a.cin, hw_in, hw_in), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 w = (torch.randn((a.cout, a.cin, 3, 3), device="cuda", generator=g) / 24).to(torch.bfloat16)
 bias = torch.randn((a.cout,), device="cuda", generator=g)
 mask = (torch.rand((a.batch, a.hw, a.hw), device="cuda", generator=g) < a.density).to(torch.uint8) if a.density < 1 else None
 if lidar_mask is not None:
     mask = lidar_mask
-    x = (x * mask.unsqueeze(1)).contiguous(memory_format=torch.channels_last)
+    x = (x * occ_in.unsqueeze(1)).contiguous(memory_format=torch.channels_last)
 ws = ops.conv3x3_workspace(a.batch, a.cout, a.hw, a.hw, "cuda") if mask is not None and os.environ.get("PNX_BENCH_WS", "1") != "0" else None
 wf = ops.conv3x3_pack_weights(w)
 res = (x[:, :a.cout] * 1.0).contiguous(memory_format=torch.channels_last) if a.res and a.cout <= a.cin else None
@@ -44,9 +48,9 @@ wcl = w.contiguous(memory_format=torch.channels_last)
 torch.backends.cudnn.benchmark = True
 def run():
     if a.miopen:
-        y = torch.nn.functional.conv2d(x, wcl, None, 1, 1)
+        y = torch.nn.functional.conv2d(x, wcl, None, a.stride, 1)
         return ops.bias_act_mask_(y, bias, mask, res, True)
-    return ops.conv3x3_masked(x, wf, bias, a.cout, 1, mask, res, True, out=ws)
+    return ops.conv3x3_masked(x, wf, bias, a.cout, a.stride, mask, res, True, out=ws)
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -65,4 +69,4 @@ if L is not None and hasattr(L, "pnx_debug_conv_timers") and not a.miopen:
     names = ["rowmask+sync", "deal rows/zero rows", "residual loads + stage issue+write", "stage barrier", "taps + epilogue", "-", "-", "tile head"]
     tot = sum(buf)
     print("  section share of wave time:", ", ".join(f"{n} {100.0*v/tot:.1f}%" for n, v in zip(names, buf) if v))
-print(f"{'miopen+epilogue' if a.miopen else 'pnx_conv3x3'} {a.cin}->{a.cout} {a.hw}^2 b{a.batch} density {a.density}: {ms*1e3:.1f} us  {fl/ms/1e9:.0f} TFLOP/s (dense-equivalent)")
+print(f"{'miopen+epilogue' if a.miopen else 'pnx_conv3x3'} {a.cin}->{a.cout} {a.hw}^2 (stride {a.stride}) b{a.batch} density {a.density}: {ms*1e3:.1f} us  {fl/ms/1e9:.0f} TFLOP/s (dense-equivalent)")
