@@ -18,13 +18,13 @@
 //             rounding; tools/study_f16x3.py).  K is a contraction index, so the only layout requirement is that A and B put a
 //             channel into the same K slot: slot (step s, lane half kg, element e) = the channel lane-half kg already holds as its
 //             value 8s + e -- no transpose.  A tile whose pillar maximum would overflow fp16 (h0 >= 937) hands its pillars to
-//             k_pfn3_big (fp32 MFMA).  PNX_PFN_F16X3=0 selects the plain fp32 form: 64 MFMAs; shift + ReLU before the max (x -> relu(x + s) is monotone); the TAIL lane of every pillar writes the
+//             k_pfn3_tail (fp32 MFMA).  PNX_PFN_F16X3=0 selects the plain fp32 form: 64 MFMAs; shift + ReLU before the max (x -> relu(x + s) is monotone); the TAIL lane of every pillar writes the
 //             finished row, in NATURAL channel order, into the wave's private LDS rows
 //   store     8 lanes per pillar read 16-byte pieces of the finished rows and store them: one store instruction writes 8 complete
 //             128-byte lines (bf16) of the NHWC canvas (round 1: 16 instructions of scattered 8-byte pieces per tile)
 // Fused fill: blocks [0, n_fill) of the SAME launch run pnx_fill_tile over the 32x32-cell tiles (HBM-write bound, almost no
 // ALU), the other blocks run the PFN (MFMA bound, little HBM) -- the two roles overlap on every CU and each canvas byte is still
-// written exactly once.  Pillars with more than 32 points go to k_pfn3_big.
+// written exactly once.  Pillars with more than 32 points go to the big-pillar role blocks (pfn3_big_walk).
 #include <vector>
 
 #include "pnx_common.h"
@@ -169,16 +169,181 @@ __device__ __forceinline__ int64_t next_window(int32_t* tick, int& shard, int& t
   }
 }
 
-// counters: [0] = P, [1] = N' (kept points = sorted records), [3] = number of big pillars appended to biglist; tick = window tickets
+// Pillars with more than 32 points: one wave per pillar, two sweeps over its tiles (layer-0 max; layer 1 + max) with per-lane
+// running maxima, then one all-lane reduction per register.  Rare at PillarNeXt-B resolution, common only for coarse voxels.
+// k_bin_sort lists them (counters[3], biglist[0, bigcap)); a few role blocks of k_pfn3 take them by ticket (counters[5]) while the
+// other blocks run the tiled PFN, and k_pfn3_tail takes what is left plus the pillars of tiles that left the fp16x3 range
+// (counters[4], biglist[bigcap, 2 bigcap)).  fp32 MFMA with the unscaled weights in both cases.
+template <int F>
+struct BigWeights {
+  static constexpr int C0 = F + 5, KS = (C0 + 2) / 2;
+  float w0f[KS], w1a[32], w1b[32];
+  const float4* s1lane;
+  __device__ __forceinline__ void load(const float* __restrict__ P, int l) {
+    constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;
+    const float* __restrict__ FP = P + FR + l;
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) w0f[kk] = FP[kk * 64];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      w1a[i] = FP[(23 + i) * 64];
+      w1b[i] = FP[(55 + i) * 64];
+    }
+    s1lane = reinterpret_cast<const float4*>(P + FR + 64 * 89 + l * 32);
+  }
+};
+
+template <int F>
+__device__ __forceinline__ void pfn3_big_pillar(const int r, const BigWeights<F>& Wt, const uint4* __restrict__ rec, const uint32_t* __restrict__ pfirst,
+                                                const uint32_t* __restrict__ pcnt, const int32_t* __restrict__ cell_of_pillar, const Pfn3Out& out,
+                                                int col, int h) {
+  constexpr int KS = BigWeights<F>::KS;
+  const float* w0f = Wt.w0f;
+  const float* w1a = Wt.w1a;
+  const float* w1b = Wt.w1b;
+  const float4* __restrict__ s1lane = Wt.s1lane;
+  const uint32_t st = pfirst[r], c = pcnt[r];
+  float g0[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) g0[i] = 0.f;  // post-ReLU maxima
+  for (uint32_t t0 = 0; t0 < c; t0 += 32) {
+    const bool act = t0 + col < c;
+    const Half cur = load_half(rec, st + min(t0 + (uint32_t)col, c - 1), h);
+    const float ff[6] = {__uint_as_float(cur.a.x), __uint_as_float(cur.a.y), __uint_as_float(cur.a.z),
+                         __uint_as_float(cur.a.w), __uint_as_float(cur.b.x), __uint_as_float(cur.b.y)};
+    v16f d0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) d0[i] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], act ? ff[kk] : 0.f, d0);
+#pragma unroll
+    for (int i = 0; i < 16; i++) g0[i] = fmaxf(g0[i], act ? fmaxf(d0[i], 0.f) : 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) g0[i] = fmaxf(g0[i], __shfl_xor(g0[i], d));  // inside each half
+  }
+  const float NI = -__builtin_inff();
+  float pa[16], pb[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    pa[i] = NI;
+    pb[i] = NI;
+  }
+  for (uint32_t t0 = 0; t0 < c; t0 += 32) {
+    const bool act = t0 + col < c;
+    const Half cur = load_half(rec, st + min(t0 + (uint32_t)col, c - 1), h);
+    const float ff[6] = {__uint_as_float(cur.a.x), __uint_as_float(cur.a.y), __uint_as_float(cur.a.z),
+                         __uint_as_float(cur.a.w), __uint_as_float(cur.b.x), __uint_as_float(cur.b.y)};
+    v16f d0, da, db;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      d0[i] = 0.f;
+      da[i] = 0.f;
+      db[i] = 0.f;
+    }
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], act ? ff[kk] : 0.f, d0);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const float u = fmaxf(d0[i], 0.f);
+      da = PNX_MFMA(w1a[i], u, da);
+      db = PNX_MFMA(w1b[i], u, db);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      da = PNX_MFMA(w1a[16 + i], g0[i], da);
+      db = PNX_MFMA(w1b[16 + i], g0[i], db);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      pa[i] = fmaxf(pa[i], act ? da[i] : NI);
+      pb[i] = fmaxf(pb[i], act ? db[i] : NI);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {
+      pa[i] = fmaxf(pa[i], __shfl_xor(pa[i], d));
+      pb[i] = fmaxf(pb[i], __shfl_xor(pb[i], d));
+    }
+  }
+  if (col == 0) {  // one lane per half: its 2 x 16 channels as 4-channel pieces
+    const int64_t cell = (int64_t)cell_of_pillar[r];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float4 sa = s1lane[j], sb = s1lane[4 + j];
+      const float va[4] = {fmaxf(pa[4 * j] + sa.x, 0.f), fmaxf(pa[4 * j + 1] + sa.y, 0.f), fmaxf(pa[4 * j + 2] + sa.z, 0.f),
+                           fmaxf(pa[4 * j + 3] + sa.w, 0.f)};
+      const float vb[4] = {fmaxf(pb[4 * j] + sb.x, 0.f), fmaxf(pb[4 * j + 1] + sb.y, 0.f), fmaxf(pb[4 * j + 2] + sb.z, 0.f),
+                           fmaxf(pb[4 * j + 3] + sb.w, 0.f)};
+#pragma unroll
+      for (int half2 = 0; half2 < 2; half2++) {
+        const float* v = half2 ? vb : va;
+        const int chan0 = 32 * half2 + 8 * j + 4 * h;
+        if (out.g1 != nullptr && (int64_t)r < out.g1_rows)
+          *reinterpret_cast<float4*>(out.g1 + (int64_t)r * 64 + chan0) = make_float4(v[0], v[1], v[2], v[3]);
+        if (out.canvas != nullptr) {
+          if (out.dt == PNX_F32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(out.canvas) + cell * 64 + chan0) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 p;
+            if (out.dt == PNX_BF16) {
+              p.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
+              p.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
+            } else {
+              p.x = f16_rne(v[0]) | (f16_rne(v[1]) << 16);
+              p.y = f16_rne(v[2]) | (f16_rne(v[3]) << 16);
+            }
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out.canvas) + cell * 64 + chan0) = p;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ticketed walk over biglist[0, nbig): at most `cap` pillars per wave (cap < 0: no limit)
+template <int F>
+__device__ __forceinline__ void pfn3_big_walk(const BigWeights<F>& Wt, int32_t* counters, const int32_t* __restrict__ biglist, int nbig, int cap,
+                                              const uint4* __restrict__ rec, const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ pcnt,
+                                              const int32_t* __restrict__ cell_of_pillar, const Pfn3Out& out, int l) {
+  const int col = l & 31, h = l >> 5;
+  for (int done = 0; cap < 0 || done < cap; done++) {
+    int bi = 0;
+    if (l == 0) bi = atomicAdd(&counters[5], 1);
+    bi = __builtin_amdgcn_readfirstlane(bi);
+    if (bi >= nbig) break;
+    pfn3_big_pillar<F>(biglist[bi], Wt, rec, pfirst, pcnt, cell_of_pillar, out, col, h);
+  }
+}
+
+// counters: [0] = P, [1] = N' (kept points = sorted records), [3] = pillars of > 32 points (listed by k_bin_sort), [4] = pillars of
+// tiles outside the fp16x3 range, [5] = big-pillar tickets; tick = window tickets
+constexpr int kBigBlocks = 8;    // role blocks of k_pfn3 for the big pillars (32 waves)
+constexpr int kBigPerWave = 64;  // ... each wave takes at most this many; k_pfn3_tail takes the rest with a full grid
 template <int F, int R, int DT, bool PACK, bool H16>
 __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ pcnt,
-                                             int32_t* __restrict__ counters, int32_t* __restrict__ tick, int32_t* __restrict__ biglist, int bigcap,
-                                             const float* __restrict__ P, Pfn3Out out, int n_fill, PnxGeomDev g, PnxFillJob fj, int dbg) {
+                                             const int32_t* __restrict__ cell_of_pillar, int32_t* counters, int32_t* __restrict__ tick,
+                                             int32_t* __restrict__ biglist, int bigcap, const float* __restrict__ P, Pfn3Out out, int n_fill, int n_bigb,
+                                             PnxGeomDev g, PnxFillJob fj, int dbg) {
   constexpr int C0 = F + 5, KS = (C0 + 2) / 2;     // K = C0 features + the constant-1 column that carries the folded BN shift
   constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;  // start of the fragment-ordered block (k_fold_bn)
   __shared__ __align__(16) uint32_t s_lds[4 * kWaveLds];
   if ((int)blockIdx.x < n_fill) {  // ---- fill role (block-uniform): this launch's share of the zero-fill tiles
     pnx_fill_share_dt<DT>(fj, g, s_lds, threadIdx.x, 256);
+    return;
+  }
+  if ((int)blockIdx.x < n_fill + n_bigb) {  // ---- big-pillar role: the pillars k_bin_sort listed, one wave each, by ticket
+    int nbig = counters[3];
+    if (nbig > bigcap) nbig = bigcap;
+    if (nbig > 0) {
+      BigWeights<F> Wt;
+      Wt.load(P, threadIdx.x & 63);
+      pfn3_big_walk<F>(Wt, counters, biglist, nbig, kBigPerWave, rec, pfirst, pcnt, cell_of_pillar, out, threadIdx.x & 63);
+    }
     return;
   }
   // ---- PFN role
@@ -220,7 +385,7 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
   // Windows of R sorted slots are handed out by ticket counters: while the fill blocks occupy their share of every CU only part of
   // the PFN blocks is resident, and a static deal would leave the late blocks' share for after the fill.
   // (experiment) phase offset between the two waves that share a SIMD (blocks b and b + resident/2): dbg bits 8.. = sleep units of 64 cycles
-  if ((dbg >> 8) != 0 && ((((int)blockIdx.x - n_fill) >> 8) & 1)) {
+  if ((dbg >> 8) != 0 && ((((int)blockIdx.x - n_fill - n_bigb) >> 8) & 1)) {
     for (int k = 0; k < (dbg >> 8); k += 64) __builtin_amdgcn_s_sleep(64);
   }
   const int64_t nwin = ((int64_t)n_kept + R - 1) / R;
@@ -251,13 +416,9 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
       const uint32_t V = (uint32_t)__ballot(complete && h == 0);
       const int nv = __builtin_popcount(V);
       if (nv == 0) {
-        // the pillar at ts has more than 32 points: hand it to k_pfn3_big and step over it
+        // the pillar at ts has more than 32 points: k_bin_sort listed it for the big-pillar role; step over it
         const int q = __builtin_amdgcn_readfirstlane((int)cur.b.w);  // lane 0 is in half 0: word = rank
         const uint32_t c = pcnt[q];
-        if (l == 0) {
-          const int at = atomicAdd(&counters[3], 1);
-          if (at < bigcap) biglist[at] = q;
-        }
         ts += c;
         if (ts < end) nxt = load_half(rec, min(ts + (uint32_t)col, end - 1), h);
         continue;
@@ -376,10 +537,10 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
       }
 #undef PNX_G0_PAIR
       if (ovf) {
-        // outside the fp16 range: every pillar of the tile goes to k_pfn3_big (fp32 MFMA, unscaled weights)
+        // outside the fp16 range: every pillar of the tile goes to k_pfn3_tail (fp32 MFMA, unscaled weights)
         if (act && idx == 0 && h == 0) {
-          const int at = atomicAdd(&counters[3], 1);
-          if (at < bigcap) biglist[at] = (int)cur.b.w;
+          const int at = atomicAdd(&counters[4], 1);
+          if (at < bigcap) biglist[bigcap + at] = (int)cur.b.w;
         }
         ts = ts_next;
         continue;
@@ -465,134 +626,21 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
   }
 }
 
-// Pillars with more than 32 points: one wave per pillar, two sweeps over its tiles (layer-0 max; layer 1 + max) with per-lane
-// running maxima, then one all-lane reduction per register.  Rare at PillarNeXt-B resolution, common only for coarse voxels.
 template <int F>
-__global__ __launch_bounds__(256) void k_pfn3_big(const uint4* __restrict__ rec, const uint32_t* __restrict__ pfirst,
-                                                 const uint32_t* __restrict__ pcnt, const int32_t* __restrict__ cell_of_pillar,
-                                                 const int32_t* __restrict__ counters, const int32_t* __restrict__ biglist, int bigcap,
-                                                 const float* __restrict__ P, Pfn3Out out) {
-  constexpr int C0 = F + 5, KS = (C0 + 2) / 2;
-  constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;
-  const int l = threadIdx.x & 63, col = l & 31, h = l >> 5;
+__global__ __launch_bounds__(256) void k_pfn3_tail(const uint4* __restrict__ rec, const uint32_t* __restrict__ pfirst,
+                                                  const uint32_t* __restrict__ pcnt, const int32_t* __restrict__ cell_of_pillar, int32_t* counters,
+                                                  const int32_t* __restrict__ biglist, int bigcap, const float* __restrict__ P, Pfn3Out out) {
+  const int l = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-  int nbig = counters[3];
+  int nbig = counters[3], novf = counters[4];
   if (nbig > bigcap) nbig = bigcap;
-  if (wave >= nbig) return;
-  const float* __restrict__ FP = P + FR + l;
-  float w0f[KS], w1a[32], w1b[32];
-#pragma unroll
-  for (int kk = 0; kk < KS; kk++) w0f[kk] = FP[kk * 64];
-#pragma unroll
-  for (int i = 0; i < 32; i++) {
-    w1a[i] = FP[(23 + i) * 64];
-    w1b[i] = FP[(55 + i) * 64];
-  }
-  const float4* __restrict__ s1lane = reinterpret_cast<const float4*>(P + FR + 64 * 89 + l * 32);
-  for (int bi = wave; bi < nbig; bi += nwaves) {
-    const int r = biglist[bi];
-    const uint32_t st = pfirst[r], c = pcnt[r];
-    float g0[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) g0[i] = 0.f;  // post-ReLU maxima
-    for (uint32_t t0 = 0; t0 < c; t0 += 32) {
-      const bool act = t0 + col < c;
-      const Half cur = load_half(rec, st + min(t0 + (uint32_t)col, c - 1), h);
-      const float ff[6] = {__uint_as_float(cur.a.x), __uint_as_float(cur.a.y), __uint_as_float(cur.a.z),
-                           __uint_as_float(cur.a.w), __uint_as_float(cur.b.x), __uint_as_float(cur.b.y)};
-      v16f d0;
-#pragma unroll
-      for (int i = 0; i < 16; i++) d0[i] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], act ? ff[kk] : 0.f, d0);
-#pragma unroll
-      for (int i = 0; i < 16; i++) g0[i] = fmaxf(g0[i], act ? fmaxf(d0[i], 0.f) : 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-#pragma unroll
-      for (int d = 16; d >= 1; d >>= 1) g0[i] = fmaxf(g0[i], __shfl_xor(g0[i], d));  // inside each half
-    }
-    const float NI = -__builtin_inff();
-    float pa[16], pb[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      pa[i] = NI;
-      pb[i] = NI;
-    }
-    for (uint32_t t0 = 0; t0 < c; t0 += 32) {
-      const bool act = t0 + col < c;
-      const Half cur = load_half(rec, st + min(t0 + (uint32_t)col, c - 1), h);
-      const float ff[6] = {__uint_as_float(cur.a.x), __uint_as_float(cur.a.y), __uint_as_float(cur.a.z),
-                           __uint_as_float(cur.a.w), __uint_as_float(cur.b.x), __uint_as_float(cur.b.y)};
-      v16f d0, da, db;
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        d0[i] = 0.f;
-        da[i] = 0.f;
-        db[i] = 0.f;
-      }
-#pragma unroll
-      for (int kk = 0; kk < KS; kk++) d0 = PNX_MFMA(w0f[kk], act ? ff[kk] : 0.f, d0);
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const float u = fmaxf(d0[i], 0.f);
-        da = PNX_MFMA(w1a[i], u, da);
-        db = PNX_MFMA(w1b[i], u, db);
-      }
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        da = PNX_MFMA(w1a[16 + i], g0[i], da);
-        db = PNX_MFMA(w1b[16 + i], g0[i], db);
-      }
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        pa[i] = fmaxf(pa[i], act ? da[i] : NI);
-        pb[i] = fmaxf(pb[i], act ? db[i] : NI);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-#pragma unroll
-      for (int d = 16; d >= 1; d >>= 1) {
-        pa[i] = fmaxf(pa[i], __shfl_xor(pa[i], d));
-        pb[i] = fmaxf(pb[i], __shfl_xor(pb[i], d));
-      }
-    }
-    if (col == 0) {  // one lane per half: its 2 x 16 channels as 4-channel pieces
-      const int64_t cell = (int64_t)cell_of_pillar[r];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const float4 sa = s1lane[j], sb = s1lane[4 + j];
-        const float va[4] = {fmaxf(pa[4 * j] + sa.x, 0.f), fmaxf(pa[4 * j + 1] + sa.y, 0.f), fmaxf(pa[4 * j + 2] + sa.z, 0.f),
-                             fmaxf(pa[4 * j + 3] + sa.w, 0.f)};
-        const float vb[4] = {fmaxf(pb[4 * j] + sb.x, 0.f), fmaxf(pb[4 * j + 1] + sb.y, 0.f), fmaxf(pb[4 * j + 2] + sb.z, 0.f),
-                             fmaxf(pb[4 * j + 3] + sb.w, 0.f)};
-#pragma unroll
-        for (int half2 = 0; half2 < 2; half2++) {
-          const float* v = half2 ? vb : va;
-          const int chan0 = 32 * half2 + 8 * j + 4 * h;
-          if (out.g1 != nullptr && (int64_t)r < out.g1_rows)
-            *reinterpret_cast<float4*>(out.g1 + (int64_t)r * 64 + chan0) = make_float4(v[0], v[1], v[2], v[3]);
-          if (out.canvas != nullptr) {
-            if (out.dt == PNX_F32) {
-              *reinterpret_cast<float4*>(reinterpret_cast<float*>(out.canvas) + cell * 64 + chan0) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-              uint2 p;
-              if (out.dt == PNX_BF16) {
-                p.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
-                p.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
-              } else {
-                p.x = f16_rne(v[0]) | (f16_rne(v[1]) << 16);
-                p.y = f16_rne(v[2]) | (f16_rne(v[3]) << 16);
-              }
-              *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out.canvas) + cell * 64 + chan0) = p;
-            }
-          }
-        }
-      }
-    }
-  }
+  if (novf > bigcap) novf = bigcap;
+  // the role blocks of k_pfn3 normally drained the list (tickets handed out >= nbig) and no tile overflowed: nothing to do
+  if (__hip_atomic_load(&counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nbig && wave >= novf) return;
+  BigWeights<F> Wt;
+  Wt.load(P, l);
+  pfn3_big_walk<F>(Wt, counters, biglist, nbig, -1, rec, pfirst, pcnt, cell_of_pillar, out, l);
+  for (int bi = wave; bi < novf; bi += nwaves) pfn3_big_pillar<F>(biglist[bigcap + bi], Wt, rec, pfirst, pcnt, cell_of_pillar, out, l & 31, l >> 5);
 }
 
 template <int F>
@@ -607,15 +655,16 @@ int launch3(const uint4* rec, const uint32_t* pfirst, const uint32_t* pcnt, cons
   const int bc = (int)(bigcap > 0x7fffffff ? 0x7fffffff : bigcap);
   const char* d_env = getenv("PNX_PFN_DBG");  // timing ablations only (results are wrong): 1 no stores, 2 no scans, 4 no layer-1 MFMAs
   const int dbg = d_env ? atoi(d_env) : 0;
+  const int n_bigb = nb > 0 ? kBigBlocks : 0;
   if (nb + n_fill > 0) {
-    const int grid = (int)(nb + n_fill);
+    const int grid = (int)(nb + n_fill + n_bigb);
     const bool pack = out.g1 == nullptr && out.canvas != nullptr && out.dt != PNX_F32;
     const char* h_env = getenv("PNX_PFN_F16X3");  // 0: plain fp32 MFMA layer 1
     const bool h16 = !(h_env && h_env[0] == '0');
 #define PNX_GO(DT_, PACK_)                                                                                                                        \
   {                                                                                                                                               \
-    if (h16) k_pfn3<F, R, DT_, PACK_, true><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, counters, tick, biglist, bc, folded, out, n_fill, g, fj, dbg); \
-    else k_pfn3<F, R, DT_, PACK_, false><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, counters, tick, biglist, bc, folded, out, n_fill, g, fj, dbg);    \
+    if (h16) k_pfn3<F, R, DT_, PACK_, true><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bc, folded, out, n_fill, n_bigb, g, fj, dbg); \
+    else k_pfn3<F, R, DT_, PACK_, false><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bc, folded, out, n_fill, n_bigb, g, fj, dbg);    \
   }
     if (out.dt == PNX_F32) {
       PNX_GO(PNX_F32, false)
@@ -628,7 +677,7 @@ int launch3(const uint4* rec, const uint32_t* pfirst, const uint32_t* pcnt, cons
     PNX_LAUNCH_CHECK();
   }
   if (n > 0) {
-    k_pfn3_big<F><<<64, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out);
+    k_pfn3_tail<F><<<64, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out);
     PNX_LAUNCH_CHECK();
   }
   return PNX_OK;

@@ -19,11 +19,60 @@ __device__ __forceinline__ uint32_t scan_value(uint32_t v) {
   return v;
 }
 
+// Level 2 as a device function: one block turns the per-block totals into exclusive offsets (in place) and publishes the grand
+// total (also stored at blk[nblk]).  Loads go to the device-coherent level: the caller may be the last block of the kernel that
+// produced the totals (scan_blocks_by_last).
+__device__ __forceinline__ void scan_blocks_body(uint32_t* blk, int nblk, int32_t* total_out) {
+  __shared__ uint32_t s_wave2[kBlock / 64];
+  __shared__ uint32_t s_carry;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblk; base += kBlock) {
+    const int i = base + t;
+    const uint32_t x = i < nblk ? __hip_atomic_load(&blk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    uint32_t inc = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t y = __shfl_up(inc, d);
+      if (lane >= d) inc += y;
+    }
+    if (lane == 63) s_wave2[wave] = inc;
+    __syncthreads();
+    uint32_t woff = s_carry;
+    for (int w = 0; w < wave; w++) woff += s_wave2[w];
+    if (i < nblk) blk[i] = woff + inc - x;
+    __syncthreads();
+    if (t == kBlock - 1) s_carry = woff + inc;
+    __syncthreads();
+  }
+  if (t == 0) {
+    blk[nblk] = s_carry;
+    if (total_out) *total_out = (int32_t)s_carry;
+  }
+}
+
+// Called by EVERY thread of EVERY block of a level-1 kernel after it wrote blk_tot[blockIdx.x] (gridDim.x == nblk): the block that
+// draws the last ticket of `done` (zero before the launch) runs level 2 right there -- a separate single-block launch costs
+// ~5 us of kernel + ~2 us of launch gap on an otherwise 600 us reader.  done == nullptr: level 2 is a separate k_scan_blocks launch.
+__device__ __forceinline__ void scan_blocks_by_last(uint32_t* blk, int32_t* total_out, int32_t* done) {
+  if (done == nullptr) return;  // kernel-uniform
+  __shared__ int s_last;
+  __threadfence();  // the total this block wrote is visible device-wide before its ticket
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(done, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  scan_blocks_body(blk, (int)gridDim.x, total_out);
+}
+
 // Level 1: each block scans PNX_SCAN_ITEMS items; out_local = exclusive prefix inside the block.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_scan_local(const uint32_t* __restrict__ in, int64_t n,
-                                                       uint32_t* __restrict__ out_local, uint32_t* __restrict__ blk_tot,
-                                                       const int32_t* __restrict__ limit = nullptr) {
+                                                       uint32_t* __restrict__ out_local, uint32_t* blk_tot,
+                                                       const int32_t* __restrict__ limit = nullptr, int32_t* total_out = nullptr,
+                                                       int32_t* done = nullptr) {
   __shared__ uint32_t s_wave[kBlock / 64];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -66,39 +115,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_local(const uint32_t* __restric
       if (base + k < n) out_local[base + k] = excl + v[k];
   }
   if (t == kBlock - 1) blk_tot[blockIdx.x] = excl + sum;
+  scan_blocks_by_last(blk_tot, total_out, done);
 }
 
 // Level 2: one block turns the per-block totals into exclusive offsets (in place) and publishes the
 // grand total (also stored at blk[nblk]).
-__global__ __launch_bounds__(kBlock) void k_scan_blocks(uint32_t* __restrict__ blk, int nblk, int32_t* __restrict__ total_out) {
-  __shared__ uint32_t s_wave[kBlock / 64];
-  __shared__ uint32_t s_carry;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t == 0) s_carry = 0;
-  __syncthreads();
-  for (int base = 0; base < nblk; base += kBlock) {
-    const int i = base + t;
-    const uint32_t x = i < nblk ? blk[i] : 0u;
-    uint32_t inc = x;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t y = __shfl_up(inc, d);
-      if (lane >= d) inc += y;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    uint32_t woff = s_carry;
-    for (int w = 0; w < wave; w++) woff += s_wave[w];
-    if (i < nblk) blk[i] = woff + inc - x;
-    __syncthreads();
-    if (t == kBlock - 1) s_carry = woff + inc;
-    __syncthreads();
-  }
-  if (t == 0) {
-    blk[nblk] = s_carry;
-    if (total_out) *total_out = (int32_t)s_carry;
-  }
-}
-
+__global__ __launch_bounds__(kBlock) void k_scan_blocks(uint32_t* blk, int nblk, int32_t* total_out) { scan_blocks_body(blk, nblk, total_out); }
 
 }  // namespace

@@ -60,8 +60,8 @@ __global__ __launch_bounds__(kBlock) void k_keys(const float* __restrict__ pts, 
 __device__ __forceinline__ uint32_t nib4(uint32_t v) { return ((v * 0x00204081u) >> 21) & 0xFu; }  // 4 bytes (0/1) -> 4 bits
 
 __global__ __launch_bounds__(kBlock) void k_pack_scan(const uint8_t* __restrict__ bytemap, int64_t nwords, uint32_t* __restrict__ bitmap,
-                                                      uint32_t* __restrict__ out_local, uint32_t* __restrict__ blk_tot,
-                                                      uint2* __restrict__ wcomb) {
+                                                      uint32_t* __restrict__ out_local, uint32_t* blk_tot, uint2* __restrict__ wcomb,
+                                                      int32_t* total_out = nullptr, int32_t* done = nullptr) {
   __shared__ uint32_t s_wave[kBlock / 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t base = (int64_t)blockIdx.x * PNX_SCAN_ITEMS + (int64_t)t * 8;
@@ -99,6 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_scan(const uint8_t* __restrict_
       if (wcomb != nullptr) wcomb[base + k] = make_uint2(w[k], excl + pre[k]);  // {bits, prefix} in one 8-byte load for the per-point rank
     }
   if (t == kBlock - 1) blk_tot[blockIdx.x] = excl + sum;
+  scan_blocks_by_last(blk_tot, total_out, done);  // binned path: the last block also turns the totals into offsets (pnx_scan.h)
 }
 
 __device__ __forceinline__ int32_t cell_rank(int32_t key, const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre,
@@ -602,7 +603,7 @@ struct ReaderWs {
   int32_t* biglist;  // pillars with more than 32 points (handled by k_pfn_big)
   int32_t* cell;     // canvas cell of every pillar
   int64_t bigcap;
-  size_t zero_bytes;  // counters | count | bytemap are contiguous: one memset per call
+  size_t zero_bytes, zero_bytes2;  // counters | tick | bytemap [| count] are contiguous: one memset per call
   int32_t *key, *rank, *slot;
   uint32_t *count, *cpre, *cblk;
   int32_t* plist;
@@ -639,13 +640,14 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   if (w.nblk_k < 1) w.nblk_k = 1;
   w.counters = c.take<int32_t>(64);
   w.tick = c.take<int32_t>(20 * 32);  // 16 window-ticket words + 4 fill-share counters, one 128-byte line each
-  w.count = c.take<uint32_t>(w.pcap + 8);
   w.bytemap = c.take<uint8_t>(cells + 64);
-  w.zero_bytes = c.used();
+  w.zero_bytes2 = c.used();            // binned path: counters | tick | bytemap
+  w.count = c.take<uint32_t>(w.pcap + 8);
+  w.zero_bytes = c.used();             // round-1 path: + count
   w.owner = c.take<int32_t>(cells + 8);
   w.rec = c.take<uint32_t>((n + 8) * 8);
   w.bigcap = w.pcap + 8;  // pillars of > 32 points and every pillar of a tile that leaves the fp16x3 range (pfn_v3.hip)
-  w.biglist = c.take<int32_t>(w.bigcap);
+  w.biglist = c.take<int32_t>(2 * w.bigcap);  // [0, bigcap): > 32 points (k_bin_sort); [bigcap, 2 bigcap): fp16x3 overflow (k_pfn3)
   w.cell = c.take<int32_t>((w.pcap > 0 ? w.pcap : 1) + 8);
   w.bitmap = c.take<uint32_t>(w.nwords + 8);
   w.wpre = c.take<uint32_t>(w.nwords + 8);
@@ -758,8 +760,10 @@ int launch_bin_sort(const GeomDev& gd, const ReaderWs& w, int32_t* coords, int64
   }
   const char* d_env = getenv("PNX_SORT_DBG");  // timing ablations only (results are wrong): 1 no fp64 sums
   const int sdbg = d_env ? atoi(d_env) : 0;
+  const int bc = (int)(w.bigcap > 0x7fffffff ? 0x7fffffff : w.bigcap);
   k_bin_sort<F><<<w.K1 + (fj.quota > 0 ? fill_blocks : 0), kSortBlock, lds, st>>>(w.rec, gd, w.sh, w.nwg, w.matlen, w.hpre, w.hblk, w.counters, w.rec64,
-                                                                                 w.pfirst, w.pcnt, w.cell, coords, pillar_capacity, sdbg, fj);
+                                                                                 w.pfirst, w.pcnt, w.cell, coords, pillar_capacity, w.biglist, bc, sdbg,
+                                                                                 fj);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -768,14 +772,18 @@ int launch_bin_sort(const GeomDev& gd, const ReaderWs& w, int32_t* coords, int64
 int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev& gd, const ReaderWs& w, int32_t* coords,
                   int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, const PnxFillJob* fill, int fill_blocks, hipStream_t st,
                   hipEvent_t bitmap_ready = nullptr) {
-  PNX_CHECK_HIP(hipMemsetAsync(w.counters, 0, w.zero_bytes, st));  // counters | count | bytemap
+  PNX_CHECK_HIP(hipMemsetAsync(w.counters, 0, w.zero_bytes2, st));  // counters | tick | bytemap
   if (n > 0) {
     k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bytemap, nullptr);
     PNX_LAUNCH_CHECK();
   }
-  k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk, w.wcomb);
+  // Level 2 of the two scans below stays a separate single-block launch (~5 us + ~2 us of launch gap each).  Folding it into the
+  // last block of the level-1 kernel (pnx_scan.h: scan_blocks_by_last, PNX_SCAN_FUSE=1) needs a device-scope release fence in
+  // every block, and on this 8-XCD part that fence writes the XCD's dirty L2 lines back: measured +115 us on the 255 us voxelize.
+  static const bool fuse_scan = getenv("PNX_SCAN_FUSE") != nullptr && getenv("PNX_SCAN_FUSE")[0] == '1';
+  k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk, w.wcomb, w.counters + 0, fuse_scan ? w.counters + 8 : nullptr);
   if (bitmap_ready != nullptr) PNX_CHECK_HIP(hipEventRecord(bitmap_ready, st));  // the zero-fill only needs the bitmap
-  k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
+  if (!fuse_scan) k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
   PNX_LAUNCH_CHECK();
   if (n <= 0) return PNX_OK;
   const size_t hl = (size_t)(w.K1 > 64 ? w.K1 : 64) * sizeof(uint32_t);
@@ -783,8 +791,8 @@ int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev&
   f0.n_main = w.nwg, f1.n_main = w.nwg, f2.n_main = w.K1;
   k_bin_count<<<w.nwg + (f0.quota > 0 ? fill_blocks : 0), kBlock, hl, st>>>(w.key, n, w.chunk, w.sh, w.K1, w.nwg, w.wcomb, w.wblk, w.rank, pillar_of_point,
                                                                            w.histmat, gd, f0);
-  k_scan_local<SCAN_IDENT><<<w.nblk_m, kBlock, 0, st>>>(w.histmat, w.matlen, w.hpre, w.hblk);
-  k_scan_blocks<<<1, kBlock, 0, st>>>(w.hblk, w.nblk_m, w.counters + 1);
+  k_scan_local<SCAN_IDENT><<<w.nblk_m, kBlock, 0, st>>>(w.histmat, w.matlen, w.hpre, w.hblk, nullptr, w.counters + 1, fuse_scan ? w.counters + 9 : nullptr);
+  if (!fuse_scan) k_scan_blocks<<<1, kBlock, 0, st>>>(w.hblk, w.nblk_m, w.counters + 1);
   k_bin_scatter<<<w.nwg + (f1.quota > 0 ? fill_blocks : 0), kBlock, hl, st>>>(points, stride, w.key, w.rank, n, w.chunk, w.sh, w.K1, w.nwg, w.hpre, w.hblk,
                                                                              w.rec, gd, f1);
   PNX_LAUNCH_CHECK();

@@ -118,10 +118,11 @@ constexpr int kSortBlock = 1024;
 template <int F>
 __global__ __launch_bounds__(kSortBlock) void k_bin_sort(const uint32_t* __restrict__ binbuf, PnxGeomDev g, int sh, int nwg, int64_t matlen,
                                                          const uint32_t* __restrict__ hpre, const uint32_t* __restrict__ hblk,
-                                                         const int32_t* __restrict__ counters, uint32_t* __restrict__ rec64,
+                                                         int32_t* counters, uint32_t* __restrict__ rec64,
                                                          uint32_t* __restrict__ pillar_first, uint32_t* __restrict__ pillar_cnt,
                                                          int32_t* __restrict__ cell_of_pillar, int32_t* __restrict__ coords,
-                                                         int64_t pillar_capacity, int dbg, PnxFillJob fj) {
+                                                         int64_t pillar_capacity, int32_t* __restrict__ biglist, int bigcap, int dbg,
+                                                         PnxFillJob fj) {
   constexpr int C0 = F + 5;
   extern __shared__ __align__(16) unsigned char s_raw[];
   const int S = 1 << sh;
@@ -234,6 +235,10 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_sort(const uint32_t* __restr
       pillar_first[gr] = bs + (u ? e1 : e0);
       pillar_cnt[gr] = cnt;
       cell_of_pillar[gr] = cell;
+      if (cnt > 32u && biglist != nullptr) {  // more points than one MFMA tile holds: the wave-per-pillar role of k_pfn3 (pfn_v3.hip)
+        const int at = atomicAdd(&counters[3], 1);
+        if (at < bigcap) biglist[at] = (int)gr;
+      }
       if (coords != nullptr && gr < pillar_capacity) {
         coords[gr * 3 + 0] = bi;  // [b, yi, xi]  (pe:125 swaps x/y)
         coords[gr * 3 + 1] = yi;
