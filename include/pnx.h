@@ -183,6 +183,12 @@ int pnx_bias_act_mask(const void* x, const void* residual, const float* bias, co
  * in fp32 in one pass,  out = [relu]( sum_k src_k + bias[c] ), bf16 NHWC.  srcs = HOST array of n_src (1..8) device pointers. */
 int pnx_sum_bias_act(const void* const* srcs, int32_t n_src, const float* bias, void* out, int64_t sites, int32_t channels, int32_t relu,
                      pnx_stream_t stream);
+/* ConvTranspose2d(cin, cout, kernel 2, stride 2, no bias) + folded BatchNorm + [ReLU] in one kernel, bf16 NHWC, fp32 accumulation:
+ * the deblock of a SepHead (det3d/models/heads/centerhead.py:17-21 via det3d/models/utils/conv.py ConvBlock with
+ * conv_layer=ConvTranspose2d).  x (B,h,w,cin) -> y (B,2h,2w,cout); wfrag = weights in MFMA-fragment order
+ * [ky*2+kx][cin/16][cout/32][lane][8] (pillarnext_amd/ops.py::deconv2x2_pack_weights); bias fp32[cout].  Kernels: 64 -> 64. */
+int pnx_deconv2x2_bf16(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                       int32_t relu, pnx_stream_t stream);
 /* Masked 3x3 convolution (pad 1, stride 1 or 2) with the same epilogue fused, bf16 NHWC, fp32 accumulation on MFMA:
  *   y = mask_out * [relu]( conv3x3(x, W) + bias [+ residual] ),  rows/tiles of the output without an active site are skipped.
  *   x (B,h,w,cin), y/residual (B,ho,wo,cout), mask uint8 (B,ho,wo) or NULL; wfrag = weights in MFMA-fragment order

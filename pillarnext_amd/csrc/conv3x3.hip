@@ -974,6 +974,60 @@ int launch_s2(const void* x, const void* wfrag, const float* bias, const uint8_t
   return PNX_OK;
 }
 
+// ---- ConvTranspose2d(64, 64, kernel 2, stride 2) + folded BN + ReLU: the deblock of every SepHead (det3d/models/heads/centerhead.py:17-21).
+// Kernel == stride, so the four output parities (ky, kx) are four independent 1x1 convolutions of the input pixel: per 32 input
+// pixels 4 x (2 output-channel tiles x 4 k-steps) MFMAs and four 128-byte output lines per pixel, written as complete lines (the
+// epilogue above with a pixel stride of two).  Weights (32 KB, fragment order) stay in registers of the persistent waves.
+__global__ __launch_bounds__(256, 2) void k_deconv2x2_64(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                      uint16_t* __restrict__ y, int B, int H, int W, int relu) {
+  constexpr int C = 64;
+  const int lane = threadIdx.x & 63, px = lane & 31, kb = lane >> 5;
+  uint4 w[4][4][2];  // [parity][k-step][output-channel tile]
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+      for (int m = 0; m < 2; m++) w[p][ks][m] = wfrag[((p * 4 + ks) * 2 + m) * 64 + lane];
+  v16f bq[2];
+#pragma unroll
+  for (int m = 0; m < 2; m++) bq[m] = bias_tile(bias, m * 32, kb);
+  const int segs = (W + 31) >> 5;
+  const int64_t n_seg = (int64_t)B * H * segs;
+  const int Wo = 2 * W;
+  for (int64_t sg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); sg < n_seg; sg += (int64_t)gridDim.x * 4) {
+    const int sx = (int)(sg % segs);
+    const int64_t row = sg / segs;  // b * H + y
+    const int x0 = sx * 32, n_valid = W - x0;
+    const bool in = x0 + px < W;
+    const uint16_t* src = x + (row * W + (in ? x0 + px : x0)) * C + 8 * kb;
+    uint4 q[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) q[ks] = in ? *reinterpret_cast<const uint4*>(src + ks * 16) : make_uint4(0, 0, 0, 0);
+    const int b = (int)(row / H), yy = (int)(row - (int64_t)b * H);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      v16f acc[2] = {bq[0], bq[1]};
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const bf16x8 bfr = __builtin_bit_cast(bf16x8, q[ks]);
+#pragma unroll
+        for (int m = 0; m < 2; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[p][ks][m]), bfr, acc[m], 0, 0, 0);
+      }
+      uint4 D[4];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        uint4 pk[2];
+        pack_tile(acc[m], true, relu, pk);
+        D[2 * m] = pk[0], D[2 * m + 1] = pk[1];
+      }
+      transpose_row64(D, lane);
+      uint16_t* orow = y + ((((int64_t)b * 2 * H + 2 * yy + (p >> 1)) * Wo) + 2 * x0 + (p & 1)) * C;
+      store_row64<2 * C>(D, orow, n_valid, lane);  // output pixel of input pixel P: 2 P + kx -> a pixel stride of 2 x 64 channels
+    }
+  }
+}
+
 // ---- final convolution of the merged SepHead branches (det3d/models/heads/centerhead.py:12-59: Conv2d(64, k_j, 3) of every
 // branch j of a task).  The first (merged) convolution leaves NBR x 64 channels per pixel; branch j reads only its own 64, so
 // the stacked weight (sum k_j <= 16 outputs x NBR*64 inputs) is block diagonal.  HBM-bound by its input (768 B per pixel at
@@ -1138,6 +1192,22 @@ int pnx_sephead_out_bf16(const void* x, const void* wfrag, const float* bias, vo
   }
   pnx_set_error("pnx_sephead_out_bf16: no kernel for %d branches", n_branch);
   return PNX_ERR_UNSUPPORTED;
+}
+
+int pnx_deconv2x2_bf16(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                       int32_t relu, pnx_stream_t stream) {
+  PNX_REQUIRE(x && wfrag && bias && y && batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "bad arguments");
+  PNX_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)wfrag | (uintptr_t)bias) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
+  if (cin != 64 || cout != 64) {
+    pnx_set_error("pnx_deconv2x2_bf16: no kernel for %d -> %d channels", cin, cout);
+    return PNX_ERR_UNSUPPORTED;
+  }
+  const int64_t n_seg = (int64_t)batch * h * ((w + 31) / 32);
+  int64_t nb = (n_seg + 3) / 4;
+  if (nb > 512) nb = 512;  // persistent: the weights are loaded once per wave
+  k_deconv2x2_64<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (uint16_t*)y, batch, h, w, relu);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
 }
 
 int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,

@@ -568,6 +568,19 @@ class _HipConv3x3(nn.Module):
         return ops.conv3x3_masked(x, self.wfrag, self.bias, self.cout, self.stride, mask, residual, True, out=out)
 
 
+class _HipDeconv2x2(nn.Module):
+    """ConvTranspose2d(k=2, s=2) + folded BN + ReLU in ONE HIP kernel (csrc/conv3x3.hip::k_deconv2x2_64): the SepHead deblock."""
+
+    def __init__(self, weight, bias, relu=True):
+        super().__init__()
+        self.cout, self.relu = weight.shape[1], relu
+        self.register_buffer("wfrag", ops.deconv2x2_pack_weights(weight))
+        self.register_buffer("bias", bias.float().contiguous())
+
+    def forward(self, x, mask=None, residual=None):
+        return ops.deconv2x2(x, self.wfrag, self.bias, self.cout, self.relu)
+
+
 class _HipSepHeadOut(nn.Module):
     """Last 3x3 conv of all SepHead branches of a task as ONE HIP kernel over the block-diagonal weight (csrc/conv3x3.hip::k_sephead_out)."""
 
@@ -646,7 +659,11 @@ class FusedPillarNeXt(nn.Module):
         for task in hd.tasks:
             db = task.deblock
             w, b = _fold_bn(db.conv.conv.weight, db.norm, transposed=True)
-            self.task_deblock.append(_FusedConv(w, b, db.conv.conv.stride, 0, transposed=True, dtype=dtype))
+            dc = db.conv.conv
+            if hip_conv and dtype == torch.bfloat16 and tuple(w.shape) == (64, 64, 2, 2) and tuple(dc.stride) == (2, 2) and tuple(dc.padding) == (0, 0):
+                self.task_deblock.append(_HipDeconv2x2(w, b))
+            else:
+                self.task_deblock.append(_FusedConv(w, b, dc.stride, 0, transposed=True, dtype=dtype))
             names = list(task.heads.keys())
             w1s, b1s, w2s, b2s, outs = [], [], [], [], []
             for nme in names:

@@ -231,6 +231,24 @@ def conv3x3_pack_weights(w):
     return v.reshape(-1).to(torch.bfloat16).contiguous()
 
 
+def deconv2x2_pack_weights(w):
+    """ConvTranspose2d weight (Cin, Cout, 2, 2) -> bf16 MFMA-fragment order [ky*2+kx][cin/16][cout/32][lane = kb*32 + n][8]."""
+    ci, co = w.shape[:2]
+    v = w.detach().float().permute(1, 0, 2, 3).reshape(co // 32, 32, ci // 16, 2, 8, 2, 2)   # (mt, n, cb, kb, e, ky, kx)
+    v = v.permute(5, 6, 2, 0, 3, 1, 4).contiguous()                                          # (ky, kx, cb, mt, kb, n, e)
+    return v.reshape(-1).to(torch.bfloat16).contiguous()
+
+
+def deconv2x2(x, wfrag, bias, cout, relu=True):
+    """x (B,Cin,H,W) channels_last bf16 -> [relu](conv_transpose2d(x, W, stride 2) + bias) as (B,Cout,2H,2W) channels_last bf16."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise PnxError("deconv2x2 needs a channels_last bf16 CUDA tensor")
+    B, ci, H, W = x.shape
+    y = torch.empty((B, cout, 2 * H, 2 * W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    check(lib().pnx_deconv2x2_bf16(ptr(x), ptr(wfrag), ptr(bias), ptr(y), B, H, W, ci, cout, 1 if relu else 0, stream_ptr()), "pnx_deconv2x2_bf16")
+    return y
+
+
 def sephead_pack_weights(w2):
     """Block-diagonal (16, nb*64, 3, 3) -> bf16 fragment order [branch][tap][kc][lane = q*16 + o][8]  (csrc/conv3x3.hip::k_sephead_out)."""
     co, ci = w2.shape[:2]

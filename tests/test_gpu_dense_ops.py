@@ -179,3 +179,22 @@ def test_sum_bias_act_matches_torch(n, relu):
         want = torch.relu(want)
     assert got.is_contiguous(memory_format=torch.channels_last)
     torch.testing.assert_close(got.float(), want.to(torch.bfloat16).float(), rtol=0, atol=0)   # fp32 sum in the same order, one rounding
+
+
+@pytest.mark.parametrize("hw", [(45, 70), (7, 33), (180, 180)])
+def test_deconv2x2_matches_torch(hw):
+    """k_deconv2x2_64 vs F.conv_transpose2d (kernel 2, stride 2) + bias + ReLU."""
+    from pillarnext_amd import ops
+
+    H, W = hw
+    g = torch.Generator(device="cuda").manual_seed(H * W)
+    x = torch.randn((2, 64, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((64, 64, 2, 2), device="cuda", generator=g) / 8).to(torch.bfloat16)
+    bias = torch.randn((64,), device="cuda", generator=g)
+    for relu in (True, False):
+        ref = torch.nn.functional.conv_transpose2d(x.float(), w.float(), None, 2) + bias.view(1, -1, 1, 1)
+        if relu:
+            ref = torch.relu(ref)
+        got = ops.deconv2x2(x, ops.deconv2x2_pack_weights(w), bias, 64, relu)
+        assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+        torch.testing.assert_close(got.float(), ref, rtol=1.6e-2, atol=2e-2)

@@ -19,7 +19,7 @@ model = FusedPillarNeXt(build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"]).c
 pts = torch.from_numpy(synth.make_batch("C2", a.batch, a.dist)).cuda()
 recs, info = defaultdict(list), {}
 for name, mod in model.named_modules():
-    if type(mod).__name__ in ("_FusedConv", "_HipConv3x3", "_HipSepHeadOut"):
+    if type(mod).__name__ in ("_FusedConv", "_HipConv3x3", "_HipSepHeadOut", "_HipDeconv2x2"):
         def pre(m, inp, name=name):
             m._t0 = torch.cuda.Event(enable_timing=True); m._t0.record()
         def post(m, inp, out, name=name):
