@@ -198,7 +198,18 @@ int pnx_deconv2x2_bf16(const void* x, const void* wfrag, const float* bias, void
  *   set (then cleared), segments with active sites are written and flagged; an all-empty segment of a PERSISTENT output buffer
  *   costs no HBM traffic at all.  Contract: (y, row_dirty) start zeroed and y is only ever written through this function. */
 int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
-                     int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, uint8_t* row_dirty, pnx_stream_t stream);
+                     int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, uint8_t* row_dirty, const int32_t* tile_list,
+                     const int32_t* tile_count, pnx_stream_t stream);
+/* Optional tile list for the stride-1 kernels: the submanifold blocks of a backbone stage share one active-site mask, so the
+ * tiles that need any work (an active site, or a stale row in one of the persistent output buffers) are listed once per stage
+ * and every convolution of the stage walks the list instead of all tiles.
+ *   pnx_conv3x3_tile_rows   rows of a tile of the kernel serving (cin, cout, stride); 0 = that kernel takes no list
+ *   pnx_conv_tile_list      mask uint8 (batch,h,w); row_dirty = HOST array of n_dirty (0..4) device pointers (the row_dirty arrays of
+ *                           the buffers the stage writes); tile_list int32[batch * ceil(h/tile_rows) * ceil(w/32)], tile_count int32[1]
+ *                           (both device; the count is reset here).  Pass both to pnx_conv3x3_bf16 (or NULL, NULL). */
+int pnx_conv3x3_tile_rows(int32_t cin, int32_t cout, int32_t stride);
+int pnx_conv_tile_list(const uint8_t* mask, const uint8_t* const* row_dirty, int32_t n_dirty, int32_t batch, int32_t h, int32_t w, int32_t tile_rows,
+                       int32_t* tile_list, int32_t* tile_count, pnx_stream_t stream);
 /* Final convolution of the merged SepHead branches of one task (det3d/models/heads/centerhead.py:12-59, the last
  * Conv2d(64, k_j, 3, padding=1, bias=True) of every branch j):  y[b,oy,ox,o] = bias[o] + sum_{j,ky,kx,c} x[b,oy+ky-1,ox+kx-1,64j+c] * W[o][64j+c][ky][kx]
  * with W block diagonal (output o belongs to exactly one branch).  x (B,h,w,64*n_branch) bf16, y (B,h,w,16) bf16 (sum k_j <= 16,

@@ -332,6 +332,18 @@ __device__ __forceinline__ void sched_draw(unsigned int* s_next, int it, int slo
 __device__ __forceinline__ int64_t sched_next(const unsigned int* s_next, int it, int slot, int64_t tile) {
   return slot >= 0 ? (int64_t)s_next[it & 1] + gridDim.x : tile + gridDim.x;
 }
+// Depth-2 pipeline of the tile loops: iteration `it` works on index A, already knows index B (its mask bytes are requested during
+// A) and draws index C.  Indices 0..2G-1 are dealt statically (G = gridDim.x), the tickets continue from 2G.  (Drawing the first B
+// by ticket as well put 2 x 512 same-address atomics at the start of every launch: 272 us instead of 228 us for 256 -> 256 at
+// 180 x 180, three runs each, no difference at the larger stages.)  With a tile list (pnx_conv_tile_list: the tiles that
+// hold an active site or a stale row) an index is a position in the list.
+__device__ __forceinline__ int64_t sched_next2(const unsigned int* s_next, int it, int slot, int64_t idx_b) {
+  return slot >= 0 ? (int64_t)s_next[it & 1] + 2 * (int64_t)gridDim.x : idx_b + gridDim.x;
+}
+__device__ __forceinline__ int64_t tile_at(const int32_t* __restrict__ tlist, int64_t idx, int64_t n) {
+  if (idx >= n) return -1;
+  return tlist != nullptr ? (int64_t)tlist[idx] : idx;
+}
 __device__ __forceinline__ void sched_done(int slot) {
   if (slot >= 0 && threadIdx.x == 0) {
     __threadfence();
@@ -495,7 +507,8 @@ template <int COUT, bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                      const float* __restrict__ bias, const uint16_t* __restrict__ res,
                                                      const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
-                                                     int relu, uint8_t* __restrict__ row_dirty, int slot) {
+                                                     int relu, uint8_t* __restrict__ row_dirty, int slot, const int32_t* __restrict__ tlist,
+                                                      const int32_t* __restrict__ tcount) {
   constexpr int CIN = 64;
   constexpr int TH = LDS_TH, HW_ = LDS_HW;
   static_assert(!HAS_RES || COUT == 64, "the residual is folded into the accumulators of a single 64-channel pass");
@@ -505,11 +518,34 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int px = lane & 31, kb = lane >> 5;
   const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
-  const int64_t n_tiles = (int64_t)B * tiles_y * tiles_x;
+  const int64_t n_tiles = tlist != nullptr ? (int64_t)__builtin_amdgcn_readfirstlane(*tcount) : (int64_t)B * tiles_y * tiles_x;
+  // requests the mask bytes / row_dirty flags of the rows this wave looks at in tile t (t < 0: none)
+  auto load_mask = [&](int64_t t, bool (&a)[4], int (&wz)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) a[j] = false, wz[j] = 1;
+    if (t < 0) return;
+    const int tx = (int)(t % tiles_x);
+    const int ty = (int)((t / tiles_x) % tiles_y);
+    const int b = (int)(t / ((int64_t)tiles_x * tiles_y));
+    const int ox = tx * 32 + px;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int oy = ty * TH + wv * 4 + j;
+      a[j] = ox < W && oy < H && (mask == nullptr || mask[((int64_t)b * H + oy) * W + ox] != 0);
+      if (row_dirty != nullptr && oy < H) wz[j] = (int)row_dirty[((int64_t)b * H + oy) * tiles_x + tx];
+    }
+  };
+  int64_t idxB = (int64_t)blockIdx.x + gridDim.x, idxC = 0;
+  int64_t tileA = tile_at(tlist, blockIdx.x, n_tiles), tileB = tile_at(tlist, idxB, n_tiles), tileC = -1;
+  bool aP[4], aN[4];
+  int wasP[4], wasN[4];
+  load_mask(tileA, aP, wasP);
+#pragma unroll
+  for (int j = 0; j < 4; j++) aN[j] = false, wasN[j] = 1;
   CT_DECL
-  int64_t next = 0;
   int it = 0;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile = next, it++) {
+  for (; tileA >= 0; tileA = tileB, tileB = tileC, idxB = idxC, it++) {
+    const int64_t tile = tileA;
     sched_draw(s_next, it, slot);
     uint32_t* const s_rowmask = s_rowmask2 + (it & 1) * TH;
     const int tx = (int)(tile % tiles_x);
@@ -518,19 +554,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
     const int x0 = tx * 32, y0 = ty * TH;
     const int ox = x0 + px;
     CT_TOCK(7)
-    // ---- active sites: one 32-bit column mask per row of the tile; was[j]: the row segment may hold stale data (pnx.h: row_dirty)
     bool was[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int oy = y0 + wv * 4 + j;
-      const bool a = ox < W && oy < H && (mask == nullptr || mask[((int64_t)b * H + oy) * W + ox] != 0);
-      was[j] = true;
-      if (row_dirty != nullptr && oy < H) was[j] = __builtin_amdgcn_readfirstlane((int)row_dirty[((int64_t)b * H + oy) * tiles_x + tx]) != 0;
-      const uint32_t bal = (uint32_t)__ballot(a);
+    for (int j = 0; j < 4; j++) {  // active sites: one 32-bit column mask per row of the tile, from the bytes requested one tile ago
+      was[j] = __builtin_amdgcn_readfirstlane(wasP[j]) != 0;
+      const uint32_t bal = (uint32_t)__ballot(aP[j]);
       if (lane == 0) s_rowmask[wv * 4 + j] = bal;
     }
     __syncthreads();  // row masks visible; everybody is done reading the previous tile's s_in
-    next = sched_next(s_next, it, slot, tile);
+    idxC = sched_next2(s_next, it, slot, idxB);
+    tileC = tile_at(tlist, idxC, n_tiles);
+    load_mask(tileB, aN, wasN);  // consumed at the top of the next iteration
+#pragma unroll
+    for (int j = 0; j < 4; j++) aP[j] = aN[j], wasP[j] = wasN[j];
     CT_TOCK(0)
     const uint32_t my_rm = s_rowmask[lane & 15];
     const uint32_t am = (uint32_t)__ballot(my_rm != 0) & 0xffffu;  // rows with an active site (wave-uniform, same in all waves)
@@ -673,7 +709,8 @@ template <int CIN, int COUT, bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                       const float* __restrict__ bias, const uint16_t* __restrict__ res,
                                                       const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
-                                                      int relu, uint8_t* __restrict__ row_dirty, int slot) {
+                                                      int relu, uint8_t* __restrict__ row_dirty, int slot, const int32_t* __restrict__ tlist,
+                                                      const int32_t* __restrict__ tcount) {
   static_assert(CIN % 64 == 0 && COUT % 128 == 0, "64-channel input slabs, 128-channel output passes");
   constexpr int TH = L128_TH, HW_ = LDS_HW;
   __shared__ uint4 s_in[L128_NSTAGE];
@@ -683,10 +720,33 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
   const int px = lane & 31, kb = lane >> 5;
   const int rg = wv & 1, mg0 = 2 * (wv >> 1);  // row group, first 32-channel output tile of this wave within a pass
   const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
-  const int64_t n_tiles = (int64_t)B * tiles_y * tiles_x;
-  int64_t next = 0;
+  const int64_t n_tiles = tlist != nullptr ? (int64_t)__builtin_amdgcn_readfirstlane(*tcount) : (int64_t)B * tiles_y * tiles_x;
+  // requests the mask bytes / row_dirty flags of the rows this wave looks at in tile t (t < 0: none)
+  auto load_mask = [&](int64_t t, bool (&a)[2], int (&wz)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) a[j] = false, wz[j] = 1;
+    if (t < 0) return;
+    const int tx = (int)(t % tiles_x);
+    const int ty = (int)((t / tiles_x) % tiles_y);
+    const int b = (int)(t / ((int64_t)tiles_x * tiles_y));
+    const int ox = tx * 32 + px;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int oy = ty * TH + wv * 2 + j;
+      a[j] = ox < W && oy < H && (mask == nullptr || mask[((int64_t)b * H + oy) * W + ox] != 0);
+      if (row_dirty != nullptr && oy < H) wz[j] = (int)row_dirty[((int64_t)b * H + oy) * tiles_x + tx];
+    }
+  };
+  int64_t idxB = (int64_t)blockIdx.x + gridDim.x, idxC = 0;
+  int64_t tileA = tile_at(tlist, blockIdx.x, n_tiles), tileB = tile_at(tlist, idxB, n_tiles), tileC = -1;
+  bool aP[2], aN[2];
+  int wasP[2], wasN[2];
+  load_mask(tileA, aP, wasP);
+#pragma unroll
+  for (int j = 0; j < 2; j++) aN[j] = false, wasN[j] = 1;
   int it = 0;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile = next, it++) {
+  for (; tileA >= 0; tileA = tileB, tileB = tileC, idxB = idxC, it++) {
+    const int64_t tile = tileA;
     sched_draw(s_next, it, slot);
     uint32_t* const s_rowmask = s_rowmask2 + (it & 1) * TH;
     const int tx = (int)(tile % tiles_x);
@@ -696,16 +756,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
     const int ox = x0 + px;
     bool was[2];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {  // active sites: one 32-bit column mask per row of the tile (wave wv looks at rows 2wv, 2wv+1)
-      const int oy = y0 + wv * 2 + j;
-      const bool a = ox < W && oy < H && (mask == nullptr || mask[((int64_t)b * H + oy) * W + ox] != 0);
-      was[j] = true;
-      if (row_dirty != nullptr && oy < H) was[j] = __builtin_amdgcn_readfirstlane((int)row_dirty[((int64_t)b * H + oy) * tiles_x + tx]) != 0;
-      const uint32_t bal = (uint32_t)__ballot(a);
+    for (int j = 0; j < 2; j++) {  // active sites: one 32-bit column mask per row of the tile, from the bytes requested one tile ago
+      was[j] = __builtin_amdgcn_readfirstlane(wasP[j]) != 0;
+      const uint32_t bal = (uint32_t)__ballot(aP[j]);
       if (lane == 0) s_rowmask[wv * 2 + j] = bal;
     }
     __syncthreads();  // row masks visible; everybody is done reading the previous tile's s_in
-    next = sched_next(s_next, it, slot, tile);
+    idxC = sched_next2(s_next, it, slot, idxB);
+    tileC = tile_at(tlist, idxC, n_tiles);
+    load_mask(tileB, aN, wasN);  // consumed at the top of the next iteration
+#pragma unroll
+    for (int j = 0; j < 2; j++) aP[j] = aN[j], wasP[j] = wasN[j];
     const uint32_t my_rm = s_rowmask[lane & 7];
     const uint32_t am = (uint32_t)__ballot(my_rm != 0) & 0xffu;
 #pragma unroll
@@ -761,16 +822,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
 
 template <int CIN, int COUT>
 int launch_ldsx(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
-                uint8_t* row_dirty, hipStream_t st) {
+                uint8_t* row_dirty, const int32_t* tlist, const int32_t* tcount, hipStream_t st) {
   const int slot = mask != nullptr ? next_sched_slot() : -1;
   int64_t nb = (int64_t)B * ((H + L128_TH - 1) / L128_TH) * ((W + 31) / 32);
   if (nb > 512) nb = 512;  // resident workgroups: 2 per CU (registers)
   if (res != nullptr)
     k_conv3x3_ldsx<CIN, COUT, true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y,
-                                                                 B, H, W, relu, row_dirty, slot);
+                                                                 B, H, W, relu, row_dirty, slot, tlist, tcount);
   else
     k_conv3x3_ldsx<CIN, COUT, false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W,
-                                                                  relu, row_dirty, slot);
+                                                                  relu, row_dirty, slot, tlist, tcount);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -1117,9 +1178,42 @@ int launch_sephead(const void* x, const void* wfrag, const float* bias, void* y,
   return PNX_OK;
 }
 
+// ---- tile list: the 32-pixel-wide, `th`-row tiles that hold an active site now or a stale row in one of the persistent output
+// buffers (row_dirty).  One wave per tile; the list order follows the atomic.  A 1440 x 1440 sweep leaves 65 % of the 16 x 32
+// tiles empty, and an empty tile costs the convolution kernels a mask read + a barrier (~1.5 us) each.
+struct DirtySet {
+  const uint8_t* p[4];
+};
+__global__ __launch_bounds__(256) void k_tile_list(const uint8_t* __restrict__ mask, DirtySet ds, int B, int H, int W, int th, int32_t* __restrict__ list,
+                                                   int32_t* __restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  const int tiles_x = (W + 31) >> 5, tiles_y = (H + th - 1) / th;
+  const int64_t n_tiles = (int64_t)B * tiles_y * tiles_x;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= n_tiles) return;  // wave-uniform
+  const int tx = (int)(tile % tiles_x);
+  const int ty = (int)((tile / tiles_x) % tiles_y);
+  const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
+  const int ox = tx * 32 + (lane & 31);
+  bool any = false;
+  for (int r = lane >> 5; r < th; r += 2) {  // the two half-waves take alternate rows
+    const int oy = ty * th + r;
+    if (oy < H && ox < W && mask[((int64_t)b * H + oy) * W + ox] != 0) any = true;
+  }
+  if (lane < th) {
+    const int oy = ty * th + lane;
+    if (oy < H) {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (ds.p[k] != nullptr && ds.p[k][((int64_t)b * H + oy) * tiles_x + tx] != 0) any = true;
+    }
+  }
+  if (__ballot(any) != 0 && lane == 0) list[atomicAdd(count, 1)] = (int32_t)tile;
+}
+
 template <int COUT>
 int launch_lds(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
-               uint8_t* row_dirty, hipStream_t st) {
+               uint8_t* row_dirty, const int32_t* tlist, const int32_t* tcount, hipStream_t st) {
   constexpr int TH = LDS_TH;
   const int64_t n_tiles = (int64_t)B * ((H + TH - 1) / TH) * ((W + 31) / 32);
   int64_t nb = n_tiles;
@@ -1129,7 +1223,7 @@ int launch_lds(const void* x, const void* wfrag, const float* bias, const void* 
   if constexpr (COUT == 64) {
     if (res != nullptr) {
       k_conv3x3_lds<COUT, true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B,
-                                                             H, W, relu, row_dirty, slot);
+                                                             H, W, relu, row_dirty, slot, tlist, tcount);
       PNX_LAUNCH_CHECK();
       return PNX_OK;
     }
@@ -1137,7 +1231,7 @@ int launch_lds(const void* x, const void* wfrag, const float* bias, const void* 
     PNX_REQUIRE(res == nullptr, PNX_ERR_UNSUPPORTED, "residual with %d output channels", COUT);
   }
   k_conv3x3_lds<COUT, false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu,
-                                                          row_dirty, slot);
+                                                          row_dirty, slot, tlist, tcount);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -1210,8 +1304,33 @@ int pnx_deconv2x2_bf16(const void* x, const void* wfrag, const float* bias, void
   return PNX_OK;
 }
 
+int pnx_conv3x3_tile_rows(int32_t cin, int32_t cout, int32_t stride) {
+  if (stride != 1) return 0;
+  if (cin == 64 && (cout == 64 || cout == 320 || cout == 384 || cout == 448)) return LDS_TH;
+  if ((cin == 128 && cout == 128) || (cin == 256 && cout == 256)) return L128_TH;
+  return 0;
+}
+
+int pnx_conv_tile_list(const uint8_t* mask, const uint8_t* const* row_dirty, int32_t n_dirty, int32_t batch, int32_t h, int32_t w, int32_t tile_rows,
+                       int32_t* tile_list, int32_t* tile_count, pnx_stream_t stream) {
+  PNX_REQUIRE(mask && tile_list && tile_count && batch > 0 && h > 0 && w > 0 && tile_rows > 0, PNX_ERR_INVALID, "bad arguments");
+  PNX_REQUIRE(n_dirty >= 0 && n_dirty <= 4 && (n_dirty == 0 || row_dirty != nullptr), PNX_ERR_INVALID, "0..4 row_dirty arrays");
+  DirtySet ds;
+  for (int k = 0; k < 4; k++) ds.p[k] = k < n_dirty ? row_dirty[k] : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  PNX_CHECK_HIP(hipMemsetAsync(tile_count, 0, sizeof(int32_t), st));
+  const int64_t n_tiles = (int64_t)batch * ((h + tile_rows - 1) / tile_rows) * ((w + 31) / 32);
+  k_tile_list<<<(unsigned)((n_tiles + 3) / 4), 256, 0, st>>>(mask, ds, batch, h, w, tile_rows, tile_list, tile_count);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
 int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
-                     int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, uint8_t* row_dirty, pnx_stream_t stream) {
+                     int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, uint8_t* row_dirty, const int32_t* tile_list,
+                     const int32_t* tile_count, pnx_stream_t stream) {
+  PNX_REQUIRE((tile_list == nullptr) == (tile_count == nullptr), PNX_ERR_INVALID, "tile_list and tile_count come together");
+  PNX_REQUIRE(tile_list == nullptr || (mask != nullptr && pnx_conv3x3_tile_rows(cin, cout, stride) > 0), PNX_ERR_INVALID,
+              "a tile list needs a mask and a kernel that takes one (pnx_conv3x3_tile_rows)");
   PNX_REQUIRE(x && wfrag && bias && y && batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "bad arguments");
   PNX_REQUIRE(stride == 1 || stride == 2, PNX_ERR_UNSUPPORTED, "stride %d", stride);
   PNX_REQUIRE(row_dirty == nullptr || mask != nullptr, PNX_ERR_INVALID, "row_dirty needs an active-site mask");
@@ -1220,12 +1339,12 @@ int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const 
   const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1 && getenv("PNX_CONV_DIRECT") == nullptr) {
-    if (cin == 64 && cout == 64) return launch_lds<64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
-    if (cin == 128 && cout == 128) return launch_ldsx<128, 128>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
-    if (cin == 256 && cout == 256) return launch_ldsx<256, 256>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
-    if (cin == 64 && cout == 384) return launch_lds<384>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
-    if (cin == 64 && cout == 320) return launch_lds<320>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
-    if (cin == 64 && cout == 448) return launch_lds<448>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, st);
+    if (cin == 64 && cout == 64) return launch_lds<64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
+    if (cin == 128 && cout == 128) return launch_ldsx<128, 128>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
+    if (cin == 256 && cout == 256) return launch_ldsx<256, 256>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
+    if (cin == 64 && cout == 384) return launch_lds<384>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
+    if (cin == 64 && cout == 320) return launch_lds<320>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
+    if (cin == 64 && cout == 448) return launch_lds<448>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
   }
   if (stride == 2 && residual == nullptr && getenv("PNX_CONV_DIRECT") == nullptr) {
     if (cin == 64 && cout == 128) return launch_s2<64, 128>(x, wfrag, bias, mask, y, batch, h, w, ho, wo, relu, row_dirty, st);

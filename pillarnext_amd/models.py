@@ -560,12 +560,13 @@ class _HipConv3x3(nn.Module):
 
     def __init__(self, weight, bias, stride=1):
         super().__init__()
-        self.cout, self.stride = weight.shape[0], int(stride)
+        self.cout, self.cin, self.stride = weight.shape[0], weight.shape[1], int(stride)
         self.register_buffer("wfrag", ops.conv3x3_pack_weights(weight))
         self.register_buffer("bias", bias.float().contiguous())
 
-    def forward(self, x, mask=None, residual=None, out=None):
-        return ops.conv3x3_masked(x, self.wfrag, self.bias, self.cout, self.stride, mask, residual, True, out=out)
+    def forward(self, x, mask=None, residual=None, out=None, tiles=None):
+        return ops.conv3x3_masked(x, self.wfrag, self.bias, self.cout, self.stride, mask, residual, True, out=out,
+                                  tiles=tiles if self.stride == 1 else None)
 
 
 class _HipDeconv2x2(nn.Module):
@@ -614,6 +615,7 @@ class FusedPillarNeXt(nn.Module):
             hip_conv = os.environ.get("PNX_HIP_CONV", "1") != "0"
         self._ws = {}
         self.sparse_ws = os.environ.get("PNX_SPARSE_WS", "1") != "0"
+        self.tile_lists = os.environ.get("PNX_TILE_LISTS", "1") != "0"
         self.reader = det.reader
         self.post_processing = det.post_processing
         self.head_ref = det.head  # predict() / rectifier / class bookkeeping
@@ -715,13 +717,14 @@ class FusedPillarNeXt(nn.Module):
             if not subm:
                 mask = ops.mask_pool3(mask, stride)
             ws, k = self._stage_workspace(si, mods, mask), 0
+            tiles = self._stage_tiles(si, mods, mask, ws)
 
             def run(m, inp, res=None):
                 nonlocal k
                 if ws is None or not isinstance(m, _HipConv3x3):   # the strided entry conv of a 256-channel stage is MIOpen + epilogue
                     return m(inp, mask, residual=res)
                 k += 1                                  # x, y, out of a block sit in three different buffers
-                return m(inp, mask, residual=res, out=ws[(k - 1) % 3])
+                return m(inp, mask, residual=res, out=ws[(k - 1) % 3], tiles=tiles)
 
             x = run(mods[0], x)
             for j in range(1, len(mods), 2):
@@ -766,6 +769,21 @@ class FusedPillarNeXt(nn.Module):
             cout = next(m.cout for m in mods if isinstance(m, _HipConv3x3))
             self._ws[key] = [ops.conv3x3_workspace(B, cout, H, W, mask.device) for _ in range(3)]
         return self._ws[key]
+
+    def _stage_tiles(self, si, mods, mask, ws):
+        """Tile list of a stage (ops.conv_tile_list): the submanifold blocks share the stage's mask, so the tiles with an active site
+        or a stale row in one of the stage's three buffers are listed once and every stride-1 convolution walks the list."""
+        if ws is None or not self.tile_lists:
+            return None
+        m = next((m for m in mods if isinstance(m, _HipConv3x3) and m.stride == 1), None)
+        rows = ops.conv_tile_rows(m.cin, m.cout, 1) if m is not None else 0
+        if rows <= 0:
+            return None
+        key = ("tiles", si) + tuple(mask.shape) + (mask.device,)
+        buf = self._ws.get(key)
+        buf = ops.conv_tile_list(mask, [w[1] for w in ws], rows, out=buf)
+        self._ws[key] = buf
+        return buf
 
     def decoder(self):
         if self._decoder is None:

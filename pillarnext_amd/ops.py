@@ -275,9 +275,27 @@ def conv3x3_workspace(batch, cout, ho, wo, device):
     return y, torch.zeros((batch, ho, (wo + 31) // 32), dtype=torch.uint8, device=device)
 
 
-def conv3x3_masked(x, wfrag, bias, cout, stride=1, mask=None, residual=None, relu=True, out=None):
+def conv_tile_rows(cin, cout, stride=1):
+    """Rows of a tile of the kernel that serves (cin, cout, stride); 0 = that kernel walks all tiles (takes no tile list)."""
+    return int(lib().pnx_conv3x3_tile_rows(cin, cout, stride))
+
+
+def conv_tile_list(mask, dirties, tile_rows, out=None):
+    """(list int32[n_tiles], count int32[1]) of the tile_rows x 32 tiles of `mask` (B,H,W uint8) that hold an active site or a stale row
+    of one of the `dirties` (row_dirty arrays of conv3x3_workspace buffers); pass it as tiles= to every stride-1 conv over this mask."""
+    B, H, W = mask.shape
+    n_tiles = B * ((H + tile_rows - 1) // tile_rows) * ((W + 31) // 32)
+    if out is None:
+        out = (torch.empty((n_tiles,), dtype=torch.int32, device=mask.device), torch.zeros((1,), dtype=torch.int32, device=mask.device))
+    arr = (ctypes.c_void_p * max(len(dirties), 1))(*[d.data_ptr() for d in dirties])
+    check(lib().pnx_conv_tile_list(ptr(mask), arr, len(dirties), B, H, W, tile_rows, ptr(out[0]), ptr(out[1]), stream_ptr()), "pnx_conv_tile_list")
+    return out
+
+
+def conv3x3_masked(x, wfrag, bias, cout, stride=1, mask=None, residual=None, relu=True, out=None, tiles=None):
     """x (B,Cin,H,W) channels_last bf16 -> (B,Cout,Ho,Wo) channels_last bf16; mask uint8 (B,Ho,Wo) of the OUTPUT sites.
-    out = (y, row_dirty) from conv3x3_workspace: write into the persistent buffer, touching only row segments that are or were active."""
+    out = (y, row_dirty) from conv3x3_workspace: write into the persistent buffer, touching only row segments that are or were active.
+    tiles = conv_tile_list(mask, ...) of the same mask (stride 1 only): walk the listed tiles instead of all of them."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):
         raise PnxError("conv3x3_masked needs a channels_last bf16 CUDA tensor")
     B, ci, H, W = x.shape
@@ -288,6 +306,7 @@ def conv3x3_masked(x, wfrag, bias, cout, stride=1, mask=None, residual=None, rel
             raise PnxError("conv3x3_masked: out= needs a mask and a workspace of the output shape")
     else:
         y, dirty = torch.empty((B, cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last), None
+    tl, tc = tiles if tiles is not None else (None, None)
     check(lib().pnx_conv3x3_bf16(ptr(x), ptr(wfrag), ptr(bias), ptr(residual), ptr(mask), ptr(y), B, H, W, ci, cout, stride, 1 if relu else 0,
-                                 ptr(dirty), stream_ptr()), "pnx_conv3x3_bf16")
+                                 ptr(dirty), ptr(tl), ptr(tc), stream_ptr()), "pnx_conv3x3_bf16")
     return y

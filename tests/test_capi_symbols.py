@@ -63,14 +63,19 @@ def test_conv_entry_points_validate_before_launching():
     L = _lib.lib()
     buf = (ctypes.c_char * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    rc = L.pnx_conv3x3_bf16(None, None, None, None, None, None, 1, 8, 8, 64, 64, 1, 1, None, None)
+    rc = L.pnx_conv3x3_bf16(None, None, None, None, None, None, 1, 8, 8, 64, 64, 1, 1, None, None, None, None)
     assert rc < 0 and b"bad arguments" in L.pnx_last_error()
-    rc = L.pnx_conv3x3_bf16(p, p, p, None, None, p, 1, 8, 8, 64, 64, 3, 1, None, None)
+    rc = L.pnx_conv3x3_bf16(p, p, p, None, None, p, 1, 8, 8, 64, 64, 3, 1, None, None, None, None)
     assert rc < 0 and b"stride" in L.pnx_last_error()
-    rc = L.pnx_conv3x3_bf16(p, p, p, None, None, p, 1, 8, 8, 64, 64, 1, 1, p, None)       # row_dirty without a mask
+    rc = L.pnx_conv3x3_bf16(p, p, p, None, None, p, 1, 8, 8, 64, 64, 1, 1, p, None, None, None)       # row_dirty without a mask
     assert rc < 0 and b"row_dirty" in L.pnx_last_error()
-    rc = L.pnx_conv3x3_bf16(p, p, p, None, p, p, 1, 8, 8, 48, 64, 1, 1, None, None)       # no kernel for 48 input channels
+    rc = L.pnx_conv3x3_bf16(p, p, p, None, p, p, 1, 8, 8, 48, 64, 1, 1, None, None, None, None)       # no kernel for 48 input channels
     assert rc < 0 and b"48" in L.pnx_last_error()
+    rc = L.pnx_conv3x3_bf16(p, p, p, None, p, p, 1, 8, 8, 64, 128, 2, 1, None, p, p, None)       # the strided kernels take no tile list
+    assert rc < 0 and b"tile list" in L.pnx_last_error()
+    rc = L.pnx_conv3x3_bf16(p, p, p, None, p, p, 1, 8, 8, 64, 64, 1, 1, None, p, None, None)         # list without its count
+    assert rc < 0 and b"tile_count" in L.pnx_last_error()
+    assert L.pnx_conv3x3_tile_rows(64, 64, 1) == 16 and L.pnx_conv3x3_tile_rows(256, 256, 1) == 8 and L.pnx_conv3x3_tile_rows(64, 128, 2) == 0
     rc = L.pnx_sephead_out_bf16(p, p, p, p, 1, 8, 8, 3, None)
     assert rc < 0 and b"branches" in L.pnx_last_error()
     rc = L.pnx_sephead_out_bf16(None, p, p, p, 1, 8, 8, 6, None)

@@ -198,3 +198,36 @@ def test_deconv2x2_matches_torch(hw):
         got = ops.deconv2x2(x, ops.deconv2x2_pack_weights(w), bias, 64, relu)
         assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
         torch.testing.assert_close(got.float(), ref, rtol=1.6e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (256, 256)])
+def test_conv3x3_tile_list_equals_full_walk(cin, cout):
+    """Three frames through one workspace, once walking all tiles and once the listed ones (active site or stale row): same bytes,
+    same row_dirty.  The list is built from the mask and the workspace's flags BEFORE the conv, as a backbone stage does."""
+    from pillarnext_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(cin)
+    B, H, W = 2, 150, 200
+    w = (torch.randn((cout, cin, 3, 3), device="cuda", generator=g) / 24).to(torch.bfloat16)
+    wf = ops.conv3x3_pack_weights(w)
+    bias = torch.randn((cout,), device="cuda", generator=g)
+    rows = ops.conv_tile_rows(cin, cout, 1)
+    assert rows in (8, 16)
+    ws_a, ws_b = ops.conv3x3_workspace(B, cout, H, W, "cuda"), ops.conv3x3_workspace(B, cout, H, W, "cuda")
+    for frame in range(3):
+        mask = torch.zeros((B, H, W), dtype=torch.uint8, device="cuda")
+        y0, x0 = 20 + 40 * frame, 30 * frame                       # a blob that moves: earlier tiles go stale
+        mask[0, y0:y0 + 35, x0:x0 + 70] = (torch.rand((35, 70), device="cuda", generator=g) > 0.7).to(torch.uint8)
+        mask[1, 5 * frame + 3, :] = 1
+        x = (torch.randn((B, cin, H, W), device="cuda", generator=g) * mask.unsqueeze(1)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        res = torch.randn((B, cout, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        tiles = ops.conv_tile_list(mask, [ws_b[1]], rows)
+        n_list = int(tiles[1].item())
+        n_all = B * ((H + rows - 1) // rows) * ((W + 31) // 32)
+        assert 0 < n_list < n_all // 2
+        ref = ops.conv3x3_masked(x, wf, bias, cout, 1, mask, res, True, out=ws_a)
+        got = ops.conv3x3_masked(x, wf, bias, cout, 1, mask, res, True, out=ws_b, tiles=tiles)
+        assert torch.equal(got, ref), f"frame {frame}"
+        assert torch.equal(ws_a[1], ws_b[1])
+        want = torch.relu(torch.nn.functional.conv2d(x.float(), w.float(), None, 1, 1) + bias.view(1, -1, 1, 1) + res.float()) * mask.unsqueeze(1)
+        torch.testing.assert_close(got.float(), want, rtol=1.6e-2, atol=2e-2)

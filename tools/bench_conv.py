@@ -9,7 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cin", type=int, default=64); ap.add_argument("--cout", type=int, default=64)
 ap.add_argument("--hw", type=int, default=1440); ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--density", type=float, default=1.0); ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--stride", type=int, default=1); ap.add_argument("--miopen", action="store_true"); ap.add_argument("--res", action="store_true")
+ap.add_argument("--stride", type=int, default=1); ap.add_argument("--tiles", action="store_true"); ap.add_argument("--miopen", action="store_true"); ap.add_argument("--res", action="store_true")
 ap.add_argument("--lidar", type=int, default=-1, help="backbone stage (0..3): active sites = the C2 sweep occupancy pooled to that stage (sets --hw)")
 a = ap.parse_args()
 lidar_mask = None
@@ -46,11 +46,15 @@ wf = ops.conv3x3_pack_weights(w)
 res = (x[:, :a.cout] * 1.0).contiguous(memory_format=torch.channels_last) if a.res and a.cout <= a.cin else None
 wcl = w.contiguous(memory_format=torch.channels_last)
 torch.backends.cudnn.benchmark = True
+tiles = None
+if a.tiles and ws is not None and a.stride == 1:
+    tiles = ops.conv_tile_list(mask, [ws[1]], ops.conv_tile_rows(a.cin, a.cout, 1))
+    print(f"tile list: {int(tiles[1].item())} of {tiles[0].numel()} tiles")
 def run():
     if a.miopen:
         y = torch.nn.functional.conv2d(x, wcl, None, a.stride, 1)
         return ops.bias_act_mask_(y, bias, mask, res, True)
-    return ops.conv3x3_masked(x, wf, bias, a.cout, a.stride, mask, res, True, out=ws)
+    return ops.conv3x3_masked(x, wf, bias, a.cout, a.stride, mask, res, True, out=ws, tiles=tiles)
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
