@@ -4,7 +4,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pillarnext_amd import ops
-nb, B, H = 6, 4, 360
+nb, B, H = 6, int(os.environ.get("B", "8")), 360
 g = torch.Generator(device="cuda").manual_seed(0)
 x = torch.relu(torch.randn((B, nb * 64, H, H), device="cuda", generator=g)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 W2 = (torch.randn((16, nb * 64, 3, 3), device="cuda", generator=g) / 24).to(torch.bfloat16)
