@@ -1181,36 +1181,58 @@ int launch_sephead(const void* x, const void* wfrag, const float* bias, void* y,
 }
 
 // ---- tile list: the 32-pixel-wide, `th`-row tiles that hold an active site now or a stale row in one of the persistent output
-// buffers (row_dirty).  One wave per tile; the list order follows the atomic.  A 1440 x 1440 sweep leaves 65 % of the 16 x 32
-// tiles empty, and an empty tile costs the convolution kernels a mask read + a barrier (~1.5 us) each.
+// buffers (row_dirty).  A 1440 x 1440 sweep leaves 65 % of the 16 x 32 tiles empty, and an empty tile costs the convolution
+// kernels a mask read + a barrier (~1.5 us) each.  One THREAD per tile (consecutive lanes read consecutive 32-byte pieces of a mask
+// row), the workgroup compacts its hits in LDS and draws ONE range of the list: a wave per tile with an atomic per hit ran 73 us
+// on the 32 400 tiles of stage 0 (11 000 same-address atomics at ~13 ns), this form ~10 us.  The list order follows the atomics.
 struct DirtySet {
   const uint8_t* p[4];
 };
 __global__ __launch_bounds__(256) void k_tile_list(const uint8_t* __restrict__ mask, DirtySet ds, int B, int H, int W, int th, int32_t* __restrict__ list,
                                                    int32_t* __restrict__ count) {
-  const int lane = threadIdx.x & 63;
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int tiles_x = (W + 31) >> 5, tiles_y = (H + th - 1) / th;
   const int64_t n_tiles = (int64_t)B * tiles_y * tiles_x;
-  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tile >= n_tiles) return;  // wave-uniform
-  const int tx = (int)(tile % tiles_x);
-  const int ty = (int)((tile / tiles_x) % tiles_y);
-  const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
-  const int ox = tx * 32 + (lane & 31);
+  const int64_t tile = (int64_t)blockIdx.x * 256 + t;
   bool any = false;
-  for (int r = lane >> 5; r < th; r += 2) {  // the two half-waves take alternate rows
-    const int oy = ty * th + r;
-    if (oy < H && ox < W && mask[((int64_t)b * H + oy) * W + ox] != 0) any = true;
-  }
-  if (lane < th) {
-    const int oy = ty * th + lane;
-    if (oy < H) {
+  if (tile < n_tiles) {
+    const int tx = (int)(tile % tiles_x);
+    const int ty = (int)((tile / tiles_x) % tiles_y);
+    const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
+    const int x0 = tx * 32;
+    const bool wide = (W & 15) == 0 && x0 + 32 <= W;  // two aligned 16-byte loads per row
+    uint32_t acc = 0;
+    for (int r = 0; r < th; r++) {
+      const int oy = ty * th + r;
+      if (oy >= H) break;
+      const uint8_t* row = mask + ((int64_t)b * H + oy) * W + x0;
+      if (wide) {
+        const uint4 a = reinterpret_cast<const uint4*>(row)[0], c = reinterpret_cast<const uint4*>(row)[1];
+        acc |= a.x | a.y | a.z | a.w | c.x | c.y | c.z | c.w;
+      } else {
+        for (int k = 0; k < 32 && x0 + k < W; k++) acc |= row[k];
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        if (ds.p[k] != nullptr && ds.p[k][((int64_t)b * H + oy) * tiles_x + tx] != 0) any = true;
+        if (ds.p[k] != nullptr) acc |= ds.p[k][((int64_t)b * H + oy) * tiles_x + tx];
     }
+    any = acc != 0;
   }
-  if (__ballot(any) != 0 && lane == 0) list[atomicAdd(count, 1)] = (int32_t)tile;
+  const unsigned long long bal = __ballot(any);
+  if (lane == 0) s_wave[wv] = __popcll(bal);
+  __syncthreads();
+  if (t == 0) {
+    const int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = tot > 0 ? atomicAdd(count, tot) : 0;
+  }
+  __syncthreads();
+  if (any) {
+    int off = s_base + __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wv; w++) off += s_wave[w];
+    list[off] = (int32_t)tile;
+  }
 }
 
 template <int COUT>
@@ -1322,7 +1344,7 @@ int pnx_conv_tile_list(const uint8_t* mask, const uint8_t* const* row_dirty, int
   hipStream_t st = (hipStream_t)stream;
   PNX_CHECK_HIP(hipMemsetAsync(tile_count, 0, sizeof(int32_t), st));
   const int64_t n_tiles = (int64_t)batch * ((h + tile_rows - 1) / tile_rows) * ((w + 31) / 32);
-  k_tile_list<<<(unsigned)((n_tiles + 3) / 4), 256, 0, st>>>(mask, ds, batch, h, w, tile_rows, tile_list, tile_count);
+  k_tile_list<<<(unsigned)((n_tiles + 255) / 256), 256, 0, st>>>(mask, ds, batch, h, w, tile_rows, tile_list, tile_count);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

@@ -200,14 +200,15 @@ def test_deconv2x2_matches_torch(hw):
         torch.testing.assert_close(got.float(), ref, rtol=1.6e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("W", [200, 224])     # the list kernel reads the mask bytewise / as aligned 16-byte pieces
 @pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (256, 256)])
-def test_conv3x3_tile_list_equals_full_walk(cin, cout):
+def test_conv3x3_tile_list_equals_full_walk(cin, cout, W):
     """Three frames through one workspace, once walking all tiles and once the listed ones (active site or stale row): same bytes,
     same row_dirty.  The list is built from the mask and the workspace's flags BEFORE the conv, as a backbone stage does."""
     from pillarnext_amd import ops
 
     g = torch.Generator(device="cuda").manual_seed(cin)
-    B, H, W = 2, 150, 200
+    B, H = 2, 150
     w = (torch.randn((cout, cin, 3, 3), device="cuda", generator=g) / 24).to(torch.bfloat16)
     wf = ops.conv3x3_pack_weights(w)
     bias = torch.randn((cout,), device="cuda", generator=g)
@@ -223,6 +224,10 @@ def test_conv3x3_tile_list_equals_full_walk(cin, cout):
         res = torch.randn((B, cout, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         tiles = ops.conv_tile_list(mask, [ws_b[1]], rows)
         n_list = int(tiles[1].item())
+        seg = torch.nn.functional.max_pool2d((mask | torch.repeat_interleave(ws_b[1], 32, dim=2)[:, :, :W]).float().unsqueeze(1), (rows, 32), (rows, 32),
+                                             ceil_mode=True)
+        assert n_list == int(seg.sum().item())                      # exactly the tiles with an active site or a stale row
+        assert sorted(tiles[0][:n_list].tolist()) == torch.nonzero(seg.flatten() > 0).flatten().tolist()
         n_all = B * ((H + rows - 1) // rows) * ((W + 31) // 32)
         assert 0 < n_list < n_all // 2
         ref = ops.conv3x3_masked(x, wf, bias, cout, 1, mask, res, True, out=ws_a)
