@@ -32,6 +32,8 @@ VARIANTS = [
     ("binned fused 0,0,24", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,24"}),
     ("binned fused 0,0,35", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,35"}),
     ("binned fused 0,0,45", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,45"}),
+    ("binned fused 0,0,60", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,60"}),
+    ("binned fused 0,0,30", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,30"}),
     ("binned fused 0,5,40", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,5,40"}),
     ("binned fused 3,5,35", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "3,5,35"}),
     ("binned fused 0,0,35 f384", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,35", "PNX_FILL_BLOCKS": "384"}),
