@@ -274,6 +274,13 @@ int pnx_decode_topk(const uint64_t* keys, int64_t n_keys, int32_t num_segments, 
                     int64_t* seg_start, int32_t* seg_len, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
 int pnx_decode_keys(const void* packed, int32_t dtype, int32_t batch, int32_t n_classes_total, const void* task_desc_host, uint64_t* keys,
                     pnx_stream_t stream);
+/* Stable sort of the candidate keys of pnx_decode_keys (all tasks, all samples) with their positions as payload -- what
+ * centerhead.py:296-300 does per class with torch.sort/topk, here once for every (sample, class) list: keys are
+ * (segment << 32 | ~score bits), invalid = all ones, so only 32 + bit_length(num_segments) bits are sorted.
+ *   sorted_keys uint64[n_keys], order int64[n_keys] (position of each sorted key in `keys`); workspace from ..._workspace_bytes. */
+size_t pnx_sort_keys_workspace_bytes(int64_t n_keys);
+int pnx_sort_keys(const uint64_t* keys, int64_t n_keys, int32_t num_segments, uint64_t* sorted_keys, int64_t* order, void* workspace,
+                  size_t workspace_bytes, pnx_stream_t stream);
 int pnx_decode_boxes(const void* const* task_ptrs_dev, const void* task_descs_dev, const int64_t* task_key_off_dev, int32_t n_tasks,
                      int32_t dtype, int32_t batch, const uint64_t* sorted_keys, const int64_t* order, const int64_t* seg_start,
                      const int32_t* seg_len, int32_t num_segments, int32_t pre_max, float* boxes9, float* boxes7, float* scores,

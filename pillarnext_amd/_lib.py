@@ -62,6 +62,8 @@ PROTOTYPES = {
     "pnx_decode_topk_workspace_bytes": (_sz, [_i64, _i32]),
     "pnx_decode_topk": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pnx_decode_keys": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "pnx_sort_keys_workspace_bytes": (ctypes.c_size_t, [_i64]),
+    "pnx_sort_keys": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "pnx_decode_boxes": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pnx_gather_kept": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "pnx_boxes_overlap_bev": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),

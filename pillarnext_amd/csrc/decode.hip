@@ -10,6 +10,9 @@
 //   k_decode_boxes  decodes full 9-d boxes (:259-303) only for the first pre_max candidates of each segment.
 //   k_gather_kept   after the batched NMS: the first post_max kept boxes of every segment into a dense block.
 // Channel order of the packed tensor = SepHead's dict order: reg(2) height(1) dim(3) rot(2) vel(2) [iou(1)] hm(ncls).
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <string.h>
 
 #include "pnx_common.h"
@@ -358,6 +361,32 @@ int pnx_decode_keys(const void* packed, int32_t dtype, int32_t batch, int32_t n_
 }
 
 size_t pnx_decode_task_desc_bytes(void) { return sizeof(DecodeTask); }
+
+// One stable radix sort of all candidate keys with their positions as payload, over the bits that can differ only: a key is
+// (segment << 32 | ~score bits) or all ones, so 32 + bit_length(num_segments) bits order everything (invalid keys stay last) --
+// 5 onesweep passes instead of the 8 a generic 64-bit sort runs.  rocPRIM is the library primitive here (as rocBLAS would be
+// for a plain GEMM); torch.sort is the same primitive without the bit range.
+size_t pnx_sort_keys_workspace_bytes(int64_t n_keys) {
+  size_t bytes = 0;
+  if (n_keys <= 0) return 256;
+  rocprim::counting_iterator<int64_t> iota(0);
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, iota, (int64_t*)nullptr,
+                                  (size_t)n_keys, 0u, 64u, (hipStream_t) nullptr);
+  return bytes + 256;
+}
+
+int pnx_sort_keys(const uint64_t* keys, int64_t n_keys, int32_t num_segments, uint64_t* sorted_keys, int64_t* order, void* workspace,
+                  size_t workspace_bytes, pnx_stream_t stream) {
+  PNX_REQUIRE(keys && sorted_keys && order && workspace && n_keys > 0 && num_segments > 0, PNX_ERR_INVALID, "bad arguments");
+  PNX_REQUIRE(workspace_bytes >= pnx_sort_keys_workspace_bytes(n_keys), PNX_ERR_INVALID, "workspace too small");
+  unsigned bits = 0;
+  while ((1 << bits) <= num_segments) bits++;  // 2^bits > num_segments: the all-ones pattern of an invalid key exceeds every valid segment
+  size_t bytes = workspace_bytes;
+  rocprim::counting_iterator<int64_t> iota(0);
+  PNX_CHECK_HIP(rocprim::radix_sort_pairs(workspace, bytes, (const unsigned long long*)keys, (unsigned long long*)sorted_keys, iota, order,
+                                          (size_t)n_keys, 0u, 32u + bits, (hipStream_t)stream));
+  return PNX_OK;
+}
 
 int pnx_decode_boxes(const void* const* task_ptrs_dev, const void* task_descs_dev, const int64_t* task_key_off_dev, int32_t n_tasks,
                      int32_t dtype, int32_t batch, const uint64_t* sorted_keys, const int64_t* order, const int64_t* seg_start,

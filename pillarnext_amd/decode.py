@@ -48,6 +48,8 @@ class PackedDecoder:
         # threshold and tens of thousands of them tie at one quantised score, so every segment sorts ~40 k candidates in LDS chunks --
         # measured 6.4 ms per 8-frame step against 1.06 ms for the sort; it pays once candidates are a few percent of the cells.
         self.use_topk = os.environ.get("PNX_DECODE_TOPK", "0") == "1"
+        self.use_torch_sort = os.environ.get("PNX_DECODE_TORCH_SORT", "0") == "1"   # the generic 64-bit torch.sort (cross-check)
+        self._sort_ws = None
         self._tptr = {}
         self._pin = {}
 
@@ -105,10 +107,21 @@ class PackedDecoder:
                 self._topk_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             check(L.pnx_decode_topk(ptr(keys), offs[-1], S, self.pre_max, ptr(skeys), ptr(order), ptr(seg_start), ptr(seg_len), ptr(self._topk_ws),
                                     self._topk_ws.numel(), stream_ptr()), "pnx_decode_topk")
-        else:
+        elif self.use_torch_sort:
             # keys are non-negative when valid ... as int64 the all-ones key is -1: sort as unsigned by flipping the sign bit
             skeys, order = torch.sort(keys ^ (-0x8000000000000000), stable=True)
             skeys = skeys ^ (-0x8000000000000000)
+            seg_start = torch.searchsorted(skeys ^ (-0x8000000000000000), bounds)
+            seg_len = torch.clamp(seg_start[1:] - seg_start[:-1], max=self.pre_max).to(torch.int32)
+        else:
+            # the same stable sort over the 32 + bit_length(S) bits that can differ (pnx_sort_keys: 5 radix passes instead of 8)
+            skeys = torch.empty_like(keys)
+            order = torch.empty_like(keys)
+            wsb = int(L.pnx_sort_keys_workspace_bytes(offs[-1]))
+            if self._sort_ws is None or self._sort_ws.numel() < wsb or self._sort_ws.device != dev:
+                self._sort_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            check(L.pnx_sort_keys(ptr(keys), offs[-1], S, ptr(skeys), ptr(order), ptr(self._sort_ws), self._sort_ws.numel(), stream_ptr()),
+                  "pnx_sort_keys")
             seg_start = torch.searchsorted(skeys ^ (-0x8000000000000000), bounds)
             seg_len = torch.clamp(seg_start[1:] - seg_start[:-1], max=self.pre_max).to(torch.int32)
         # pointer table of the task tensors: a torch.tensor(list, device=...) is a blocking copy from pageable memory (it would make

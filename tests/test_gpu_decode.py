@@ -273,3 +273,45 @@ def test_segmented_topk_equals_the_full_stable_sort():
         assert torch.equal(out_o[s * pre_max: s * pre_max + k], order[a0: a0 + k]), s
         assert torch.equal(out_k[s * pre_max: s * pre_max + k], skeys[a0: a0 + k]), s
         assert int(out_s[s]) == s * pre_max
+
+
+@pytest.mark.parametrize("S", [23, 31, 32, 80])
+def test_bit_ranged_key_sort_equals_the_full_stable_sort(S):
+    """pnx_sort_keys sorts only the 32 + bit_length(S) bits that can differ; keys, order (stability under heavy ties) and the place of the
+    invalid keys must equal one generic stable 64-bit sort.  S = 31 / 32: the all-ones segment pattern just above / one bit above."""
+    from pillarnext_amd._lib import check, lib, ptr, stream_ptr
+
+    L = lib()
+    g = torch.Generator(device="cuda").manual_seed(S)
+    n = 700_001
+    seg = torch.randint(0, S, (n,), device="cuda", generator=g)
+    sc = (torch.rand((n,), device="cuda", generator=g) * 0.9 + 0.1).to(torch.bfloat16).float()        # heavy ties
+    valid = torch.rand((n,), device="cuda", generator=g) < 0.5
+    low = (0xFFFFFFFF - sc.view(torch.int32).to(torch.int64))
+    keys = torch.where(valid, (seg.to(torch.int64) << 32) | low, torch.full_like(low, -1))
+    want_k, want_o = torch.sort(keys ^ (-0x8000000000000000), stable=True)
+    want_k = want_k ^ (-0x8000000000000000)
+    got_k, got_o = torch.empty_like(keys), torch.empty_like(keys)
+    ws = torch.empty(int(L.pnx_sort_keys_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    check(L.pnx_sort_keys(ptr(keys), n, S, ptr(got_k), ptr(got_o), ptr(ws), ws.numel(), stream_ptr()), "pnx_sort_keys")
+    assert torch.equal(got_k, want_k) and torch.equal(got_o, want_o)
+
+
+def test_decoder_sort_paths_agree(monkeypatch):
+    """PackedDecoder with pnx_sort_keys (default) and with the generic torch.sort: identical detections."""
+    from pillarnext_amd.decode import PackedDecoder
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, H, W = 2, 64, 64
+    cfg = dict(nms=dict(nms_pre_max_size=200, nms_post_max_size=40, nms_iou_threshold=[[0.2], [0.2, 0.2]]), score_threshold=0.1,
+               pc_range=[-25.6, -25.6], voxel_size=[0.1, 0.1], out_size_factor=[8, 8], post_center_limit_range=[-30, -30, -10, 30, 30, 10])
+    packed = [(torch.randn((B, 16, H, W), device="cuda", generator=g) * 0.7).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(2)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PNX_DECODE_TORCH_SORT", mode)
+        dec = PackedDecoder([1, 2], [[0.5], [0.5, 0.5]], cfg, True, [16, 16])
+        res[mode] = dec(packed)
+    for a, b in zip(res["0"], res["1"]):
+        assert a["box3d_lidar"].shape[0] > 0
+        for k in ("box3d_lidar", "scores", "label_preds"):
+            assert torch.equal(a[k], b[k]), k
