@@ -655,7 +655,7 @@ __device__ __forceinline__ void conv_rows_x(uint4* __restrict__ s_in, const uint
                                             const float* __restrict__ bias, const uint16_t* __restrict__ res, const int (&rrow)[4],
                                             const int (&rbase)[4], const uint32_t (&rmask)[4], uint16_t* const (&yrow)[4], int b, int H, int W,
                                             int y0, int x0, uint32_t need, int mg0, int relu, int px, int kb, int lane) {
-  constexpr int NH = COUT / 128, NS = CIN / 64, NRA = NR > 0 ? NR : 1;
+  constexpr int NH = (COUT + 127) / 128, NS = CIN / 64, NRA = NR > 0 ? NR : 1;
   const int ox = x0 + px;
 #pragma unroll 1
   for (int h = 0; h < NH; h++) {
@@ -711,14 +711,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
                                                       const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
                                                       int relu, uint8_t* __restrict__ row_dirty, int slot, const int32_t* __restrict__ tlist,
                                                       const int32_t* __restrict__ tcount) {
-  static_assert(CIN % 64 == 0 && COUT % 128 == 0, "64-channel input slabs, 128-channel output passes");
+  static_assert(CIN % 64 == 0 && (COUT % 128 == 0 || COUT == 64), "64-channel input slabs, 128-channel output passes (or one of 64)");
   constexpr int TH = L128_TH, HW_ = LDS_HW;
+  constexpr int NRG = COUT == 64 ? 4 : 2, NRMAX = TH / NRG;  // row groups (the other waves split the 128 output channels of a pass)
   __shared__ uint4 s_in[L128_NSTAGE];
   __shared__ uint32_t s_rowmask2[2 * TH];  // double-buffered by iteration parity (an empty tile has a single barrier)
   __shared__ unsigned int s_next[2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int px = lane & 31, kb = lane >> 5;
-  const int rg = wv & 1, mg0 = 2 * (wv >> 1);  // row group, first 32-channel output tile of this wave within a pass
+  const int rg = wv % NRG, mg0 = 2 * (wv / NRG);  // row group, first 32-channel output tile of this wave within a pass
   const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
   const int64_t n_tiles = tlist != nullptr ? (int64_t)__builtin_amdgcn_readfirstlane(*tcount) : (int64_t)B * tiles_y * tiles_x;
   // requests the mask bytes / row_dirty flags of the rows this wave looks at in tile t (t < 0: none)
@@ -785,13 +786,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
     int rbase[4], rrow[4];
     {  // the active rows, dealt round-robin to the 2 row groups
       uint32_t rest = am;
-      if (rg && rest) rest &= rest - 1;
+      for (int k = 0; k < rg && rest; k++) rest &= rest - 1;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const bool has = rest != 0;
+        const bool has = j < NRMAX && rest != 0;
         rrow[j] = has ? __builtin_ctz(rest) : 0;  // dummy rows point at row 0
         nr += has ? 1 : 0;
-        for (int k = 0; k < 2 && rest; k++) rest &= rest - 1;
+        for (int k = 0; k < NRG && rest; k++) rest &= rest - 1;
       }
     }
     nr = __builtin_amdgcn_readfirstlane(nr);
@@ -807,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
     const uint32_t need = am | (am << 1) | (am << 2);  // halo rows some active row reads
     stage_tile64<CIN, TH>(s_in, x, b, H, W, 0, y0, x0, need);
     __syncthreads();
-#define PNX_ROWS_X(N_) conv_rows_x<N_, CIN, COUT, HAS_RES>(s_in, x, wfrag, bias, res, rrow, rbase, rmask, yrow, b, H, W, y0, x0, need, mg0, relu, px, kb, lane)
+#define PNX_ROWS_X(N_) conv_rows_x<(N_ <= NRMAX ? N_ : NRMAX), CIN, COUT, HAS_RES>(s_in, x, wfrag, bias, res, rrow, rbase, rmask, yrow, b, H, W, y0, x0, need, mg0, relu, px, kb, lane)
     switch (nr) {  // wave-uniform; every case runs the same barriers
       case 0: PNX_ROWS_X(0); break;
       case 1: PNX_ROWS_X(1); break;
@@ -1331,7 +1332,7 @@ int pnx_deconv2x2_bf16(const void* x, const void* wfrag, const float* bias, void
 int pnx_conv3x3_tile_rows(int32_t cin, int32_t cout, int32_t stride) {
   if (stride != 1) return 0;
   if (cin == 64 && (cout == 64 || cout == 320 || cout == 384 || cout == 448)) return LDS_TH;
-  if ((cin == 128 && cout == 128) || (cin == 256 && cout == 256)) return L128_TH;
+  if ((cin == 128 && cout == 128) || (cin == 256 && (cout == 256 || cout == 64))) return L128_TH;
   return 0;
 }
 
@@ -1365,6 +1366,7 @@ int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const 
   if (stride == 1 && getenv("PNX_CONV_DIRECT") == nullptr) {
     if (cin == 64 && cout == 64) return launch_lds<64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
     if (cin == 128 && cout == 128) return launch_ldsx<128, 128>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
+    if (cin == 256 && cout == 64) return launch_ldsx<256, 64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
     if (cin == 256 && cout == 256) return launch_ldsx<256, 256>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
     if (cin == 64 && cout == 384) return launch_lds<384>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
     if (cin == 64 && cout == 320) return launch_lds<320>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);

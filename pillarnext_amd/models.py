@@ -524,16 +524,17 @@ def _fold_bn(weight, bn, conv_bias=None, transposed=False):
 
 
 def fold_aspp(nk):
-    """ASPPNeck (eval) after pre_conv as ONE sum of convolutions of x: returns (w_1x1 (O,C,1,1), [w_d (O,C,3,3) for d in 1,6,12,18], shift (O,))
-    with  relu(conv1x1(x, w_1x1) + sum_d conv_d(x, w_d) + shift) == post_conv(cat(x, conv1x1(x), conv_d(x, W)...))  (aspp.py:19-32)."""
+    """ASPPNeck (eval) after pre_conv as ONE sum of four dilated convolutions of x: returns ([w_d (O,C,3,3) for d in 1,6,12,18], shift (O,))
+    with  relu(sum_d conv_d(x, w_d) + shift) == post_conv(cat(x, conv1x1(x), conv_d(x, W)...))  (aspp.py:19-32).  The identity and
+    1x1 branches are 1x1 convolutions of x, i.e. centre taps: they are added to the centre tap of the dilation-1 kernel."""
     wp, bp = _fold_bn(nk.post_conv.conv.conv.weight, nk.post_conv.norm)
     C = nk.weight.shape[0]
     P = wp.detach().float().reshape(wp.shape[0], 6, C)                       # (out, branch, mid): column blocks of the post weight
     w1 = nk.conv1x1.weight.detach().float().reshape(C, C)
-    wa = (P[:, 0] + P[:, 1] @ w1).reshape(wp.shape[0], C, 1, 1)
     ws = nk.weight.detach().float()
     wds = [torch.einsum("om,mikl->oikl", P[:, 2 + k], ws) for k in range(4)]
-    return wa, wds, bp.float()
+    wds[0][:, :, 1, 1] += P[:, 0] + P[:, 1] @ w1
+    return wds, bp.float()
 
 
 class _FusedConv(nn.Module):
@@ -644,15 +645,16 @@ class FusedPillarNeXt(nn.Module):
         # ASPP (aspp.py:19-32): the identity, the 1x1 branch and the four dilated branches have no BN/activation of their own and
         # post_conv is a 1x1 over their concat, so it distributes over the branches:
         #     post(cat(x, conv1x1(x), conv_d(x, Ws)...)) = conv1x1(x, P0 + P1.W1) + sum_d conv_d(x, P_d.Ws)
-        # (P_k = the k-th 256-column block of the BN-folded post weight).  The 1536-channel concat and the 1536 -> 256 GEMM disappear;
-        # the five partial results are summed in fp32 by one pass (pnx_sum_bias_act) that also applies the folded-BN shift + ReLU.
-        wa, wds, bp = fold_aspp(nk)
-        self.register_buffer("aspp_1x1", wa.to(dtype).contiguous(memory_format=torch.channels_last))
+        # (P_k = the k-th 256-column block of the BN-folded post weight), and the 1x1 term is a centre tap, added to the dilation-1
+        # kernel.  The 1536-channel concat, the 1536 -> 256 GEMM and the 1x1 branch disappear; the four partial results are summed
+        # in fp32 by one pass (pnx_sum_bias_act) that also applies the folded-BN shift + ReLU.
+        wds, bp = fold_aspp(nk)
         for k, wd in enumerate(wds):
             self.register_buffer(f"aspp_w{k}", wd.to(dtype).contiguous(memory_format=torch.channels_last))
         self.register_buffer("aspp_bias", bp.float().contiguous())
         hd = det.head
-        self.shared = _FusedConv(*_fold_bn(hd.shared_conv[0].weight, hd.shared_conv[1], hd.shared_conv[0].bias), 1, 1, dtype=dtype)
+        sc = hd.shared_conv[0]
+        self.shared = _backbone_conv(*_fold_bn(sc.weight, hd.shared_conv[1], sc.bias), sc.stride[0], sc.padding[0], dtype, hip_conv)
         self.task_deblock = nn.ModuleList()
         self.task_conv1 = nn.ModuleList()
         self.task_conv2 = nn.ModuleList()
@@ -737,7 +739,7 @@ class FusedPillarNeXt(nn.Module):
         # BasicBlock (utils/conv.py): act(block2(block1(x)) + x) where block2 already ends in a ReLU, so the residual is added
         # AFTER that ReLU; both terms are >= 0, which makes the trailing act() the identity.
         x = self.pre2(self.pre1(x)) + x
-        parts = [F.conv2d(x, self.aspp_1x1)] + [F.conv2d(x, getattr(self, f"aspp_w{k}"), None, 1, d, d) for k, d in enumerate((1, 6, 12, 18))]
+        parts = [F.conv2d(x, getattr(self, f"aspp_w{k}"), None, 1, d, d) for k, d in enumerate((1, 6, 12, 18))]
         parts = [p if p.is_contiguous(memory_format=torch.channels_last) else p.contiguous(memory_format=torch.channels_last) for p in parts]
         x = ops.sum_bias_act(parts, self.aspp_bias, relu=True)
         mark("mapping+neck")

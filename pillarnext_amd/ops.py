@@ -219,7 +219,7 @@ def mask_pool3(mask, stride):
 
 # (Cin, Cout) pairs pnx_conv3x3_bf16 has kernels for.  Stride 1: backbone blocks, + the merged SepHead branches (5/6/7 x 64).
 # Stride 2: the entry convolutions of backbone stages 1-3 (no residual).
-CONV3X3_SHAPES_S1 = {(64, 64), (64, 128), (128, 128), (256, 256), (64, 320), (64, 384), (64, 448)}
+CONV3X3_SHAPES_S1 = {(64, 64), (64, 128), (128, 128), (256, 256), (256, 64), (64, 320), (64, 384), (64, 448)}
 CONV3X3_SHAPES_S2 = {(64, 64), (64, 128), (128, 128), (128, 256), (256, 256)}
 
 

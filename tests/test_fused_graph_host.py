@@ -105,8 +105,8 @@ def test_aspp_fold_equals_the_module():
     with torch.no_grad():
         want = nk(x)
         xin = nk.pre_conv(x)
-        wa, wds, shift = fold_aspp(nk)
-        got = F.conv2d(xin, wa.double())
+        wds, shift = fold_aspp(nk)
+        got = 0
         for wd, d in zip(wds, (1, 6, 12, 18)):
             got = got + F.conv2d(xin, wd.double(), None, 1, d, d)
         got = torch.relu(got + shift.double().view(1, -1, 1, 1))

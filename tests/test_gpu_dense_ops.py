@@ -54,7 +54,7 @@ def test_point_uploader_roundtrip():
         assert np.array_equal(np.unique(ref[:, 0]), [0, 1, 2])
 
 
-@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 128, 2), (128, 128, 1), (64, 64, 2), (64, 384, 1), (64, 320, 1), (256, 256, 1), (128, 256, 2),
+@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 128, 2), (128, 128, 1), (64, 64, 2), (64, 384, 1), (64, 320, 1), (256, 256, 1), (256, 64, 1), (128, 256, 2),
                                                (256, 256, 2)])
 @pytest.mark.parametrize("residual", [False, True])
 def test_conv3x3_masked_matches_torch(cin, cout, stride, residual):
@@ -87,7 +87,7 @@ def test_conv3x3_masked_matches_torch(cin, cout, stride, residual):
     torch.testing.assert_close(got2, ref2, rtol=1.6e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("cin,cout,residual", [(64, 64, False), (64, 64, True), (64, 384, False), (128, 128, False), (128, 128, True), (256, 256, False),
+@pytest.mark.parametrize("cin,cout,residual", [(64, 64, False), (64, 64, True), (64, 384, False), (128, 128, False), (128, 128, True), (256, 64, False), (256, 256, False),
                                                (256, 256, True)])
 def test_conv3x3_sparse_rows(cin, cout, residual):
     """Few active rows per 16-row tile: the per-row-count (NR = 1..3) paths, dummy rows and zero-filled rows of the LDS kernel."""
