@@ -173,6 +173,8 @@ int pnx_merge_sweeps(const float* raw, int64_t n_raw, int32_t raw_stride, int32_
 /* ------------------------------------------------------------------------------------------------
  * Epilogue of the masked-dense backbone (the dense stand-in for det3d/models/utils/sparse_conv.py:16-63 with BatchNorm
  * folded into the conv):  out = [relu]( x + bias[c] [+ residual] ) * mask[site]   in one pass, bf16 NHWC.
+ *   relu: 0 none, 1 as written, 2 = ( relu(x + bias[c]) + residual ) * mask  (det3d/models/utils/conv.py BasicBlock of the neck:
+ *   the identity joins after block2's own ReLU)
  *   x, residual, out  (sites, channels) bf16 (residual may be NULL; out may alias x)
  *   bias              fp32[channels];  mask  uint8[sites] or NULL (= all active)
  */

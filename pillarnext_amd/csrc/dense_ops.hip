@@ -19,7 +19,8 @@ __device__ __forceinline__ uint32_t f2bf(float f) {
 }
 
 // x, res, out: bf16 NHWC with C channels (C % 8 == 0); bias fp32[C]; mask u8[sites] (or null) ; one thread = 8 channels
-template <bool HAS_RES, bool HAS_MASK, bool RELU>
+// RELU: 0 none, 1 relu(x + b + res), 2 relu(x + b) + res (BasicBlock of the neck: the residual joins after block2's own ReLU)
+template <bool HAS_RES, bool HAS_MASK, int RELU>
 __global__ __launch_bounds__(256) void k_bias_act_mask_bf16(const uint4* __restrict__ x, const uint4* __restrict__ res,
                                                             const float* __restrict__ bias, const uint8_t* __restrict__ mask,
                                                             uint4* __restrict__ out, int64_t n_vec, int cvec) {
@@ -39,11 +40,15 @@ __global__ __launch_bounds__(256) void k_bias_act_mask_bf16(const uint4* __restr
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         float lo = bf2f(vw[k] & 0xffffu) + bb[2 * k], hi = bf2f(vw[k] >> 16) + bb[2 * k + 1];
+        if (RELU == 2) {
+          lo = fmaxf(lo, 0.f);
+          hi = fmaxf(hi, 0.f);
+        }
         if (HAS_RES) {
           lo += bf2f(rw[k] & 0xffffu);
           hi += bf2f(rw[k] >> 16);
         }
-        if (RELU) {
+        if (RELU == 1) {
           lo = fmaxf(lo, 0.f);
           hi = fmaxf(hi, 0.f);
         }
@@ -112,6 +117,41 @@ __global__ __launch_bounds__(256) void k_mask_pool(const uint8_t* __restrict__ i
   out[idx] = m ? 1 : 0;
 }
 
+// Four output sites per thread from aligned 32-bit reads (three words per input row instead of up to 36 byte loads): W and Wo
+// multiples of 4, stride 1 or 2.  Byte k of a word = column x + k (little endian); mask values may be any non-zero byte.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void k_mask_pool4(const uint8_t* __restrict__ in, int B, int H, int W, uint8_t* __restrict__ out, int Ho, int Wo) {
+  const int wq = Wo >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * Ho * wq) return;
+  const int xo = (int)(idx % wq) * 4, yo = (int)((idx / wq) % Ho), b = (int)(idx / ((int64_t)wq * Ho));
+  const int x0 = xo * STRIDE;
+  uint32_t A = 0, M = 0, C = 0;
+#pragma unroll
+  for (int dy = -1; dy <= 1; dy++) {
+    const int y = yo * STRIDE + dy;
+    if (y < 0 || y >= H) continue;
+    const uint8_t* row = in + ((int64_t)b * H + y) * W;
+    if (x0 >= 4) A |= *reinterpret_cast<const uint32_t*>(row + x0 - 4);
+    M |= *reinterpret_cast<const uint32_t*>(row + x0);
+    if (x0 + 4 < W) C |= *reinterpret_cast<const uint32_t*>(row + x0 + 4);
+  }
+  uint32_t r;
+  if (STRIDE == 1) {
+    r = M | ((M >> 8) | (C << 24)) | ((M << 8) | (A >> 24));
+  } else {
+    const uint32_t o0 = (A >> 24) | M | (M >> 8);          // byte 0: columns -1, 0, 1
+    const uint32_t o1 = (M >> 8) | (M >> 16) | (M >> 24);  // byte 0: columns 1, 2, 3
+    const uint32_t o2 = (M >> 24) | C | (C >> 8);          // byte 0: columns 3, 4, 5
+    const uint32_t o3 = (C >> 8) | (C >> 16) | (C >> 24);  // byte 0: columns 5, 6, 7
+    r = (o0 & 0xffu) | ((o1 & 0xffu) << 8) | ((o2 & 0xffu) << 16) | ((o3 & 0xffu) << 24);
+  }
+  r |= r >> 4;  // any bit of a byte -> its bit 0
+  r |= r >> 2;
+  r |= r >> 1;
+  *reinterpret_cast<uint32_t*>(out + ((int64_t)b * Ho + yo) * Wo + xo) = r & 0x01010101u;
+}
+
 }  // namespace
 
 extern "C" {
@@ -132,14 +172,16 @@ int pnx_bias_act_mask(const void* x, const void* residual, const float* bias, co
   uint4* ov = (uint4*)out;
 #define PNX_LAUNCH_BAM(R_, M_, A_) k_bias_act_mask_bf16<R_, M_, A_><<<(unsigned)nb, 256, 0, st>>>(xv, rv, bias, mask, ov, n_vec, cvec)
   const bool r = residual != nullptr, m = mask != nullptr, a = relu != 0;
-  if (r && m && a) PNX_LAUNCH_BAM(true, true, true);
-  else if (r && m) PNX_LAUNCH_BAM(true, true, false);
-  else if (r && a) PNX_LAUNCH_BAM(true, false, true);
-  else if (r) PNX_LAUNCH_BAM(true, false, false);
-  else if (m && a) PNX_LAUNCH_BAM(false, true, true);
-  else if (m) PNX_LAUNCH_BAM(false, true, false);
-  else if (a) PNX_LAUNCH_BAM(false, false, true);
-  else PNX_LAUNCH_BAM(false, false, false);
+  if (relu == 2 && r && m) PNX_LAUNCH_BAM(true, true, 2);
+  else if (relu == 2 && r) PNX_LAUNCH_BAM(true, false, 2);
+  else if (r && m && a) PNX_LAUNCH_BAM(true, true, 1);
+  else if (r && m) PNX_LAUNCH_BAM(true, true, 0);
+  else if (r && a) PNX_LAUNCH_BAM(true, false, 1);
+  else if (r) PNX_LAUNCH_BAM(true, false, 0);
+  else if (m && a) PNX_LAUNCH_BAM(false, true, 1);
+  else if (m) PNX_LAUNCH_BAM(false, true, 0);
+  else if (a) PNX_LAUNCH_BAM(false, false, 1);
+  else PNX_LAUNCH_BAM(false, false, 0);
 #undef PNX_LAUNCH_BAM
   PNX_LAUNCH_CHECK();
   return PNX_OK;
@@ -149,6 +191,13 @@ int pnx_mask_pool3(const uint8_t* mask_in, int32_t batch, int32_t h, int32_t w, 
   PNX_REQUIRE(mask_in && mask_out && batch > 0 && h > 0 && w > 0 && stride >= 1, PNX_ERR_INVALID, "bad arguments");
   const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
   const int64_t n = (int64_t)batch * ho * wo;
+  if ((stride == 1 || stride == 2) && (w & 3) == 0 && (wo & 3) == 0 && (((uintptr_t)mask_in | (uintptr_t)mask_out) & 3) == 0) {
+    const int64_t n4 = n / 4;
+    if (stride == 1) k_mask_pool4<1><<<(unsigned)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(mask_in, batch, h, w, mask_out, ho, wo);
+    else k_mask_pool4<2><<<(unsigned)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(mask_in, batch, h, w, mask_out, ho, wo);
+    PNX_LAUNCH_CHECK();
+    return PNX_OK;
+  }
   k_mask_pool<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(mask_in, batch, h, w, stride, mask_out, ho, wo);
   PNX_LAUNCH_CHECK();
   return PNX_OK;

@@ -546,13 +546,16 @@ class _FusedConv(nn.Module):
         self.register_buffer("bias", bias.float().contiguous())
         self.stride, self.padding, self.dilation, self.relu, self.transposed = stride, padding, dilation, relu, transposed
 
-    def forward(self, x, mask=None, residual=None):
+    def forward(self, x, mask=None, residual=None, post_residual=None):
+        """post_residual: added AFTER this layer's ReLU (relu mode 2 of the epilogue) instead of before it."""
         if self.transposed:
             y = F.conv_transpose2d(x, self.weight, None, self.stride, self.padding)
         else:
             y = F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation)
         if not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)
+        if post_residual is not None:
+            return ops.bias_act_mask_(y, self.bias, mask, post_residual, 2 if self.relu else 0)
         return ops.bias_act_mask_(y, self.bias, mask, residual, self.relu)
 
 
@@ -738,7 +741,7 @@ class FusedPillarNeXt(nn.Module):
         x = self.mapping(x, mask)
         # BasicBlock (utils/conv.py): act(block2(block1(x)) + x) where block2 already ends in a ReLU, so the residual is added
         # AFTER that ReLU; both terms are >= 0, which makes the trailing act() the identity.
-        x = self.pre2(self.pre1(x)) + x
+        x = self.pre2(self.pre1(x), post_residual=x)
         parts = [F.conv2d(x, getattr(self, f"aspp_w{k}"), None, 1, d, d) for k, d in enumerate((1, 6, 12, 18))]
         parts = [p if p.is_contiguous(memory_format=torch.channels_last) else p.contiguous(memory_format=torch.channels_last) for p in parts]
         x = ops.sum_bias_act(parts, self.aspp_bias, relu=True)

@@ -184,13 +184,14 @@ def nms_single(boxes, thresh, rotated=True, post_max=0):
 
 # --------------------------------------------------------------------------------------------- dense epilogue
 def bias_act_mask_(x, bias, mask=None, residual=None, relu=True):
-    """In place on a channels_last bf16 (B,C,H,W) tensor: x = [relu](x + bias[c] [+ residual]) * mask[b,h,w]."""
+    """In place on a channels_last bf16 (B,C,H,W) tensor: x = [relu](x + bias[c] [+ residual]) * mask[b,h,w];
+    relu=2: (relu(x + bias[c]) + residual) * mask."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):
         raise PnxError("bias_act_mask_ needs a channels_last bf16 CUDA tensor")
     B, C, H, W = x.shape
     if residual is not None and not (residual.dtype == x.dtype and residual.shape == x.shape and residual.is_contiguous(memory_format=torch.channels_last)):
         raise PnxError("residual must match x (bf16, channels_last)")
-    check(lib().pnx_bias_act_mask(ptr(x), ptr(residual), ptr(bias), ptr(mask), ptr(x), B * H * W, C, PNX_BF16, 1 if relu else 0, stream_ptr()),
+    check(lib().pnx_bias_act_mask(ptr(x), ptr(residual), ptr(bias), ptr(mask), ptr(x), B * H * W, C, PNX_BF16, int(relu), stream_ptr()),
           "pnx_bias_act_mask")
     return x
 

@@ -30,13 +30,35 @@ def test_bias_act_mask_matches_torch(residual, masked, relu):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_bias_act_mask_residual_after_relu(masked):
+    """relu mode 2: (relu(x + b) + residual) * mask -- the neck's BasicBlock, whose identity joins after block2's own ReLU."""
+    from pillarnext_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, C, H, W = 2, 24, 37, 53
+    x = torch.randn((B, C, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = torch.randn((B, C, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn((C,), device="cuda", generator=g)
+    mask = (torch.rand((B, H, W), device="cuda", generator=g) > 0.6).to(torch.uint8) if masked else None
+    ref = (torch.relu(x.float() + bias.view(1, -1, 1, 1)) + res.float()).to(torch.bfloat16)
+    if masked:
+        ref = ref * mask.unsqueeze(1).to(torch.bfloat16)
+    got = ops.bias_act_mask_(x.clone(memory_format=torch.channels_last), bias, mask, res, 2)
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("hw", [(45, 62), (45, 64), (37, 120), (8, 8), (5, 4)])   # W, Wo multiples of 4: the 4-sites-per-thread kernel
 @pytest.mark.parametrize("stride", [1, 2])
-def test_mask_pool3_matches_maxpool(stride):
+def test_mask_pool3_matches_maxpool(stride, hw):
     from pillarnext_amd import ops
 
     g = torch.Generator(device="cuda").manual_seed(1)
-    m = (torch.rand((3, 45, 62), device="cuda", generator=g) > 0.9).to(torch.uint8)
-    ref = torch.nn.functional.max_pool2d(m.float().unsqueeze(1), 3, stride, 1).squeeze(1).to(torch.uint8)
+    m = (torch.rand((3,) + hw, device="cuda", generator=g) > 0.9).to(torch.uint8)
+    m = m * torch.randint(1, 256, m.shape, device="cuda", generator=g).to(torch.uint8)      # any non-zero byte marks an active site
+    m[0, :, -1] = 128                                                                       # right border
+    m[1, -1, :] = 0
+    ref = torch.nn.functional.max_pool2d((m != 0).float().unsqueeze(1), 3, stride, 1).squeeze(1).to(torch.uint8)
     assert torch.equal(ops.mask_pool3(m, stride), ref)
 
 
