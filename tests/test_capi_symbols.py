@@ -82,6 +82,26 @@ def test_conv_entry_points_validate_before_launching():
     assert rc < 0 and b"bad arguments" in L.pnx_last_error()
 
 
+def test_round2_entry_points_validate_before_launching():
+    """The entry points added in round 2 reject bad arguments before any HIP call (runs without a GPU)."""
+    from pillarnext_amd import _lib
+
+    L = _lib.lib()
+    buf = (ctypes.c_char * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    arr = (ctypes.c_void_p * 9)(*([p.value] * 9))
+    assert L.pnx_sum_bias_act(arr, 9, p, p, 10, 64, 1, None) < 0 and b"summands" in L.pnx_last_error()
+    assert L.pnx_sum_bias_act(arr, 2, p, p, 10, 60, 1, None) < 0 and b"multiple of 8" in L.pnx_last_error()
+    assert L.pnx_sum_bias_act(None, 2, p, p, 10, 64, 1, None) < 0 and b"bad arguments" in L.pnx_last_error()
+    assert L.pnx_deconv2x2_bf16(p, p, p, p, 1, 8, 8, 128, 64, 1, None) < 0 and b"128" in L.pnx_last_error()
+    assert L.pnx_deconv2x2_bf16(None, p, p, p, 1, 8, 8, 64, 64, 1, None) < 0 and b"bad arguments" in L.pnx_last_error()
+    assert L.pnx_conv_tile_list(None, arr, 1, 1, 8, 8, 16, p, p, None) < 0 and b"bad arguments" in L.pnx_last_error()
+    assert L.pnx_conv_tile_list(p, arr, 5, 1, 8, 8, 16, p, p, None) < 0 and b"row_dirty" in L.pnx_last_error()
+    assert L.pnx_sort_keys(p, 0, 4, p, p, p, 1 << 20, None) < 0 and b"bad arguments" in L.pnx_last_error()
+    assert L.pnx_sort_keys(p, 1000, 4, p, p, p, 8, None) < 0 and b"workspace" in L.pnx_last_error()
+    assert L.pnx_sort_keys_workspace_bytes(0) >= 256
+
+
 def test_decode_descriptor_layout_matches_the_library():
     from pillarnext_amd import _lib
     from pillarnext_amd.decode import pack_task
