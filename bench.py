@@ -202,6 +202,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MIOPEN_USER_DB_PATH" not in os.environ and not a.dry_run:
+            # every rank times MIOpen's solvers for the same few conv shapes during warm-up: give each its own find-db so that N
+            # processes do not serialise on one sqlite file lock
+            db = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pnx_miopen_rank{rank}")
+            os.makedirs(db, exist_ok=True)
+            os.environ["MIOPEN_USER_DB_PATH"] = db
         dist.init_process_group("gloo" if a.dry_run else a.backend, init_method="env://")
 
     if a.dry_run:
