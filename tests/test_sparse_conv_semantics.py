@@ -1,15 +1,11 @@
 """The masked-dense backbone blocks (models.SparseConvBlock / SparseBasicBlock / SparseResNet) against a rulebook restatement of spconv's
 SubMConv2d / SparseConv2d semantics (oracle/sparse_conv_ref.py) -- spconv itself is absent and unpinned (docker/Dockerfile:18), so this
 checks the H2 rule "SubM -> conv * mask, strided sparse conv -> mask_out = maxpool(mask)", not spconv's binaries.  CPU, fp64."""
-import os
-import sys
-
 import numpy as np
 import pytest
 
 torch = pytest.importorskip("torch")
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-import sparse_conv_ref as ref  # noqa: E402
+from oracle import sparse_conv_ref as ref  # noqa: E402  (tests/conftest.py puts the repo root on sys.path)
 
 
 def _randomise_bn(mod, g):
