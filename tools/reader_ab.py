@@ -34,6 +34,11 @@ VARIANTS = [
     ("binned fused 0,0,45", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,45"}),
     ("binned fused 0,0,60", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,60"}),
     ("binned fused 0,0,30", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,30"}),
+    ("binned pfnblocks 384", {"PNX_READER_IMPL": "2", "PNX_PFN_BLOCKS": "384"}),
+    ("binned pfnblocks 448", {"PNX_READER_IMPL": "2", "PNX_PFN_BLOCKS": "448"}),
+    ("binned pfnblocks 512", {"PNX_READER_IMPL": "2", "PNX_PFN_BLOCKS": "512"}),
+    ("binned pfnblocks 640", {"PNX_READER_IMPL": "2", "PNX_PFN_BLOCKS": "640"}),
+    ("binned pfnblocks 768", {"PNX_READER_IMPL": "2", "PNX_PFN_BLOCKS": "768"}),
     ("binned fused 0,5,40", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,5,40"}),
     ("binned fused 3,5,35", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "3,5,35"}),
     ("binned fused 0,0,35 f384", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,35", "PNX_FILL_BLOCKS": "384"}),
