@@ -30,131 +30,9 @@
 #include "pnx_common.h"
 #include "pnx_dppscan.h"
 #include "pnx_fill.h"
+#include "pfn_common.h"
 
 namespace {
-
-typedef float v16f __attribute__((ext_vector_type(16)));
-#define PNX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
-#define PNX_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-__device__ __forceinline__ v8h as_v8h(const uint32_t* w) {
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4 t = {w[0], w[1], w[2], w[3]};
-  return __builtin_bit_cast(v8h, t);
-}
-// two non-negative fp32 values -> packed fp16 hi (round toward zero) and lo = fp16(x - hi) (x - hi is exact in fp32)
-__device__ __forceinline__ void split2_f16(float x0, float x1, uint32_t& hi, uint32_t& lo) {
-  const auto hv = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-  const float r0 = __fsub_rn(x0, (float)hv[0]), r1 = __fsub_rn(x1, (float)hv[1]);
-  const auto lv = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-  hi = __builtin_bit_cast(uint32_t, hv);
-  lo = __builtin_bit_cast(uint32_t, lv);
-}
-
-constexpr int kZS = 68;                 // words per LDS row (64 channels + 4: rows stay 16-byte aligned, 8 consecutive rows cover all banks)
-constexpr int kZSP = 36;                // the same for rows of 64 16-bit values (128 bytes + 16)
-constexpr int kWaveLds = 32 * kZS + 64;  // per wave: 32 pillar rows + rank[32] + cell[32], in words
-
-struct Pfn3Out {
-  float* g1;  // (rows, 64) fp32 or null
-  int64_t g1_rows;
-  void* canvas;  // NHWC canvas or null
-  int dt;        // PNX_F32 / PNX_BF16 / PNX_F16
-};
-
-__device__ __forceinline__ uint32_t bf16_rne(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);  // inputs are finite post-ReLU values
-  return u >> 16;
-}
-__device__ __forceinline__ uint32_t f16_rne(float f) {
-  const _Float16 hv = (_Float16)f;
-  return (uint32_t)__builtin_bit_cast(unsigned short, hv);
-}
-
-// the two 16-byte quads of one half of a sorted record (reader_bins.h)
-struct Half {
-  uint4 a, b;  // a = f[h], f[2+h], f[4+h], f[6+h]   b = f[8+h], f[10+h], aux, (h ? cell : rank)
-};
-__device__ __forceinline__ Half load_half(const uint4* __restrict__ rec, uint32_t slot, int h) {
-  const uint4* p = rec + (int64_t)slot * 4 + 2 * h;
-  Half r;
-  r.a = p[0];
-  r.b = p[1];
-  return r;
-}
-
-// First slot of the pillar after the one that contains `slot`.
-__device__ __forceinline__ uint32_t pillar_end_at(const uint4* __restrict__ rec, int64_t slot, const uint32_t* __restrict__ pfirst,
-                                                  const uint32_t* __restrict__ pcnt, bool* is_head) {
-  const uint4 w = rec[slot * 4 + 1];
-  const uint32_t idx = w.z & 0xFFFFu, rem = w.z >> 16;
-  *is_head = idx == 0;
-  if (idx < 0xFFFFu && rem < 0xFFFFu) return (uint32_t)slot + rem + 1u;
-  return pfirst[w.w] + pcnt[w.w];  // 16-bit fields saturated: a pillar with >= 65535 points
-}
-
-// wave-synchronous LDS exchange: the LDS unit executes one wave's DS instructions in order; the fences only pin the compiler
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// two fp32 -> two 16-bit floats of the canvas dtype, round-to-nearest-even, low half = first argument
-template <int DT>
-__device__ __forceinline__ uint32_t cvt_pk16(float a, float b) {
-  uint32_t r;
-  if (DT == PNX_BF16) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  else asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// 8 consecutive channels (chan0 = 8q) of one pillar: canvas cell and/or feat_max row
-template <int DT>
-__device__ __forceinline__ void store_chunk(const Pfn3Out& o, int rank, int64_t cell, int q, const float* v) {
-  if (o.g1 != nullptr && (int64_t)rank < o.g1_rows) {
-    float4* d = reinterpret_cast<float4*>(o.g1 + (int64_t)rank * 64 + 8 * q);
-    d[0] = make_float4(v[0], v[1], v[2], v[3]);
-    d[1] = make_float4(v[4], v[5], v[6], v[7]);
-  }
-  if (o.canvas != nullptr) {
-    if (DT == PNX_F32) {
-      float4* d = reinterpret_cast<float4*>(reinterpret_cast<float*>(o.canvas) + cell * 64 + 8 * q);
-      d[0] = make_float4(v[0], v[1], v[2], v[3]);
-      d[1] = make_float4(v[4], v[5], v[6], v[7]);
-    } else {
-      uint4 p;
-      if (DT == PNX_BF16) {
-        p.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
-        p.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
-        p.z = bf16_rne(v[4]) | (bf16_rne(v[5]) << 16);
-        p.w = bf16_rne(v[6]) | (bf16_rne(v[7]) << 16);
-      } else {
-        p.x = f16_rne(v[0]) | (f16_rne(v[1]) << 16);
-        p.y = f16_rne(v[2]) | (f16_rne(v[3]) << 16);
-        p.z = f16_rne(v[4]) | (f16_rne(v[5]) << 16);
-        p.w = f16_rne(v[6]) | (f16_rne(v[7]) << 16);
-      }
-      *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(o.canvas) + cell * 64 + 8 * q) = p;
-    }
-  }
-}
-
-// Window tickets without a stall: hipcc's atomic optimizer expands atomicAdd into ballot + one atomic + an immediate
-// s_waitcnt vmcnt(0) + readfirstlane, i.e. a fabric round trip (and a drain of the record prefetch) in front of every window.
-// The asm form returns into a VGPR that nobody reads until ticket_wait(); the hardware vmcnt only ever makes hipcc's own waits
-// more conservative (MI355X guide 5.7: an uncounted asm memory op).
-__device__ __forceinline__ int ticket_issue(int32_t* counter, int lane) {
-  int ret = 0;
-  const int one = 1;
-  if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ret) : "v"(counter), "v"(one) : "memory");
-  return ret;
-}
-__device__ __forceinline__ int ticket_wait(int tk) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(tk)::"memory");
-  return __builtin_amdgcn_readfirstlane(tk);
-}
 
 // One word hands out ~88 tickets/us (MI355X guide, "dequeue"): 16 ticket words in separate 128-byte lines, word s serving the
 // windows s, s+16, ...; a wave starts on word (block & 15) and moves on when its word runs dry.  Returns the window or -1.
@@ -703,4 +581,27 @@ int pnx_launch_pfn_v3(int F, const uint32_t* rec64, const uint32_t* pfirst, cons
   }
   pnx_set_error("num_point_features %d not in 3..6", F);
   return PNX_ERR_UNSUPPORTED;
+}
+
+// k_pfn3_tail alone, for the LDS-sorted path (pfn_bins.hip): the pillars it spilled to the 64-byte record stream -- more than 32
+// points (biglist[0, bigcap), counters[3]) or a tile outside the fp16x3 range (biglist[bigcap, 2 bigcap), counters[4]).
+int pnx_launch_pfn3_tail(int F, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar, int32_t* counters,
+                         const int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows, void* canvas, int canvas_dt, int blocks,
+                         hipStream_t st) {
+  Pfn3Out out;
+  out.g1 = g1;
+  out.g1_rows = g1_rows;
+  out.canvas = canvas;
+  out.dt = canvas_dt;
+  const uint4* rec = reinterpret_cast<const uint4*>(rec64);
+  const int bc = (int)(bigcap > 0x7fffffff ? 0x7fffffff : bigcap);
+  switch (F) {
+    case 3: k_pfn3_tail<3><<<blocks, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out); break;
+    case 4: k_pfn3_tail<4><<<blocks, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out); break;
+    case 5: k_pfn3_tail<5><<<blocks, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out); break;
+    case 6: k_pfn3_tail<6><<<blocks, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out); break;
+    default: pnx_set_error("num_point_features %d not in 3..6", F); return PNX_ERR_UNSUPPORTED;
+  }
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
 }

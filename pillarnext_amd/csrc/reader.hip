@@ -508,6 +508,14 @@ __global__ __launch_bounds__(kBlock) void k_canvas_fill_nhwc(const uint32_t* __r
   pnx_fill_tile<DT, NT>(bitmap, g, canvas, occ, blockIdx.x, s_word, threadIdx.x, kBlock);
 }
 
+// The same tiles taken one by one from a ticket counter by a grid-capped launch (<= a few workgroups per CU): it can sit on a second
+// stream beside the latency-bound grouping kernels without flooding the dispatcher the way one block per tile does.
+template <int DT>
+__global__ __launch_bounds__(kBlock) void k_canvas_fill_persist(PnxFillJob fj, GeomDev g) {
+  __shared__ uint32_t s_word[36];
+  pnx_fill_share_dt<DT>(fj, g, s_word, threadIdx.x, kBlock);
+}
+
 // NCHW canvas (what .dense() returns).  Not the performance layout; same tile scheme, one element per store.
 template <int DT>
 __global__ __launch_bounds__(kBlock) void k_canvas_nchw(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre,
@@ -614,6 +622,7 @@ struct ReaderWs {
   int nblk_w, nblk_c, nblk_k;
   // binned path (reader_bins.h): bins of 2^sh pillars, K1 bins, points handled in `nwg` chunks of `chunk`
   int sh, K1, chunk, nwg, nblk_m;
+  int gthreads;  // threads per workgroup of k_bin_count / k_bin_scatter
   int64_t matlen;
   uint32_t *histmat, *hpre, *hblk;
   uint32_t* rec64;               // pillar-sorted decorated records, 64 B per kept point
@@ -621,6 +630,14 @@ struct ReaderWs {
   uint2* wcomb;                  // {bitmap word, popcount prefix} pairs
   size_t bytes;
 };
+
+// PNX_READER_IMPL: 1 = round-1 pipeline, 2 = binned grouping + k_bin_sort + k_pfn3 (records through HBM), 3 (default) = binned grouping +
+// k_bin_pfn (pfn_bins.hip: sort and PFN in LDS).  Read on every call: the workspace layout follows it.
+int reader_impl() {
+  const char* e = getenv("PNX_READER_IMPL");
+  const int v = e ? atoi(e) : 3;
+  return v >= 1 && v <= 3 ? v : 3;
+}
 
 int64_t cells_padded(const pnx_geom* g, int32_t batch) {
   const int64_t gyp = (g->gy + 31) / 32 * 32;
@@ -639,7 +656,7 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   w.nblk_k = (int)((n + PNX_SCAN_ITEMS - 1) / PNX_SCAN_ITEMS);
   if (w.nblk_k < 1) w.nblk_k = 1;
   w.counters = c.take<int32_t>(64);
-  w.tick = c.take<int32_t>(20 * 32);  // 16 window-ticket words + 4 fill-share counters, one 128-byte line each
+  w.tick = c.take<int32_t>(24 * 32);  // 16 window-ticket words (word 0: bin tickets of pfn_bins.hip) + 5 fill-share counters, one 128-byte line each
   w.bytemap = c.take<uint8_t>(cells + 64);
   w.zero_bytes2 = c.used();            // binned path: counters | tick | bytemap
   w.count = c.take<uint32_t>(w.pcap + 8);
@@ -662,18 +679,37 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   w.kblk = c.take<uint32_t>(w.nblk_k + 8);
   w.mean = c.take<float>(w.pcap * 3 + 8);
   w.g1 = c.take<float>(w.pcap * 64 + 8);
-  // binned path: bins small enough for k_bin_sort's LDS (<= 2048 pillars), at most ~1200 of them for the usual sizes; chunks sized so
-  // that the (bin x workgroup) matrix stays ~0.5 M entries while >= 128 workgroups share the point passes
-  w.sh = 8;
-  static const char* sh_env = getenv("PNX_BIN_SH");  // experiment: bins of 2^sh pillars
-  static const int k1max = getenv("PNX_BIN_K1MAX") ? atoi(getenv("PNX_BIN_K1MAX")) : 2400;
-  while (w.sh < 11 && ((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh) > k1max) w.sh++;
-  if (sh_env) w.sh = atoi(sh_env);
-  w.K1 = (int)((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh);
-  int64_t chunk = (n / 512 + 255) / 256 * 256;
-  if (chunk < 2048) chunk = 2048;
-  w.chunk = (int)chunk;
-  w.nwg = (int)((n + chunk - 1) / chunk);
+  // binned paths.  PNX_READER_IMPL=2 (round 2, k_bin_sort + k_pfn3): bins small enough for k_bin_sort's LDS (<= 2048 pillars), at most
+  // ~2400 of them, 512 chunks of points.  Default (3, pfn_bins.hip: the bin is sorted AND consumed in LDS): bins of 256 pillars
+  // (~770 points on a nuScenes sweep, one LDS segment), up to 16384 of them; the chunks grow (and the count/scatter workgroups get
+  // 1024 threads) so that the (bin x workgroup) matrix stays ~1.25 M entries.
+  const char* sh_env = getenv("PNX_BIN_SH");  // experiment: bins of 2^sh pillars
+  if (reader_impl() == 3) {
+    w.sh = 8;
+    while (w.sh < 11 && ((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh) > 16384) w.sh++;
+    if (sh_env && atoi(sh_env) >= 8 && atoi(sh_env) <= 11) w.sh = atoi(sh_env);
+    w.K1 = (int)((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh);
+    const int nwg_env = getenv("PNX_BIN_NWG") ? atoi(getenv("PNX_BIN_NWG")) : 0;
+    int64_t nwg = nwg_env > 0 ? nwg_env : 1250000 / (w.K1 > 0 ? w.K1 : 1);
+    if (nwg > 512) nwg = 512;
+    if (nwg < 32) nwg = 32;
+    int64_t chunk = ((n + nwg - 1) / nwg + 255) / 256 * 256;
+    if (chunk < 2048) chunk = 2048;
+    w.chunk = (int)chunk;
+    const int thr_env = getenv("PNX_BIN_THREADS") ? atoi(getenv("PNX_BIN_THREADS")) : 0;
+    w.gthreads = thr_env > 0 ? thr_env : (chunk >= 8192 ? 1024 : (chunk >= 4096 ? 512 : 256));
+  } else {
+    w.sh = 8;
+    static const int k1max = getenv("PNX_BIN_K1MAX") ? atoi(getenv("PNX_BIN_K1MAX")) : 2400;
+    while (w.sh < 11 && ((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh) > k1max) w.sh++;
+    if (sh_env) w.sh = atoi(sh_env);
+    w.K1 = (int)((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh);
+    int64_t chunk = (n / 512 + 255) / 256 * 256;
+    if (chunk < 2048) chunk = 2048;
+    w.chunk = (int)chunk;
+    w.gthreads = kBlock;
+  }
+  w.nwg = (int)((n + w.chunk - 1) / w.chunk);
   if (w.nwg < 1) w.nwg = 1;
   w.matlen = (int64_t)w.K1 * w.nwg;
   w.nblk_m = (int)((w.matlen + PNX_SCAN_ITEMS - 1) / PNX_SCAN_ITEMS);
@@ -769,9 +805,10 @@ int launch_bin_sort(const GeomDev& gd, const ReaderWs& w, int32_t* coords, int64
 }
 
 // fill[0..2]: shares of the canvas zero-fill carried by extra blocks of k_bin_count / k_bin_scatter / k_bin_sort (quota 0 = none)
+// sort = false: stop behind k_bin_scatter (the LDS-sorted path consumes the bins itself, pfn_bins.hip)
 int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev& gd, const ReaderWs& w, int32_t* coords,
                   int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, const PnxFillJob* fill, int fill_blocks, hipStream_t st,
-                  hipEvent_t bitmap_ready = nullptr) {
+                  hipEvent_t bitmap_ready = nullptr, bool sort = true) {
   PNX_CHECK_HIP(hipMemsetAsync(w.counters, 0, w.zero_bytes2, st));  // counters | tick | bytemap
   if (n > 0) {
     k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bytemap, nullptr);
@@ -789,15 +826,15 @@ int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev&
   const size_t hl = (size_t)(w.K1 > 64 ? w.K1 : 64) * sizeof(uint32_t);
   PnxFillJob f0 = fill[0], f1 = fill[1], f2 = fill[2];
   f0.n_main = w.nwg, f1.n_main = w.nwg, f2.n_main = w.K1;
-  k_bin_count<<<w.nwg + (f0.quota > 0 ? fill_blocks : 0), kBlock, hl, st>>>(w.key, n, w.chunk, w.sh, w.K1, w.nwg, w.wcomb, w.wblk, w.rank, pillar_of_point,
+  k_bin_count<<<w.nwg + (f0.quota > 0 ? fill_blocks : 0), w.gthreads, hl, st>>>(w.key, n, w.chunk, w.sh, w.K1, w.nwg, w.wcomb, w.wblk, w.rank, pillar_of_point,
                                                                            w.histmat, gd, f0);
   k_scan_local<SCAN_IDENT><<<w.nblk_m, kBlock, 0, st>>>(w.histmat, w.matlen, w.hpre, w.hblk, nullptr, w.counters + 1, fuse_scan ? w.counters + 9 : nullptr);
   if (!fuse_scan) k_scan_blocks<<<1, kBlock, 0, st>>>(w.hblk, w.nblk_m, w.counters + 1);
-  k_bin_scatter<<<w.nwg + (f1.quota > 0 ? fill_blocks : 0), kBlock, hl, st>>>(points, stride, w.key, w.rank, n, w.chunk, w.sh, w.K1, w.nwg, w.hpre, w.hblk,
+  k_bin_scatter<<<w.nwg + (f1.quota > 0 ? fill_blocks : 0), w.gthreads, hl, st>>>(points, stride, w.key, w.rank, n, w.chunk, w.sh, w.K1, w.nwg, w.hpre, w.hblk,
                                                                              w.rec, gd, f1);
   PNX_LAUNCH_CHECK();
-  int rc;
-  switch (stride - 1) {
+  int rc = PNX_OK;
+  if (sort) switch (stride - 1) {
     case 3: rc = launch_bin_sort<3>(gd, w, coords, pillar_capacity, f2, fill_blocks / 2, st); break;
     case 4: rc = launch_bin_sort<4>(gd, w, coords, pillar_capacity, f2, fill_blocks / 2, st); break;
     case 5: rc = launch_bin_sort<5>(gd, w, coords, pillar_capacity, f2, fill_blocks / 2, st); break;
@@ -835,6 +872,15 @@ int pnx_launch_pfn_mfma(int F, const uint32_t* rec, const PnxGeomDev& geom, cons
 int pnx_launch_pfn_v3(int F, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar,
                       int32_t* counters, int32_t* tick, int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows,
                       void* canvas, int canvas_dt, int64_t n_points, int n_fill, const PnxGeomDev& geom, const PnxFillJob& fj, hipStream_t st);
+
+// implemented in pfn_bins.hip: in-LDS bin sort + PFN in one launch; pfn_v3.hip: the one-wave-per-pillar kernel for what it spills
+int pnx_launch_bin_pfn(int F, const uint32_t* binbuf, const uint32_t* hpre, const uint32_t* hblk, int64_t matlen, int sh, int nwg, int K1,
+                       int32_t* counters, int32_t* tick, uint32_t* rec64, uint32_t* pfirst, uint32_t* pcnt, int32_t* cell_of_pillar, int32_t* coords,
+                       int64_t pillar_capacity, int write_pillars, int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows,
+                       void* canvas, int canvas_dt, int64_t n_points, int n_fill, const PnxGeomDev& geom, const PnxFillJob& fj, hipStream_t st);
+int pnx_launch_pfn3_tail(int F, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar, int32_t* counters,
+                         const int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows, void* canvas, int canvas_dt, int blocks,
+                         hipStream_t st);
 
 // implemented in pfn_train.hip
 int pnx_launch_pfn_train(int F, int pass, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* counters,
@@ -877,12 +923,15 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   const GeomDev gd = make_geom(g, batch);
 
   // PNX_PFN_IMPL=0: per-pillar cross-check PFN kernel.  PNX_READER_IMPL=1: round-1 pipeline (global-atomic slots, 32-byte records,
-  // DPP-scan PFN); default 2: binned pipeline (reader_bins.h) + LDS-max PFN fused with the canvas zero-fill (pfn_v3.hip).
+  // DPP-scan PFN); 2: binned pipeline (reader_bins.h) + k_bin_sort + k_pfn3 (64-byte sorted records through HBM, pfn_v3.hip);
+  // default 3: binned grouping, then ONE launch sorts every bin in LDS and runs the PFN on it (pfn_bins.hip).
   const char* impl_env = getenv("PNX_PFN_IMPL");
   const int impl = impl_env ? atoi(impl_env) : 1;
-  const char* rimpl_env = getenv("PNX_READER_IMPL");
-  const bool binned = (rimpl_env ? atoi(rimpl_env) : 2) != 1 && impl != 0 && w.K1 <= 16384;
+  const int rimpl = reader_impl();
+  const bool binned = rimpl != 1 && impl != 0 && w.K1 <= 16384;
   const int F = stride - 1;
+  const char* h_env = getenv("PNX_PFN_F16X3");  // 0: plain fp32 MFMA layer 1 (pfn_v3.hip only)
+  const bool lds_sorted = binned && rimpl == 3 && F <= 5 && w.sh <= 10 && !(h_env && h_env[0] == '0');
   // Direct mode (NHWC canvas, MFMA PFN): the PFN kernel stores each pillar straight into its canvas cell and fill blocks (or a fill
   // kernel) write the zeros of every other cell -- no (P,64) fp32 intermediate, every canvas byte still written exactly once.
   const bool direct = canvas != nullptr && canvas_layout == PNX_NHWC && impl != 0;
@@ -893,20 +942,30 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   const size_t canvas_bytes = (size_t)gd.B * gd.gx * gd.gy * 64 * (canvas_dtype == PNX_F32 ? 4 : 2);
   const char* nt_env = getenv("PNX_FILL_NT");
   const bool fill_nt = nt_env ? nt_env[0] == '1' : canvas_bytes >= ((size_t)3 << 29);  // >= 1.5 GiB: far beyond what the Infinity Cache absorbs
-  const char* fuse_env = getenv("PNX_READER_FUSE");  // 0: zero-fill as its own kernel in front of the PFN
+  // PNX_READER_FUSE: 0 = zero-fill as its own kernel in front of the PFN; 1 = fill tiles carried by blocks of the reader's own
+  // launches; 2 = the stand-alone fill kernel (one block per tile) on a second stream; 3 = a PERSISTENT, grid-capped fill kernel on a
+  // second stream from the moment the bitmap exists (PNX_FILL_SIDE percent of the tiles, the reader's launches carry the rest).
+  const char* fuse_env = getenv("PNX_READER_FUSE");
   const char* fb_env = getenv("PNX_FILL_BLOCKS");
-  const bool side_fill = binned && direct && fuse_env && fuse_env[0] == '2';  // experiment: stand-alone fill kernel on a second stream
+  const bool side_fill = binned && direct && fuse_env && fuse_env[0] == '2';
   const bool fuse = binned && direct && !(fuse_env && (fuse_env[0] == '0' || fuse_env[0] == '2'));
-  // The zero-fill's 32x32-cell tiles are dealt to four launches: extra blocks of k_bin_count / k_bin_scatter / k_bin_sort (latency-bound
-  // kernels that leave HBM idle) take `split` percent each, the PFN launch the rest (pnx_fill.h).  PNX_FILL_SPLIT="a,b,c".
-  PnxFillJob fjob[4];
+  const char* fs_env = getenv("PNX_FILL_SIDE");
+  int side_pct = (fuse && fuse_env && fuse_env[0] == '3') ? (fs_env ? atoi(fs_env) : 100) : 0;
+  side_pct = side_pct < 0 ? 0 : (side_pct > 100 ? 100 : side_pct);
+  // The zero-fill's 32x32-cell tiles are dealt to the launches that leave HBM idle (pnx_fill.h): extra blocks of k_bin_count /
+  // k_bin_scatter / k_bin_sort take `split` percent each, the PFN launch the rest.  PNX_FILL_SPLIT="a,b,c".
+  PnxFillJob fjob[4], fside;
   {
     int split[3];
     pnx_reader_fill_split(split);
+    if (lds_sorted) split[2] = 0;  // no k_bin_sort launch on this path
     const int tiles = pnx_fill_tiles(gd);
-    int base = 0;
+    int base = (fuse && n > 0) ? (int)((int64_t)tiles * side_pct / 100) : 0;
+    fside.bitmap = w.bitmap, fside.canvas = canvas, fside.occ = occupancy, fside.counter = w.tick + 20 * 32;
+    fside.base = 0, fside.quota = base, fside.dt = canvas_dtype, fside.nt = fill_nt ? 1 : 0, fside.n_main = 0;
+    const int rest = tiles - base;
     for (int k = 0; k < 4; k++) {
-      int q = k < 3 ? (int)((int64_t)tiles * split[k] / 100) : tiles - base;
+      int q = k < 3 ? (int)((int64_t)rest * split[k] / 100) : tiles - base;
       if (!fuse || n <= 0) q = k < 3 ? 0 : (fuse ? tiles : 0);
       if (q > tiles - base) q = tiles - base;
       fjob[k].bitmap = w.bitmap, fjob[k].canvas = canvas, fjob[k].occ = occupancy, fjob[k].counter = w.tick + (16 + k) * 32;
@@ -918,12 +977,18 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   prof_mark(0, st);
   static hipStream_t side2 = nullptr;
   static hipEvent_t ev_bitmap = nullptr, ev_filled = nullptr;
-  if (side_fill && side2 == nullptr) {
-    PNX_CHECK_HIP(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
+  const bool side_any = side_fill || fside.quota > 0;
+  if (side_any && side2 == nullptr) {
+    int lo = 0, hi = 0;
+    PNX_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = lowest priority (numerically greatest)
+    const char* pr_env = getenv("PNX_FILL_PRIO");
+    PNX_CHECK_HIP(hipStreamCreateWithPriority(&side2, hipStreamNonBlocking, pr_env && pr_env[0] == '0' ? 0 : lo));
     PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_bitmap, hipEventDisableTiming));
     PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_filled, hipEventDisableTiming));
   }
-  if (binned) rc = run_voxelize2(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, fjob, fill_blocks, st, side_fill ? ev_bitmap : nullptr);
+  if (binned)
+    rc = run_voxelize2(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, fjob, fill_blocks, st, side_any ? ev_bitmap : nullptr,
+                       !lds_sorted);
   else rc = run_voxelize(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, unq_inv != nullptr, st);
   if (rc != PNX_OK) return rc;
   prof_mark(6, st);
@@ -958,6 +1023,14 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
     rc = launch_fill(side2);
     if (rc != PNX_OK) return rc;
     PNX_CHECK_HIP(hipEventRecord(ev_filled, side2));
+  } else if (fside.quota > 0) {
+    const int sb = getenv("PNX_FILL_SIDE_BLOCKS") ? atoi(getenv("PNX_FILL_SIDE_BLOCKS")) : 256;
+    PNX_CHECK_HIP(hipStreamWaitEvent(side2, ev_bitmap, 0));
+    if (canvas_dtype == PNX_F32) k_canvas_fill_persist<PNX_F32><<<sb, kBlock, 0, side2>>>(fside, gd);
+    else if (canvas_dtype == PNX_BF16) k_canvas_fill_persist<PNX_BF16><<<sb, kBlock, 0, side2>>>(fside, gd);
+    else k_canvas_fill_persist<PNX_F16><<<sb, kBlock, 0, side2>>>(fside, gd);
+    PNX_LAUNCH_CHECK();
+    PNX_CHECK_HIP(hipEventRecord(ev_filled, side2));
   } else if (direct && !fuse) {
     if (overlap) {
       PNX_CHECK_HIP(hipEventRecord(ev_fork, st));
@@ -972,7 +1045,24 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
       prof_mark(2, st);
     }
   }
-  if (binned) {
+  if (lds_sorted) {
+    const int n_fill = (fuse && fjob[3].quota > 0) ? fill_blocks : 0;
+    prof_mark(4, st);
+    if (fuse) prof_mark(1, st);
+    // the pillar arrays (first slot / count / cell) are only written for spilled pillars; nothing downstream reads the others
+    rc = pnx_launch_bin_pfn(F, w.rec, w.hpre, w.hblk, w.matlen, w.sh, w.nwg, w.K1, w.counters, w.tick, w.rec64, w.pfirst, w.pcnt, w.cell, coords,
+                            pillar_capacity, 0, w.biglist, w.bigcap, pfn_folded, g1, g1_rows, direct ? canvas : nullptr, canvas_dtype, n, n_fill, gd,
+                            fjob[3], st);
+    if (rc != PNX_OK) return rc;
+    if (n > 0) {
+      static const int tb = getenv("PNX_TAIL_BLOCKS") ? atoi(getenv("PNX_TAIL_BLOCKS")) : 128;
+      rc = pnx_launch_pfn3_tail(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.biglist, w.bigcap, pfn_folded, g1, g1_rows, direct ? canvas : nullptr,
+                                canvas_dtype, tb, st);
+      if (rc != PNX_OK) return rc;
+    }
+    prof_mark(5, st);
+    if (fuse) prof_mark(2, st);
+  } else if (binned) {
     const int n_fill = fuse ? fill_blocks : 0;
     prof_mark(4, st);
     if (fuse) prof_mark(1, st);
@@ -1020,10 +1110,12 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
     }
     prof_mark(2, st);
   }
-  if (side_fill) {
+  if (side_any) {
     PNX_CHECK_HIP(hipStreamWaitEvent(st, ev_filled, 0));
-    prof_mark(1, st);
-    prof_mark(2, st);
+    if (side_fill) {
+      prof_mark(1, st);
+      prof_mark(2, st);
+    }
   }
   if (counts) PNX_CHECK_HIP(hipMemcpyAsync(counts, w.counters, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   prof_mark(3, st);
@@ -1079,7 +1171,7 @@ int pnx_pfn_backward(int32_t pass, int64_t n, int32_t stride, int32_t batch, con
 }
 
 void pnx_reader_fill_split(int32_t* percent3) {
-  percent3[0] = 0, percent3[1] = 0, percent3[2] = 24;  // measured on C2 / 8 frames (tools/reader_ab.py): only k_bin_sort's share pays
+  percent3[0] = 0, percent3[1] = 0, percent3[2] = reader_impl() == 3 ? 0 : 24;  // round-2 pipeline, measured on C2 / 8 frames (tools/reader_ab.py): only k_bin_sort's share pays
   const char* sp_env = getenv("PNX_FILL_SPLIT");
   if (sp_env) sscanf(sp_env, "%d,%d,%d", &percent3[0], &percent3[1], &percent3[2]);
   for (int k = 0; k < 3; k++) percent3[k] = percent3[k] < 0 ? 0 : (percent3[k] > 100 ? 100 : percent3[k]);

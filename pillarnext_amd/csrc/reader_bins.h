@@ -23,22 +23,22 @@
 #pragma once
 
 // ---- k_bin_count: rank of every point + one histogram row per workgroup
-__global__ __launch_bounds__(kBlock) void k_bin_count(const int32_t* __restrict__ key, int64_t n, int chunk, int sh, int K1, int nwg,
+__global__ __launch_bounds__(1024) void k_bin_count(const int32_t* __restrict__ key, int64_t n, int chunk, int sh, int K1, int nwg,
                                                       const uint2* __restrict__ wcomb, const uint32_t* __restrict__ wblk,
                                                       int32_t* __restrict__ rank_out,
                                                       int32_t* __restrict__ pillar_of_point, uint32_t* __restrict__ histmat, PnxGeomDev g,
                                                       PnxFillJob fj) {
   extern __shared__ uint32_t s_hist[];
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, nt = blockDim.x;  // 256..1024 threads: few, large chunks keep the (bin x workgroup) matrix small
   if (fj.quota > 0 && (int)blockIdx.x >= fj.n_main) {  // fill share (pnx_fill.h)
-    pnx_fill_share(fj, g, s_hist, t, kBlock);
+    pnx_fill_share(fj, g, s_hist, t, nt);
     return;
   }
-  for (int b = t; b < K1; b += kBlock) s_hist[b] = 0u;
+  for (int b = t; b < K1; b += nt) s_hist[b] = 0u;
   __syncthreads();
   const int64_t i0 = (int64_t)blockIdx.x * chunk;
   const int64_t i1 = i0 + chunk < n ? i0 + chunk : n;
-  for (int64_t i = i0 + t; i < i1; i += kBlock) {
+  for (int64_t i = i0 + t; i < i1; i += nt) {
     const int32_t k = key[i];
     int32_t r = -1;
     if (k >= 0) {
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_count(const int32_t* __restrict_
     if (pillar_of_point) pillar_of_point[i] = r;
   }
   __syncthreads();
-  for (int b = t; b < K1; b += kBlock) histmat[(int64_t)b * nwg + blockIdx.x] = s_hist[b];
+  for (int b = t; b < K1; b += nt) histmat[(int64_t)b * nwg + blockIdx.x] = s_hist[b];
 }
 
 __device__ __forceinline__ uint32_t mat_prefix(int64_t v, const uint32_t* __restrict__ hpre, const uint32_t* __restrict__ hblk) {
@@ -57,22 +57,22 @@ __device__ __forceinline__ uint32_t mat_prefix(int64_t v, const uint32_t* __rest
 }
 
 // ---- k_bin_scatter: raw records into the bins
-__global__ __launch_bounds__(kBlock) void k_bin_scatter(const float* __restrict__ pts, int stride, const int32_t* __restrict__ key,
+__global__ __launch_bounds__(1024) void k_bin_scatter(const float* __restrict__ pts, int stride, const int32_t* __restrict__ key,
                                                         const int32_t* __restrict__ rank, int64_t n, int chunk, int sh, int K1, int nwg,
                                                         const uint32_t* __restrict__ hpre, const uint32_t* __restrict__ hblk,
                                                         uint32_t* __restrict__ binbuf, PnxGeomDev g, PnxFillJob fj) {
   extern __shared__ uint32_t s_cur[];
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, nt = blockDim.x;
   if (fj.quota > 0 && (int)blockIdx.x >= fj.n_main) {  // fill share (pnx_fill.h)
-    pnx_fill_share(fj, g, s_cur, t, kBlock);
+    pnx_fill_share(fj, g, s_cur, t, nt);
     return;
   }
-  for (int b = t; b < K1; b += kBlock) s_cur[b] = mat_prefix((int64_t)b * nwg + blockIdx.x, hpre, hblk);
+  for (int b = t; b < K1; b += nt) s_cur[b] = mat_prefix((int64_t)b * nwg + blockIdx.x, hpre, hblk);
   __syncthreads();
   const int64_t i0 = (int64_t)blockIdx.x * chunk;
   const int64_t i1 = i0 + chunk < n ? i0 + chunk : n;
   const uint32_t smask = (1u << sh) - 1u;
-  for (int64_t i = i0 + t; i < i1; i += kBlock) {
+  for (int64_t i = i0 + t; i < i1; i += nt) {
     const int32_t r = rank[i];
     if (r < 0) continue;
     const uint32_t pos = atomicAdd(&s_cur[r >> sh], 1u);  // LDS; the range [prefix, prefix + hist) is private to this workgroup

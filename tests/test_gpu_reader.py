@@ -27,14 +27,20 @@ def make_net(pc_range, voxel_size, layers, F=5, num_filters=(64, 64)):
     return net.eval()
 
 
-@pytest.fixture(params=["binned", "binned_unfused", "round1", "pillar"])
+@pytest.fixture(params=["ldsbins", "ldsbins_seg", "ldsbins_side", "binned", "binned_unfused", "round1", "pillar"])
 def pfn_impl(request, monkeypatch):
-    """binned = default pipeline (reader_bins.h + pfn_v3.hip, zero-fill fused into the PFN launch); binned_unfused = the same with
-    the fill as its own kernel; round1 = global-atomic slots + DPP-scan PFN; pillar = thread-per-pillar cross-check kernel."""
-    monkeypatch.setenv("PNX_PFN_IMPL", "0" if request.param == "pillar" else "1")
-    monkeypatch.setenv("PNX_READER_IMPL", "1" if request.param == "round1" else "2")
-    monkeypatch.setenv("PNX_READER_FUSE", "0" if request.param == "binned_unfused" else "1")
-    return request.param
+    """ldsbins = default pipeline (reader_bins.h grouping, then pfn_bins.hip: every bin sorted and consumed in LDS, zero-fill tiles
+    carried by the same launch); ldsbins_seg = the same with 96 LDS record slots, so that every bin takes several segments;
+    ldsbins_side = the zero-fill as a persistent kernel on a second stream; binned = round-2 pipeline (k_bin_sort + pfn_v3.hip,
+    64-byte sorted records through HBM); binned_unfused = that with the fill as its own kernel; round1 = global-atomic slots +
+    DPP-scan PFN; pillar = thread-per-pillar cross-check kernel."""
+    p = request.param
+    monkeypatch.setenv("PNX_PFN_IMPL", "0" if p == "pillar" else "1")
+    monkeypatch.setenv("PNX_READER_IMPL", "1" if p == "round1" else ("3" if p.startswith("ldsbins") else "2"))
+    monkeypatch.setenv("PNX_READER_FUSE", "0" if p == "binned_unfused" else ("3" if p == "ldsbins_side" else "1"))
+    if p == "ldsbins_seg":
+        monkeypatch.setenv("PNX_BINS_CAP", "96")
+    return p
 
 
 @pytest.mark.parametrize("case", READER_CASES)

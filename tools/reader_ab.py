@@ -3,12 +3,15 @@
 
 Variants are environment settings read by pnx_reader_forward on every call:
   PNX_READER_IMPL=1            round-1 pipeline (global-atomic slots, 32-byte records, DPP-scan PFN, separate fill kernel)
-  PNX_READER_IMPL=2            binned pipeline (reader_bins.h) + PFN v3 (pfn_v3.hip)
-    PNX_READER_FUSE=0|1        zero-fill as its own kernel | as extra blocks of the PFN launch and of the grouping kernels
+  PNX_READER_IMPL=2            round-2 pipeline: binned grouping (reader_bins.h) + k_bin_sort + PFN v3 (pfn_v3.hip), records through HBM
+  PNX_READER_IMPL=3            default: binned grouping + ONE launch that sorts every bin in LDS and runs the PFN on it (pfn_bins.hip)
+    PNX_READER_FUSE=0|1|3      zero-fill as its own kernel | as extra blocks of the PFN launch and of the grouping kernels |
+                               as a persistent grid-capped kernel on a second stream (PNX_FILL_SIDE percent, PNX_FILL_SIDE_BLOCKS)
+    PNX_BIN_NWG, PNX_BIN_THREADS, PNX_BIN_SH   chunks / threads of k_bin_count and k_bin_scatter, pillars per bin (2^sh)
     PNX_FILL_SPLIT=a,b,c       percent of the fill tiles carried by k_bin_count / k_bin_scatter / k_bin_sort
     PNX_PFN_F16X3=0|1          layer 1 as fp32 MFMA | fp16 hi/lo splits
     PNX_FILL_BLOCKS, PNX_PFN_BLOCKS   block counts of the two roles
-Variants with the same arithmetic must equal the first variant's canvas bit for bit (fp16x3 vs fp32 layer 1 differ in the last bits).
+Every variant must equal the first variant's canvas bit for bit.
 """
 import argparse
 import ctypes
@@ -22,29 +25,29 @@ from pillarnext_amd import _lib, synth  # noqa: E402
 from pillarnext_amd.reader import PillarFeatureNet  # noqa: E402
 
 VARIANTS = [
+    ("r2 binned default", {"PNX_READER_IMPL": "2"}),
+    ("lds default", {"PNX_READER_IMPL": "3"}),
+    ("lds fill384", {"PNX_READER_IMPL": "3", "PNX_FILL_BLOCKS": "384"}),
+    ("lds fill192", {"PNX_READER_IMPL": "3", "PNX_FILL_BLOCKS": "192"}),
+    ("lds pfnblocks768", {"PNX_READER_IMPL": "3", "PNX_PFN_BLOCKS": "768"}),
+    ("lds unfused", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "0"}),
+    ("lds side100", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3"}),
+    ("lds side100 b512", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_BLOCKS": "512"}),
+    ("lds side100 b128", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_BLOCKS": "128"}),
+    ("lds side60", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE": "60"}),
+    ("lds side40", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE": "40"}),
+    ("lds side25", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE": "25"}),
+    ("lds nwg256 t512", {"PNX_READER_IMPL": "3", "PNX_BIN_NWG": "256", "PNX_BIN_THREADS": "512"}),
+    ("lds nwg256 t1024", {"PNX_READER_IMPL": "3", "PNX_BIN_NWG": "256", "PNX_BIN_THREADS": "1024"}),
+    ("lds nwg128 t512", {"PNX_READER_IMPL": "3", "PNX_BIN_NWG": "128", "PNX_BIN_THREADS": "512"}),
+    ("lds sh9", {"PNX_READER_IMPL": "3", "PNX_BIN_SH": "9"}),
+    ("lds split 10,10", {"PNX_READER_IMPL": "3", "PNX_FILL_SPLIT": "10,10,0"}),
+    ("r2 binned unfused", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "0"}),
+    ("r2 side-stream fill", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "2"}),
     ("round1", {"PNX_READER_IMPL": "1"}),
-    ("binned unfused fp32-L1", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "0", "PNX_PFN_F16X3": "0"}),
-    ("binned unfused", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "0"}),
-    ("binned default", {"PNX_READER_IMPL": "2"}),
-    ("binned side-stream fill", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "2"}),
-    ("binned fused pfn-only", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,0"}),
-    ("binned fused 5,9,24", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "5,9,24"}),
-    ("binned fused 0,0,24", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,24"}),
-    ("binned fused 0,0,35", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,35"}),
-    ("binned fused 0,0,45", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,45"}),
-    ("binned fused 0,0,60", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,60"}),
-    ("binned fused 0,0,30", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,30"}),
-    ("binned pfnblocks 384", {"PNX_READER_IMPL": "2", "PNX_PFN_BLOCKS": "384"}),
-    ("binned pfnblocks 448", {"PNX_READER_IMPL": "2", "PNX_PFN_BLOCKS": "448"}),
-    ("binned pfnblocks 512", {"PNX_READER_IMPL": "2", "PNX_PFN_BLOCKS": "512"}),
-    ("binned pfnblocks 640", {"PNX_READER_IMPL": "2", "PNX_PFN_BLOCKS": "640"}),
-    ("binned pfnblocks 768", {"PNX_READER_IMPL": "2", "PNX_PFN_BLOCKS": "768"}),
-    ("binned fused 0,5,40", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,5,40"}),
-    ("binned fused 3,5,35", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "3,5,35"}),
-    ("binned fused 0,0,35 f384", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,35", "PNX_FILL_BLOCKS": "384"}),
-    ("binned fused 0,0,35 f192", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "0,0,35", "PNX_FILL_BLOCKS": "192"}),
 ]
-KEYS = ["PNX_READER_IMPL", "PNX_READER_FUSE", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS", "PNX_FILL_SPLIT", "PNX_PFN_F16X3"]
+KEYS = ["PNX_READER_IMPL", "PNX_READER_FUSE", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS", "PNX_FILL_SPLIT", "PNX_PFN_F16X3", "PNX_FILL_SIDE",
+        "PNX_FILL_SIDE_BLOCKS", "PNX_BIN_NWG", "PNX_BIN_THREADS", "PNX_BIN_SH", "PNX_BINS_CAP", "PNX_BINS_LDS"]
 
 
 def main():
