@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpnx_hip.so")
+LIB_PATH = os.environ.get("PNX_LIB") or os.path.join(_HERE, "libpnx_hip.so")  # PNX_LIB: an instrumented build of the same library (tools/)
 
 PNX_F32, PNX_BF16, PNX_F16 = 0, 1, 2
 PNX_NHWC, PNX_NCHW = 0, 1

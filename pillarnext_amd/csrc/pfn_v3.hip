@@ -507,17 +507,23 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
 template <int F>
 __global__ __launch_bounds__(256) void k_pfn3_tail(const uint4* __restrict__ rec, const uint32_t* __restrict__ pfirst,
                                                   const uint32_t* __restrict__ pcnt, const int32_t* __restrict__ cell_of_pillar, int32_t* counters,
-                                                  const int32_t* __restrict__ biglist, int bigcap, const float* __restrict__ P, Pfn3Out out) {
+                                                  const int32_t* __restrict__ biglist, int bigcap, const float* __restrict__ P, Pfn3Out out,
+                                                  int stat = 0) {
   const int l = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   int nbig = counters[3], novf = counters[4];
   if (nbig > bigcap) nbig = bigcap;
   if (novf > bigcap) novf = bigcap;
   // the role blocks of k_pfn3 normally drained the list (tickets handed out >= nbig) and no tile overflowed: nothing to do
-  if (__hip_atomic_load(&counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nbig && wave >= novf) return;
+  if (!stat && __hip_atomic_load(&counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nbig && wave >= novf) return;
+  if (stat && wave >= nbig && wave >= novf) return;
   BigWeights<F> Wt;
   Wt.load(P, l);
-  pfn3_big_walk<F>(Wt, counters, biglist, nbig, -1, rec, pfirst, pcnt, cell_of_pillar, out, l);
+  if (stat) {  // nobody else draws tickets (pfn_bins.hip): a static deal, no atomic round trip per pillar
+    for (int bi = wave; bi < nbig; bi += nwaves) pfn3_big_pillar<F>(biglist[bi], Wt, rec, pfirst, pcnt, cell_of_pillar, out, l & 31, l >> 5);
+  } else {
+    pfn3_big_walk<F>(Wt, counters, biglist, nbig, -1, rec, pfirst, pcnt, cell_of_pillar, out, l);
+  }
   for (int bi = wave; bi < novf; bi += nwaves) pfn3_big_pillar<F>(biglist[bigcap + bi], Wt, rec, pfirst, pcnt, cell_of_pillar, out, l & 31, l >> 5);
 }
 
@@ -596,10 +602,10 @@ int pnx_launch_pfn3_tail(int F, const uint32_t* rec64, const uint32_t* pfirst, c
   const uint4* rec = reinterpret_cast<const uint4*>(rec64);
   const int bc = (int)(bigcap > 0x7fffffff ? 0x7fffffff : bigcap);
   switch (F) {
-    case 3: k_pfn3_tail<3><<<blocks, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out); break;
-    case 4: k_pfn3_tail<4><<<blocks, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out); break;
-    case 5: k_pfn3_tail<5><<<blocks, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out); break;
-    case 6: k_pfn3_tail<6><<<blocks, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out); break;
+    case 3: k_pfn3_tail<3><<<blocks, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out, 1); break;
+    case 4: k_pfn3_tail<4><<<blocks, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out, 1); break;
+    case 5: k_pfn3_tail<5><<<blocks, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out, 1); break;
+    case 6: k_pfn3_tail<6><<<blocks, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, biglist, bc, folded, out, 1); break;
     default: pnx_set_error("num_point_features %d not in 3..6", F); return PNX_ERR_UNSUPPORTED;
   }
   PNX_LAUNCH_CHECK();

@@ -682,7 +682,8 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   // binned paths.  PNX_READER_IMPL=2 (round 2, k_bin_sort + k_pfn3): bins small enough for k_bin_sort's LDS (<= 2048 pillars), at most
   // ~2400 of them, 512 chunks of points.  Default (3, pfn_bins.hip: the bin is sorted AND consumed in LDS): bins of 256 pillars
   // (~770 points on a nuScenes sweep, one LDS segment), up to 16384 of them; the chunks grow (and the count/scatter workgroups get
-  // 1024 threads) so that the (bin x workgroup) matrix stays ~1.25 M entries.
+  // 1024 threads) so that the (bin x workgroup) matrix stays ~2.5 M entries (measured: 256 chunks x 1024 threads 148 us of grouping at
+  // C2 / 8 frames, 128 x 1024 165 us).
   const char* sh_env = getenv("PNX_BIN_SH");  // experiment: bins of 2^sh pillars
   if (reader_impl() == 3) {
     w.sh = 8;
@@ -690,8 +691,10 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
     if (sh_env && atoi(sh_env) >= 8 && atoi(sh_env) <= 11) w.sh = atoi(sh_env);
     w.K1 = (int)((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh);
     const int nwg_env = getenv("PNX_BIN_NWG") ? atoi(getenv("PNX_BIN_NWG")) : 0;
-    int64_t nwg = nwg_env > 0 ? nwg_env : 1250000 / (w.K1 > 0 ? w.K1 : 1);
-    if (nwg > 512) nwg = 512;
+    // one wave of workgroups: 1024-thread workgroups sit one per CU, and a 257th would run alone behind the other 256
+    // (measured: 261 chunks 194 us of grouping at C2 / 8 frames, 254 chunks 154 us)
+    int64_t nwg = nwg_env > 0 ? nwg_env : 2500000 / (w.K1 > 0 ? w.K1 : 1);
+    if (nwg > 256) nwg = 256;
     if (nwg < 32) nwg = 32;
     int64_t chunk = ((n + nwg - 1) / nwg + 255) / 256 * 256;
     if (chunk < 2048) chunk = 2048;
@@ -986,9 +989,13 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
     PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_bitmap, hipEventDisableTiming));
     PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_filled, hipEventDisableTiming));
   }
-  if (binned)
-    rc = run_voxelize2(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, fjob, fill_blocks, st, side_any ? ev_bitmap : nullptr,
-                       !lds_sorted);
+  const char* sa_env = getenv("PNX_FILL_SIDE_AT");  // "pfn": the side-stream fill starts with the PFN launch instead of with the bitmap
+  const bool side_at_pfn = side_any && sa_env && sa_env[0] == 'p';
+  if (binned) {
+    rc = run_voxelize2(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, fjob, fill_blocks, st,
+                       (side_any && !side_at_pfn) ? ev_bitmap : nullptr, !lds_sorted);
+    if (rc == PNX_OK && side_at_pfn) PNX_CHECK_HIP(hipEventRecord(ev_bitmap, st));
+  }
   else rc = run_voxelize(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, unq_inv != nullptr, st);
   if (rc != PNX_OK) return rc;
   prof_mark(6, st);

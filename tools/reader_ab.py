@@ -37,6 +37,9 @@ VARIANTS = [
     ("lds side60", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE": "60"}),
     ("lds side40", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE": "40"}),
     ("lds side25", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE": "25"}),
+    ("lds side100 atpfn", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn"}),
+    ("lds side100 atpfn b512", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_FILL_SIDE_BLOCKS": "512"}),
+    ("lds side50 atpfn", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_FILL_SIDE": "50"}),
     ("lds nwg256 t512", {"PNX_READER_IMPL": "3", "PNX_BIN_NWG": "256", "PNX_BIN_THREADS": "512"}),
     ("lds nwg256 t1024", {"PNX_READER_IMPL": "3", "PNX_BIN_NWG": "256", "PNX_BIN_THREADS": "1024"}),
     ("lds nwg128 t512", {"PNX_READER_IMPL": "3", "PNX_BIN_NWG": "128", "PNX_BIN_THREADS": "512"}),
@@ -47,7 +50,7 @@ VARIANTS = [
     ("round1", {"PNX_READER_IMPL": "1"}),
 ]
 KEYS = ["PNX_READER_IMPL", "PNX_READER_FUSE", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS", "PNX_FILL_SPLIT", "PNX_PFN_F16X3", "PNX_FILL_SIDE",
-        "PNX_FILL_SIDE_BLOCKS", "PNX_BIN_NWG", "PNX_BIN_THREADS", "PNX_BIN_SH", "PNX_BINS_CAP", "PNX_BINS_LDS"]
+        "PNX_FILL_SIDE_BLOCKS", "PNX_FILL_SIDE_AT", "PNX_BIN_NWG", "PNX_BIN_THREADS", "PNX_BIN_SH", "PNX_BINS_CAP", "PNX_BINS_LDS"]
 
 
 def main():
