@@ -18,6 +18,37 @@ def init(backend=None):
     return int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def all_reduce_sum(t, group=None):
+    """In-place SUM all-reduce that also works when the backend cannot take device tensors (gloo with ROCm tensors, the
+    one-GPU world-2 tests): such tensors are staged through the host."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+class _AllReduceSumFn(torch.autograd.Function):
+    """Differentiable SUM all-reduce (what torch.distributed.nn.functional.all_reduce is), on top of all_reduce_sum."""
+
+    @staticmethod
+    def forward(ctx, t, group):
+        ctx.group = group
+        return all_reduce_sum(t.clone(), group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return all_reduce_sum(g.clone(), ctx.group), None
+
+
+def all_reduce_sum_autograd(t, group=None):
+    return _AllReduceSumFn.apply(t, group)
+
+
 def shard_frames(n_frames, rank, world):
     """DistributedSampler(shuffle=False) semantics: rank r takes r, r+world, ...; padded by wrap-around so all ranks get equally many."""
     per = (n_frames + world - 1) // world
@@ -40,7 +71,8 @@ def wrap_ddp(model, device_ids=None, sync_batchnorm=True):
     if sync_batchnorm:
         from .models import convert_sync_batchnorm
 
-        model = convert_sync_batchnorm(model)  # masked BN -> global active-site statistics; plain BN -> SyncBatchNorm (CUDA)
+        # masked BN -> global active-site statistics; every plain BN -> SyncBatchNorm (a CPU/gloo run keeps them, with a warning)
+        model = convert_sync_batchnorm(model, cpu_ok=dist.get_backend() == "gloo")
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=device_ids, find_unused_parameters=False)
 
 

@@ -67,9 +67,9 @@ class MaskedBatchNorm(nn.BatchNorm2d):
 
         if not (self.sync and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.sync_group) > 1):
             return t
-        from torch.distributed.nn.functional import all_reduce
+        from .dist_utils import all_reduce_sum_autograd
 
-        return all_reduce(t, group=self.sync_group)
+        return all_reduce_sum_autograd(t, self.sync_group)
 
     def forward(self, x, mask=None):
         if not self.training or mask is None:
@@ -89,21 +89,36 @@ class MaskedBatchNorm(nn.BatchNorm2d):
         return (y * self.weight.view(1, -1, 1, 1) + self.bias.view(1, -1, 1, 1)).to(x.dtype)
 
 
-def convert_sync_batchnorm(module, process_group=None):
-    """tools/train.py:56 for this model: MaskedBatchNorm layers switch to global active-site statistics in place, every other
-    BatchNorm becomes torch.nn.SyncBatchNorm (CUDA only -- torch's SyncBatchNorm has no CPU forward)."""
+def convert_sync_batchnorm(module, process_group=None, cpu_ok=False):
+    """tools/train.py:56 for this model, callable BEFORE or after .cuda() like torch's own converter (the reference converts first,
+    train.py:56 then :59): MaskedBatchNorm layers switch to global active-site statistics in place; the reader's fused training
+    passes exchange their statistics themselves (pfn_train.py) AND its BatchNorm1d modules become SyncBatchNorm, so the unfused
+    fallback (PNX_TRAIN_FUSED=0, CPU points) synchronises too; every other BatchNorm becomes torch.nn.SyncBatchNorm.
+    torch's SyncBatchNorm has no CPU forward: a module whose parameters sit on the CPU is converted all the same unless
+    cpu_ok=True (gloo test runs), in which case it is left per-rank WITH a warning -- never silently."""
+    import warnings
+
     from .reader import PillarFeatureNet
 
+    def plain(parent, name, child):
+        on_cpu = not next(child.parameters()).is_cuda
+        if on_cpu and cpu_ok:
+            warnings.warn(f"convert_sync_batchnorm: {type(child).__name__} '{name}' stays a per-rank BatchNorm (CPU run, cpu_ok=True)")
+            return
+        setattr(parent, name, nn.SyncBatchNorm.convert_sync_batchnorm(child, process_group))
+
     for name, child in list(module.named_children()):
-        if isinstance(child, PillarFeatureNet) and child._fused_supported():
-            child.enable_sync(process_group)  # its fused training passes exchange the statistics themselves (pfn_train.py)
+        if isinstance(child, PillarFeatureNet):
+            if child._fused_supported():
+                child.enable_sync(process_group)
+            for layer in child.pfn_layers:
+                plain(layer, "norm", layer.norm)
         elif isinstance(child, MaskedBatchNorm):
             child.enable_sync(process_group)
         elif isinstance(child, nn.modules.batchnorm._BatchNorm):
-            if next(child.parameters()).is_cuda:
-                setattr(module, name, nn.SyncBatchNorm.convert_sync_batchnorm(child, process_group))
+            plain(module, name, child)
         else:
-            convert_sync_batchnorm(child, process_group)
+            convert_sync_batchnorm(child, process_group, cpu_ok)
     return module
 
 

@@ -20,10 +20,10 @@ from ._lib import check, lib, ptr, stream_ptr
 
 
 def _all_reduce(t, group):
-    import torch.distributed as dist
+    if group is not False:
+        from .dist_utils import all_reduce_sum
 
-    if group is not False and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, group=group)
+        all_reduce_sum(t, group)
     return t
 
 

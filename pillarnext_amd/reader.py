@@ -104,7 +104,8 @@ class PillarFeatureNet(nn.Module):
 
     def _fused_supported(self):
         return (len(self.pfn_layers) == 2 and self.pfn_layers[0].units == 32 and self.pfn_layers[1].units == 64
-                and 3 <= self.num_point_features <= 6 and all(isinstance(l.norm, nn.BatchNorm1d) for l in self.pfn_layers))
+                and 3 <= self.num_point_features <= 6
+                and all(isinstance(l.norm, (nn.BatchNorm1d, nn.SyncBatchNorm)) for l in self.pfn_layers))
 
     @staticmethod
     def _unfused_training():
@@ -158,6 +159,14 @@ class PillarFeatureNet(nn.Module):
         return feat_max[:P], coords[:P], self.grid_size
 
     def _forward_unfused(self, points, batch_size=None):
+        if self.training and self.sync:
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.sync_group) > 1 and \
+                    not all(isinstance(l.norm, nn.SyncBatchNorm) for l in self.pfn_layers):
+                raise PnxError("PillarFeatureNet is in synchronised-BatchNorm mode but its unfused training path would use per-rank "
+                               "BatchNorm1d statistics: convert the model with models.convert_sync_batchnorm (it turns the reader's norms "
+                               "into SyncBatchNorm) or keep PNX_TRAIN_FUSED=1 with the points on the GPU")
         features, coords, unq_inv, grid_size = self.voxelization(points, batch_size)
         P = coords.shape[0]
         for pfn in self.pfn_layers:
