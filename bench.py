@@ -13,11 +13,16 @@ under a launcher (RANK/LOCAL_RANK/WORLD_SIZE set) it is one rank.  Frames are sh
                   from the reader's first to its last kernel, HIP events recorded on the reader's own stream inside libpnx_hip.so
   roofline_fill   its dominant launch (PFN + canvas zero-fill fused, HBM-write bound) with the canvas bytes it writes
   roofline_pfn    the same launch read as MFMA work (8 832 FLOP per kept point)
+  value_with_h2d_merge   the same loop fed the way the reference's loader feeds it (collate.py:15-22, trainer.py:111, nusc.py:101-121):
+                  every step the frames' RAW sweeps are copied into pinned memory, uploaded on a side stream (double-buffered) and merged
+                  on the device (pnx_merge_sweeps: per-sweep transform, time lag, batch index) before the reader sees them
   value_uniform   frames/s on the worst-case uniform cloud (~1.2 points per pillar)
+  value_c4/_c5    frames/s of the Waymo detector (configs/pillarnext_b_waymo.yaml) at BASELINE configs[3] / [4]: 180 k points bf16, 540 k fp16
   sections_us     reader / backbone / neck / head / decode+NMS per step (torch.cuda events, separate short pass)
   nms_us          stand-alone batched rotated NMS on SURVEY 8d's box sets
   cpu_baseline    the CPU oracle ("port") on a bounded sample of the same frames, hot path only: all cores (threads over frames)
-                  as `value`, one thread and an own PyTorch-CPU statement of the op sequence beside it
+                  as `value`, one thread and an own PyTorch-CPU statement of the op sequence beside it; `c1` = the same on BASELINE
+                  configs[0] (50 k points, 0.2 m, 512 x 512, the reference's CPU-runnable case)
 """
 import argparse
 import json
@@ -48,7 +53,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry-run", action="store_true",
                     help="launch/rendezvous/timing/JSON plumbing only, no GPU work (CPU test of the --gpus path, backend gloo)")
-    ap.add_argument("--include-h2d", action="store_true", help="also time the loop with the frames uploaded from pinned host memory each step")
+    ap.add_argument("--include-h2d", action="store_true", help="also time the loop with the COLLATED frames uploaded from pinned host memory each step (no merge)")
     ap.add_argument("--no-extras", action="store_true", help="skip value_uniform / sections / NMS / CPU legs (profiling runs)")
     return ap.parse_args()
 
@@ -114,6 +119,25 @@ def cpu_baselines(cfg, config, dist_name, frames_1t):
             T.reader_forward(pool[i % len(pool)], cfg["pc_range"], cfg["voxel_size"], layers)
         tc[f"threads_{thr}"] = {"frames_per_s": round(nfr / (time.perf_counter() - t0), 3), "frames": nfr}
     res["torch_cpu"] = tc
+    # BASELINE configs[0]: the reference's own CPU-runnable case (C1: 50 k points, 0.2 m pillars, 512 x 512)
+    c1 = synth.CONFIGS["C1"]
+    pool1 = [synth.make_batch("C1", 1, dist_name, frame0=f) for f in range(8)]
+
+    def one1(i):
+        O.reader_forward(pool1[i % 8], c1["pc_range"], c1["voxel_size"], [64, 64], layers, B=1, want_canvas=True)
+
+    one1(0)
+    t0 = time.perf_counter()
+    for i in range(48):
+        one1(i)
+    t1c = time.perf_counter() - t0
+    with ThreadPoolExecutor(nthr) as ex:
+        list(ex.map(one1, range(nthr)))
+        t0 = time.perf_counter()
+        list(ex.map(one1, range(nthr * 8)))
+        tallc = time.perf_counter() - t0
+    res["c1"] = {"value": round(nthr * 8 / tallc, 2), "cores": nthr, "value_1thread": round(48 / t1c, 2),
+                 "sample": f"C1/{dist_name}: 48 frames on 1 thread, {nthr * 8} frames over {nthr} threads, same C port"}
     return res
 
 
@@ -143,6 +167,25 @@ def serving_loop(model, examples, steps, upload=None):
     if pending is not None:
         out = model.detections(pending.result())
     return out
+
+
+def waymo_model(config, dtype, dev):
+    """configs/pillarnext_b_waymo.yaml (the reference's waymo_det_pp18_aspp_iou_car_sp.yaml model block) at the geometry of BASELINE's
+    synthetic Waymo configs, random-init weights, as the fused inference graph."""
+    import torch
+
+    from pillarnext_amd import config as C
+    from pillarnext_amd import synth
+    from pillarnext_amd.models import FusedPillarNeXt
+
+    cfg = C.load(os.path.join(ROOT, "configs", "pillarnext_b_waymo.yaml"))
+    g = synth.CONFIGS[config]
+    for blk in ("reader", "head", "post_processing"):
+        cfg["model"][blk]["voxel_size"] = list(g["voxel_size"])
+        cfg["model"][blk]["pc_range"] = list(g["pc_range"])
+    torch.manual_seed(0)
+    det = C.instantiate(cfg["model"]).to(dev).eval()
+    return FusedPillarNeXt(det, dtype=dtype).to(dev).eval()
 
 
 def nms_bench(dev):
@@ -297,6 +340,28 @@ def main():
                 model(ex2[i])
             dt2, _ = timed(ex2, max(a.steps // 2, 4))
             extras[f"value_{other}"] = round(a.batch * world * max(a.steps // 2, 4) / dt2, 2)
+            # the loader's side of the contract in the loop: raw sweeps -> pinned memory -> H2D on a side stream -> device merge
+            from pillarnext_amd.io import PointUploader, SweepMerger
+
+            raws = [synth.raw_sweeps(e["points"].cpu().numpy()) for e in examples]
+            upr = PointUploader(max(len(r) for r, _ in raws), 4, dev)
+            merger = SweepMerger()
+            descs = [merger.descriptors(sg, dev) for _, sg in raws]
+            mbuf = [torch.empty((max(len(r) for r, _ in raws), 6), dtype=torch.float32, device=dev) for _ in range(2)]
+            mcnt = torch.zeros(1, dtype=torch.int32, device=dev)
+
+            def upload_merge(i):
+                k = i % ROTATE
+                raw_dev = upr.upload_rows(raws[k][0])
+                pts, _ = merger(raw_dev, descs[k], n_copy=4, out=mbuf[i % 2], n_out=mcnt)
+                return {"points": pts, "token": examples[k]["token"], "batch_size": a.batch}
+
+            for i in range(ROTATE):
+                model(upload_merge(i))
+            dt4, out4 = timed(examples, a.steps, upload_merge)
+            extras["value_with_h2d_merge"] = round(a.batch * world * a.steps / dt4, 2)
+            extras["h2d_merge"] = {"raw_rows_per_step": int(len(raws[0][0])), "sweeps_per_frame": len(raws[0][1]) // a.batch,
+                                   "bytes_per_step": int(raws[0][0].nbytes), "detections_last_step": int(sum(len(v["scores"]) for v in out4.values()))}
             if a.include_h2d:
                 from pillarnext_amd.io import PointUploader
 
@@ -307,10 +372,38 @@ def main():
                     pts, B = up.upload(host[i % ROTATE])
                     return {"points": pts, "token": examples[i % ROTATE]["token"], "batch_size": B}
 
+
                 for i in range(ROTATE):
                     model(upload(i))
                 dt3, _ = timed(examples, a.steps, upload)
                 extras["value_with_h2d"] = round(a.batch * world * a.steps / dt3, 2)
+            # BASELINE configs[3] / [4]: the Waymo detector (configs/pillarnext_b_waymo.yaml: 2 tasks, iou head, NMS pre 4096 / post 500)
+            # at the synthetic Waymo geometry -- C4 180 k points bf16, C5 540 k points (3 sweeps) fp16 -- same serving loop, resident inputs
+            if a.config == "C2" and not os.environ.get("PNX_BENCH_NO_WAYMO"):
+                for wc, wdt, wb in (("C4", torch.bfloat16, a.batch), ("C5", torch.float16, max(a.batch // 2, 1))):
+                    wm = waymo_model(wc, wdt, dev)
+                    wex = []
+                    for k in range(2):
+                        wp = torch.from_numpy(synth.make_batch(wc, wb, "sweep", frame0=(rank * 2 + k) * wb)).to(dev)
+                        wex.append({"points": wp, "token": [f"w{k}f{i}" for i in range(wb)], "batch_size": wb})
+                    for i in range(3):
+                        wm(wex[i % 2])
+                    wsteps = max(a.steps // 3, 4)
+                    barrier()
+                    t0 = time.perf_counter()
+                    serving_loop(wm, wex, wsteps)
+                    barrier()
+                    wdt_s = time.perf_counter() - t0
+                    if world > 1:
+                        t = torch.tensor([wdt_s], dtype=torch.float64, device=dev)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        wdt_s = float(t.item())
+                    extras[f"value_{wc.lower()}"] = round(wb * world * wsteps / wdt_s, 2)
+                    extras.setdefault("waymo", {})[wc] = {"frames_per_gpu_per_step": wb, "steps": wsteps, "dtype": str(wdt).split(".")[-1],
+                                                         "points_per_frame": synth.CONFIGS[wc]["n"], "grid": [1504, 1504],
+                                                         "ms_per_step": round(wdt_s / wsteps * 1e3, 3)}
+                    del wm, wex
+                    torch.cuda.empty_cache()
             if rank == 0:
                 extras["sections_us"] = sections(model, examples, a.batch)
                 extras["nms_us"] = nms_bench(dev)
@@ -346,20 +439,21 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{a.config}: PillarNeXt-B nuScenes inference, {cfg['n']} pts/frame, voxel {cfg['voxel_size'][0]} m, BEV {nx}x{ny}, "
-                               f"6 tasks/10 classes, cloud={a.dist}, random-init weights, {ROTATE} distinct frame batches rotating",
+                               f"6 tasks/10 classes, cloud={a.dist} (1.5 % of the rows outside the range), random-init weights, {ROTATE} distinct frame batches rotating, "
+                               f"inputs resident in HBM (value_with_h2d_merge: raw sweeps uploaded from pinned memory + merged on the device every step)",
                    "frames_per_gpu_per_step": a.batch, "global_batch": a.batch * world, "parallelism": f"frame-sharded replicas x{world}",
                    "reader_dtype": "fp32 layer 0 + fp16x3 (22-bit) layer 1 on MFMA -> bf16 canvas", "pillars_per_launch": P,
                    "kept_points_per_launch": n_kept},
-        "roofline": {"bound": "hbm", "kernel": "reader, ALL of its kernels (keys, bitmap scan, binning, bin sort, PFN + canvas zero-fill)",
+        "roofline": {"bound": "hbm", "kernel": "reader, ALL of its kernels (keys, bitmap scan, bin count + scatter, in-LDS bin sort + PFN + canvas zero-fill, tail)",
                      "achieved": round(reader_gbs, 1) if reader_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(reader_gbs / HBM_PEAK_GBS, 4) if reader_gbs else None, "traffic": traffic, "traffic_source": tsrc,
                      "algorithmic_bytes_per_launch": reader_bytes, "kernel_us": round(r_us.value, 2), "samples": ns.value,
                      "voxelize_us": round(vox_us, 2)},
-        "roofline_fill": {"bound": "hbm", "kernel": "k_pfn3 (PFN blocks + zero-fill blocks in one launch: the pillar cells and this launch's share of the pillar-free tiles)",
+        "roofline_fill": {"bound": "hbm", "kernel": "k_bin_pfn (bin sort + PFN blocks and zero-fill blocks in one launch: the pillar cells and this launch's share of the pillar-free tiles)",
                           "achieved": round(fill_gbs, 1) if fill_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(fill_gbs / HBM_PEAK_GBS, 4) if fill_gbs else None, "algorithmic_bytes_per_launch": launch_bytes,
                           "kernel_us": round(c_us.value, 2), "zero_fill_percent_carried_by_grouping_kernels": [int(v) for v in split]},
-        "roofline_pfn": {"bound": "mfma", "kernel": "k_pfn3 (same launch): fp32 v_mfma_f32_32x32x2_f32 layer 0 + 3 x v_mfma_f32_32x32x16_f16 layer 1",
+        "roofline_pfn": {"bound": "mfma", "kernel": "k_bin_pfn (same launch): fp32 v_mfma_f32_32x32x2_f32 layer 0 + 3 x v_mfma_f32_32x32x16_f16 layer 1",
                          "achieved": round(pfn_tf, 2) if pfn_tf else None, "peak": 157.3, "unit": "TFLOP/s (reference fp32 FLOPs)",
                          "frac": round(pfn_tf / 157.3, 4) if pfn_tf else None, "kernel_us": round(pfn_us, 2), "algorithmic_flops_per_launch": pfn_flops},
     }

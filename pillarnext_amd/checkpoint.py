@@ -21,17 +21,34 @@ def extract_state_dict(checkpoint):
 
 
 def load_checkpoint(model, filename, map_location=None, strict=False):
+    import os
+
+    if not os.path.isfile(filename):  # trainer/utils/checkpoint.py:21-22
+        raise IOError(f"{filename} is not a checkpoint file")
     checkpoint = torch.load(filename, map_location=map_location, weights_only=False)
     target = model.module if hasattr(model, "module") else model
     missing, unexpected = target.load_state_dict(extract_state_dict(checkpoint), strict=strict)
     return checkpoint, missing, unexpected
 
 
-def save_checkpoint(model, filename, optimizer=None, scheduler=None, meta=None):
+def save_checkpoint(model, filename, optimizer=None, scheduler=None, meta=None, layout="spconv"):
+    """layout="spconv" (default): the weights of the dense stand-ins of SubMConv2d / SparseConv2d (models._SpConv2d) are written in
+    spconv >= 2.2's (Cout, kH, kW, Cin) layout, so that the REFERENCE's modules load the file (their load_state_dict checks shapes);
+    this package reads either layout back.  layout="dense" keeps nn.Conv2d's (Cout, Cin, kH, kW)."""
     if meta is not None and not isinstance(meta, dict):
         raise TypeError("meta must be a dict or None")
+    if layout not in ("spconv", "dense"):
+        raise ValueError("layout must be 'spconv' or 'dense'")
     target = model.module if hasattr(model, "module") else model
-    ck = {"meta": meta or {}, "state_dict": OrderedDict((k, v.cpu()) for k, v in target.state_dict().items())}
+    sd = OrderedDict((k, v.cpu()) for k, v in target.state_dict().items())
+    if layout == "spconv":
+        from .models import _SpConv2d
+
+        for name, m in target.named_modules():
+            if isinstance(m, _SpConv2d):
+                k = (name + "." if name else "") + "weight"
+                sd[k] = sd[k].permute(0, 2, 3, 1).contiguous()
+    ck = {"meta": meta or {}, "state_dict": sd}
     if optimizer is not None:
         ck["optimizer"] = optimizer.state_dict()
     if scheduler is not None:

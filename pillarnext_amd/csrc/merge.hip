@@ -8,6 +8,7 @@
 // as one stable compaction over the raw sweeps already resident in HBM, writing the collated (N, 2+C) buffer the reader consumes.
 // Segment s = rows [seg_offsets[s], seg_offsets[s+1]) of `raw`; per segment: optional 3x4 transform (fp64, row-major), close-point
 // radius (0 = keep all), time value, batch index.  Row order is preserved (sweep order, then the file's order), like np.concatenate.
+// Rows [n_out, n_raw) of `out` are filled with batch index -1 (dropped by the reader): `out` is usable as a whole without reading n_out.
 #include "pnx_common.h"
 #include "pnx_scan.h"
 
@@ -54,12 +55,21 @@ __global__ __launch_bounds__(kBlock) void k_merge_flags(const float* __restrict_
 
 __global__ __launch_bounds__(kBlock) void k_merge_write(const float* __restrict__ raw, int stride, int64_t n, const SegDesc* __restrict__ segs, int nseg,
                                                         const uint32_t* __restrict__ keep, const uint32_t* __restrict__ pre, const uint32_t* __restrict__ blk,
-                                                        int ncopy, float* __restrict__ out, int out_stride) {
+                                                        int ncopy, float* __restrict__ out, int out_stride, const int32_t* __restrict__ n_out) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n || !keep[i]) return;
+  if (i >= n) return;
+  const int64_t before = (int64_t)blk[i >> PNX_SCAN_SHIFT] + pre[i];  // kept rows in front of row i
+  if (!keep[i]) {
+    // a dropped row becomes one of the rows [n_out, n) of `out`: batch index -1, which the reader masks out (pillar_encoder.py:98-104
+    // keeps only rows inside the grid; reader.hip drops b outside [0,B)) -- the consumer can take N = n from the shape, no host sync
+    float* o = out + ((int64_t)n_out[0] + (i - before)) * out_stride;
+    o[0] = -1.0f;
+    for (int k = 1; k < out_stride; k++) o[k] = 0.f;
+    return;
+  }
   const SegDesc& s = segs[find_seg(segs, nseg, i)];
   const float* p = raw + i * stride;
-  float* o = out + (int64_t)(blk[i >> PNX_SCAN_SHIFT] + pre[i]) * out_stride;
+  float* o = out + before * out_stride;
   float x[3];
   xform(s, p, x);
   o[0] = (float)s.batch;
@@ -102,7 +112,7 @@ int pnx_merge_sweeps(const float* raw, int64_t n_raw, int32_t raw_stride, int32_
   k_merge_flags<<<nb, kBlock, 0, st>>>(raw, raw_stride, n_raw, segs, n_segments, keep);
   k_scan_local<SCAN_IDENT><<<nblk, kBlock, 0, st>>>(keep, n_raw, pre, blk);
   k_scan_blocks<<<1, kBlock, 0, st>>>(blk, nblk, n_out_dev);
-  k_merge_write<<<nb, kBlock, 0, st>>>(raw, raw_stride, n_raw, segs, n_segments, keep, pre, blk, n_copy, out, n_copy + 2);
+  k_merge_write<<<nb, kBlock, 0, st>>>(raw, raw_stride, n_raw, segs, n_segments, keep, pre, blk, n_copy, out, n_copy + 2, n_out_dev);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

@@ -6,6 +6,8 @@ batch needs one key kernel per task, ONE device sort, one box kernel, ONE batche
 import ctypes
 import struct
 
+import weakref
+
 import torch
 
 from . import ops
@@ -148,19 +150,22 @@ class PackedDecoder:
               "pnx_gather_kept")
         # the one device->host hand-off of the frame batch: asynchronous into pinned memory; PendingDetections.result() waits
         # three rotating pinned result buffers per shape (a serving loop has at most two batches in flight: bench.py / forward_async)
+        # a slot is only reused once the PendingDetections that owns it was resolved (result()); otherwise the ring grows
         pk2 = (tuple(out.shape), S)
-        ring = self._pin.setdefault(pk2, {"k": 0, "bufs": []})
-        if len(ring["bufs"]) < 3:
-            ring["bufs"].append((torch.empty(out.shape, dtype=out.dtype, pin_memory=True), torch.empty((S,), dtype=cnt.dtype, pin_memory=True)))
-            out_h, cnt_h = ring["bufs"][-1]
-        else:
-            ring["k"] = (ring["k"] + 1) % 3
-            out_h, cnt_h = ring["bufs"][ring["k"]]
+        ring = self._pin.setdefault(pk2, [])
+        slot = next((sl for sl in ring if sl["owner"] is None or sl["owner"]() is None or sl["owner"]().done), None)
+        if slot is None:
+            slot = {"out": torch.empty(out.shape, dtype=out.dtype, pin_memory=True), "cnt": torch.empty((S,), dtype=cnt.dtype, pin_memory=True),
+                    "owner": None}
+            ring.append(slot)
+        out_h, cnt_h = slot["out"], slot["cnt"]
         out_h.copy_(out, non_blocking=True)
         cnt_h.copy_(cnt[:S], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return PendingDetections(ev, out_h, cnt_h, B, self.nc_total, tokens if tokens else [None] * B)
+        pend = PendingDetections(ev, out_h, cnt_h, B, self.nc_total, tokens if tokens else [None] * B)
+        slot["owner"] = weakref.ref(pend)
+        return pend
 
     def __call__(self, packed, tokens=None):
         return self.launch(packed, tokens).result()
@@ -172,8 +177,12 @@ class PendingDetections:
 
     def __init__(self, event, out_h, cnt_h, batch, nc_total, tokens):
         self.event, self.out_h, self.cnt_h, self.batch, self.nc_total, self.tokens = event, out_h, cnt_h, batch, nc_total, tokens
+        self.done = False  # the pinned buffers may be handed to a later launch once this is True (or this object is gone)
+        self._res = None
 
     def result(self):
+        if self._res is not None:
+            return self._res
         self.event.synchronize()
         out_c, cnt_c = self.out_h, self.cnt_h.tolist()
         res = []
@@ -186,4 +195,5 @@ class PendingDetections:
                 ss.append(blk[:, 9])
                 ll.append(torch.full((k,), c, dtype=torch.int64))
             res.append({"box3d_lidar": torch.cat(bb), "scores": torch.cat(ss), "label_preds": torch.cat(ll), "token": self.tokens[b]})
+        self._res, self.done = res, True  # torch.cat made copies: the pinned slot is free again
         return res

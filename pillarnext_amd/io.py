@@ -36,11 +36,19 @@ class PointUploader:
 
     def upload(self, clouds):
         """Returns (device tensor view (N,1+F), batch size); the copy is ordered before later work on the CURRENT stream."""
+        return self._go(sum(len(c) for c in clouds), lambda buf: collate_points(clouds, buf)), len(clouds)
+
+    def upload_rows(self, rows):
+        """rows: (n, 1+F) fp32 host array (e.g. the raw sweeps of a batch, back to back) -> device view of the same rows."""
+        def fill(buf):
+            buf[:len(rows)] = rows
+        return self._go(len(rows), fill)
+
+    def _go(self, n, fill):
         i = self.k % len(self.host)
         self.k += 1
         self.done[i].synchronize()                      # the pinned staging buffer of this slot is free again (its copy ran)
-        n = sum(len(c) for c in clouds)
-        collate_points(clouds, self.host[i].numpy())
+        fill(self.host[i].numpy())
         # The DEVICE buffer of the slot may still be read by reader kernels of the batch that used it `depth` uploads ago.  Every call
         # records an event on the compute stream first: the event of call j covers the consumers of batches < j, so the consumers of
         # batch j - depth are covered by the event of call j - depth + 1 -- waiting for THAT one (not for "now") keeps the copy of
@@ -58,7 +66,7 @@ class PointUploader:
             ev.record(self.stream)
         torch.cuda.current_stream(self.device).wait_event(ev)
         self.done[i] = ev
-        return self.dev[i][:n], len(clouds)
+        return self.dev[i][:n]
 
 
 # --------------------------------------------------------------------------------------------- multi-sweep merge on the device
@@ -83,20 +91,32 @@ class SweepMerger:
     def __init__(self):
         self._ws = None
 
-    def __call__(self, raw, segments, n_copy=4):
+    def descriptors(self, segments, device):
+        """Segment descriptors on the device (build once per segment layout, reuse every step)."""
+        from . import _lib
+
+        blob = pack_segments(segments)
+        assert len(blob) == len(segments) * _lib.lib().pnx_merge_sweeps_desc_bytes(), "SegDesc layout drifted"
+        return torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device), len(segments)
+
+    def __call__(self, raw, segments, n_copy=4, out=None, n_out=None):
+        """segments: list of dicts (pack_segments) or the (tensor, count) pair of descriptors().  Returns (out (n, n_copy+2), n_out (1,) int32):
+        rows [0, n_out) are the merged cloud, rows [n_out, n) carry batch index -1 (the reader drops them), so `out` can be handed to
+        the reader as a whole without a host sync."""
         from . import _lib
 
         L = _lib.lib()
         assert raw.is_cuda and raw.dtype == torch.float32 and raw.is_contiguous()
         n, stride = raw.shape
-        blob = pack_segments(segments)
-        assert len(blob) == len(segments) * L.pnx_merge_sweeps_desc_bytes(), "SegDesc layout drifted"
-        desc = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(raw.device)
+        desc, nseg = segments if isinstance(segments, tuple) else self.descriptors(segments, raw.device)
         need = int(L.pnx_merge_sweeps_workspace_bytes(n)) + 256
         if self._ws is None or self._ws.numel() < need or self._ws.device != raw.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=raw.device)
-        out = torch.empty((n, n_copy + 2), dtype=torch.float32, device=raw.device)
-        n_out = torch.zeros(1, dtype=torch.int32, device=raw.device)
-        _lib.check(L.pnx_merge_sweeps(_lib.ptr(raw), n, stride, n_copy, _lib.ptr(desc), len(segments), _lib.ptr(out), _lib.ptr(n_out), _lib.ptr(self._ws),
+        if out is None:
+            out = torch.empty((n, n_copy + 2), dtype=torch.float32, device=raw.device)
+        assert out.shape[0] >= n and out.shape[1] == n_copy + 2 and out.is_contiguous()
+        if n_out is None:
+            n_out = torch.zeros(1, dtype=torch.int32, device=raw.device)
+        _lib.check(L.pnx_merge_sweeps(_lib.ptr(raw), n, stride, n_copy, _lib.ptr(desc), nseg, _lib.ptr(out), _lib.ptr(n_out), _lib.ptr(self._ws),
                                       self._ws.numel(), _lib.stream_ptr()), "pnx_merge_sweeps")
-        return out, n_out
+        return out[:n], n_out

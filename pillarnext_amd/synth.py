@@ -85,11 +85,59 @@ def sweep_cloud(n, pc_range, seed, batch_idx=0, beams=32, sweeps=10):
     return pts
 
 
-def make_batch(config="C2", batch=1, dist="uniform", frame0=0, n=None):
-    """Collated batch (sum N, 6) fp32; seeds follow SURVEY 8d: cloud seed = 1000 + frame index."""
+def push_outside(pts, pc_range, share, seed):
+    """~1-2 % of the points lie outside the x/y range (they exercise the range mask, pillar_encoder.py:98-104).  A seeded
+    `share` of the rows is moved radially to 1.01 .. 1.3 x the half-range (in place)."""
+    n = len(pts)
+    k = int(round(n * share))
+    if k <= 0:
+        return pts
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(n, k, replace=False)
+    cx, cy = 0.5 * (pc_range[3] + pc_range[0]), 0.5 * (pc_range[4] + pc_range[1])
+    R = 0.5 * (pc_range[3] - pc_range[0])
+    dx, dy = pts[idx, 1].astype(np.float64) - cx, pts[idx, 2].astype(np.float64) - cy
+    m = np.maximum(np.maximum(np.abs(dx), np.abs(dy)), 1e-3)
+    f = R * rng.uniform(1.01, 1.3, k) / m
+    pts[idx, 1] = (cx + dx * f).astype(np.float32)
+    pts[idx, 2] = (cy + dy * f).astype(np.float32)
+    return pts
+
+
+def make_batch(config="C2", batch=1, dist="uniform", frame0=0, n=None, outside=None):
+    """Collated batch (sum N, 6) fp32; seeds follow SURVEY 8d: cloud seed = 1000 + frame index.  `outside`: share of the rows pushed
+    outside the x/y range (default: 1.5 % of a sweep cloud; the uniform disc already reaches 1.05 R)."""
     cfg = CONFIGS[config]
     gen = uniform_cloud if dist == "uniform" else sweep_cloud
-    return np.concatenate([gen(n or cfg["n"], cfg["pc_range"], 1000 + frame0 + b, batch_idx=b) for b in range(batch)])
+    share = (0.015 if dist != "uniform" else 0.0) if outside is None else outside
+    return np.concatenate([push_outside(gen(n or cfg["n"], cfg["pc_range"], 1000 + frame0 + b, batch_idx=b), cfg["pc_range"], share, 77000 + frame0 + b)
+                           for b in range(batch)])
+
+
+def raw_sweeps(batch_pts, sweep_dt=0.05):
+    """The collated batch taken apart into what a nuScenes sample is BEFORE det3d/datasets/nuscenes/nusc.py:76-121 merges it: per frame
+    one raw (n_s, 5) array [x, y, z, intensity, ring] per sweep (the points that carry that sweep's time lag, in the key frame's
+    coordinates minus a per-sweep translation, so that the merge has a transform to apply), plus the segment table for
+    io.SweepMerger.  Returns (raw (M, 5) fp32, segments).  Merging gives the batch back up to the fp32 rounding of x - t + t."""
+    raws, segs, o = [], [], 0
+    B = int(batch_pts[:, 0].max()) + 1 if len(batch_pts) else 0
+    for b in range(B):
+        f = batch_pts[batch_pts[:, 0] == b]
+        sidx = np.rint(f[:, 5] / sweep_dt).astype(np.int64)
+        for s in np.unique(sidx):
+            p = f[sidx == s]
+            T = None
+            r = np.zeros((len(p), 5), np.float32)
+            r[:, :4] = p[:, 1:5]
+            if s > 0:
+                t = np.array([0.4 * s * np.cos(0.3), 0.4 * s * np.sin(0.3), 0.01 * s])
+                T = np.eye(4)
+                T[:3, 3] = t
+                r[:, :3] = (p[:, 1:4].astype(np.float64) - t).astype(np.float32)
+            raws.append(r)
+            segs.append(dict(begin=o, end=o + len(r), batch=b, time=float(sweep_dt * s), radius=0.0, transform=T))
+            o += len(r)
+    return (np.concatenate(raws) if raws else np.zeros((0, 5), np.float32)), segs
 
 
 def pfn_params(num_input_features=5, num_filters=(64, 64), seed=0):

@@ -63,3 +63,50 @@ def test_reference_shaped_checkpoint_round_trip(tmp_path):
     again = torch.load(out, weights_only=False)
     assert set(again) == {"meta", "state_dict"} and list(again["state_dict"]) == list(sd2)
     assert all(not v.is_cuda for v in again["state_dict"].values())
+
+
+def test_saved_checkpoint_carries_spconv_layout_and_loads_back(tmp_path):
+    """save_checkpoint writes the sparse-conv stand-ins in spconv's (Cout, kH, kW, Cin) layout -- what the reference's modules check on
+    load (trainer/utils/checkpoint.py:8-44) -- and this package reads the file back bit for bit."""
+    import torch
+
+    from pillarnext_amd import checkpoint
+    from pillarnext_amd.models import SparseResNet, _SpConv2d
+
+    torch.manual_seed(3)
+    net = SparseResNet([1, 1], [1, 2], [8, 16], 8, kernel_size=(3, 3), out_channels=16)
+    f = str(tmp_path / "ck.pth")
+    checkpoint.save_checkpoint(net, f, meta={"epoch": 1})
+    raw = torch.load(f, weights_only=False)["state_dict"]
+    for name, m in net.named_modules():
+        if isinstance(m, _SpConv2d):
+            co, ci, kh, kw = m.weight.shape
+            assert tuple(raw[name + ".weight"].shape) == (co, kh, kw, ci)
+    net2 = SparseResNet([1, 1], [1, 2], [8, 16], 8, kernel_size=(3, 3), out_channels=16)
+    _, missing, unexpected = checkpoint.load_checkpoint(net2, f, strict=True)
+    assert not missing and not unexpected
+    for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert torch.equal(a, b), k
+    import pytest
+
+    with pytest.raises(IOError):
+        checkpoint.load_checkpoint(net2, str(tmp_path / "nope.pth"))
+
+
+def test_waymo_yaml_instantiates_with_the_iou_head():
+    """configs/pillarnext_b_waymo.yaml = the model block of the reference's waymo_det_pp18_aspp_iou_car_sp.yaml (:11, :43-73): 2 tasks, an
+    `iou` branch in every SepHead, IoU-rectified scores, NMS pre 4096 / post 500 / thresholds [[0.7], [0.2, 0.25]], 2048 x 2048 pillars."""
+    from pillarnext_amd import config, models
+
+    cfg = config.load(os.path.join(ROOT, "configs", "pillarnext_b_waymo.yaml"))
+    det = config.instantiate(cfg["model"])
+    assert isinstance(det, models.SingleStageDetector) and len(det.head.tasks) == 2 and det.head.with_iou and det.head.with_reg_iou
+    assert list(det.reader.grid_size) == [2048, 2048] and det.head.weight == 1
+    assert det.head.rectifier == [[0.68], [0.71, 0.65]] and det.head.num_classes == [1, 2]
+    pp = det.post_processing
+    assert pp["nms"]["nms_pre_max_size"] == 4096 and pp["nms"]["nms_post_max_size"] == 500 and pp["nms"]["nms_iou_threshold"] == [[0.7], [0.2, 0.25]]
+    assert pp["post_center_limit_range"][3] == 80.0
+    keys = set(det.state_dict())
+    for k in ("head.tasks.0.iou.0.weight", "head.tasks.1.iou.3.bias", "head.tasks.1.hm.3.weight"):
+        assert k in keys, k
+    assert det.state_dict()["head.tasks.1.hm.3.weight"].shape[0] == 2
