@@ -133,8 +133,9 @@ int pnx_pfn_backward(int32_t pass, int64_t n_points, int32_t row_stride, int32_t
                      pnx_stream_t stream);
 
 /* Voxelizer alone (PillarNet.forward :78-125): indices plus the decorated (N', F+5) features
- * (rows in kept-point order; may be NULL).  Used by the training path, where Linear/BN stay in
- * PyTorch so that SyncBatchNorm semantics are the reference's. */
+ * (rows in kept-point order; may be NULL).  The reference-API surface of PillarNet and the UNFUSED training fallback
+ * (PNX_TRAIN_FUSED=0, PFN shapes other than [64,64]: torch Linear/BatchNorm on these features + pnx_scatter_max); the default
+ * training path is pnx_pfn_forward_train / pnx_pfn_backward above, which never materialises the features. */
 int pnx_voxelize(const float* points, int64_t n_points, int32_t row_stride, int32_t batch, const pnx_geom* geom_host,
                  float* features, int32_t* coords, int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point,
                  int32_t* counts, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
@@ -182,9 +183,10 @@ int pnx_bias_act_mask(const void* x, const void* residual, const float* bias, co
                       int32_t channels, int32_t dtype, int32_t relu, pnx_stream_t stream);
 /* ASPP neck with the 1x1 post_conv folded into the branches (det3d/models/necks/aspp.py:19-32: post_conv(cat(x, conv1x1(x),
  * conv_d(x, W) for d in 1,6,12,18)) == sum of six convolutions of x with post-multiplied weights): the partial results are summed
- * in fp32 in one pass,  out = [relu]( sum_k src_k + bias[c] ), bf16 NHWC.  srcs = HOST array of n_src (1..8) device pointers. */
-int pnx_sum_bias_act(const void* const* srcs, int32_t n_src, const float* bias, void* out, int64_t sites, int32_t channels, int32_t relu,
-                     pnx_stream_t stream);
+ * in fp32 in one pass,  out = [relu]( sum_k src_k + bias[c] ), NHWC in `dtype` (PNX_BF16 / PNX_F16).  srcs = HOST array of n_src (1..8)
+ * device pointers. */
+int pnx_sum_bias_act(const void* const* srcs, int32_t n_src, const float* bias, void* out, int64_t sites, int32_t channels, int32_t dtype,
+                     int32_t relu, pnx_stream_t stream);
 /* ConvTranspose2d(cin, cout, kernel 2, stride 2, no bias) + folded BatchNorm + [ReLU] in one kernel, bf16 NHWC, fp32 accumulation:
  * the deblock of a SepHead (det3d/models/heads/centerhead.py:17-21 via det3d/models/utils/conv.py ConvBlock with
  * conv_layer=ConvTranspose2d).  x (B,h,w,cin) -> y (B,2h,2w,cout); wfrag = weights in MFMA-fragment order

@@ -18,9 +18,21 @@ __device__ __forceinline__ uint32_t f2bf(float f) {
   return u >> 16;
 }
 
+// 16-bit element <-> fp32 for the two canvas dtypes (DT = PNX_BF16 / PNX_F16)
+template <int DT>
+__device__ __forceinline__ float h2f(uint32_t h) {
+  if (DT == PNX_BF16) return bf2f(h);
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+}
+template <int DT>
+__device__ __forceinline__ uint32_t f2h(float f) {
+  if (DT == PNX_BF16) return f2bf(f);
+  return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f);  // round to nearest even
+}
+
 // x, res, out: bf16 NHWC with C channels (C % 8 == 0); bias fp32[C]; mask u8[sites] (or null) ; one thread = 8 channels
 // RELU: 0 none, 1 relu(x + b + res), 2 relu(x + b) + res (BasicBlock of the neck: the residual joins after block2's own ReLU)
-template <bool HAS_RES, bool HAS_MASK, int RELU>
+template <bool HAS_RES, bool HAS_MASK, int RELU, int DT>
 __global__ __launch_bounds__(256) void k_bias_act_mask_bf16(const uint4* __restrict__ x, const uint4* __restrict__ res,
                                                             const float* __restrict__ bias, const uint8_t* __restrict__ mask,
                                                             uint4* __restrict__ out, int64_t n_vec, int cvec) {
@@ -39,20 +51,20 @@ __global__ __launch_bounds__(256) void k_bias_act_mask_bf16(const uint4* __restr
       uint32_t ow[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        float lo = bf2f(vw[k] & 0xffffu) + bb[2 * k], hi = bf2f(vw[k] >> 16) + bb[2 * k + 1];
+        float lo = h2f<DT>(vw[k] & 0xffffu) + bb[2 * k], hi = h2f<DT>(vw[k] >> 16) + bb[2 * k + 1];
         if (RELU == 2) {
           lo = fmaxf(lo, 0.f);
           hi = fmaxf(hi, 0.f);
         }
         if (HAS_RES) {
-          lo += bf2f(rw[k] & 0xffffu);
-          hi += bf2f(rw[k] >> 16);
+          lo += h2f<DT>(rw[k] & 0xffffu);
+          hi += h2f<DT>(rw[k] >> 16);
         }
         if (RELU == 1) {
           lo = fmaxf(lo, 0.f);
           hi = fmaxf(hi, 0.f);
         }
-        ow[k] = f2bf(lo) | (f2bf(hi) << 16);
+        ow[k] = f2h<DT>(lo) | (f2h<DT>(hi) << 16);
       }
       o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
     }
@@ -65,7 +77,7 @@ __global__ __launch_bounds__(256) void k_bias_act_mask_bf16(const uint4* __restr
 struct SumSrcs {
   const uint4* p[8];
 };
-template <int N, bool RELU>
+template <int N, bool RELU, int DT>
 __global__ __launch_bounds__(256) void k_sum_bias_act_bf16(SumSrcs srcs, const float* __restrict__ bias, uint4* __restrict__ out, int64_t n_vec,
                                                            int cvec) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * 256) {
@@ -80,8 +92,8 @@ __global__ __launch_bounds__(256) void k_sum_bias_act_bf16(SumSrcs srcs, const f
       const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        a[2 * q] += bf2f(w[q] & 0xffffu);
-        a[2 * q + 1] += bf2f(w[q] >> 16);
+        a[2 * q] += h2f<DT>(w[q] & 0xffffu);
+        a[2 * q + 1] += h2f<DT>(w[q] >> 16);
       }
     }
     uint32_t ow[4];
@@ -92,7 +104,7 @@ __global__ __launch_bounds__(256) void k_sum_bias_act_bf16(SumSrcs srcs, const f
         lo = fmaxf(lo, 0.f);
         hi = fmaxf(hi, 0.f);
       }
-      ow[q] = f2bf(lo) | (f2bf(hi) << 16);
+      ow[q] = f2h<DT>(lo) | (f2h<DT>(hi) << 16);
     }
     out[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
   }
@@ -159,7 +171,7 @@ extern "C" {
 int pnx_bias_act_mask(const void* x, const void* residual, const float* bias, const uint8_t* mask, void* out, int64_t sites,
                       int32_t channels, int32_t dtype, int32_t relu, pnx_stream_t stream) {
   PNX_REQUIRE(x && bias && out, PNX_ERR_INVALID, "null pointer");
-  PNX_REQUIRE(dtype == PNX_BF16, PNX_ERR_UNSUPPORTED, "pnx_bias_act_mask is built for bf16 NHWC tensors");
+  PNX_REQUIRE(dtype == PNX_BF16 || dtype == PNX_F16, PNX_ERR_UNSUPPORTED, "pnx_bias_act_mask is built for bf16 / f16 NHWC tensors");
   PNX_REQUIRE(channels > 0 && channels % 8 == 0 && sites >= 0, PNX_ERR_INVALID, "channels must be a positive multiple of 8");
   PNX_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)bias) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
   if (sites == 0) return PNX_OK;
@@ -170,18 +182,22 @@ int pnx_bias_act_mask(const void* x, const void* residual, const float* bias, co
   if (nb > 256 * 32) nb = 256 * 32;
   const uint4 *xv = (const uint4*)x, *rv = (const uint4*)residual;
   uint4* ov = (uint4*)out;
-#define PNX_LAUNCH_BAM(R_, M_, A_) k_bias_act_mask_bf16<R_, M_, A_><<<(unsigned)nb, 256, 0, st>>>(xv, rv, bias, mask, ov, n_vec, cvec)
+#define PNX_LAUNCH_BAM(R_, M_, A_)                                                                                         \
+  {                                                                                                                       \
+    if (dtype == PNX_BF16) k_bias_act_mask_bf16<R_, M_, A_, PNX_BF16><<<(unsigned)nb, 256, 0, st>>>(xv, rv, bias, mask, ov, n_vec, cvec); \
+    else k_bias_act_mask_bf16<R_, M_, A_, PNX_F16><<<(unsigned)nb, 256, 0, st>>>(xv, rv, bias, mask, ov, n_vec, cvec);     \
+  }
   const bool r = residual != nullptr, m = mask != nullptr, a = relu != 0;
-  if (relu == 2 && r && m) PNX_LAUNCH_BAM(true, true, 2);
-  else if (relu == 2 && r) PNX_LAUNCH_BAM(true, false, 2);
-  else if (r && m && a) PNX_LAUNCH_BAM(true, true, 1);
-  else if (r && m) PNX_LAUNCH_BAM(true, true, 0);
-  else if (r && a) PNX_LAUNCH_BAM(true, false, 1);
-  else if (r) PNX_LAUNCH_BAM(true, false, 0);
-  else if (m && a) PNX_LAUNCH_BAM(false, true, 1);
-  else if (m) PNX_LAUNCH_BAM(false, true, 0);
-  else if (a) PNX_LAUNCH_BAM(false, false, 1);
-  else PNX_LAUNCH_BAM(false, false, 0);
+  if (relu == 2 && r && m) PNX_LAUNCH_BAM(true, true, 2)
+  else if (relu == 2 && r) PNX_LAUNCH_BAM(true, false, 2)
+  else if (r && m && a) PNX_LAUNCH_BAM(true, true, 1)
+  else if (r && m) PNX_LAUNCH_BAM(true, true, 0)
+  else if (r && a) PNX_LAUNCH_BAM(true, false, 1)
+  else if (r) PNX_LAUNCH_BAM(true, false, 0)
+  else if (m && a) PNX_LAUNCH_BAM(false, true, 1)
+  else if (m) PNX_LAUNCH_BAM(false, true, 0)
+  else if (a) PNX_LAUNCH_BAM(false, false, 1)
+  else PNX_LAUNCH_BAM(false, false, 0)
 #undef PNX_LAUNCH_BAM
   PNX_LAUNCH_CHECK();
   return PNX_OK;
@@ -203,9 +219,10 @@ int pnx_mask_pool3(const uint8_t* mask_in, int32_t batch, int32_t h, int32_t w, 
   return PNX_OK;
 }
 
-int pnx_sum_bias_act(const void* const* srcs, int32_t n_src, const float* bias, void* out, int64_t sites, int32_t channels, int32_t relu,
-                     pnx_stream_t stream) {
+int pnx_sum_bias_act(const void* const* srcs, int32_t n_src, const float* bias, void* out, int64_t sites, int32_t channels, int32_t dtype,
+                     int32_t relu, pnx_stream_t stream) {
   PNX_REQUIRE(srcs && bias && out && sites > 0, PNX_ERR_INVALID, "bad arguments");
+  PNX_REQUIRE(dtype == PNX_BF16 || dtype == PNX_F16, PNX_ERR_UNSUPPORTED, "dtype %d (bf16 / f16 only)", dtype);
   PNX_REQUIRE(n_src >= 1 && n_src <= 8, PNX_ERR_UNSUPPORTED, "%d summands (1..8)", n_src);
   PNX_REQUIRE(channels > 0 && channels % 8 == 0, PNX_ERR_UNSUPPORTED, "channels %d not a multiple of 8", channels);
   SumSrcs ss;
@@ -218,15 +235,21 @@ int pnx_sum_bias_act(const void* const* srcs, int32_t n_src, const float* bias, 
   const int64_t n_vec = sites * cvec;
   int64_t nb = (n_vec + 255) / 256;
   if (nb > 256 * 32) nb = 256 * 32;
-#define PNX_SUM_CASE(N_)                                                                                      \
-  case N_:                                                                                                    \
-    if (relu) k_sum_bias_act_bf16<N_, true><<<(unsigned)nb, 256, 0, st>>>(ss, bias, (uint4*)out, n_vec, cvec); \
-    else k_sum_bias_act_bf16<N_, false><<<(unsigned)nb, 256, 0, st>>>(ss, bias, (uint4*)out, n_vec, cvec);     \
+#define PNX_SUM_GO(N_, R_)                                                                                                  \
+  {                                                                                                                         \
+    if (dtype == PNX_BF16) k_sum_bias_act_bf16<N_, R_, PNX_BF16><<<(unsigned)nb, 256, 0, st>>>(ss, bias, (uint4*)out, n_vec, cvec); \
+    else k_sum_bias_act_bf16<N_, R_, PNX_F16><<<(unsigned)nb, 256, 0, st>>>(ss, bias, (uint4*)out, n_vec, cvec);            \
+  }
+#define PNX_SUM_CASE(N_)                 \
+  case N_:                               \
+    if (relu) PNX_SUM_GO(N_, true)       \
+    else PNX_SUM_GO(N_, false)           \
     break;
   switch (n_src) {
     PNX_SUM_CASE(1) PNX_SUM_CASE(2) PNX_SUM_CASE(3) PNX_SUM_CASE(4) PNX_SUM_CASE(5) PNX_SUM_CASE(6) PNX_SUM_CASE(7) PNX_SUM_CASE(8)
   }
 #undef PNX_SUM_CASE
+#undef PNX_SUM_GO
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

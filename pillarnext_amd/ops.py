@@ -184,14 +184,14 @@ def nms_single(boxes, thresh, rotated=True, post_max=0):
 
 # --------------------------------------------------------------------------------------------- dense epilogue
 def bias_act_mask_(x, bias, mask=None, residual=None, relu=True):
-    """In place on a channels_last bf16 (B,C,H,W) tensor: x = [relu](x + bias[c] [+ residual]) * mask[b,h,w];
+    """In place on a channels_last bf16 / fp16 (B,C,H,W) tensor: x = [relu](x + bias[c] [+ residual]) * mask[b,h,w];
     relu=2: (relu(x + bias[c]) + residual) * mask."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):
-        raise PnxError("bias_act_mask_ needs a channels_last bf16 CUDA tensor")
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous(memory_format=torch.channels_last)):
+        raise PnxError("bias_act_mask_ needs a channels_last bf16 / fp16 CUDA tensor")
     B, C, H, W = x.shape
     if residual is not None and not (residual.dtype == x.dtype and residual.shape == x.shape and residual.is_contiguous(memory_format=torch.channels_last)):
-        raise PnxError("residual must match x (bf16, channels_last)")
-    check(lib().pnx_bias_act_mask(ptr(x), ptr(residual), ptr(bias), ptr(mask), ptr(x), B * H * W, C, PNX_BF16, int(relu), stream_ptr()),
+        raise PnxError("residual must match x (dtype, channels_last)")
+    check(lib().pnx_bias_act_mask(ptr(x), ptr(residual), ptr(bias), ptr(mask), ptr(x), B * H * W, C, _DT[x.dtype], int(relu), stream_ptr()),
           "pnx_bias_act_mask")
     return x
 
@@ -200,12 +200,13 @@ def sum_bias_act(parts, bias, relu=True):
     """[relu](sum(parts) + bias[c]) for channels_last bf16 (B,C,H,W) tensors of one shape, summed in fp32 in one pass."""
     x = parts[0]
     for t in parts:
-        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.shape == x.shape and t.is_contiguous(memory_format=torch.channels_last)):
-            raise PnxError("sum_bias_act needs channels_last bf16 CUDA tensors of one shape")
+        if not (t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.dtype == x.dtype and t.shape == x.shape
+                and t.is_contiguous(memory_format=torch.channels_last)):
+            raise PnxError("sum_bias_act needs channels_last bf16 / fp16 CUDA tensors of one shape and dtype")
     B, C, H, W = x.shape
     out = torch.empty_like(x, memory_format=torch.channels_last)
     arr = (ctypes.c_void_p * len(parts))(*[t.data_ptr() for t in parts])
-    check(lib().pnx_sum_bias_act(arr, len(parts), ptr(bias), ptr(out), B * H * W, C, 1 if relu else 0, stream_ptr()), "pnx_sum_bias_act")
+    check(lib().pnx_sum_bias_act(arr, len(parts), ptr(bias), ptr(out), B * H * W, C, _DT[x.dtype], 1 if relu else 0, stream_ptr()), "pnx_sum_bias_act")
     return out
 
 

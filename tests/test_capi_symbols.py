@@ -90,9 +90,9 @@ def test_round2_entry_points_validate_before_launching():
     buf = (ctypes.c_char * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p)
     arr = (ctypes.c_void_p * 9)(*([p.value] * 9))
-    assert L.pnx_sum_bias_act(arr, 9, p, p, 10, 64, 1, None) < 0 and b"summands" in L.pnx_last_error()
-    assert L.pnx_sum_bias_act(arr, 2, p, p, 10, 60, 1, None) < 0 and b"multiple of 8" in L.pnx_last_error()
-    assert L.pnx_sum_bias_act(None, 2, p, p, 10, 64, 1, None) < 0 and b"bad arguments" in L.pnx_last_error()
+    assert L.pnx_sum_bias_act(arr, 9, p, p, 10, 64, 1, 1, None) < 0 and b"summands" in L.pnx_last_error()
+    assert L.pnx_sum_bias_act(arr, 2, p, p, 10, 60, 1, 1, None) < 0 and b"multiple of 8" in L.pnx_last_error()
+    assert L.pnx_sum_bias_act(None, 2, p, p, 10, 64, 1, 1, None) < 0 and b"bad arguments" in L.pnx_last_error()
     assert L.pnx_deconv2x2_bf16(p, p, p, p, 1, 8, 8, 128, 64, 1, None) < 0 and b"128" in L.pnx_last_error()
     assert L.pnx_deconv2x2_bf16(None, p, p, p, 1, 8, 8, 64, 64, 1, None) < 0 and b"bad arguments" in L.pnx_last_error()
     assert L.pnx_conv_tile_list(None, arr, 1, 1, 8, 8, 16, p, p, None) < 0 and b"bad arguments" in L.pnx_last_error()
