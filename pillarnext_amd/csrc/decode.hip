@@ -42,6 +42,14 @@ template <>
 __device__ __forceinline__ float ldf<uint16_t>(const uint16_t* p, int i) {
   return __uint_as_float((uint32_t)p[i] << 16);
 }
+struct f16bits {  // an fp16 head output: the same 16-bit storage, IEEE half instead of bfloat16
+  unsigned short v;
+};
+template <>
+__device__ __forceinline__ float ldf<f16bits>(const f16bits* p, int i) {
+  return (float)__builtin_bit_cast(_Float16, p[i].v);
+}
+
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -355,7 +363,8 @@ int pnx_decode_keys(const void* packed, int32_t dtype, int32_t batch, int32_t n_
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PNX_F32) k_decode_keys<float><<<nb, 256, 0, st>>>((const float*)packed, tk, batch, n_classes_total, (unsigned long long*)keys);
   else if (dtype == PNX_BF16) k_decode_keys<uint16_t><<<nb, 256, 0, st>>>((const uint16_t*)packed, tk, batch, n_classes_total, (unsigned long long*)keys);
-  else PNX_REQUIRE(false, PNX_ERR_UNSUPPORTED, "decode is built for fp32 and bf16 head outputs");
+  else if (dtype == PNX_F16) k_decode_keys<f16bits><<<nb, 256, 0, st>>>((const f16bits*)packed, tk, batch, n_classes_total, (unsigned long long*)keys);
+  else PNX_REQUIRE(false, PNX_ERR_UNSUPPORTED, "decode is built for fp32, bf16 and fp16 head outputs");
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -405,7 +414,11 @@ int pnx_decode_boxes(const void* const* task_ptrs_dev, const void* task_descs_de
     k_decode_boxes<uint16_t><<<nb, 256, 0, st>>>((const uint16_t* const*)task_ptrs_dev, (const DecodeTask*)task_descs_dev, task_key_off_dev, n_tasks,
                                                  batch, (const unsigned long long*)sorted_keys, order, seg_start, seg_len, num_segments, pre_max, boxes9,
                                                  boxes7, scores);
-  else PNX_REQUIRE(false, PNX_ERR_UNSUPPORTED, "decode is built for fp32 and bf16 head outputs");
+  else if (dtype == PNX_F16)
+    k_decode_boxes<f16bits><<<nb, 256, 0, st>>>((const f16bits* const*)task_ptrs_dev, (const DecodeTask*)task_descs_dev, task_key_off_dev, n_tasks,
+                                                batch, (const unsigned long long*)sorted_keys, order, seg_start, seg_len, num_segments, pre_max, boxes9,
+                                                boxes7, scores);
+  else PNX_REQUIRE(false, PNX_ERR_UNSUPPORTED, "decode is built for fp32, bf16 and fp16 head outputs");
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

@@ -11,7 +11,7 @@ import weakref
 import torch
 
 from . import ops
-from ._lib import PNX_BF16, PNX_F32, check, lib, ptr, stream_ptr
+from ._lib import PNX_BF16, PNX_F16, PNX_F32, check, lib, ptr, stream_ptr
 
 
 def _get(cfg, name):
@@ -71,7 +71,7 @@ class PackedDecoder:
         Enqueues decode + NMS + the D2H copy and returns a PendingDetections."""
         B = packed[0].shape[0]
         dev = packed[0].device
-        dt = PNX_F32 if packed[0].dtype == torch.float32 else PNX_BF16
+        dt = {torch.float32: PNX_F32, torch.bfloat16: PNX_BF16, torch.float16: PNX_F16}[packed[0].dtype]
         T = len(packed)
         shapes = [(p.shape[2], p.shape[3]) for p in packed]
         for p in packed:

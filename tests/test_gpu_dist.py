@@ -32,5 +32,6 @@ def _run(args, timeout=420):
 
 
 def test_fused_reader_syncbn_world2_on_one_gpu():
+    torch.cuda.empty_cache()  # the two ranks share this process's GPU: hand back what earlier tests left in the caching allocator
     r = _run(["--backend", "gloo", "--one-gpu"])
     assert r.returncode == 0 and "DDP PARITY OK" in r.stdout, r.stdout[-4000:]
