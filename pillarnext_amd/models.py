@@ -89,6 +89,80 @@ class MaskedBatchNorm(nn.BatchNorm2d):
         return (y * self.weight.view(1, -1, 1, 1) + self.bias.view(1, -1, 1, 1)).to(x.dtype)
 
 
+class _MaskedBNActFn(torch.autograd.Function):
+    """y = relu(BN_active_sites(x) [+ residual]) * mask in ONE autograd node (train mode).  The module-by-module form keeps ~6 full-size
+    fp32 tensors per layer alive for the backward (x.float(), the masked products, the normalised map, the ReLU output ...); this node
+    keeps x (in its own dtype), the residual (the block's input, alive anyway) and two per-channel vectors, and recomputes the rest:
+    106 -> GiB-scale savings at 1440 x 1440 x 4 frames (profiles/).  SyncBatchNorm mode all-reduces [sum x, count], [sum (x-mu)^2]
+    forward and [sum g, sum g*xhat] backward over the ACTIVE sites of the global batch (dist_utils.all_reduce_sum)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, weight, bias, residual, norm, relu):
+        m = mask if mask.dtype == torch.float32 else mask.float()
+        xf = x.float()
+        s1 = torch.cat([(xf * m).sum(dim=(0, 2, 3)), m.sum().view(1)])
+        group = norm.sync_group if norm.sync else False
+        if group is not False:
+            from .dist_utils import all_reduce_sum
+
+            all_reduce_sum(s1, group)
+        cnt = s1[-1].clamp(min=1.0)
+        mean = s1[:-1] / cnt
+        xf = xf - mean.view(1, -1, 1, 1)
+        ssd = (xf * xf * m).sum(dim=(0, 2, 3))
+        if group is not False:
+            all_reduce_sum(ssd, group)
+        var = ssd / cnt
+        invstd = torch.rsqrt(var + norm.eps)
+        with torch.no_grad():
+            mom = norm.momentum
+            norm.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            norm.running_var.mul_(1 - mom).add_(var * cnt / (cnt - 1).clamp(min=1.0), alpha=mom)
+            norm.num_batches_tracked += 1
+        xf.mul_((invstd * weight.float()).view(1, -1, 1, 1)).add_(bias.float().view(1, -1, 1, 1))
+        if residual is not None:
+            xf.add_(residual)
+        if relu:
+            xf.clamp_(min=0)
+        xf.mul_(m)
+        ctx.save_for_backward(x, m, weight, bias, residual, mean, invstd, cnt)
+        ctx.group, ctx.relu = group, relu
+        return xf.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, m, weight, bias, residual, mean, invstd, cnt = ctx.saved_tensors
+        xhat = (x.float() - mean.view(1, -1, 1, 1)).mul_(invstd.view(1, -1, 1, 1))
+        g = gy.float() * m
+        if ctx.relu:
+            pre = xhat * weight.float().view(1, -1, 1, 1) + bias.float().view(1, -1, 1, 1)
+            if residual is not None:
+                pre = pre + residual
+            g = g * (pre > 0)
+            del pre
+        gres = g.to(residual.dtype) if residual is not None and ctx.needs_input_grad[4] else None
+        sg = torch.cat([g.sum(dim=(0, 2, 3)), (g * xhat).sum(dim=(0, 2, 3))])
+        C = weight.numel()
+        dbeta, dgamma = sg[:C].clone(), sg[C:].clone()          # parameter gradients: local sums (DDP averages them)
+        if ctx.group is not False:
+            from .dist_utils import all_reduce_sum
+
+            all_reduce_sum(sg, ctx.group)
+        mg, mgx = (sg[:C] / cnt).view(1, -1, 1, 1), (sg[C:] / cnt).view(1, -1, 1, 1)
+        dx = (g - mg - xhat * mgx).mul_((weight.float() * invstd).view(1, -1, 1, 1)).mul_(m)
+        return dx.to(x.dtype), None, dgamma.to(weight.dtype), dbeta.to(bias.dtype), gres, None, None
+
+
+def masked_bn_act(x, mask, norm, residual=None, relu=True):
+    """relu(norm(x, mask) [+ residual]) * mask -- one fused autograd node in train mode, the plain modules otherwise."""
+    if norm.training and mask is not None and torch.is_grad_enabled():
+        return _MaskedBNActFn.apply(x, mask, norm.weight, norm.bias, residual, norm, relu)
+    out = norm(x, mask)
+    if residual is not None:
+        out = out + residual
+    return (F.relu(out) if relu else out) * mask
+
+
 def convert_sync_batchnorm(module, process_group=None, cpu_ok=False):
     """tools/train.py:56 for this model, callable BEFORE or after .cuda() like torch's own converter (the reference converts first,
     train.py:56 then :59): MaskedBatchNorm layers switch to global active-site statistics in place; the reader's fused training
@@ -136,8 +210,7 @@ class SparseConvBlock(nn.Module):
     def forward(self, x, mask):
         if not self.subm:
             mask = F.max_pool2d(mask, self.kernel_size, self.stride, self.kernel_size // 2)
-        out = self.conv(x)
-        out = F.relu(self.norm(out, mask)) * mask
+        out = masked_bn_act(self.conv(x), mask, self.norm)
         return out, mask
 
 
@@ -152,8 +225,7 @@ class SparseBasicBlock(nn.Module):
 
     def forward(self, x, mask):
         out, _ = self.block1(x, mask)
-        out = self.norm2(self.conv2(out), mask)
-        out = F.relu(out + x) * mask
+        out = masked_bn_act(self.conv2(out), mask, self.norm2, residual=x)
         return out, mask
 
 
@@ -186,8 +258,7 @@ class SparseResNet(nn.Module):
         x = canvas
         for blk in self.blocks:
             x, mask = blk(x, mask)
-        x = F.relu(self.mapping[1](self.mapping[0](x), mask)) * mask
-        return x
+        return masked_bn_act(self.mapping[0](x), mask, self.mapping[1])
 
     def forward(self, pillar_features, coors, input_shape, batch_size=None):
         """Reference signature (sparse_resnet.py:61): builds the canvas from the sparse list first."""

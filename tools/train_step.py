@@ -4,7 +4,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/train_step.py --batch 4
 
 Mirrors tools/train.py:26-67 + trainer/trainer/trainer.py:94-108 of the reference: SyncBatchNorm conversion, DDP wrap
-(bucketed gradient all-reduce overlapped with backward), AdamW(0.9,0.99,wd .01), clip 35."""
+(bucketed gradient all-reduce overlapped with backward), AdamW(0.9,0.99,wd .01, configs/optimizer/adamW.yaml), OneCycleLR(max_lr .002,
+div_factor 10, pct_start .4, configs/scheduler/onecycle.yaml) stepped every iteration, clip 35.  --amp runs the dense graph under bf16
+autocast in channels_last (the reference trains fp32; its Waymo 3-frame config uses fp16 AMP).  The masked BatchNorm + ReLU + mask of
+every sparse block is one recomputing autograd node (models.masked_bn_act) either way."""
 import argparse
 import os
 import sys
@@ -38,6 +41,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--check", action="store_true", help="assert finite loss / gradients and print the peak device memory")
+    ap.add_argument("--amp", action="store_true", help="bf16 autocast + channels_last for the dense backbone / neck / head")
+    ap.add_argument("--total-steps", type=int, default=1000, help="length of the OneCycle schedule the steps are taken from")
     a = ap.parse_args()
     rank, world, local = dist_utils.init()
     torch.cuda.set_device(local)
@@ -45,8 +50,11 @@ def main():
     cfg = synth.CONFIGS[a.config]
     torch.manual_seed(0)
     model = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"]).to(dev).train()
+    if a.amp:
+        model = model.to(memory_format=torch.channels_last)
     model = dist_utils.wrap_ddp(model, device_ids=[local])
     opt = torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=0.002, total_steps=max(a.total_steps, a.steps + 1), div_factor=10.0, pct_start=0.4)
     pts = torch.from_numpy(synth.make_batch(a.config, a.batch, "sweep", frame0=rank * a.batch)).to(dev)
     net = model.module if hasattr(model, "module") else model
     ny, nx = (int(v) for v in net.reader.grid_size)
@@ -55,20 +63,22 @@ def main():
     for it in range(a.steps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        loss, _ = model(ex)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.amp):
+            loss, _ = model(ex)
         opt.zero_grad()
         loss.backward()                                   # DDP: bucketed all-reduce over RCCL overlapped with backward
         gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 35)
         if a.check:
             assert bool(torch.isfinite(loss)) and bool(torch.isfinite(gn)) and float(gn) > 0, (float(loss), float(gn))
         opt.step()
+        sched.step()
         torch.cuda.synchronize()
         dt = dist_utils.max_over_ranks(time.perf_counter() - t0, dev)
         if rank == 0:
             print(f"step {it}: loss {loss.item():.4f}  {dt*1e3:.1f} ms  ({a.batch * world / dt:.1f} frames/s over {world} GPU)")
     if rank == 0 and a.check:
         print(f"peak device memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB allocated, {torch.cuda.max_memory_reserved() / 2**30:.2f} GiB reserved "
-              f"({a.config}, {a.batch} frames per GPU, fp32 training)")
+              f"({a.config}, {a.batch} frames per GPU, {'bf16 autocast' if a.amp else 'fp32'} training)")
 
 
 if __name__ == "__main__":
