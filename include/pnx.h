@@ -292,6 +292,30 @@ int pnx_decode_boxes(const void* const* task_ptrs_dev, const void* task_descs_de
 int pnx_gather_kept(const float* boxes9, const float* scores, const int32_t* keep, const int32_t* keep_count, int32_t num_segments,
                     int32_t pre_max, int32_t post_max, float* out, pnx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * CenterHead training losses over the (B, M) label lists of ONE task, forward and backward (csrc/center_loss.hip):
+ * det3d/models/loss/centerloss.py FastFocalLoss :8-37, RegLoss :40-60 (NaN-target rule :55-56), IouLoss :63-87 (target 2*IoU3D-1 from the
+ * aligned rotated IoU), IouRegLoss :90-110 + DIoU :139-176, as combined by det3d/models/heads/centerhead.py:142-229; labels in the format
+ * of det3d/datasets/pipelines/assign.py:113-114.
+ *   maps7      HOST array of 7 device pointers, fp32 (B,C,H,W): hm (C = n_classes, LOGITS), reg (2), height (1), dim (3), rot (2), vel (2),
+ *              iou (1) or NULL (no IoU head)
+ *   hm_target  (B,n_classes,H,W) fp32;  ind, cat (B,M) int64;  mask (B,M) uint8;  anno_box (B,M,10) fp32 in the order reg height dim vel rot
+ *              (NaN = "no target");  gt_boxes (B,M,7)
+ *   geom4_host {out_size_factor*voxel_x, out_size_factor*voxel_y, pc_min_x, pc_min_y}
+ *   losses15   device out: [0] hm_loss, [1..10] regression loss per box-code element (before code weights), [11] iou_loss,
+ *              [12] iou_reg_loss (0 unless with_reg_iou), [13] number of positives, [14] internal
+ * backward: grads7 = gradient buffers of the seven maps (hm is written densely; the other six must be zero on entry, the listed cells
+ * are accumulated); upstream13 = device array, gradients of losses15[0..12]; workspace = the forward call's, untouched in between. */
+size_t pnx_center_loss_workspace_bytes(int32_t batch, int32_t max_objs);
+int pnx_center_loss_forward(const void* const* maps7, const float* hm_target, const int64_t* ind, const uint8_t* mask, const int64_t* cat,
+                            const float* anno_box, const float* gt_boxes, int32_t batch, int32_t n_classes, int32_t h, int32_t w, int32_t max_objs,
+                            const float* geom4_host, int32_t with_reg_iou, float* losses15, void* workspace, size_t workspace_bytes,
+                            pnx_stream_t stream);
+int pnx_center_loss_backward(const void* const* maps7, void* const* grads7, const float* hm_target, const int64_t* ind, const uint8_t* mask,
+                             const int64_t* cat, const float* anno_box, const float* gt_boxes, int32_t batch, int32_t n_classes, int32_t h, int32_t w,
+                             int32_t max_objs, const float* geom4_host, int32_t with_reg_iou, const float* losses15, const float* upstream13,
+                             float* coef_scratch, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

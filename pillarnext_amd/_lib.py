@@ -66,6 +66,9 @@ PROTOTYPES = {
     "pnx_sort_keys": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "pnx_decode_boxes": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pnx_gather_kept": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "pnx_center_loss_workspace_bytes": (_sz, [_i32, _i32]),
+    "pnx_center_loss_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "pnx_center_loss_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pnx_boxes_overlap_bev": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "pnx_boxes_iou_bev": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "pnx_boxes_aligned_overlap_bev": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),

@@ -76,3 +76,66 @@ class IouLoss(nn.Module):
         with torch.no_grad():
             target = 2 * ops.boxes_aligned_iou3d(pb, box_gt[m].float().contiguous()) - 1   # HIP: BEV overlap x height / union
         return F.l1_loss(pred, target, reduction="sum") / (m.sum() + 1e-4)
+
+
+# --------------------------------------------------------------------------------------------- fused (HIP) form of the four losses
+class _CenterLossFn(torch.autograd.Function):
+    """All four CenterHead losses of one task in a handful of launches over the (B,M) lists (csrc/center_loss.hip): returns
+    (hm_loss, box_loss_elem (10,), iou_loss, iou_reg_loss) exactly as FastFocalLoss / RegLoss / IouLoss / IouRegLoss above do."""
+
+    @staticmethod
+    def forward(ctx, hm, reg, height, dim, rot, vel, iou, hm_t, ind, mask, cat, anno, gtb, geom4, with_reg_iou):
+        import ctypes
+
+        from ._lib import check, lib, ptr, stream_ptr
+
+        L = lib()
+        maps = [t.contiguous() if t is not None else None for t in (hm, reg, height, dim, rot, vel, iou)]
+        for t in maps:
+            if t is not None and not (t.is_cuda and t.dtype == torch.float32):
+                raise ops.PnxError("fused center loss needs fp32 CUDA head maps")
+        B, C, H, W = maps[0].shape
+        M = ind.shape[1]
+        hm_t, ind, mask, cat = hm_t.contiguous().float(), ind.contiguous(), mask.contiguous().to(torch.uint8), cat.contiguous()
+        anno, gtb = anno.contiguous().float(), gtb.contiguous().float()
+        dev = maps[0].device
+        losses = torch.empty(16, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(L.pnx_center_loss_workspace_bytes(B, M)) + 256, dtype=torch.uint8, device=dev)
+        arr = (ctypes.c_void_p * 7)(*[t.data_ptr() if t is not None else None for t in maps])
+        g4 = (ctypes.c_float * 4)(*[float(v) for v in geom4])
+        check(L.pnx_center_loss_forward(arr, ptr(hm_t), ptr(ind), ptr(mask), ptr(cat), ptr(anno), ptr(gtb), B, C, H, W, M, g4, int(bool(with_reg_iou)),
+                                        ptr(losses), ptr(ws), ws.numel(), stream_ptr()), "pnx_center_loss_forward")
+        ctx.save_for_backward(*maps, hm_t, ind, mask, cat, anno, gtb, losses, ws)
+        ctx.misc = (tuple(float(v) for v in geom4), bool(with_reg_iou))
+        return losses[0].clone(), losses[1:11].clone(), losses[11].clone(), losses[12].clone()
+
+    @staticmethod
+    def backward(ctx, g_hm, g_box, g_iou, g_ioureg):
+        import ctypes
+
+        from ._lib import check, lib, ptr, stream_ptr
+
+        L = lib()
+        saved = ctx.saved_tensors
+        maps = list(saved[:7])
+        hm_t, ind, mask, cat, anno, gtb, losses, ws = saved[7:]
+        geom4, with_reg_iou = ctx.misc
+        B, C, H, W = maps[0].shape
+        M = ind.shape[1]
+        dev = maps[0].device
+        up = torch.cat([g_hm.reshape(1), g_box.reshape(10), g_iou.reshape(1), g_ioureg.reshape(1)]).float().contiguous()
+        grads = [torch.empty_like(maps[0])] + [torch.zeros_like(t) if t is not None else None for t in maps[1:]]
+        coef = torch.empty(4, dtype=torch.float32, device=dev)
+        a_m = (ctypes.c_void_p * 7)(*[t.data_ptr() if t is not None else None for t in maps])
+        a_g = (ctypes.c_void_p * 7)(*[t.data_ptr() if t is not None else None for t in grads])
+        g4 = (ctypes.c_float * 4)(*geom4)
+        check(L.pnx_center_loss_backward(a_m, a_g, ptr(hm_t), ptr(ind), ptr(mask), ptr(cat), ptr(anno), ptr(gtb), B, C, H, W, M, g4, int(with_reg_iou),
+                                         ptr(losses), ptr(up), ptr(coef), ptr(ws), ws.numel(), stream_ptr()), "pnx_center_loss_backward")
+        return (*grads, None, None, None, None, None, None, None, None)
+
+
+def fused_center_loss(pd, hm_target, ind, mask, cat, anno_box, gt_boxes, geom4, with_reg_iou):
+    """pd: the task's dict of head maps (hm = logits).  Returns (hm_loss, box_loss_elem, iou_loss, iou_reg_loss)."""
+    f = lambda t: t.float()
+    return _CenterLossFn.apply(f(pd["hm"]), f(pd["reg"]), f(pd["height"]), f(pd["dim"]), f(pd["rot"]), f(pd["vel"]),
+                               f(pd["iou"]) if "iou" in pd else None, hm_target, ind, mask, cat, anno_box, gt_boxes, geom4, with_reg_iou)

@@ -396,7 +396,30 @@ class CenterHead(nn.Module):
 
         crit, crit_reg = FastFocalLoss(), RegLoss()
         rets, total = [], None
+        import os
+
+        fused = preds_dicts[0]["hm"].is_cuda and os.environ.get("PNX_FUSED_LOSS", "1") != "0"
         for t, pd in enumerate(preds_dicts):
+            if fused:
+                # the four losses of the task in a handful of launches over the (B,500) lists (csrc/center_loss.hip), no host sync
+                from .losses import fused_center_loss
+
+                geom4 = (self.out_size_factor[t] * self.voxel_size[0], self.out_size_factor[t] * self.voxel_size[1], self.pc_range[0], self.pc_range[1])
+                hm_loss, box_loss, iou_loss, iou_reg = fused_center_loss(pd, example["hm"][t], example["ind"][t], example["mask"][t], example["cat"][t],
+                                                                        example["anno_box"][t], example["gt_boxes"][t], geom4, self.with_reg_iou)
+                loc_loss = (box_loss * box_loss.new_tensor(self.code_weights)).sum()
+                loss = hm_loss + self.weight * loc_loss
+                ret = OrderedDict(task=self.class_names[t], loss=loss, hm_loss=hm_loss.detach(), loc_loss=loc_loss.detach(),
+                                  loc_loss_elem=box_loss.detach(), num_positive=example["mask"][t].float().sum())
+                if self.with_iou:
+                    loss = loss + iou_loss
+                    ret["iou_loss"] = iou_loss.detach()
+                if self.with_reg_iou:
+                    loss = loss + self.weight * iou_reg
+                    ret["iou_reg_loss"] = iou_reg.detach()
+                rets.append(ret)
+                total = loss if total is None else total + loss
+                continue
             hm = torch.clamp(torch.sigmoid(pd["hm"].float()), min=1e-4, max=1 - 1e-4)
             hm_loss = crit(hm, example["hm"][t], example["ind"][t], example["mask"][t], example["cat"][t])
             anno = torch.cat((pd["reg"], pd["height"], pd["dim"], pd["vel"], pd["rot"]), dim=1).float()
