@@ -409,14 +409,16 @@ class CenterHead(nn.Module):
                                                                         example["anno_box"][t], example["gt_boxes"][t], geom4, self.with_reg_iou)
                 loc_loss = (box_loss * box_loss.new_tensor(self.code_weights)).sum()
                 loss = hm_loss + self.weight * loc_loss
-                ret = OrderedDict(task=self.class_names[t], loss=loss, hm_loss=hm_loss.detach(), loc_loss=loc_loss.detach(),
-                                  loc_loss_elem=box_loss.detach(), num_positive=example["mask"][t].float().sum())
+                # the log dict holds host tensors, as the reference's does (centerhead.py:165,212-222): ONE device->host copy per task
+                host = torch.cat([hm_loss.detach().view(1), loc_loss.detach().view(1), box_loss.detach(), iou_loss.detach().view(1),
+                                  iou_reg.detach().view(1), example["mask"][t].float().sum().view(1)]).cpu()
+                ret = OrderedDict(task=self.class_names[t], loss=loss, hm_loss=host[0], loc_loss=host[1], loc_loss_elem=host[2:12], num_positive=host[14])
                 if self.with_iou:
                     loss = loss + iou_loss
-                    ret["iou_loss"] = iou_loss.detach()
+                    ret["iou_loss"] = host[12]
                 if self.with_reg_iou:
                     loss = loss + self.weight * iou_reg
-                    ret["iou_reg_loss"] = iou_reg.detach()
+                    ret["iou_reg_loss"] = host[13]
                 rets.append(ret)
                 total = loss if total is None else total + loss
                 continue
