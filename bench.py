@@ -220,7 +220,7 @@ def sections(model, examples, batch):
         marks = []
         packed = []
         model.forward_preds(examples[i % len(examples)]["points"], batch, marks=marks, packed_out=packed)
-        pend = model.decoder().launch(packed, None)
+        pend = model.launch_decode(packed, None)
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         marks.append(("decode+nms", e))

@@ -217,9 +217,18 @@ int pnx_conv_tile_list(const uint8_t* mask, const uint8_t* const* row_dirty, int
 /* Final convolution of the merged SepHead branches of one task (det3d/models/heads/centerhead.py:12-59, the last
  * Conv2d(64, k_j, 3, padding=1, bias=True) of every branch j):  y[b,oy,ox,o] = bias[o] + sum_{j,ky,kx,c} x[b,oy+ky-1,ox+kx-1,64j+c] * W[o][64j+c][ky][kx]
  * with W block diagonal (output o belongs to exactly one branch).  x (B,h,w,64*n_branch) bf16, y (B,h,w,16) bf16 (sum k_j <= 16,
- * unused outputs have zero weights), bias fp32[16], wfrag from pillarnext_amd/ops.py::sephead_pack_weights; n_branch in 5..7. */
+ * unused outputs have zero weights), bias fp32[16], wfrag from pillarnext_amd/ops.py::sephead_pack_weights; n_branch in {1, 2, 5, 6, 7}
+ * (1/2: the dense [iou] hm branches of the lazy head). */
 int pnx_sephead_out_bf16(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t n_branch,
                          pnx_stream_t stream);
+/* Lazy SepHead: the five regression branches of a task (reg 2, height 1, dim 3, rot 2, vel 2: centerhead.py:12-59, conv3x3 64->64 + BN + ReLU, then
+ * conv3x3 64->k) evaluated only at n candidate cells (the cells CenterHead.post_processing keeps, centerhead.py:341-363) instead of over the map.
+ * up (B,h,w,64) bf16 = the head's shared-conv output; local int64[n] = b*h*w + y*w + x; valid uint8[n] (0: the row of out is zeroed);
+ * wfrag1 = ops.conv3x3_pack_weights of the five first convolutions stacked (320,64,3,3) with BN folded, bias1 fp32[320];
+ * w2c fp32[10][9][32][4] = ops.sephead_lazy_pack_w2 (per 32-channel tile and 3x3 position: the <=3 output weights of the tile's branch, bf16-rounded);
+ * bias2 fp32[10]; out fp32 (n,10), values rounded to bf16 exactly as the dense kernels' output is. */
+int pnx_sephead_lazy_bf16(const void* up, int32_t batch, int32_t h, int32_t w, const int64_t* local, const uint8_t* valid, int64_t n, const void* wfrag1,
+                          const float* bias1, const float* w2c, const float* bias2, float* out, pnx_stream_t stream);
 /* Active-site rule of SparseConv2d(k=3, stride, pad=1): mask_out = maxpool3x3(mask_in, stride, 1); uint8 (B,h,w) -> (B,ho,wo). */
 int pnx_mask_pool3(const uint8_t* mask_in, int32_t batch, int32_t h, int32_t w, int32_t stride, uint8_t* mask_out, pnx_stream_t stream);
 
@@ -289,6 +298,17 @@ int pnx_decode_boxes(const void* const* task_ptrs_dev, const void* task_descs_de
                      int32_t dtype, int32_t batch, const uint64_t* sorted_keys, const int64_t* order, const int64_t* seg_start,
                      const int32_t* seg_len, int32_t num_segments, int32_t pre_max, float* boxes9, float* boxes7, float* scores,
                      pnx_stream_t stream);
+/* Lazy head (pillarnext_amd/models.py FusedPillarNeXt, PNX_HEAD_LAZY): only the class (and iou) branches of a SepHead are computed for
+ * every cell; the regression branches (reg, height, dim, rot, vel) are evaluated at the selected candidates only.  pnx_decode_keys then
+ * runs on the [iou] hm packing (task descriptor: o_hm, o_iou, lazy = 1: no centre / range test), the sort selects the candidates, and
+ * pnx_decode_boxes_lazy decodes them from cand = (num_segments * pre_max, 10) fp32 [reg 2, height 1, dim 3, rot 2, vel 2], applies the
+ * range test of centerhead.py:343-346 and compacts the survivors (seg_len updated in place).  seg_total = candidates per segment before
+ * the pre_max cut; *flag_dev |= 1 when a cut segment lost a candidate to the range test (the reference would have admitted the next
+ * one: the caller re-runs that batch through the dense path). */
+int pnx_decode_boxes_lazy(const void* task_descs_dev, const int64_t* task_key_off_dev, int32_t n_tasks, int32_t n_classes_total,
+                          const uint64_t* sorted_keys, const int64_t* order, const int64_t* seg_start, int32_t* seg_len, const int32_t* seg_total,
+                          int32_t num_segments, int32_t pre_max, const float* cand, float* boxes9, float* boxes7, float* scores, int32_t* flag_dev,
+                          pnx_stream_t stream);
 int pnx_gather_kept(const float* boxes9, const float* scores, const int32_t* keep, const int32_t* keep_count, int32_t num_segments,
                     int32_t pre_max, int32_t post_max, float* out, pnx_stream_t stream);
 

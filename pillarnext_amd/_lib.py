@@ -54,6 +54,7 @@ PROTOTYPES = {
     "pnx_sum_bias_act": (ctypes.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "pnx_deconv2x2_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pnx_sephead_out_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pnx_sephead_lazy_bf16": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pnx_conv3x3_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pnx_conv3x3_tile_rows": (ctypes.c_int, [_i32, _i32, _i32]),
     "pnx_conv_tile_list": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -65,6 +66,7 @@ PROTOTYPES = {
     "pnx_sort_keys_workspace_bytes": (ctypes.c_size_t, [_i64]),
     "pnx_sort_keys": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "pnx_decode_boxes": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pnx_decode_boxes_lazy": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pnx_gather_kept": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "pnx_center_loss_workspace_bytes": (_sz, [_i32, _i32]),
     "pnx_center_loss_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),

@@ -30,6 +30,9 @@ struct DecodeTask {
   float lim[6];  // post_center_limit_range
   int use_lim;
   float rect[4];  // rectifier per class
+  int o_hm, o_iou;  // channel of the first class logit / of the iou logit in the packed tensor (10 + has_iou / 10 for the full packing)
+  int lazy;         // 1: the packed tensor holds [iou] hm only; centre / range test happen after the regression branches were
+                    //    evaluated at the selected candidates (k_decode_boxes_lazy)
 };
 
 template <typename T>
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void k_decode_keys(const T* __restrict__ x, De
   if (idx >= (int64_t)B * HW) return;
   const int cell = (int)(idx % HW), b = (int)(idx / HW);
   const T* p = x + idx * tk.C;
-  const int o_hm = 10 + tk.has_iou;
+  const int o_hm = tk.o_hm;
   float best = -1.f;
   int lab = 0;
   for (int c = 0; c < tk.ncls; c++) {
@@ -72,15 +75,16 @@ __global__ __launch_bounds__(256) void k_decode_keys(const T* __restrict__ x, De
     }
   }
   bool ok = best > tk.score_thr;
-  const float xs = ((float)(cell % tk.W) + ldf<T>(p, 0)) * tk.osf * tk.vx + tk.pcx;
-  const float ys = ((float)(cell / tk.W) + ldf<T>(p, 1)) * tk.osf * tk.vy + tk.pcy;
-  const float z = ldf<T>(p, 2);
-  if (tk.use_lim)
+  if (tk.use_lim && !tk.lazy) {
+    const float xs = ((float)(cell % tk.W) + ldf<T>(p, 0)) * tk.osf * tk.vx + tk.pcx;
+    const float ys = ((float)(cell / tk.W) + ldf<T>(p, 1)) * tk.osf * tk.vy + tk.pcy;
+    const float z = ldf<T>(p, 2);
     ok = ok && xs >= tk.lim[0] && ys >= tk.lim[1] && z >= tk.lim[2] && xs <= tk.lim[3] && ys <= tk.lim[4] && z <= tk.lim[5];
+  }
   unsigned long long key = ~0ULL;
   if (ok) {
     float iou = 1.f;
-    if (tk.has_iou) iou = fminf(fmaxf((ldf<T>(p, 10) + 1.f) * 0.5f, 0.f), 1.f);
+    if (tk.has_iou) iou = fminf(fmaxf((ldf<T>(p, tk.o_iou) + 1.f) * 0.5f, 0.f), 1.f);
     const float a = tk.rect[lab];
     const float sc = powf(best, 1.f - a) * powf(iou, a);
     const unsigned seg = (unsigned)(b * n_classes_total + tk.cls_off + lab);
@@ -128,6 +132,73 @@ __global__ __launch_bounds__(256) void k_decode_boxes(const T* const* __restrict
   for (int k = 0; k < 6; k++) b7[k] = o[k];
   b7[6] = o[8];
   scores[idx] = __uint_as_float(0xFFFFFFFFu - (unsigned)(sorted_keys[pos] & 0xFFFFFFFFull));
+}
+
+// Lazy head (models.FusedPillarNeXt): only the class / iou maps are dense; the regression branches were evaluated at the first
+// seg_len[s] candidates of every segment (cand, 10 values per slot: reg 2, height 1, dim 3, rot 2, vel 2, in slot order s * pre_max + j).
+// One workgroup per segment decodes its candidates, applies the centre range test of centerhead.py:343-346 -- which the reference
+// applies BEFORE the top-pre_max cut -- and compacts the survivors in order.  If a segment that was cut at pre_max loses a candidate
+// here, the reference would have admitted a lower-ranked one: *flag is raised and the host re-runs that batch through the dense path.
+__global__ __launch_bounds__(256) void k_decode_boxes_lazy(const DecodeTask* __restrict__ tasks, const int64_t* __restrict__ task_key_off, int n_tasks,
+                                                           int n_classes_total, const unsigned long long* __restrict__ sorted_keys,
+                                                           const int64_t* __restrict__ order, const int64_t* __restrict__ seg_start,
+                                                           int32_t* __restrict__ seg_len, const int32_t* __restrict__ seg_total, int pre_max,
+                                                           const float* __restrict__ cand, float* __restrict__ boxes9, float* __restrict__ boxes7,
+                                                           float* __restrict__ scores, int32_t* __restrict__ flag) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int n = seg_len[s];
+  const int cls = s % n_classes_total;
+  int ti = 0;
+  while (ti + 1 < n_tasks && cls >= tasks[ti + 1].cls_off) ti++;
+  const DecodeTask tk = tasks[ti];
+  const int HW = tk.H * tk.W;
+  if (t == 0) s_base = 0;
+  __syncthreads();
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    const int j = j0 + t;
+    bool ok = false;
+    float o[9], sc = 0.f;
+    if (j < n) {
+      const int64_t pos = seg_start[s] + j;
+      const int64_t local = order[pos] - task_key_off[ti];  // = b * HW + cell
+      const int cell = (int)(local % HW);
+      const float* v = cand + ((int64_t)s * pre_max + j) * 10;
+      o[0] = ((float)(cell % tk.W) + v[0]) * tk.osf * tk.vx + tk.pcx;
+      o[1] = ((float)(cell / tk.W) + v[1]) * tk.osf * tk.vy + tk.pcy;
+      o[2] = v[2];
+      o[3] = expf(v[3]);
+      o[4] = expf(v[4]);
+      o[5] = expf(v[5]);
+      o[6] = v[8];
+      o[7] = v[9];
+      o[8] = atan2f(v[6], v[7]);
+      sc = __uint_as_float(0xFFFFFFFFu - (unsigned)(sorted_keys[pos] & 0xFFFFFFFFull));
+      ok = !tk.use_lim || (o[0] >= tk.lim[0] && o[1] >= tk.lim[1] && o[2] >= tk.lim[2] && o[0] <= tk.lim[3] && o[1] <= tk.lim[4] && o[2] <= tk.lim[5]);
+    }
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) s_wave[wv] = __popcll(m);
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wv; w++) before += s_wave[w];
+    if (ok) {
+      const int64_t dst = (int64_t)s * pre_max + before + __popcll(m & ((1ull << lane) - 1ull));
+#pragma unroll
+      for (int k = 0; k < 9; k++) boxes9[dst * 9 + k] = o[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) boxes7[dst * 7 + k] = o[k];
+      boxes7[dst * 7 + 6] = o[8];
+      scores[dst] = sc;
+    }
+    __syncthreads();
+    if (t == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (s_base < n && seg_total[s] > pre_max) atomicOr(flag, 1);
+    seg_len[s] = s_base;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_gather_kept(const float* __restrict__ boxes9, const float* __restrict__ scores,
@@ -419,6 +490,23 @@ int pnx_decode_boxes(const void* const* task_ptrs_dev, const void* task_descs_de
                                                 batch, (const unsigned long long*)sorted_keys, order, seg_start, seg_len, num_segments, pre_max, boxes9,
                                                 boxes7, scores);
   else PNX_REQUIRE(false, PNX_ERR_UNSUPPORTED, "decode is built for fp32, bf16 and fp16 head outputs");
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+// Lazy-head variant of pnx_decode_boxes (see k_decode_boxes_lazy): cand = (num_segments * pre_max, 10) fp32 regression values per
+// candidate slot; seg_len is updated in place to the survivors of the centre range test; seg_total = candidates per segment before
+// the pre_max cut; *flag_dev |= 1 if a cut segment lost a candidate (the caller then falls back to the dense path).
+int pnx_decode_boxes_lazy(const void* task_descs_dev, const int64_t* task_key_off_dev, int32_t n_tasks, int32_t n_classes_total,
+                          const uint64_t* sorted_keys, const int64_t* order, const int64_t* seg_start, int32_t* seg_len, const int32_t* seg_total,
+                          int32_t num_segments, int32_t pre_max, const float* cand, float* boxes9, float* boxes7, float* scores, int32_t* flag_dev,
+                          pnx_stream_t stream) {
+  PNX_REQUIRE(task_descs_dev && task_key_off_dev && sorted_keys && order && seg_start && seg_len && seg_total && cand && boxes9 && boxes7 && scores && flag_dev,
+              PNX_ERR_INVALID, "null pointer");
+  PNX_REQUIRE(n_tasks > 0 && num_segments > 0 && pre_max > 0 && n_classes_total > 0, PNX_ERR_INVALID, "bad sizes");
+  k_decode_boxes_lazy<<<num_segments, 256, 0, (hipStream_t)stream>>>((const DecodeTask*)task_descs_dev, task_key_off_dev, n_tasks, n_classes_total,
+                                                                     (const unsigned long long*)sorted_keys, order, seg_start, seg_len, seg_total, pre_max,
+                                                                     cand, boxes9, boxes7, scores, flag_dev);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

@@ -18,13 +18,15 @@ def _get(cfg, name):
     return cfg[name] if isinstance(cfg, dict) else getattr(cfg, name)
 
 
-def pack_task(C, has_iou, ncls, cls_off, H, W, osf, vs, pc_range, score_thr, lim, rect):
-    """Host descriptor matching `struct DecodeTask` in csrc/decode.hip."""
+def pack_task(C, has_iou, ncls, cls_off, H, W, osf, vs, pc_range, score_thr, lim, rect, lazy=False):
+    """Host descriptor matching `struct DecodeTask` in csrc/decode.hip.  lazy: the packed tensor is [iou] hm only."""
     lim6 = [float(v) for v in lim] if len(lim) > 0 else [0.0] * 6
     r4 = [float(v) for v in rect] + [0.0] * (4 - len(rect))
-    blob = struct.pack("6i6f6fi4f", int(C), int(bool(has_iou)), int(ncls), int(cls_off), int(H), int(W),
+    o_iou = 0 if lazy else 10
+    o_hm = (1 if has_iou else 0) if lazy else 10 + int(bool(has_iou))
+    blob = struct.pack("6i6f6fi4f3i", int(C), int(bool(has_iou)), int(ncls), int(cls_off), int(H), int(W),
                        float(osf), float(vs[0]), float(vs[1]), float(pc_range[0]), float(pc_range[1]), float(score_thr),
-                       *lim6, int(len(lim) > 0), *r4)
+                       *lim6, int(len(lim) > 0), *r4, int(o_hm), int(o_iou), int(bool(lazy)))
     assert len(blob) == lib().pnx_decode_task_desc_bytes(), "DecodeTask layout drifted"
     return blob
 
@@ -144,6 +146,10 @@ class PackedDecoder:
         scores = torch.empty((n_rows,), dtype=torch.float32, device=dev)
         check(L.pnx_decode_boxes(ptr(tptr), ptr(tdesc), ptr(koff), T, dt, B, ptr(skeys), ptr(order), ptr(seg_start), ptr(seg_len), S,
                                  self.pre_max, ptr(boxes9), ptr(boxes7), ptr(scores), stream_ptr()), "pnx_decode_boxes")
+        return self._finish(boxes9, boxes7, scores, seg_off, thr, seg_len, S, B, dev, tokens)
+
+    def _finish(self, boxes9, boxes7, scores, seg_off, thr, seg_len, S, B, dev, tokens, flag=None, fallback=None):
+        L = lib()
         keep, cnt = ops.nms_batched(boxes7, seg_off, thr, self.pre_max, post_max=self.post_max, seg_len=seg_len)
         out = torch.empty((S, self.post_max, 10), dtype=torch.float32, device=dev)
         check(L.pnx_gather_kept(ptr(boxes9), ptr(scores), ptr(keep), ptr(cnt), S, self.pre_max, self.post_max, ptr(out), stream_ptr()),
@@ -164,8 +170,88 @@ class PackedDecoder:
         ev = torch.cuda.Event()
         ev.record()
         pend = PendingDetections(ev, out_h, cnt_h, B, self.nc_total, tokens if tokens else [None] * B)
+        if flag is not None:  # lazy head: the range-test flag rides on the same stream; result() falls back to the dense path if it is set
+            if "flag" not in slot:
+                slot["flag"] = torch.zeros((1,), dtype=torch.int32, pin_memory=True)
+            slot["flag"].copy_(flag, non_blocking=True)
+            ev.record()
+            pend.flag_h, pend.fallback = slot["flag"], fallback
         slot["owner"] = weakref.ref(pend)
         return pend
+
+    @torch.no_grad()
+    def launch_lazy(self, dense, evaluator, tokens=None, fallback=None):
+        """Lazy head: dense = list (one per task) of (B, 16, H, W) channels_last maps holding [iou] hm only; evaluator(t, local, valid)
+        returns the (n, 10) fp32 regression values [reg 2, height 1, dim 3, rot 2, vel 2] of task t at the cells local = b*H*W + cell
+        (rows with valid == False are ignored).  Same selection as launch(): scores come from the dense maps, the candidates are the
+        first pre_max of every (sample, class) list; the centre range test runs on the evaluated candidates (pnx_decode_boxes_lazy) and
+        `fallback()` (the dense path) is taken by result() in the one case where that could change the selection."""
+        B = dense[0].shape[0]
+        dev = dense[0].device
+        dt = {torch.float32: PNX_F32, torch.bfloat16: PNX_BF16, torch.float16: PNX_F16}[dense[0].dtype]
+        T = len(dense)
+        shapes = [(p.shape[2], p.shape[3]) for p in dense]
+        cfg = self.cfg
+        descs, off = [], 0
+        for t, (H, W) in enumerate(shapes):
+            descs.append(pack_task(dense[t].shape[1], self.has_iou, self.num_classes[t], off, H, W, _get(cfg, "out_size_factor")[t],
+                                   _get(cfg, "voxel_size"), _get(cfg, "pc_range"), _get(cfg, "score_threshold"),
+                                   _get(cfg, "post_center_limit_range"), self.rectifier[t], lazy=True))
+            off += self.num_classes[t]
+        sizes = [B * h * w for h, w in shapes]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        keys = torch.empty((offs[-1],), dtype=torch.int64, device=dev)
+        L = lib()
+        for t, p in enumerate(dense):
+            assert p.is_contiguous(memory_format=torch.channels_last), "dense head outputs must be channels_last"
+            kp = ctypes.c_void_p(keys.data_ptr() + 8 * offs[t])
+            check(L.pnx_decode_keys(ptr(p), dt, B, self.nc_total, descs[t], kp, stream_ptr()), "pnx_decode_keys")
+        S = B * self.nc_total
+        ck = ("lazy", B, T, dt, tuple(shapes), dev)
+        if ck not in self._dev:
+            tdesc = torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev)
+            koff = torch.tensor(offs, dtype=torch.int64, device=dev)
+            seg_off = (torch.arange(S + 1, dtype=torch.int32, device=dev) * self.pre_max).contiguous()
+            thr = torch.tensor(self.thr, dtype=torch.float32, device=dev).repeat(B)
+            bounds = (torch.arange(S + 1, device=dev, dtype=torch.int64) << 32) ^ (-0x8000000000000000)
+            seg_cls = torch.arange(S, device=dev) % self.nc_total
+            segs, kofs, c0 = [], torch.zeros((S,), dtype=torch.int64, device=dev), 0
+            for t in range(T):
+                m = (seg_cls >= c0) & (seg_cls < c0 + self.num_classes[t])
+                segs.append(torch.nonzero(m).flatten())
+                kofs[m] = offs[t]
+                c0 += self.num_classes[t]
+            jj = torch.arange(self.pre_max, device=dev, dtype=torch.int64)
+            self._dev[ck] = (tdesc, koff, seg_off, thr, bounds, segs, kofs, jj)
+        tdesc, koff, seg_off, thr, bounds, segs, kofs, jj = self._dev[ck]
+        skeys = torch.empty_like(keys)
+        order = torch.empty_like(keys)
+        wsb = int(L.pnx_sort_keys_workspace_bytes(offs[-1]))
+        if self._sort_ws is None or self._sort_ws.numel() < wsb or self._sort_ws.device != dev:
+            self._sort_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        check(L.pnx_sort_keys(ptr(keys), offs[-1], S, ptr(skeys), ptr(order), ptr(self._sort_ws), self._sort_ws.numel(), stream_ptr()), "pnx_sort_keys")
+        seg_start = torch.searchsorted(skeys ^ (-0x8000000000000000), bounds)
+        seg_total = (seg_start[1:] - seg_start[:-1]).to(torch.int32)
+        seg_len = torch.clamp(seg_total, max=self.pre_max)
+        # candidate cells per slot (s, j): local index b*H*W + cell inside the slot's task
+        pos = torch.clamp(seg_start[:S, None] + jj[None, :], max=offs[-1] - 1)
+        valid = jj[None, :] < seg_len[:, None]
+        local = order[pos] - kofs[:, None]
+        n_rows = S * self.pre_max
+        cand = torch.zeros((S, self.pre_max, 10), dtype=torch.float32, device=dev)
+        for t in range(T):
+            st = segs[t]
+            vals = evaluator(t, local[st].reshape(-1), valid[st].reshape(-1))
+            cand[st] = vals.reshape(len(st), self.pre_max, 10)
+        boxes9 = torch.empty((n_rows, 9), dtype=torch.float32, device=dev)
+        boxes7 = torch.zeros((n_rows, 7), dtype=torch.float32, device=dev)
+        scores = torch.empty((n_rows,), dtype=torch.float32, device=dev)
+        flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+        check(L.pnx_decode_boxes_lazy(ptr(tdesc), ptr(koff), T, self.nc_total, ptr(skeys), ptr(order), ptr(seg_start), ptr(seg_len), ptr(seg_total), S,
+                                      self.pre_max, ptr(cand), ptr(boxes9), ptr(boxes7), ptr(scores), ptr(flag), stream_ptr()), "pnx_decode_boxes_lazy")
+        return self._finish(boxes9, boxes7, scores, seg_off, thr, seg_len, S, B, dev, tokens, flag=flag, fallback=fallback)
 
     def __call__(self, packed, tokens=None):
         return self.launch(packed, tokens).result()
@@ -179,11 +265,16 @@ class PendingDetections:
         self.event, self.out_h, self.cnt_h, self.batch, self.nc_total, self.tokens = event, out_h, cnt_h, batch, nc_total, tokens
         self.done = False  # the pinned buffers may be handed to a later launch once this is True (or this object is gone)
         self._res = None
+        self.flag_h, self.fallback = None, None
 
     def result(self):
         if self._res is not None:
             return self._res
         self.event.synchronize()
+        if self.flag_h is not None and int(self.flag_h[0]) != 0 and self.fallback is not None:
+            # a segment cut at pre_max lost a candidate to the centre range test: the dense path decides (exact, and rare)
+            self._res, self.done = self.fallback().result(), True
+            return self._res
         out_c, cnt_c = self.out_h, self.cnt_h.tolist()
         res = []
         for b in range(self.batch):

@@ -14,6 +14,7 @@ that reproduces spconv's active-site semantics exactly in eval mode (SURVEY.md H
     BatchNorm1d over sites: per-channel affine at active sites, zero elsewhere (all convs are bias-free).
 """
 import copy
+import os
 
 import numpy as np
 import torch
@@ -718,6 +719,14 @@ def _backbone_conv(weight, bias, stride, padding, dtype, hip_conv):
     return _FusedConv(weight, bias, stride, padding, dtype=dtype)
 
 
+class LazyTask:
+    """What the lazy head hands the decoder for one task: the dense [iou] hm map and the deblocked features the regression branches
+    are evaluated on at the selected candidates."""
+
+    def __init__(self, dense, up):
+        self.dense, self.up = dense, up
+
+
 class FusedPillarNeXt(nn.Module):
     """Inference-only re-expression of SingleStageDetector (eval BN folded, epilogues fused, the 6-7 SepHead branches of a
     task merged into two convolutions).  Mathematically the same network; weights come from the trained modules."""
@@ -774,6 +783,13 @@ class FusedPillarNeXt(nn.Module):
         self.task_conv2 = nn.ModuleList()
         self.task_split = []
         self.task_chans = []
+        # Lazy head (PNX_HEAD_LAZY, default on): per task only the class (and iou) branches run over the whole map; the five regression
+        # branches (reg, height, dim, rot, vel = 5/6 of the head's convolution work and its 9.6 GB/step intermediate) are evaluated
+        # at the <= pre_max candidates per (sample, class) that the decoder selects -- what CenterHead.predict does after the fact
+        # (centerhead.py:341-363) done before the fact.
+        self.lazy_head = bool(hip_conv) and dtype == torch.bfloat16 and os.environ.get("PNX_HEAD_LAZY", "1") != "0"
+        self.lazy_conv1, self.lazy_conv2 = nn.ModuleList(), nn.ModuleList()
+        self._lazy_ok = []
         for task in hd.tasks:
             db = task.deblock
             w, b = _fold_bn(db.conv.conv.weight, db.norm, transposed=True)
@@ -814,9 +830,49 @@ class FusedPillarNeXt(nn.Module):
             self.task_conv2.append(_HipSepHeadOut(W2, B2) if hip_out else _FusedConv(W2, B2, 1, 1, relu=False, dtype=dtype))
             self.task_chans.append(tot_p)
             self.task_split.append((names, outs))
+            ti = len(self.task_split) - 1
+            ok = (self.lazy_head and hip_out and names[:5] == ["reg", "height", "dim", "rot", "vel"] and outs[:5] == [2, 1, 3, 2, 2]
+                  and names[5:] in (["hm"], ["iou", "hm"]))
+            self._lazy_ok.append(ok)
+            if ok:
+                dn = list(range(5, len(names)))                          # dense branches: [iou] hm
+                W1d, b1d = torch.cat([w1s[j] for j in dn], 0), torch.cat([b1s[j] for j in dn])
+                W2d = torch.zeros((16, hc * len(dn), 3, 3), dtype=torch.float32, device=W1.device)
+                B2d = torch.zeros((16,), dtype=torch.float32, device=W1.device)
+                o = 0
+                for q, j in enumerate(dn):
+                    W2d[o:o + outs[j], q * hc:(q + 1) * hc] = w2s[j]
+                    B2d[o:o + outs[j]] = b2s[j]
+                    o += outs[j]
+                self.lazy_conv1.append(_HipConv3x3(W1d, b1d, 1))
+                self.lazy_conv2.append(_HipSepHeadOut(W2d, B2d))
+                # regression branches as matrices over (tap, channel): conv1 (576 -> 320), conv2 (9 positions x 320 -> 10, block-diagonal)
+                W1z = torch.cat(w1s[:5], 0)                               # (320, 64, 3, 3)
+                w1m = W1z.permute(2, 3, 1, 0).reshape(9 * hc, 5 * hc)     # rows (ky, kx, cin)
+                w2m = torch.zeros((9 * 5 * hc, 10), dtype=torch.float32, device=W1.device)
+                b2z = torch.zeros((10,), dtype=torch.float32, device=W1.device)
+                o = 0
+                for j in range(5):
+                    w2 = w2s[j]                                          # (k, 64, 3, 3)
+                    for pos in range(9):
+                        w2m[pos * 5 * hc + j * hc: pos * 5 * hc + (j + 1) * hc, o:o + outs[j]] = w2[:, :, pos // 3, pos % 3].t()
+                    b2z[o:o + outs[j]] = b2s[j]
+                    o += outs[j]
+                self.register_buffer(f"lazy_w1_{ti}", w1m.to(torch.bfloat16).contiguous())
+                self.register_buffer(f"lazy_b1_{ti}", torch.cat(b1s[:5]).float().contiguous())
+                self.register_buffer(f"lazy_w2_{ti}", w2m.to(torch.bfloat16).float().contiguous())   # the dense kernels hold W2 in bf16
+                self.register_buffer(f"lazy_b2_{ti}", b2z)
+                self.register_buffer(f"lazy_wf1_{ti}", ops.conv3x3_pack_weights(W1z))
+                self.register_buffer(f"lazy_w2c_{ti}", ops.sephead_lazy_pack_w2(getattr(self, f"lazy_w2_{ti}")))
+            else:
+                self.lazy_conv1.append(nn.Identity())
+                self.lazy_conv2.append(nn.Identity())
+        self.lazy_head = self.lazy_head and all(self._lazy_ok)
 
     @torch.no_grad()
-    def forward_preds(self, points, batch_size, marks=None, packed_out=None, taps=None):
+    def forward_preds(self, points, batch_size, marks=None, packed_out=None, taps=None, lazy=None):
+        """packed_out: a list that receives, per task, the packed NHWC head output -- or, with the lazy head (lazy=None: the model's
+        setting), a LazyTask (dense [iou] hm map + deblocked features) for launch_decode()."""
         def mark(name):
             if marks is not None:
                 e = torch.cuda.Event(enable_timing=True)
@@ -861,8 +917,13 @@ class FusedPillarNeXt(nn.Module):
             taps["neck"] = x
         x = self.shared(x)
         preds = []
-        for db, c1, c2, (names, outs_n) in zip(self.task_deblock, self.task_conv1, self.task_conv2, self.task_split):
-            t = c2(c1(db(x)))
+        lazy = packed_out is not None and self.lazy_head and (lazy is None or lazy)
+        for ti, (db, c1, c2, (names, outs_n)) in enumerate(zip(self.task_deblock, self.task_conv1, self.task_conv2, self.task_split)):
+            up = db(x)
+            if lazy:
+                packed_out.append(LazyTask(self.lazy_conv2[ti](self.lazy_conv1[ti](up)), up))
+                continue
+            t = c2(c1(up))
             if packed_out is not None:
                 packed_out.append(t)
                 continue
@@ -919,11 +980,48 @@ class FusedPillarNeXt(nn.Module):
         return self._decoder
 
     @torch.no_grad()
+    def lazy_eval(self, ti, up, local, valid):
+        """The five regression branches of task ti at the cells `local` (= b*H*W + cell) of the deblocked map `up` (B,64,H,W channels_last
+        bf16): conv3x3 (64 -> 5*64) + folded BN + ReLU at the 3 x 3 neighbours of every cell, rounded to bf16 like the dense kernel's
+        intermediate, then the block-diagonal 3x3 conv (-> 10) at the cell; zero padding at the map border.  Returns (n, 10) fp32 in the
+        order reg 2, height 1, dim 3, rot 2, vel 2, rounded to bf16 like the dense output."""
+        if os.environ.get("PNX_HEAD_LAZY_TORCH", "0") != "1":
+            return ops.sephead_lazy(up, getattr(self, f"lazy_wf1_{ti}"), getattr(self, f"lazy_b1_{ti}"), getattr(self, f"lazy_w2c_{ti}"),
+                                    getattr(self, f"lazy_b2_{ti}"), local, valid)
+        B, C, H, W = up.shape
+        n = local.shape[0]
+        upf = up.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        local = torch.where(valid, local, torch.zeros_like(local))
+        b, cell = local // (H * W), local % (H * W)
+        y, x = cell // W, cell % W
+        d = torch.arange(-2, 3, device=up.device)
+        yy, xx = y[:, None] + d[None, :], x[:, None] + d[None, :]
+        vy, vx = (yy >= 0) & (yy < H), (xx >= 0) & (xx < W)
+        idx = (b[:, None, None] * H + yy.clamp(0, H - 1)[:, :, None]) * W + xx.clamp(0, W - 1)[:, None, :]
+        patch = upf[idx.reshape(-1)].reshape(n, 5, 5, C) * (vy[:, :, None] & vx[:, None, :])[..., None].to(up.dtype)
+        cols = patch.unfold(1, 3, 1).unfold(2, 3, 1).permute(0, 1, 2, 4, 5, 3).reshape(n * 9, 9 * C)
+        t1 = torch.relu(cols.float() @ getattr(self, f"lazy_w1_{ti}").float() + getattr(self, f"lazy_b1_{ti}"))
+        inside = (vy[:, 1:4, None] & vx[:, None, 1:4]).reshape(n * 9, 1)
+        t1 = (t1 * inside).to(torch.bfloat16).float().reshape(n, -1)
+        out = t1 @ getattr(self, f"lazy_w2_{ti}") + getattr(self, f"lazy_b2_{ti}")
+        return out.to(torch.bfloat16).float()
+
+    @torch.no_grad()
     def forward_async(self, example):
         """Enqueue the whole frame batch (reader -> ... -> NMS -> D2H copy) and return a decode.PendingDetections."""
         packed = []
         self.forward_preds(example["points"], example["batch_size"], packed_out=packed)
-        return self.decoder().launch(packed, example.get("token"))
+        return self.launch_decode(packed, example.get("token"))
+
+    def launch_decode(self, packed, tokens=None):
+        if not (packed and isinstance(packed[0], LazyTask)):
+            return self.decoder().launch(packed, tokens)
+        ups = [p.up for p in packed]
+
+        def dense_path():  # the exact fallback (decode.PendingDetections.result): every branch over the whole map
+            return self.decoder().launch([c2(c1(u)) for u, c1, c2 in zip(ups, self.task_conv1, self.task_conv2)], tokens)
+
+        return self.decoder().launch_lazy([p.dense for p in packed], lambda t, local, valid: self.lazy_eval(t, ups[t], local, valid), tokens, dense_path)
 
     @staticmethod
     def detections(outputs):

@@ -271,6 +271,33 @@ def sephead_out(x, wfrag, bias):
     return y
 
 
+def sephead_lazy_pack_w2(w2m):
+    """(9*320, 10) matrix of the five regression branches' second convolutions (rows (pos, channel), block diagonal over the branches
+    reg 2 | height 1 | dim 3 | rot 2 | vel 2) -> fp32 [M tile 10][pos 9][channel 32][4]: per 32-channel tile the <= 3 outputs of its branch."""
+    off, k = [0, 2, 3, 6, 8], [2, 1, 3, 2, 2]
+    v = w2m.detach().float().reshape(9, 10, 32, 10)                               # (pos, mt, cl, o)
+    out = torch.zeros((10, 9, 32, 4), dtype=torch.float32, device=w2m.device)
+    for mt in range(10):
+        j = mt // 2
+        out[mt, :, :, :k[j]] = v[:, mt, :, off[j]:off[j] + k[j]]
+    return out.contiguous()
+
+
+def sephead_lazy(up, wfrag1, bias1, w2c, bias2, local, valid):
+    """The regression branches of one task at the cells local (= b*H*W + cell) of up (B,64,H,W channels_last bf16): (n,10) fp32
+    (csrc/conv3x3.hip::k_sephead_lazy).  Rows with valid == 0 are zero."""
+    if not (up.is_cuda and up.dtype == torch.bfloat16 and up.shape[1] == 64 and up.is_contiguous(memory_format=torch.channels_last)):
+        raise PnxError("sephead_lazy needs a 64-channel channels_last bf16 CUDA tensor")
+    B, _, H, W = up.shape
+    n = local.numel()
+    local = local.contiguous()
+    valid = valid.to(torch.uint8).contiguous()
+    out = torch.empty((n, 10), dtype=torch.float32, device=up.device)
+    check(lib().pnx_sephead_lazy_bf16(ptr(up), B, H, W, ptr(local), ptr(valid), n, ptr(wfrag1), ptr(bias1), ptr(w2c), ptr(bias2), ptr(out), stream_ptr()),
+          "pnx_sephead_lazy_bf16")
+    return out
+
+
 def conv3x3_workspace(batch, cout, ho, wo, device):
     """A persistent (output buffer, row_dirty flags) pair for conv3x3_masked(out=...): both start zeroed (pnx.h: row_dirty)."""
     y = torch.zeros((batch, cout, ho, wo), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)

@@ -107,4 +107,4 @@ def test_decode_descriptor_layout_matches_the_library():
     from pillarnext_amd.decode import pack_task
 
     blob = pack_task(16, True, 2, 3, 360, 360, 4, (0.075, 0.075), (-54.0, -54.0), 0.1, [-61.2, -61.2, -10, 61.2, 61.2, 10], [0.5, 0.5])
-    assert len(blob) == _lib.lib().pnx_decode_task_desc_bytes() == 92
+    assert len(blob) == _lib.lib().pnx_decode_task_desc_bytes() == 104  # 92 + o_hm, o_iou, lazy

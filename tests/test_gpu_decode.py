@@ -142,7 +142,7 @@ def _same(a, b, what):
 def _packed(fused, pts):
     packed = []
     with torch.no_grad():
-        fused.forward_preds(pts, 2, packed_out=packed)
+        fused.forward_preds(pts, 2, packed_out=packed, lazy=False)
     torch.cuda.synchronize()
     return packed
 

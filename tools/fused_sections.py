@@ -23,7 +23,7 @@ for it in range(a.iters + 2):
     marks = []
     packed = []
     model.forward_preds(pts, a.batch, marks, packed_out=packed)
-    out = model.decoder()(packed, ex["token"])
+    out = model.launch_decode(packed, ex["token"]).result()
     e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(("predict", e))
     torch.cuda.synchronize()
     if it >= 2:
