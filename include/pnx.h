@@ -221,14 +221,24 @@ int pnx_conv_tile_list(const uint8_t* mask, const uint8_t* const* row_dirty, int
  * (1/2: the dense [iou] hm branches of the lazy head). */
 int pnx_sephead_out_bf16(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t n_branch,
                          pnx_stream_t stream);
-/* Lazy SepHead: the five regression branches of a task (reg 2, height 1, dim 3, rot 2, vel 2: centerhead.py:12-59, conv3x3 64->64 + BN + ReLU, then
- * conv3x3 64->k) evaluated only at n candidate cells (the cells CenterHead.post_processing keeps, centerhead.py:341-363) instead of over the map.
- * up (B,h,w,64) bf16 = the head's shared-conv output; local int64[n] = b*h*w + y*w + x; valid uint8[n] (0: the row of out is zeroed);
- * wfrag1 = ops.conv3x3_pack_weights of the five first convolutions stacked (320,64,3,3) with BN folded, bias1 fp32[320];
- * w2c fp32[10][9][32][4] = ops.sephead_lazy_pack_w2 (per 32-channel tile and 3x3 position: the <=3 output weights of the tile's branch, bf16-rounded);
- * bias2 fp32[10]; out fp32 (n,10), values rounded to bf16 exactly as the dense kernels' output is. */
-int pnx_sephead_lazy_bf16(const void* up, int32_t batch, int32_t h, int32_t w, const int64_t* local, const uint8_t* valid, int64_t n, const void* wfrag1,
-                          const float* bias1, const float* w2c, const float* bias2, float* out, pnx_stream_t stream);
+/* Lazy SepHead: the five regression branches of every task (reg 2, height 1, dim 3, rot 2, vel 2: centerhead.py:12-59, conv3x3 64->64 + BN + ReLU,
+ * then conv3x3 64->k) evaluated only at the candidate cells CenterHead.post_processing keeps (centerhead.py:341-363) instead of over the map, all
+ * tasks in one launch.  Candidate lists: batch*nc_total lists (list s = sample s / nc_total, class s % nc_total, task class_task[class]) of pre_max
+ * slots; local int64[n_lists*pre_max] = b*h*w + y*w + x inside the list's task map; slots j >= seg_len[s] are not evaluated (their rows are zeroed).
+ * Per task: up (B,h,w,64) bf16 = the head's shared-conv output; wfrag1 = ops.conv3x3_pack_weights of the five first convolutions stacked
+ * (320,64,3,3) with BN folded, bias1 fp32[320]; w2c fp32[10][9][32][3] = ops.sephead_lazy_pack_w2 (per 32-channel tile and 3x3 position: the <=3
+ * output weights of the tile's branch, bf16-rounded); bias2 fp32[10].  out fp32 (n_lists*pre_max, 10), rounded to bf16 as the dense output is.
+ * class_task is a HOST array of nc_total entries. */
+typedef struct {
+  const void* up;
+  const void* wfrag1;
+  const float* bias1;
+  const float* w2c;
+  const float* bias2;
+  int32_t h, w;
+} PnxLazyTask;
+int pnx_sephead_lazy_bf16(const PnxLazyTask* tasks, int32_t n_tasks, const int32_t* class_task, int32_t nc_total, int32_t batch, const int64_t* local,
+                          const int32_t* seg_len, int32_t pre_max, float* out, pnx_stream_t stream);
 /* Active-site rule of SparseConv2d(k=3, stride, pad=1): mask_out = maxpool3x3(mask_in, stride, 1); uint8 (B,h,w) -> (B,ho,wo). */
 int pnx_mask_pool3(const uint8_t* mask_in, int32_t batch, int32_t h, int32_t w, int32_t stride, uint8_t* mask_out, pnx_stream_t stream);
 

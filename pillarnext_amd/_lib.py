@@ -54,7 +54,7 @@ PROTOTYPES = {
     "pnx_sum_bias_act": (ctypes.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "pnx_deconv2x2_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pnx_sephead_out_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "pnx_sephead_lazy_bf16": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pnx_sephead_lazy_bf16": (ctypes.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "pnx_conv3x3_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pnx_conv3x3_tile_rows": (ctypes.c_int, [_i32, _i32, _i32]),
     "pnx_conv_tile_list": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),

@@ -1399,160 +1399,189 @@ int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const 
 // ReLU, then conv3x3 64 -> k each; det3d/models/heads/centerhead.py:12-59) evaluated ONLY at the candidate cells the decoder selected
 // (<= pre_max per sample and class, centerhead.py:341-363) instead of at every cell: 5/6 of the head's convolution work and its
 // 384-channel intermediate (9.6 GB of HBM traffic per 8-frame step) shrink to ~8 % of the cells.
-// One workgroup = 32 candidates.  The 5 x 5 x 64 input patch of every candidate is staged in LDS (swizzled 16-byte chunks); the first
-// convolution is an implicit GEMM on v_mfma_f32_32x32x16_bf16 with M = 320 output channels (10 tiles, dealt to the 4 waves), N = 32
-// candidates x 9 neighbour positions = 288 pixels (9 tiles), K = 9 taps x 64 channels; its outputs are rounded to bf16 like the dense
-// kernel's intermediate and contracted on the spot with the second convolution's weights of their branch (the intermediate never
-// exists); per-(pixel, M-tile) partial sums go through LDS and are added in a fixed order: deterministic.
+// One launch covers every task.  One workgroup (8 waves) = 32 consecutive candidates of one (sample, class) list.  The 5 x 5 x 64 input
+// patch of every candidate is staged in LDS (swizzled 16-byte chunks); the first convolution is an implicit GEMM on
+// v_mfma_f32_32x32x16_bf16 with M = 320 output channels (10 tiles), N = 32 candidates x 9 neighbour positions = 288 pixels (9 tiles),
+// K = 9 taps x 64 channels, dealt to the waves as 15 items (branch = 2 M tiles) x (3 N tiles); its outputs are rounded to bf16 like the
+// dense kernel's intermediate and contracted on the spot with the second convolution's weights of their branch (the intermediate never
+// exists); per-(pixel, branch) partial sums go through LDS and are added in a fixed order: deterministic.
 namespace {
 
 constexpr int kLzG = 32, kLzN = kLzG * 9, kLzNT = kLzN / 32;  // candidates, pixels, N tiles per workgroup
 constexpr int kLzPatch = kLzG * 25 * 8;                       // uint4 slots of the staged patches
+constexpr int kLzW2 = 10 * 9 * 32 * 3;                        // floats of the packed second-convolution weights
+constexpr int kLzMaxTasks = 8, kLzMaxClasses = 32;
 
-__global__ __launch_bounds__(256) void k_sephead_lazy(const uint16_t* __restrict__ up, int B, int H, int W, const int64_t* __restrict__ local,
-                                                      const uint8_t* __restrict__ valid, int n, const uint4* __restrict__ wfrag,
-                                                      const float* __restrict__ b1, const float4* __restrict__ w2c, const float* __restrict__ b2,
+struct LazyTaskDev {
+  const uint16_t* up;
+  const uint4* wfrag;
+  const float *b1, *w2c, *b2;
+  int h, w;
+};
+struct LazyArgs {
+  LazyTaskDev t[kLzMaxTasks];
+  signed char class_task[kLzMaxClasses];
+  int nc_total, pre_max, bps;
+};
+
+__global__ __launch_bounds__(512) void k_sephead_lazy(const LazyArgs A, const int64_t* __restrict__ local, const int32_t* __restrict__ seg_len,
                                                       float* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char s_lz[];
   uint4* s_patch = reinterpret_cast<uint4*>(s_lz);                                    // [cand][cell 25][chunk 8 ^ swz]
-  float4* s_w2 = reinterpret_cast<float4*>(s_patch + kLzPatch);                       // [wave][pos 9][channel 32]
-  float* s_part = reinterpret_cast<float*>(s_w2 + 4 * 9 * 32);                        // [pixel 288][M tile 10][3]
-  int* s_cell = reinterpret_cast<int*>(s_part + kLzN * 10 * 3);                       // [cand]: b*H*W + cell, or -1
+  float* s_w2 = reinterpret_cast<float*>(s_patch + kLzPatch);                         // [M tile 10][pos 9][channel 32][3]
+  float* s_part = s_w2 + kLzW2;                                                       // [pixel 288][branch 5][3]
+  int* s_cell = reinterpret_cast<int*>(s_part + kLzN * 5 * 3);                        // [cand]: b*H*W + cell, or -1
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, px = lane & 31, kb = lane >> 5;
-  const int c0 = blockIdx.x * kLzG;
-  if (t < kLzG) {
-    const int i = c0 + t;
-    s_cell[t] = (i < n && valid[i]) ? (int)local[i] : -1;
+  const int seg = blockIdx.x / A.bps, c0 = (blockIdx.x - seg * A.bps) * kLzG;
+  const int len = seg_len[seg];
+  const int rows = min(kLzG, A.pre_max - c0);
+  float* const outp = out + ((int64_t)seg * A.pre_max + c0) * 10;
+  if (c0 >= len) {  // behind the end of the list: zero rows, no work
+    for (int i = t; i < rows * 10; i += 512) outp[i] = 0.f;
+    return;
   }
+  const LazyTaskDev T = A.t[A.class_task[seg % A.nc_total]];
+  const int H = T.h, W = T.w, HW = H * W;
+  if (t < kLzG) s_cell[t] = (c0 + t < len) ? (int)local[(int64_t)seg * A.pre_max + c0 + t] : -1;
+  for (int e = t; e < kLzW2 / 4; e += 512) reinterpret_cast<float4*>(s_w2)[e] = reinterpret_cast<const float4*>(T.w2c)[e];
   __syncthreads();
-  {  // all candidates of the workgroup invalid (slots behind the end of a segment's list): nothing to do but the zeros
-    bool any = false;
-    for (int k = 0; k < kLzG; k++) any = any || s_cell[k] >= 0;
-    if (!any) {
-      for (int i = t; i < kLzG * 10; i += 256)
-        if (c0 + i / 10 < n) out[(int64_t)(c0 + i / 10) * 10 + i % 10] = 0.f;
-      return;
-    }
-  }
-  // ---- stage the 5 x 5 patches (zeros outside the map / for invalid candidates)
-  const int HW = H * W;
-  for (int e = t; e < kLzPatch; e += 256) {
+  // ---- stage the 5 x 5 patches (zeros outside the map / for the slots behind the end of the list)
+  for (int e = t; e < kLzPatch; e += 512) {
     const int q = e & 7, cell = (e >> 3) % 25, c = e / 200;
     const int lc = s_cell[c];
     uint4 v = make_uint4(0, 0, 0, 0);
     if (lc >= 0) {
       const int b = lc / HW, rem = lc - b * HW;
       const int y = rem / W + cell / 5 - 2, x = rem % W + cell % 5 - 2;
-      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = *reinterpret_cast<const uint4*>(up + (((int64_t)b * H + y) * W + x) * 64 + q * 8);
+      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+        v = *reinterpret_cast<const uint4*>(T.up + (((int64_t)b * H + y) * W + x) * 64 + q * 8);
     }
     s_patch[(c * 25 + cell) * 8 + (q ^ (cell & 7))] = v;
   }
   __syncthreads();
-  // per N tile: this lane's pixel = candidate px_c, neighbour position pos (py, px_); outside the map -> its t is zero
-  for (int mt = wv; mt < 10; mt += 4) {
-    // the second convolution's weights of this M tile's 32 channels: [pos][channel] x (up to 3 outputs of the branch)
-    for (int e = lane; e < 9 * 32; e += 64) s_w2[wv * 288 + e] = w2c[mt * 288 + e];
-    float bq[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) bq[i] = b1[mt * 32 + 8 * (i >> 2) + 4 * kb + (i & 3)];
 #pragma unroll 1
-    for (int g0 = 0; g0 < kLzNT; g0 += 3) {
-      v16f acc[3];
-      int pbase[3];
+  for (int item = wv; item < 15; item += 8) {
+    const int br = item / 3, g0 = (item - br * 3) * 3;
+    int pb[3], wc[3], posv[3];
+    bool inside[3];
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[j][i] = bq[i];
-        const int pix = (g0 + j) * 32 + px;
-        const int cand = pix / 9, pos = pix - cand * 9;
-        pbase[j] = cand * 25 + (pos / 3) * 5 + (pos % 3);  // top-left cell of this pixel's 3 x 3 window inside the 5 x 5 patch
+    for (int j = 0; j < 3; j++) {
+      const int pix = (g0 + j) * 32 + px;
+      const int cand = pix / 9, pos = pix - cand * 9;
+      posv[j] = pos;
+      wc[j] = (pos / 3) * 5 + (pos % 3);  // top-left cell of this pixel's 3 x 3 window inside the 5 x 5 patch
+      pb[j] = cand * 25 * 8;
+      const int lc = s_cell[cand];
+      inside[j] = lc >= 0;
+      if (inside[j]) {
+        const int rem = lc % HW;
+        const int y = rem / W + pos / 3 - 1, x = rem % W + pos % 3 - 1;
+        inside[j] = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
       }
+    }
+    float ps[3][3] = {};
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+      const int mt = 2 * br + half;
+      v16f acc[3];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const float bq = T.b1[mt * 32 + 8 * (i >> 2) + 4 * kb + (i & 3)];
+#pragma unroll
+        for (int j = 0; j < 3; j++) acc[j][i] = bq;
+      }
+      const uint4* wp = T.wfrag + mt * 64 + lane;
+      uint4 an[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) an[ks] = wp[ks * 640];
 #pragma unroll 1
       for (int tap = 0; tap < 9; tap++) {
+        uint4 a[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) a[ks] = an[ks];
+        const int tn = min(tap + 1, 8);  // the last iteration re-reads its own fragments (cached), no branch in the loop
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) an[ks] = wp[(tn * 4 + ks) * 640];
         const int toff = (tap / 3) * 5 + (tap % 3);
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-          const uint4 a = wfrag[((tap * 4 + ks) * 10 + mt) * 64 + lane];
 #pragma unroll
           for (int j = 0; j < 3; j++) {
-            const int cell = pbase[j] + toff;
-            const uint4 bq4 = s_patch[cell * 8 + ((ks * 2 + kb) ^ ((cell % 25) & 7))];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq4), acc[j], 0, 0, 0);
+            const int cw = wc[j] + toff;
+            const uint4 bq4 = s_patch[pb[j] + cw * 8 + ((ks * 2 + kb) ^ (cw & 7))];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks]), __builtin_bit_cast(bf16x8, bq4), acc[j], 0, 0, 0);
           }
         }
       }
       // ---- ReLU, bf16 rounding (the dense kernel's intermediate), contraction with the second convolution
 #pragma unroll
       for (int j = 0; j < 3; j++) {
-        const int pix = (g0 + j) * 32 + px;
-        const int cand = pix / 9, pos = pix - cand * 9;
-        const int lc = s_cell[cand];
-        bool inside = lc >= 0;
-        if (inside) {
-          const int rem = lc % HW;
-          const int y = rem / W + pos / 3 - 1, x = rem % W + pos % 3 - 1;
-          inside = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        }
-        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+        const float* w2p = s_w2 + ((mt * 9 + posv[j]) * 32 + 4 * kb) * 3;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-          const float tv = inside ? bf2f_lo(pack_bf16(fmaxf(acc[j][i], 0.f), 0.f)) : 0.f;
-          const float4 w = s_w2[wv * 288 + pos * 32 + 8 * (i >> 2) + 4 * kb + (i & 3)];
-          p0 = __builtin_fmaf(tv, w.x, p0);
-          p1 = __builtin_fmaf(tv, w.y, p1);
-          p2 = __builtin_fmaf(tv, w.z, p2);
+          const float tv = inside[j] ? bf2f_lo(pack_bf16(fmaxf(acc[j][i], 0.f), 0.f)) : 0.f;
+          const float* w = w2p + (8 * (i >> 2) + (i & 3)) * 3;
+          ps[j][0] = __builtin_fmaf(tv, w[0], ps[j][0]);
+          ps[j][1] = __builtin_fmaf(tv, w[1], ps[j][1]);
+          ps[j][2] = __builtin_fmaf(tv, w[2], ps[j][2]);
         }
-        // the other half of the wave holds the other 16 channels of the same pixel
-        p0 += __shfl_xor(p0, 32);
-        p1 += __shfl_xor(p1, 32);
-        p2 += __shfl_xor(p2, 32);
-        if (kb == 0) {
-          float* d = s_part + (pix * 10 + mt) * 3;
-          d[0] = p0, d[1] = p1, d[2] = p2;
-        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int pix = (g0 + j) * 32 + px;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const float v = ps[j][q] + __shfl_xor(ps[j][q], 32);  // the other half of the wave holds the other 16 channels of each tile
+        if (kb == 0) s_part[(pix * 5 + br) * 3 + q] = v;
       }
     }
   }
   __syncthreads();
-  // ---- out[cand][o] = b2[o] + sum over the 9 positions and the 2 M tiles of the output's branch, in a fixed order; rounded to bf16
-  for (int e = t; e < kLzG * 10; e += 256) {
+  // ---- out[cand][o] = b2[o] + sum over the 9 positions of the output's branch, in a fixed order; rounded to bf16
+  for (int e = t; e < rows * 10; e += 512) {
     const int cand = e / 10, o = e - cand * 10;
-    if (c0 + cand >= n) continue;
     const int br = o < 2 ? 0 : (o < 3 ? 1 : (o < 6 ? 2 : (o < 8 ? 3 : 4)));
     const int q = o - (br == 0 ? 0 : (br == 1 ? 2 : (br == 2 ? 3 : (br == 3 ? 6 : 8))));
-    float s = b2[o];
+    float s = 0.f;
     if (s_cell[cand] >= 0) {
-      for (int pos = 0; pos < 9; pos++) {
-        const int pix = cand * 9 + pos;
-        s += s_part[(pix * 10 + 2 * br) * 3 + q];
-        s += s_part[(pix * 10 + 2 * br + 1) * 3 + q];
-      }
+      s = T.b2[o];
+      for (int pos = 0; pos < 9; pos++) s += s_part[((cand * 9 + pos) * 5 + br) * 3 + q];
       s = bf2f_lo(pack_bf16(s, 0.f));
-    } else {
-      s = 0.f;
     }
-    out[(int64_t)(c0 + cand) * 10 + o] = s;
+    outp[e] = s;
   }
 }
 
-constexpr size_t kLzLds = (size_t)kLzPatch * 16 + 4 * 9 * 32 * 16 + (size_t)kLzN * 10 * 3 * 4 + kLzG * 4;
+constexpr size_t kLzLds = (size_t)kLzPatch * 16 + (size_t)kLzW2 * 4 + (size_t)kLzN * 5 * 3 * 4 + kLzG * 4;
+static_assert(kLzLds <= 160 * 1024, "k_sephead_lazy: LDS budget");
 
 }  // namespace
 
-extern "C" int pnx_sephead_lazy_bf16(const void* up, int32_t batch, int32_t h, int32_t w, const int64_t* local, const uint8_t* valid, int64_t n,
-                                     const void* wfrag1, const float* bias1, const float* w2c, const float* bias2, float* out, pnx_stream_t stream) {
-  PNX_REQUIRE(up && local && valid && wfrag1 && bias1 && w2c && bias2 && out && batch > 0 && h > 0 && w > 0 && n >= 0, PNX_ERR_INVALID, "bad arguments");
-  PNX_REQUIRE((int64_t)batch * h * w < ((int64_t)1 << 31), PNX_ERR_UNSUPPORTED, "map too large for 32-bit cell indices");
-  PNX_REQUIRE((((uintptr_t)up | (uintptr_t)wfrag1 | (uintptr_t)w2c) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
-  if (n == 0) return PNX_OK;
+extern "C" int pnx_sephead_lazy_bf16(const PnxLazyTask* tasks, int32_t n_tasks, const int32_t* class_task, int32_t nc_total, int32_t batch,
+                                     const int64_t* local, const int32_t* seg_len, int32_t pre_max, float* out, pnx_stream_t stream) {
+  PNX_REQUIRE(tasks && class_task && local && seg_len && out && batch > 0 && pre_max > 0, PNX_ERR_INVALID, "bad arguments");
+  PNX_REQUIRE(n_tasks >= 1 && n_tasks <= kLzMaxTasks && nc_total >= 1 && nc_total <= kLzMaxClasses, PNX_ERR_UNSUPPORTED, "at most 8 tasks / 32 classes");
+  LazyArgs a;
+  for (int i = 0; i < n_tasks; i++) {
+    const PnxLazyTask& s = tasks[i];
+    PNX_REQUIRE(s.up && s.wfrag1 && s.bias1 && s.w2c && s.bias2 && s.h > 0 && s.w > 0, PNX_ERR_INVALID, "bad task");
+    PNX_REQUIRE((int64_t)batch * s.h * s.w < ((int64_t)1 << 31), PNX_ERR_UNSUPPORTED, "map too large for 32-bit cell indices");
+    PNX_REQUIRE((((uintptr_t)s.up | (uintptr_t)s.wfrag1 | (uintptr_t)s.w2c) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
+    a.t[i] = LazyTaskDev{(const uint16_t*)s.up, (const uint4*)s.wfrag1, s.bias1, s.w2c, s.bias2, s.h, s.w};
+  }
+  for (int c = 0; c < nc_total; c++) {
+    PNX_REQUIRE(class_task[c] >= 0 && class_task[c] < n_tasks, PNX_ERR_INVALID, "class_task out of range");
+    a.class_task[c] = (signed char)class_task[c];
+  }
+  a.nc_total = nc_total, a.pre_max = pre_max, a.bps = (pre_max + kLzG - 1) / kLzG;
   static bool attr = false;
   if (!attr) {
     PNX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sephead_lazy), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLzLds));
     attr = true;
   }
-  const unsigned nb = (unsigned)((n + kLzG - 1) / kLzG);
-  k_sephead_lazy<<<nb, 256, kLzLds, (hipStream_t)stream>>>((const uint16_t*)up, batch, h, w, local, valid, (int)n, (const uint4*)wfrag1, bias1,
-                                                            (const float4*)w2c, bias2, out);
+  const unsigned nb = (unsigned)((int64_t)batch * nc_total * a.bps);
+  k_sephead_lazy<<<nb, 512, kLzLds, (hipStream_t)stream>>>(a, local, seg_len, out);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

@@ -181,9 +181,10 @@ class PackedDecoder:
 
     @torch.no_grad()
     def launch_lazy(self, dense, evaluator, tokens=None, fallback=None):
-        """Lazy head: dense = list (one per task) of (B, 16, H, W) channels_last maps holding [iou] hm only; evaluator(t, local, valid)
-        returns the (n, 10) fp32 regression values [reg 2, height 1, dim 3, rot 2, vel 2] of task t at the cells local = b*H*W + cell
-        (rows with valid == False are ignored).  Same selection as launch(): scores come from the dense maps, the candidates are the
+        """Lazy head: dense = list (one per task) of (B, 16, H, W) channels_last maps holding [iou] hm only;
+        evaluator(local (S, pre_max) int64, seg_len (S,) int32, valid (S, pre_max) bool, segs = per task the rows of its lists) returns the
+        (S, pre_max, 10) fp32 regression values [reg 2, height 1, dim 3, rot 2, vel 2] at the cells local = b*H*W + cell of each list's task
+        (slots behind seg_len are ignored).  Same selection as launch(): scores come from the dense maps, the candidates are the
         first pre_max of every (sample, class) list; the centre range test runs on the evaluated candidates (pnx_decode_boxes_lazy) and
         `fallback()` (the dense path) is taken by result() in the one case where that could change the selection."""
         B = dense[0].shape[0]
@@ -240,11 +241,7 @@ class PackedDecoder:
         valid = jj[None, :] < seg_len[:, None]
         local = order[pos] - kofs[:, None]
         n_rows = S * self.pre_max
-        cand = torch.zeros((S, self.pre_max, 10), dtype=torch.float32, device=dev)
-        for t in range(T):
-            st = segs[t]
-            vals = evaluator(t, local[st].reshape(-1), valid[st].reshape(-1))
-            cand[st] = vals.reshape(len(st), self.pre_max, 10)
+        cand = evaluator(local, seg_len, valid, segs)                          # (S, pre_max, 10) fp32
         boxes9 = torch.empty((n_rows, 9), dtype=torch.float32, device=dev)
         boxes7 = torch.zeros((n_rows, 7), dtype=torch.float32, device=dev)
         scores = torch.empty((n_rows,), dtype=torch.float32, device=dev)

@@ -980,14 +980,24 @@ class FusedPillarNeXt(nn.Module):
         return self._decoder
 
     @torch.no_grad()
-    def lazy_eval(self, ti, up, local, valid):
-        """The five regression branches of task ti at the cells `local` (= b*H*W + cell) of the deblocked map `up` (B,64,H,W channels_last
-        bf16): conv3x3 (64 -> 5*64) + folded BN + ReLU at the 3 x 3 neighbours of every cell, rounded to bf16 like the dense kernel's
-        intermediate, then the block-diagonal 3x3 conv (-> 10) at the cell; zero padding at the map border.  Returns (n, 10) fp32 in the
-        order reg 2, height 1, dim 3, rot 2, vel 2, rounded to bf16 like the dense output."""
+    def lazy_eval(self, ups, local, seg_len, valid, segs):
+        """The five regression branches of every task at the candidate cells (local (S, pre_max) = b*H*W + cell inside the list's task map,
+        lists s = sample * nc_total + class) of the deblocked maps ups[t] (B,64,H,W channels_last bf16): conv3x3 (64 -> 5*64) + folded BN +
+        ReLU at the 3 x 3 neighbours of every cell, rounded to bf16 like the dense kernel's intermediate, then the block-diagonal 3x3 conv
+        (-> 10) at the cell; zero padding at the map border.  Returns (S, pre_max, 10) fp32 in the order reg 2, height 1, dim 3, rot 2,
+        vel 2, rounded to bf16 like the dense output.  One HIP launch (ops.sephead_lazy); PNX_HEAD_LAZY_TORCH=1 runs the torch statement
+        of the same arithmetic below instead (tests compare the two)."""
         if os.environ.get("PNX_HEAD_LAZY_TORCH", "0") != "1":
-            return ops.sephead_lazy(up, getattr(self, f"lazy_wf1_{ti}"), getattr(self, f"lazy_b1_{ti}"), getattr(self, f"lazy_w2c_{ti}"),
-                                    getattr(self, f"lazy_b2_{ti}"), local, valid)
+            tasks = [(ups[ti], getattr(self, f"lazy_wf1_{ti}"), getattr(self, f"lazy_b1_{ti}"), getattr(self, f"lazy_w2c_{ti}"),
+                      getattr(self, f"lazy_b2_{ti}")) for ti in range(len(ups))]
+            class_task = [ti for ti, (names, outs) in enumerate(self.task_split) for _ in range(outs[-1])]
+            return ops.sephead_lazy(tasks, class_task, ups[0].shape[0], local, seg_len, local.shape[1])
+        cand = torch.zeros((*local.shape, 10), dtype=torch.float32, device=local.device)
+        for ti, st in enumerate(segs):
+            cand[st] = self._lazy_eval_torch(ti, ups[ti], local[st].reshape(-1), valid[st].reshape(-1)).reshape(len(st), local.shape[1], 10)
+        return cand
+
+    def _lazy_eval_torch(self, ti, up, local, valid):
         B, C, H, W = up.shape
         n = local.shape[0]
         upf = up.permute(0, 2, 3, 1).reshape(B * H * W, C)
@@ -1004,7 +1014,7 @@ class FusedPillarNeXt(nn.Module):
         inside = (vy[:, 1:4, None] & vx[:, None, 1:4]).reshape(n * 9, 1)
         t1 = (t1 * inside).to(torch.bfloat16).float().reshape(n, -1)
         out = t1 @ getattr(self, f"lazy_w2_{ti}") + getattr(self, f"lazy_b2_{ti}")
-        return out.to(torch.bfloat16).float()
+        return out.to(torch.bfloat16).float() * valid[:, None]
 
     @torch.no_grad()
     def forward_async(self, example):
@@ -1021,7 +1031,7 @@ class FusedPillarNeXt(nn.Module):
         def dense_path():  # the exact fallback (decode.PendingDetections.result): every branch over the whole map
             return self.decoder().launch([c2(c1(u)) for u, c1, c2 in zip(ups, self.task_conv1, self.task_conv2)], tokens)
 
-        return self.decoder().launch_lazy([p.dense for p in packed], lambda t, local, valid: self.lazy_eval(t, ups[t], local, valid), tokens, dense_path)
+        return self.decoder().launch_lazy([p.dense for p in packed], lambda *a: self.lazy_eval(ups, *a), tokens, dense_path)
 
     @staticmethod
     def detections(outputs):

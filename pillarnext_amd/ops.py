@@ -273,28 +273,40 @@ def sephead_out(x, wfrag, bias):
 
 def sephead_lazy_pack_w2(w2m):
     """(9*320, 10) matrix of the five regression branches' second convolutions (rows (pos, channel), block diagonal over the branches
-    reg 2 | height 1 | dim 3 | rot 2 | vel 2) -> fp32 [M tile 10][pos 9][channel 32][4]: per 32-channel tile the <= 3 outputs of its branch."""
+    reg 2 | height 1 | dim 3 | rot 2 | vel 2) -> fp32 [M tile 10][pos 9][channel 32][3]: per 32-channel tile the <= 3 outputs of its branch."""
     off, k = [0, 2, 3, 6, 8], [2, 1, 3, 2, 2]
     v = w2m.detach().float().reshape(9, 10, 32, 10)                               # (pos, mt, cl, o)
-    out = torch.zeros((10, 9, 32, 4), dtype=torch.float32, device=w2m.device)
+    out = torch.zeros((10, 9, 32, 3), dtype=torch.float32, device=w2m.device)
     for mt in range(10):
         j = mt // 2
         out[mt, :, :, :k[j]] = v[:, mt, :, off[j]:off[j] + k[j]]
     return out.contiguous()
 
 
-def sephead_lazy(up, wfrag1, bias1, w2c, bias2, local, valid):
-    """The regression branches of one task at the cells local (= b*H*W + cell) of up (B,64,H,W channels_last bf16): (n,10) fp32
-    (csrc/conv3x3.hip::k_sephead_lazy).  Rows with valid == 0 are zero."""
-    if not (up.is_cuda and up.dtype == torch.bfloat16 and up.shape[1] == 64 and up.is_contiguous(memory_format=torch.channels_last)):
-        raise PnxError("sephead_lazy needs a 64-channel channels_last bf16 CUDA tensor")
-    B, _, H, W = up.shape
-    n = local.numel()
-    local = local.contiguous()
-    valid = valid.to(torch.uint8).contiguous()
-    out = torch.empty((n, 10), dtype=torch.float32, device=up.device)
-    check(lib().pnx_sephead_lazy_bf16(ptr(up), B, H, W, ptr(local), ptr(valid), n, ptr(wfrag1), ptr(bias1), ptr(w2c), ptr(bias2), ptr(out), stream_ptr()),
-          "pnx_sephead_lazy_bf16")
+class _PnxLazyTask(ctypes.Structure):
+    _fields_ = [("up", ctypes.c_void_p), ("wfrag1", ctypes.c_void_p), ("bias1", ctypes.c_void_p), ("w2c", ctypes.c_void_p), ("bias2", ctypes.c_void_p),
+                ("h", ctypes.c_int32), ("w", ctypes.c_int32)]
+
+
+def sephead_lazy(tasks, class_task, batch, local, seg_len, pre_max):
+    """The regression branches of every task at the candidate cells (csrc/conv3x3.hip::k_sephead_lazy, one launch).
+    tasks: list of (up (B,64,H,W) channels_last bf16, wfrag1, bias1, w2c, bias2); class_task: task index of every class (host list);
+    local int64 (batch*len(class_task), pre_max) = b*H*W + cell per slot; seg_len int32 (batch*len(class_task),).  -> (lists, pre_max, 10) fp32,
+    rows behind seg_len zero."""
+    arr = (_PnxLazyTask * len(tasks))()
+    for i, (up, wf, b1, w2c, b2) in enumerate(tasks):
+        if not (up.is_cuda and up.dtype == torch.bfloat16 and up.shape[1] == 64 and up.is_contiguous(memory_format=torch.channels_last)
+                and up.shape[0] == batch):
+            raise PnxError("sephead_lazy needs 64-channel channels_last bf16 CUDA tensors")
+        arr[i] = _PnxLazyTask(up.data_ptr(), wf.data_ptr(), b1.data_ptr(), w2c.data_ptr(), b2.data_ptr(), up.shape[2], up.shape[3])
+    nc = len(class_task)
+    ct = (ctypes.c_int32 * nc)(*[int(v) for v in class_task])
+    S = batch * nc
+    if not (local.is_cuda and local.dtype == torch.int64 and local.numel() == S * pre_max and seg_len.dtype == torch.int32 and seg_len.numel() == S):
+        raise PnxError("sephead_lazy: local must be int64 (lists*pre_max), seg_len int32 (lists)")
+    local, seg_len = local.contiguous(), seg_len.contiguous()
+    out = torch.empty((S, pre_max, 10), dtype=torch.float32, device=local.device)
+    check(lib().pnx_sephead_lazy_bf16(arr, len(tasks), ct, nc, batch, ptr(local), ptr(seg_len), pre_max, ptr(out), stream_ptr()), "pnx_sephead_lazy_bf16")
     return out
 
 

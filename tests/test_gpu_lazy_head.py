@@ -30,28 +30,32 @@ def _w2m(W2):
     return m
 
 
-@pytest.mark.parametrize("shape,n", [((2, 40, 36), 1000), ((1, 7, 5), 35), ((3, 64, 64), 33)])
-def test_lazy_kernel_equals_dense_convolutions_at_the_cells(shape, n):
+@pytest.mark.parametrize("shape,pre_max,lens", [((2, 40, 36), 500, [500, 123]), ((1, 7, 5), 35, [35]), ((3, 64, 64), 40, [40, 17, 0]),
+                                                ((2, 33, 47), 64, [64, 1])])
+def test_lazy_kernel_equals_dense_convolutions_at_the_cells(shape, pre_max, lens):
     from pillarnext_amd import ops
 
     B, H, W = shape
-    W1, b1, W2, b2 = _weights(3)
     g = torch.Generator(device="cuda").manual_seed(5)
-    up = torch.randn((B, 64, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    t = torch.relu(torch.nn.functional.conv2d(up.float(), W1, b1, padding=1)).to(torch.bfloat16).float()
-    dense = torch.nn.functional.conv2d(t, W2, b2, padding=1).to(torch.bfloat16).float()                 # (B,10,H,W)
-    local = torch.randint(0, B * H * W, (n,), device="cuda", generator=g)
-    local[:4] = torch.tensor([0, W - 1, (H - 1) * W, B * H * W - 1], device="cuda")                       # the four kinds of corner
-    valid = torch.rand((n,), device="cuda", generator=g) < 0.9
-    valid[:4] = True
-    got = ops.sephead_lazy(up, ops.conv3x3_pack_weights(W1), b1, ops.sephead_lazy_pack_w2(_w2m(W2)), b2, local, valid)
-    ref = dense.permute(0, 2, 3, 1).reshape(-1, 10)[local] * valid[:, None]
+    tasks, dense = [], []
+    for ti in range(2):                                                                               # two tasks of one class each
+        W1, b1, W2, b2 = _weights(3 + ti)
+        up = torch.randn((B, 64, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        t = torch.relu(torch.nn.functional.conv2d(up.float(), W1, b1, padding=1)).to(torch.bfloat16).float()
+        dense.append(torch.nn.functional.conv2d(t, W2, b2, padding=1).to(torch.bfloat16).float().permute(0, 2, 3, 1).reshape(-1, 10))
+        tasks.append((up, ops.conv3x3_pack_weights(W1), b1, ops.sephead_lazy_pack_w2(_w2m(W2)), b2))
+    S = 2 * B
+    local = torch.randint(0, B * H * W, (S, pre_max), device="cuda", generator=g)
+    local[:, :4] = torch.tensor([0, W - 1, (H - 1) * W, B * H * W - 1], device="cuda")                # the four kinds of corner
+    seg_len = torch.tensor([lens[s // 2] for s in range(S)], dtype=torch.int32, device="cuda")       # lists s = sample * 2 + class
+    got = ops.sephead_lazy(tasks, [0, 1], B, local, seg_len, pre_max)
+    valid = torch.arange(pre_max, device="cuda")[None, :] < seg_len[:, None]
+    ref = torch.stack([dense[s % 2][local[s]] for s in range(S)]) * valid[..., None]
     assert bool((got[~valid] == 0).all())
     # fp32 sums in a different order than the library convolution: an intermediate may round to the neighbouring bf16 value
     torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
     assert float((got == ref).float().mean()) > 0.8
-    again = ops.sephead_lazy(up, ops.conv3x3_pack_weights(W1), b1, ops.sephead_lazy_pack_w2(_w2m(W2)), b2, local, valid)
-    assert torch.equal(got, again)                                                                          # deterministic
+    assert torch.equal(got, ops.sephead_lazy(tasks, [0, 1], B, local, seg_len, pre_max))              # deterministic
 
 
 def _fused(lazy):

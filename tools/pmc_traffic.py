@@ -11,7 +11,7 @@ import csv
 import json
 import sys
 
-READER = ["k_keys", "k_pack_scan", "k_scan_blocks", "k_scan_local", "k_bin_count", "k_bin_scatter", "k_bin_sort", "k_pfn3", "k_canvas_fill",
+READER = ["k_keys", "k_pack_scan", "k_scan_blocks", "k_scan_local", "k_bin_count", "k_bin_scatter", "k_bin_sort", "k_bin_pfn", "k_pfn3", "k_canvas_fill",
           "k_rank", "k_fill", "k_pfn_mfma", "k_pfn_big", "fillBufferAligned"]
 
 
