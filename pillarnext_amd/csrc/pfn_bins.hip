@@ -347,7 +347,8 @@ __global__ __launch_bounds__(kBinBlock, 2) void k_bin_pfn(BinPfnArgs A, Pfn3Out 
             const int yi = k % g.gyp;
             const int tq = k / g.gyp;
             const int xi = tq % g.gx, bi = tq / g.gx;
-            const int32_t cell = (bi * g.gy + yi) * g.gx + xi;
+            // rows mode (pnx_reader_forward_rows, write_pillars & 2): the 'canvas' is a (P, 64) row buffer, a pillar's line goes to its rank
+            const int32_t cell = (A.write_pillars & 2) ? (int32_t)(r0 + p) : (bi * g.gy + yi) * g.gx + xi;
             float* info = reinterpret_cast<float*>(&s_sum[3 * p]);  // overlays this thread's own three sums
             // mean: fp32 divide of the fp64 sum (pe:113-114); centre: idx*vs + vs/2 + min, each step rounded (pe:119-120)
             const float mx = __fdiv_rn((float)sx, fc), my = __fdiv_rn((float)sy, fc), mz = __fdiv_rn((float)sz, fc);
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(kBinBlock, 2) void k_bin_pfn(BinPfnArgs A, Pfn3Out 
             info[0] = mx, info[1] = my, info[2] = mz, info[3] = ctrx, info[4] = ctry;
             info[5] = __int_as_float(cell);
             const int64_t gr = r0 + p;
-            if (A.write_pillars || cnt > 32u) {
+            if ((A.write_pillars & 1) || cnt > 32u) {
               A.pfirst[gr] = bs + eg;
               A.pcnt[gr] = cnt;
               A.cell_of_pillar[gr] = cell;

@@ -890,6 +890,32 @@ int pnx_launch_pfn_train(int F, int pass, const uint32_t* rec64, const uint32_t*
                          const float* prm, float* part, const float* G, const float* out_saved, float* out, int64_t out_rows, hipStream_t st);
 int pnx_pfn_train_blocks(void);
 
+namespace {
+// Sparse view of the voxelization for the backbone's first stage (conv3x3.hip: k_subm64_sparse, k_conv3x3_s2 with gathered input):
+// wfull[word] = {occupancy bits of the 32 cells yi = 32 (word % wpr) .. +31 of (b, xi) = word / wpr, rank of the word's first pillar};
+// the rank of cell (b, xi, yi) is wfull.y + popcount(bits below yi & 31) -- torch.unique order, the row of the pillar in the (P, 64)
+// feature rows.  occupancy (optional): the same bits as bytes in canvas order (b, yi, xi), what pnx_mask_pool3 consumes.
+__global__ __launch_bounds__(256) void k_sparse_index(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre, const uint32_t* __restrict__ wblk,
+                                                      GeomDev g, uint2* __restrict__ wfull, uint8_t* __restrict__ occ) {
+  const int wpr = g.gyp >> 5;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // lanes run over xi: the occupancy rows are written in 64-byte pieces
+  if (idx >= (int64_t)g.B * wpr * g.gx) return;
+  const int xi = (int)(idx % g.gx);
+  const int yw = (int)((idx / g.gx) % wpr);
+  const int b = (int)(idx / ((int64_t)g.gx * wpr));
+  const int64_t w = ((int64_t)b * g.gx + xi) * wpr + yw;
+  const uint32_t bits = bitmap[w];
+  wfull[w] = make_uint2(bits, wblk[w >> PNX_SCAN_SHIFT] + wpre[w]);
+  if (occ != nullptr) {
+#pragma unroll 4
+    for (int j = 0; j < 32; j++) {
+      const int yi = yw * 32 + j;
+      if (yi < g.gy) occ[((int64_t)b * g.gy + yi) * g.gx + xi] = (uint8_t)((bits >> j) & 1u);
+    }
+  }
+}
+}  // namespace
+
 extern "C" {
 
 size_t pnx_reader_workspace_bytes(int64_t n_points, int32_t batch, const pnx_geom* g) {
@@ -1127,6 +1153,44 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   if (counts) PNX_CHECK_HIP(hipMemcpyAsync(counts, w.counters, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   prof_mark(3, st);
   if (g_prof.on && g_prof.n < g_prof.cap) g_prof.n++;
+  return PNX_OK;
+}
+
+int64_t pnx_reader_sparse_words(int32_t batch, const pnx_geom* g) {
+  if (!g || batch < 1) return 0;
+  return cells_padded(g, batch) / 32;
+}
+
+int pnx_reader_forward_rows(const float* points, int64_t n, int32_t stride, int32_t batch, const pnx_geom* g, const float* pfn_folded, void* rows,
+                            int32_t rows_dtype, int64_t row_capacity, int32_t* counts, void* wfull, uint8_t* occupancy, void* workspace,
+                            size_t workspace_bytes, pnx_stream_t stream) {
+  int rc = check_common(points, n, stride, batch, g, workspace, workspace_bytes);
+  if (rc != PNX_OK) return rc;
+  PNX_REQUIRE(pfn_folded != nullptr && rows != nullptr && wfull != nullptr, PNX_ERR_INVALID, "pfn_folded / rows / wfull is NULL");
+  PNX_REQUIRE(rows_dtype == PNX_BF16 || rows_dtype == PNX_F16, PNX_ERR_INVALID, "rows_dtype %d: bf16 or fp16", rows_dtype);
+  PNX_REQUIRE((((uintptr_t)rows | (uintptr_t)wfull) & 15) == 0, PNX_ERR_INVALID, "rows and wfull must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const ReaderWs w = carve(workspace, n, batch, g);
+  const GeomDev gd = make_geom(g, batch);
+  const int F = stride - 1;
+  PNX_REQUIRE(reader_impl() == 3 && w.K1 <= 16384 && F <= 5 && w.sh <= 10, PNX_ERR_UNSUPPORTED, "the row output exists on the in-LDS bin path only");
+  PNX_REQUIRE(row_capacity >= w.pcap, PNX_ERR_INVALID, "row_capacity %lld < worst-case pillar count %lld", (long long)row_capacity, (long long)w.pcap);
+  PnxFillJob nofill[4] = {};
+  rc = run_voxelize2(points, n, stride, gd, w, nullptr, 0, nullptr, nullptr, nofill, 0, st, nullptr, false);
+  if (rc != PNX_OK) return rc;
+  {
+    const int64_t items = (int64_t)gd.B * (gd.gyp >> 5) * gd.gx;
+    k_sparse_index<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(w.bitmap, w.wpre, w.wblk, gd, (uint2*)wfull, occupancy);
+    PNX_LAUNCH_CHECK();
+  }
+  rc = pnx_launch_bin_pfn(F, w.rec, w.hpre, w.hblk, w.matlen, w.sh, w.nwg, w.K1, w.counters, w.tick, w.rec64, w.pfirst, w.pcnt, w.cell, nullptr, 0, 2,
+                          w.biglist, w.bigcap, pfn_folded, nullptr, 0, rows, rows_dtype, n, 0, gd, nofill[3], st);
+  if (rc != PNX_OK) return rc;
+  if (n > 0) {
+    rc = pnx_launch_pfn3_tail(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.biglist, w.bigcap, pfn_folded, nullptr, 0, rows, rows_dtype, 128, st);
+    if (rc != PNX_OK) return rc;
+  }
+  if (counts) PNX_CHECK_HIP(hipMemcpyAsync(counts, w.counters, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   return PNX_OK;
 }
 

@@ -76,6 +76,40 @@ def test_point_uploader_roundtrip():
         assert np.array_equal(np.unique(ref[:, 0]), [0, 1, 2])
 
 
+@pytest.fixture(params=["rows", "gather"])
+def conv64_impl(request, monkeypatch):
+    """64 -> 64 masked stride-1 convolutions have two kernels: N = a 32-pixel row segment (default) or N = 32 active pixels of the tile
+    (k_conv3x3_gat, PNX_CONV_GATHER=1)."""
+    monkeypatch.setenv("PNX_CONV_GATHER", "1" if request.param == "gather" else "0")
+    return request.param
+
+
+@pytest.mark.parametrize("residual", [False, True])
+def test_conv3x3_64_both_kernels(conv64_impl, residual):
+    """The pixel-gather kernel and the row kernel on dense-ish, sparse and empty tiles, with a workspace that goes stale (row_dirty)."""
+    from pillarnext_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, H, W = 2, 83, 101
+    w = (torch.randn((64, 64, 3, 3), device="cuda", generator=g) / 24).to(torch.bfloat16)
+    wf = ops.conv3x3_pack_weights(w)
+    bias = torch.randn((64,), device="cuda", generator=g)
+    ws = ops.conv3x3_workspace(B, 64, H, W, "cuda")
+    for frame in range(3):
+        mask = (torch.rand((B, H, W), device="cuda", generator=g) > (0.2, 0.9, 0.97)[frame]).to(torch.uint8)   # > 256 active pixels per tile, then sparse
+        mask[0, 16 * frame:16 * frame + 20] = 0
+        x = (torch.randn((B, 64, H, W), device="cuda", generator=g) * mask.unsqueeze(1)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        res = torch.randn((B, 64, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if residual else None
+        ref = torch.nn.functional.conv2d(x.float(), w.float(), None, 1, 1) + bias.view(1, -1, 1, 1)
+        if residual:
+            ref = ref + res.float()
+        ref = torch.relu(ref) * mask.unsqueeze(1).float()
+        tiles = ops.conv_tile_list(mask, [ws[1]], ops.conv_tile_rows(64, 64, 1))
+        got = ops.conv3x3_masked(x, wf, bias, 64, 1, mask, res, True, out=ws, tiles=tiles).float()
+        assert bool((got[(mask == 0).unsqueeze(1).expand_as(got)] == 0).all()), frame
+        torch.testing.assert_close(got, ref, rtol=1.6e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 128, 2), (128, 128, 1), (64, 64, 2), (64, 384, 1), (64, 320, 1), (256, 256, 1), (256, 64, 1), (128, 256, 2),
                                                (256, 256, 2)])
 @pytest.mark.parametrize("residual", [False, True])
