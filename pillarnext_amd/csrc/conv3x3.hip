@@ -958,7 +958,8 @@ __device__ __forceinline__ void conv_taps_ws(v16f (&acc)[NR], const uint4* __res
     int cbj[NR], swk[NR];
 #pragma unroll
     for (int j = 0; j < NR; j++) {
-      const int c = col[j] + dx;
+      int c = col[j] + dx;
+      asm volatile("" : "+v"(c));  // recomputed per tap: hoisted out of the round loop, the 72 LDS addresses spill
       cbj[j] = rb[j] + (dy * LDS_HW + c) * 8;
       swk[j] = lds_swz(c) ^ kb;
     }
@@ -2087,6 +2088,7 @@ constexpr int kLzG = 32, kLzN = kLzG * 9, kLzNT = kLzN / 32;  // candidates, pix
 constexpr int kLzPatch = kLzG * 25 * 8;                       // uint4 slots of the staged patches
 constexpr int kLzW2 = 10 * 9 * 32 * 3;                        // floats of the packed second-convolution weights
 constexpr int kLzMaxTasks = 8, kLzMaxClasses = 32;
+constexpr int kLzAhead = 2;  // taps of weight-fragment lookahead
 
 struct LazyTaskDev {
   const uint16_t* up;
@@ -2178,28 +2180,39 @@ __global__ __launch_bounds__(512) void k_sephead_lazy(const LazyArgs A, const in
 #pragma unroll
         for (int j = 0; j < 3; j++) acc[j][i] = bq;
       }
+      // Weight fragments (L2): kLzAhead taps ahead in straight-line code.  A tap is 12 MFMAs (~400 cycles) per wave; with one tap of lookahead
+      // in a rolled loop the k-steps ran at the latency of their fragment loads (the kernel took 620 us for 2.6 M MFMAs = 110 us of pipe time).
       const uint4* wp = T.wfrag + mt * 64 + lane;
-      uint4 an[4];
+      uint4 wq[9][4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) an[ks] = wp[ks * 640];
-#pragma unroll 1
+      for (int tp = 0; tp < kLzAhead; tp++)
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) wq[tp][ks] = wp[(tp * 4 + ks) * 640];
+#pragma unroll
       for (int tap = 0; tap < 9; tap++) {
-        uint4 a[4];
+        if (tap + kLzAhead < 9) {
+          const uint4* wpt = wp;
+          asm volatile("" : "+v"(wpt));  // the loads of a later tap are not hoisted to the top (144 live registers)
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) a[ks] = an[ks];
-        const int tn = min(tap + 1, 8);  // the last iteration re-reads its own fragments (cached), no branch in the loop
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) an[ks] = wp[(tn * 4 + ks) * 640];
+          for (int ks = 0; ks < 4; ks++) wq[tap + kLzAhead][ks] = wpt[((tap + kLzAhead) * 4 + ks) * 640];
+        }
         const int toff = (tap / 3) * 5 + (tap % 3);
+        int cwj[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          cwj[j] = wc[j] + toff;
+          asm volatile("" : "+v"(cwj[j]));  // recomputed per tap: hoisted out of the loops, the 108 LDS addresses of an item spill
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
 #pragma unroll
           for (int j = 0; j < 3; j++) {
-            const int cw = wc[j] + toff;
+            const int cw = cwj[j];
             const uint4 bq4 = s_patch[pb[j] + cw * 8 + ((ks * 2 + kb) ^ (cw & 7))];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks]), __builtin_bit_cast(bf16x8, bq4), acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[tap][ks]), __builtin_bit_cast(bf16x8, bq4), acc[j], 0, 0, 0);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);  // keeps the fragment loads where they are: kLzAhead taps ahead, not all at the top (registers)
       }
       // ---- ReLU, bf16 rounding (the dense kernel's intermediate), contraction with the second convolution
 #pragma unroll

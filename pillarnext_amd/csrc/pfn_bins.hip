@@ -13,8 +13,9 @@
 //   layout   the order of the records in LDS is OURS to choose, so pillars are grouped by SIZE CLASS: a pillar of n <= 32 points
 //            gets an aligned group of G = 1, 2, 4, 8, 16 or 32 slots (the next power of two; the spare slots repeat its last point,
 //            which no maximum notices), and a tile = 32 consecutive slots of ONE class = 32/G whole pillars
-//   pass 2   every point -> a 48-byte decorated record [f0 f2 f4 f6 | f1 f3 f5 f7 | f8 - f9 pillar] at its slot (the operand order
-//            of v_mfma_f32_32x32x2_f32: lane (point, h) feeds K elements 2kk+h)
+//   pass 2   every point's RAW 32-byte record -> its slot; the tile decorates it (pe:116-123) from the pillar's constants into the operand
+//            order of v_mfma_f32_32x32x2_f32 (lane (point, h) feeds K elements 2kk+h).  (48-byte decorated LDS records were tried: fewer
+//            record slots fit, bins became multi-segment, slower.)
 //   PFN      per tile: layer 0 (fp32 MFMA), per-pillar max = an UNMASKED xor butterfly inside aligned lane groups (one
 //            v_max_f32_dpp per register and step, log2 G steps, the result lands in every lane of the group: no masks, no
 //            ballots, no bpermute, nothing for single-point pillars), layer 1 (fp16x3 MFMA, pfn_v3.hip), the same butterfly on the

@@ -94,7 +94,7 @@ class _MaskedBNActFn(torch.autograd.Function):
     """y = relu(BN_active_sites(x) [+ residual]) * mask in ONE autograd node (train mode).  The module-by-module form keeps ~6 full-size
     fp32 tensors per layer alive for the backward (x.float(), the masked products, the normalised map, the ReLU output ...); this node
     keeps x (in its own dtype), the residual (the block's input, alive anyway) and two per-channel vectors, and recomputes the rest:
-    106 -> GiB-scale savings at 1440 x 1440 x 4 frames (profiles/).  SyncBatchNorm mode all-reduces [sum x, count], [sum (x-mu)^2]
+    the C2 x 4-frame training step went from 106 to 50.5 GiB (profiles/r03_train_step_c2_b4_fp32.log).  SyncBatchNorm mode all-reduces [sum x, count], [sum (x-mu)^2]
     forward and [sum g, sum g*xhat] backward over the ACTIVE sites of the global batch (dist_utils.all_reduce_sum)."""
 
     @staticmethod

@@ -26,6 +26,8 @@ def main():
         d = json.load(open(out))
     except Exception:
         d = {}
+    for k in [k for k in d if k.startswith(key + ":")]:   # per-kernel entries of an earlier pipeline
+        del d[k]
     calls = max(sum(1 for n, _ in f if "k_keys" in n), 1)
     tot_f = sum(v for n, v in f if any(k in n for k in READER))
     tot_w = sum(v for n, v in w if any(k in n for k in READER))
