@@ -283,6 +283,12 @@ def main():
     import ctypes
 
     torch.cuda.set_device(local)
+    # The dense 256-channel layers at 180 x 180 (neck pre_conv, ASPP) are MIOpen's.  Its find step times CK's grouped convolution (287 us) and the
+    # asm implicit-GEMM solver (477 us) and picked the slower one in about one run of four (and in every run under rocprofv3): +0.95 ms per
+    # step.  With that solver out of the search the choice is CK in every run (562-564 frames/s, three runs).  The naive reference solver
+    # (0.46 s per call, 40 calls) only lengthens the find step.
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC", "0")
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
     if not os.environ.get("PNX_NO_MIOPEN_BENCH"):
         torch.backends.cudnn.benchmark = True  # MIOpen times its applicable solvers once per conv shape (during warm-up)
     dev = torch.device("cuda", local)

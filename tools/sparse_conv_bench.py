@@ -69,8 +69,8 @@ if hasattr(L, "pnx_debug_conv_timers"):   # instrumented build (PNX_CONV_TIMERS=
         print(f"   section {names[k]:32s} {100 * buf[k] / tot:5.1f} %")
 print(f"sparse  subm64 + residual {timed(lambda: ops.subm64_sparse(rows, wfull, B, nx, wpr, wt, bias, residual=res, out=out, tiles=tiles)):8.1f} us")
 print(f"sparse  tile list         {timed(lambda: ops.sparse_tile_list(wfull, B, nx, wpr, out=tiles)):8.1f} us")
-# dense-layout kernel on the same active set
-b, yi, xi = torch.nonzero(mask, as_tuple=True)
+# dense-layout kernel on the same active set (rows are in rank order = (b, xi, yi) order = nonzero() order of the transposed mask)
+b, xi, yi = torch.nonzero(mt, as_tuple=True)
 xd = torch.zeros((B, ny, nx, 64), dtype=torch.bfloat16, device="cuda")
 xd[b, yi, xi] = rows
 xd = xd.permute(0, 3, 1, 2)
@@ -80,11 +80,12 @@ rd = rd.permute(0, 3, 1, 2)
 wf = ops.conv3x3_pack_weights(w)
 ws = ops.conv3x3_workspace(B, 64, ny, nx, "cuda")
 tl = ops.conv_tile_list(mask, [ws[1]], ops.conv_tile_rows(64, 64, 1))
-print(f"dense   conv3x3_masked    {timed(lambda: ops.conv3x3_masked(xd, wf, bias, 64, 1, mask, None, True, out=ws, tiles=tl)):8.1f} us")
-print(f"dense   + residual        {timed(lambda: ops.conv3x3_masked(xd, wf, bias, 64, 1, mask, rd, True, out=ws, tiles=tl)):8.1f} us")
+for name, env in (("row kernel", "0"), ("pixel-gather kernel", "1")):
+    os.environ["PNX_CONV_GATHER"] = env
+    print(f"dense   {name:20s} {timed(lambda: ops.conv3x3_masked(xd, wf, bias, 64, 1, mask, None, True, out=ws, tiles=tl)):8.1f} us   "
+          f"+ residual {timed(lambda: ops.conv3x3_masked(xd, wf, bias, 64, 1, mask, rd, True, out=ws, tiles=tl)):8.1f} us")
+os.environ.pop("PNX_CONV_GATHER")
 got = ops.subm64_sparse(rows, wfull, B, nx, wpr, wt, bias, residual=res, out=out, tiles=tiles)
 ref = ops.conv3x3_masked(xd, wf, bias, 64, 1, mask, rd, True, out=ws, tiles=tl).permute(0, 2, 3, 1)[b, yi, xi]
-# rank order is (b, xi, yi); nonzero() order is (b, yi, xi)
-order = torch.argsort((b * nx + xi) * ny + yi)
-d = (got.float() - ref[order].float()).abs()
+d = (got.float() - ref.float()).abs()
 print(f"sparse vs dense kernel: max |diff| {float(d.max()):.4f}, mean {float(d.mean()):.6f}, equal {float((d == 0).float().mean()):.4f}")
