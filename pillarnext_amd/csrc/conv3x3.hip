@@ -294,16 +294,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const uint16_t* __restrict__
 // its input once and reuses it six times).
 #ifdef PNX_CONV_TIMERS  // section timers (build with PNX_CONV_TIMERS=1 in the environment of build.py)
 __device__ unsigned long long g_conv_T[8];
-#define CT_DECL unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk = __builtin_amdgcn_s_memtime();
+#define CT_DECL unsigned long long ct_T[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk = __builtin_amdgcn_s_memtime();
 #define CT_TOCK(k)                                              \
   {                                                             \
     const unsigned long long _n = __builtin_amdgcn_s_memtime(); \
-    T[k] += _n - tk;                                            \
+    ct_T[k] += _n - tk;                                         \
     tk = _n;                                                    \
   }
 #define CT_FLUSH                                                                     \
   if ((threadIdx.x & 63) == 0) {                                                     \
-    for (int k = 0; k < 8; k++) atomicAdd(&g_conv_T[k], T[k]);                        \
+    for (int k = 0; k < 8; k++) atomicAdd(&g_conv_T[k], ct_T[k]);                     \
   }
 #else
 #define CT_DECL
@@ -2119,10 +2119,12 @@ __global__ __launch_bounds__(512) void k_sephead_lazy(const LazyArgs A, const in
     return;
   }
   const LazyTaskDev T = A.t[A.class_task[seg % A.nc_total]];
+  CT_DECL
   const int H = T.h, W = T.w, HW = H * W;
   if (t < kLzG) s_cell[t] = (c0 + t < len) ? (int)local[(int64_t)seg * A.pre_max + c0 + t] : -1;
   for (int e = t; e < kLzW2 / 4; e += 512) reinterpret_cast<float4*>(s_w2)[e] = reinterpret_cast<const float4*>(T.w2c)[e];
   __syncthreads();
+  CT_TOCK(0)
   // ---- stage the 5 x 5 patches (zeros outside the map / for the slots behind the end of the list): all of a thread's 16-byte
   // gathers are in flight before the first LDS write (one after the other they cost a memory latency each)
   {
@@ -2148,7 +2150,9 @@ __global__ __launch_bounds__(512) void k_sephead_lazy(const LazyArgs A, const in
       if (e < kLzPatch) s_patch[(c * 25 + cell) * 8 + (q ^ (cell & 7))] = v[k];
     }
   }
+  CT_TOCK(1)
   __syncthreads();
+  CT_TOCK(2)
 #pragma unroll 1
   for (int item = wv; item < 15; item += 8) {
     const int br = item / 3, g0 = (item - br * 3) * 3;
@@ -2214,6 +2218,7 @@ __global__ __launch_bounds__(512) void k_sephead_lazy(const LazyArgs A, const in
         }
         __builtin_amdgcn_sched_barrier(0);  // keeps the fragment loads where they are: kLzAhead taps ahead, not all at the top (registers)
       }
+      CT_TOCK(3)
       // ---- ReLU, bf16 rounding (the dense kernel's intermediate), contraction with the second convolution
 #pragma unroll
       for (int j = 0; j < 3; j++) {
@@ -2227,6 +2232,7 @@ __global__ __launch_bounds__(512) void k_sephead_lazy(const LazyArgs A, const in
           ps[j][2] = __builtin_fmaf(tv, w[2], ps[j][2]);
         }
       }
+      CT_TOCK(4)
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -2238,7 +2244,9 @@ __global__ __launch_bounds__(512) void k_sephead_lazy(const LazyArgs A, const in
       }
     }
   }
+  CT_TOCK(5)
   __syncthreads();
+  CT_TOCK(6)
   // ---- out[cand][o] = b2[o] + sum over the 9 positions of the output's branch, in a fixed order; rounded to bf16
   for (int e = t; e < rows * 10; e += 512) {
     const int cand = e / 10, o = e - cand * 10;
@@ -2252,6 +2260,8 @@ __global__ __launch_bounds__(512) void k_sephead_lazy(const LazyArgs A, const in
     }
     outp[e] = s;
   }
+  CT_TOCK(7)
+  CT_FLUSH
 }
 
 constexpr size_t kLzLds = (size_t)kLzPatch * 16 + (size_t)kLzW2 * 4 + (size_t)kLzN * 5 * 3 * 4 + kLzG * 4;

@@ -84,11 +84,13 @@ def test_fused_inference_graph_matches_module_graph():
         ref_taps["neck"] = model.neck(x)
         ref = model.head(ref_taps["neck"])
         got = fused.forward_preds(pts, 2, taps=taps)
-    # bf16 storage between ~30 layers: the relative error grows with depth; bounds = 2x what one MI355X run measured (printed on failure)
-    bound = {"stage0": 0.02, "stage1": 0.03, "stage2": 0.04, "stage3": 0.05, "neck": 0.06}
+    # bf16 storage between ~30 layers.  Bounds = 1.25 x what an MI355X run of round 3 measured (printed below; run with -s): stages 0.0031 /
+    # 0.0028 / 0.0027 / 0.0028, neck 0.0037; head maps: relative L2 <= 0.0103, max error <= 0.0136 of the map's scale
+    bound = {"stage0": 0.0039, "stage1": 0.0035, "stage2": 0.0034, "stage3": 0.0035, "neck": 0.0047}
     for k, tol in bound.items():
         a, b = ref_taps[k].float(), taps[k].float()
         rel = ((a - b).norm() / (a.norm() + 1e-6)).item()
+        print(f"[fused-vs-module] {k}: rel {rel:.5f} (bound {tol})")
         assert rel <= tol, (k, rel)
         assert bool(((a == 0) == (b == 0))[..., ::1].float().mean() > 0.97), k  # the same active-site pattern (exact zeros elsewhere)
     assert len(ref) == len(got) == 2
@@ -100,7 +102,8 @@ def test_fused_inference_graph_matches_module_graph():
             rel = ((a - b).norm() / (a.norm() + 1e-6)).item()
             err = (a - b).abs().max().item()
             scale = a.abs().max().item() + 1e-3
-            assert rel <= 0.08 and err <= 0.06 * scale + 0.03, (k, rel, err, scale)
+            print(f"[fused-vs-module] head {k}: rel {rel:.5f} max err {err:.5f} scale {scale:.4f}")
+            assert rel <= 0.0128 and err <= 0.017 * scale, (k, rel, err, scale)
             assert torch.corrcoef(torch.stack([a.flatten(), b.flatten()]))[0, 1] > 0.997, k
     d = fused({"points": pts, "token": ["a", "b"], "batch_size": 2})
     assert set(d) == {"a", "b"} and d["a"]["box3d_lidar"].shape[1] == 9
