@@ -88,7 +88,9 @@ def main():
         cmp("output", y, y2[:B], 1e-3, 1e-5)
         pfn = 0
         for k, p in ref.named_parameters():
-            cmp("grad " + k, grads[k], p.grad, 5e-3, 1e-6)
+            # norm-wise: the joint-batch reference runs its convolutions at another batch size, i.e. on other MIOpen solvers (Winograd / implicit
+            # GEMM / direct differ at the 1e-3 level of a gradient's scale in fp32); a missing or wrong all-reduce is an O(1) error
+            cmp("grad " + k, grads[k], p.grad, 5e-3, 1e-2 * float(p.grad.abs().max()) + 1e-7)
             pfn += k.startswith("reader.pfn_layers")
         assert pfn == 6, pfn  # W0, gamma0, beta0, W1, gamma1, beta1
         for k, v in ref.state_dict().items():
