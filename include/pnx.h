@@ -319,11 +319,14 @@ int pnx_nms_normal_batched(const float* boxes, const int32_t* seg_offsets, const
 size_t pnx_decode_task_desc_bytes(void);
 /* Segmented top-k over the keys of all tasks (box_torch_ops.py:13-15 for every (sample, class) list at once): the first pre_max
  * candidates of each segment in descending-score order, ties in ascending key index (= what a stable sort of `keys` would give), without
- * sorting the whole key array: per-segment score histogram -> threshold bin -> collect -> sort in LDS.  Outputs are laid out as
- * pnx_decode_boxes expects them: row s*pre_max + j = j-th candidate of segment s, seg_start[s] = s*pre_max, seg_len[s] <= pre_max. */
+ * sorting the key array: an exact radix select on the composite (score key, key index), most significant digit first -- per pass one
+ * histogram launch (LDS histograms per 16 384-key chunk, no global atomics) and one per-segment digit selection; segments finish early when
+ * they hold fewer than pre_max valid keys or a digit bucket is wanted completely; then one collect pass and a per-segment sort of the
+ * <= pre_max survivors.  pre_max <= 4096.  Outputs are laid out as pnx_decode_boxes expects them: row s*pre_max + j = j-th candidate of
+ * segment s, seg_start[s] = s*pre_max, seg_len[s] <= pre_max; seg_total (optional) = number of valid keys of the segment. */
 size_t pnx_decode_topk_workspace_bytes(int64_t n_keys, int32_t num_segments);
 int pnx_decode_topk(const uint64_t* keys, int64_t n_keys, int32_t num_segments, int32_t pre_max, uint64_t* sorted_keys, int64_t* order,
-                    int64_t* seg_start, int32_t* seg_len, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
+                    int64_t* seg_start, int32_t* seg_len, int32_t* seg_total, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
 int pnx_decode_keys(const void* packed, int32_t dtype, int32_t batch, int32_t n_classes_total, const void* task_desc_host, uint64_t* keys,
                     pnx_stream_t stream);
 /* Stable sort of the candidate keys of pnx_decode_keys (all tasks, all samples) with their positions as payload -- what

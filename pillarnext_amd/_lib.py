@@ -66,7 +66,7 @@ PROTOTYPES = {
     "pnx_mask_pool3": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pnx_decode_task_desc_bytes": (_sz, []),
     "pnx_decode_topk_workspace_bytes": (_sz, [_i64, _i32]),
-    "pnx_decode_topk": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pnx_decode_topk": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pnx_decode_keys": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pnx_sort_keys_workspace_bytes": (ctypes.c_size_t, [_i64]),
     "pnx_sort_keys": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, ctypes.c_size_t, _vp]),

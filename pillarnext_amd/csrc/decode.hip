@@ -387,37 +387,275 @@ __global__ __launch_bounds__(256) void k_topk_sort(const unsigned long long* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- exact radix select
+// Segmented top-k WITHOUT sorting the key array and without a weak spot: the histogram form above collects the whole threshold bin and
+// sorts it, which is fine for a trained head (a few thousand candidates) and a disaster for a freshly initialised one, where half of all
+// cells pass the score threshold and tens of thousands share one bf16-quantised score (6.4 ms against 0.87 ms for the sort).  Here the
+// k-th smallest COMPOSITE  C = (low 32 key bits = ~score bits) << 32 | key index  of every segment is found exactly, most significant
+// digit first (11 + 11 + 10 bits of the score, then -- only while a segment still has more ties than it needs -- 11 + 11 + 10 bits of the
+// index): composites are unique, so "C <= threshold" selects exactly min(k, valid) keys, ties resolved by ascending index like a stable sort.
+// A pass = one histogram launch (a workgroup owns 16 384 consecutive keys; they belong to at most a handful of segments, so it
+// histograms into 4 LDS slots of 2 048 bins -- no global atomics -- and writes its rows; keys of a fifth segment fall back to global
+// atomics) + one select launch (per segment: sum the rows of its slots, find the digit, narrow the prefix).  Segments finish early: fewer
+// than k valid keys (every pass after the first is then a no-op for them) or a digit bucket that is needed completely.
+constexpr int kRsBins = 2048, kRsSlots = 4, kRsChunk = 16384, kRsThreads = 512, kRsMaxK = 4096;
+
+__device__ __forceinline__ int rs_shift(int p) { return p == 0 ? 53 : p == 1 ? 42 : p == 2 ? 32 : p == 3 ? 21 : p == 4 ? 10 : 0; }
+__device__ __forceinline__ int rs_width(int p) { return (p == 2 || p == 5) ? 10 : 11; }
+
+struct RsState {
+  unsigned long long* prefix;  // [S] digits selected so far
+  unsigned long long* thr;     // [S] final threshold composite (inclusive), valid once flag != 0
+  uint32_t* rem;               // [S] rank (1-based) of the wanted composite inside the current prefix bucket
+  uint32_t* flag;              // [S] 1 = finished
+  uint32_t* total;             // [S] valid keys of the segment
+  uint32_t* cursor;            // [S] collect cursor
+  int32_t* n_open;             // segments not finished
+};
+
+__global__ __launch_bounds__(256) void k_rs_init(RsState st, int S, int k) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < S) st.prefix[s] = 0ull, st.thr[s] = 0ull, st.rem[s] = (uint32_t)k, st.flag[s] = 0u, st.total[s] = 0u, st.cursor[s] = 0u;
+  if (s == 0) *st.n_open = S;
+}
+
+__global__ __launch_bounds__(kRsThreads) void k_rs_hist(const unsigned long long* __restrict__ keys, int64_t n, int p, RsState st, int32_t* __restrict__ slotseg,
+                                                        uint32_t* __restrict__ rows, uint32_t* __restrict__ ovf) {
+  __shared__ uint32_t s_hist[kRsSlots * kRsBins];
+  __shared__ int s_seg[kRsSlots];
+  __shared__ unsigned long long s_pref[kRsSlots];
+  __shared__ int s_fin[kRsSlots];
+  if (*st.n_open <= 0) return;  // uniform: every segment is finished
+  const int t = threadIdx.x, lane = t & 63;
+  const int chunk = blockIdx.x;
+  const int64_t i0 = (int64_t)chunk * kRsChunk;
+  for (int e = t; e < kRsSlots * kRsBins; e += kRsThreads) s_hist[e] = 0u;
+  if (t < kRsSlots) {
+    int sg = -1;
+    if (p > 0) sg = slotseg[chunk * kRsSlots + t];
+    s_seg[t] = sg;
+    s_pref[t] = sg >= 0 ? st.prefix[sg] : 0ull;
+    s_fin[t] = sg >= 0 ? (int)st.flag[sg] : 1;
+  }
+  __syncthreads();
+  const int shift = rs_shift(p), width = rs_width(p);
+  const uint32_t dmask = (1u << width) - 1u;
+  for (int j = t; j < kRsChunk; j += kRsThreads) {
+    const int64_t i = i0 + j;
+    const unsigned long long key = i < n ? keys[i] : ~0ULL;
+    const bool valid = key != ~0ULL;
+    const int seg = (int)(key >> 32);
+    const unsigned long long C = (key << 32) | (unsigned long long)(uint32_t)i;
+    int slot = -1;
+#pragma unroll
+    for (int q = 0; q < kRsSlots; q++)
+      if (s_seg[q] == seg) slot = q;
+    if (p == 0 && valid && slot < 0) {  // first pass: the chunk's segments claim the slots in the order they turn up
+      for (int q = 0; q < kRsSlots && slot < 0; q++) {
+        const int old = atomicCAS(&s_seg[q], -1, seg);
+        if (old == -1 || old == seg) slot = q;
+      }
+    }
+    bool part = valid;
+    if (p > 0 && valid) {
+      if (slot >= 0) part = !s_fin[slot] && (C >> (shift + width)) == s_pref[slot];
+      else part = st.flag[seg] == 0u && (C >> (shift + width)) == st.prefix[seg];
+    }
+    const uint32_t bin = (uint32_t)(C >> shift) & dmask;
+    if (part && slot < 0) {
+      atomicAdd(&ovf[(size_t)seg * kRsBins + bin], 1u);
+      part = false;
+    }
+    // same-address LDS atomics serialise: when many lanes of the wave hit one bin (a fresh head: every key in one or two score digits;
+    // the high index digits of a chunk are equal by construction) the group is served by one add
+    const int mine = part ? (int)(slot * kRsBins + bin) : -1;
+    const unsigned long long act = __ballot(part);
+    if (act) {
+      const int lead = __shfl(mine, __ffsll((long long)act) - 1);
+      const unsigned long long grp = __ballot(mine == lead);
+      if (__popcll(grp) >= 8) {
+        if (lane == __ffsll((long long)grp) - 1) atomicAdd(&s_hist[lead], (uint32_t)__popcll(grp));
+        if (mine == lead) part = false;
+      }
+    }
+    if (part) atomicAdd(&s_hist[mine], 1u);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int q = 0; q < kRsSlots; q++) {
+    if (s_seg[q] < 0) continue;  // uniform
+    uint32_t* dst = rows + ((size_t)chunk * kRsSlots + q) * kRsBins;
+    for (int b = t; b < kRsBins; b += kRsThreads) dst[b] = s_hist[q * kRsBins + b];
+  }
+  if (p == 0 && t < kRsSlots) slotseg[chunk * kRsSlots + t] = s_seg[t];
+}
+
+__global__ __launch_bounds__(256) void k_rs_select(int p, RsState st, const int32_t* __restrict__ slotseg, int n_slots, const uint32_t* __restrict__ rows,
+                                                   uint32_t* __restrict__ ovf) {
+  __shared__ int s_list[256];
+  __shared__ int s_nlist;
+  __shared__ uint32_t s_sum[256];
+  __shared__ uint32_t s_res[4];
+  const int seg = blockIdx.x, t = threadIdx.x;
+  if (st.flag[seg] != 0u) return;  // uniform
+  if (t == 0) s_nlist = 0;
+  __syncthreads();
+  for (int e = t; e < n_slots; e += 256)
+    if (slotseg[e] == seg) {
+      const int pos = atomicAdd(&s_nlist, 1);
+      if (pos < 256) s_list[pos] = e;
+    }
+  __syncthreads();
+  const int nl = s_nlist;
+  uint32_t c[8];
+  {
+    uint32_t* o = ovf + (size_t)seg * kRsBins + 8 * t;
+#pragma unroll
+    for (int b = 0; b < 8; b++) c[b] = o[b], o[b] = 0u;  // the overflow row is re-armed for the next pass
+  }
+  if (nl <= 256) {
+    for (int l = 0; l < nl; l++) {
+      const uint4* r = reinterpret_cast<const uint4*>(rows + (size_t)s_list[l] * kRsBins + 8 * t);
+      const uint4 a = r[0], b = r[1];
+      c[0] += a.x, c[1] += a.y, c[2] += a.z, c[3] += a.w, c[4] += b.x, c[5] += b.y, c[6] += b.z, c[7] += b.w;
+    }
+  } else {  // a segment spread over more than 256 chunk slots: walk the table
+    for (int e = 0; e < n_slots; e++)
+      if (slotseg[e] == seg) {
+        const uint32_t* r = rows + (size_t)e * kRsBins + 8 * t;
+#pragma unroll
+        for (int b = 0; b < 8; b++) c[b] += r[b];
+      }
+  }
+  uint32_t tot = 0;
+#pragma unroll
+  for (int b = 0; b < 8; b++) tot += c[b];
+  s_sum[t] = tot;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (int q = 0; q < 256; q++) {
+    const uint32_t v = s_sum[q];
+    if (q < t) before += v;
+    total += v;
+  }
+  const uint32_t rem = st.rem[seg];
+  if (p == 0 && t == 0) st.total[seg] = total;
+  if (total < rem) {  // fewer valid keys than k (first pass only): everything is taken
+    if (t == 0) {
+      st.thr[seg] = ~0ULL;
+      st.flag[seg] = 1u;
+      atomicSub(st.n_open, 1);
+    }
+    return;
+  }
+  if (before < rem && before + tot >= rem) {  // exactly one thread
+    uint32_t run = before;
+    int d = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      if (run < rem && run + c[b] >= rem) {
+        d = b;
+        s_res[0] = (uint32_t)(8 * t + b), s_res[1] = run, s_res[2] = c[b];
+      }
+      run += c[b];
+    }
+    (void)d;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const int shift = rs_shift(p), width = rs_width(p);
+    const unsigned long long np = (st.prefix[seg] << width) | (unsigned long long)s_res[0];
+    const uint32_t nrem = rem - s_res[1], bucket = s_res[2];
+    if (bucket == nrem || p == 5) {  // the whole bucket is wanted (or the composite is pinned down to its last bit)
+      st.thr[seg] = ((np + 1ull) << shift) - 1ull;
+      st.flag[seg] = 1u;
+      atomicSub(st.n_open, 1);
+    } else {
+      st.prefix[seg] = np;
+      st.rem[seg] = nrem;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rs_collect(const unsigned long long* __restrict__ keys, int64_t n, RsState st, int k, unsigned long long* __restrict__ list) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long key = i < n ? keys[i] : ~0ULL;
+  const uint32_t seg = (uint32_t)(key >> 32);
+  const unsigned long long C = (key << 32) | (unsigned long long)(uint32_t)i;
+  const bool ok = key != ~0ULL && C <= st.thr[seg];
+  const uint32_t pos = wave_agg_add(st.cursor, ok ? seg : 0u, ok);
+  if (ok && pos < (uint32_t)k) list[(size_t)seg * k + pos] = C;
+}
+
+// one block per segment: sort the <= k collected composites, emit them in pnx_decode_boxes' layout
+__global__ __launch_bounds__(256) void k_rs_sort(const unsigned long long* __restrict__ list, RsState st, int k, unsigned long long* __restrict__ sorted_keys,
+                                                 int64_t* __restrict__ order, int64_t* __restrict__ seg_start, int32_t* __restrict__ seg_len,
+                                                 int32_t* __restrict__ seg_total) {
+  __shared__ unsigned long long s_a[kRsMaxK];
+  const int s = blockIdx.x, t = threadIdx.x;
+  const int n = (int)min(st.cursor[s], (uint32_t)k);
+  int n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  for (int i = t; i < n2; i += 256) s_a[i] = i < n ? list[(size_t)s * k + i] : ~0ULL;
+  __syncthreads();
+  if (n2 > 1) bitonic_lds(s_a, n2, t);
+  const unsigned long long segbits = (unsigned long long)(uint32_t)s << 32;
+  for (int j = t; j < n; j += 256) {
+    const unsigned long long v = s_a[j];
+    sorted_keys[(int64_t)s * k + j] = segbits | (v >> 32);
+    order[(int64_t)s * k + j] = (int64_t)(uint32_t)v;
+  }
+  if (t == 0) {
+    seg_start[s] = (int64_t)s * k;
+    seg_len[s] = n;
+    if (seg_total != nullptr) seg_total[s] = (int32_t)st.total[s];
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t pnx_decode_topk_workspace_bytes(int64_t n_keys, int32_t num_segments) {
   if (n_keys < 0 || num_segments < 1) return 0;
-  return pnx_align_up((size_t)num_segments * kBins * 4, 256) + 4 * pnx_align_up((size_t)(num_segments + 8) * 4, 256) + pnx_align_up((size_t)(n_keys + 8) * 8, 256);
+  const size_t nchunks = (size_t)((n_keys + kRsChunk - 1) / kRsChunk) + 1;
+  const size_t S = (size_t)num_segments;
+  return pnx_align_up(nchunks * kRsSlots * kRsBins * 4, 256) + pnx_align_up(nchunks * kRsSlots * 4, 256) + pnx_align_up(S * kRsBins * 4, 256) +
+         2 * pnx_align_up((S + 8) * 8, 256) + 5 * pnx_align_up((S + 8) * 4, 256) + pnx_align_up(S * kRsMaxK * 8, 256) + 256;
 }
 
 // keys = the concatenated outputs of pnx_decode_keys for all tasks; outputs in the layout pnx_decode_boxes consumes
 int pnx_decode_topk(const uint64_t* keys, int64_t n_keys, int32_t num_segments, int32_t pre_max, uint64_t* sorted_keys, int64_t* order, int64_t* seg_start,
-                    int32_t* seg_len, void* workspace, size_t workspace_bytes, pnx_stream_t stream) {
+                    int32_t* seg_len, int32_t* seg_total, void* workspace, size_t workspace_bytes, pnx_stream_t stream) {
   PNX_REQUIRE(keys && sorted_keys && order && seg_start && seg_len && workspace, PNX_ERR_INVALID, "null pointer");
-  PNX_REQUIRE(n_keys >= 0 && n_keys < ((int64_t)1 << 32) && num_segments >= 1 && pre_max >= 1 && pre_max <= kSortCap / 2, PNX_ERR_INVALID,
-              "bad sizes (pre_max <= %d)", kSortCap / 2);
+  PNX_REQUIRE(n_keys >= 0 && n_keys < ((int64_t)1 << 32) && num_segments >= 1 && pre_max >= 1 && pre_max <= kRsMaxK, PNX_ERR_INVALID,
+              "bad sizes (pre_max <= %d)", kRsMaxK);
   PNX_REQUIRE(workspace_bytes >= pnx_decode_topk_workspace_bytes(n_keys, num_segments), PNX_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
+  const int S = num_segments;
+  const int nchunks = (int)((n_keys + kRsChunk - 1) / kRsChunk);
   PnxCarver c(workspace);
-  uint32_t* hist = c.take<uint32_t>((size_t)num_segments * kBins);
-  int32_t* tb = c.take<int32_t>(num_segments + 8);
-  uint32_t* need = c.take<uint32_t>(num_segments + 8);
-  uint32_t* base = c.take<uint32_t>(num_segments + 8);
-  uint32_t* cursor = c.take<uint32_t>(num_segments + 8);
-  unsigned long long* list = c.take<unsigned long long>(n_keys + 8);
-  PNX_CHECK_HIP(hipMemsetAsync(hist, 0, (size_t)num_segments * kBins * 4, st));
+  uint32_t* rows = c.take<uint32_t>((size_t)(nchunks + 1) * kRsSlots * kRsBins);
+  int32_t* slotseg = c.take<int32_t>((size_t)(nchunks + 1) * kRsSlots);
+  uint32_t* ovf = c.take<uint32_t>((size_t)S * kRsBins);
+  RsState rs;
+  rs.prefix = c.take<unsigned long long>(S + 8);
+  rs.thr = c.take<unsigned long long>(S + 8);
+  rs.rem = c.take<uint32_t>(S + 8);
+  rs.flag = c.take<uint32_t>(S + 8);
+  rs.total = c.take<uint32_t>(S + 8);
+  rs.cursor = c.take<uint32_t>(S + 8);
+  rs.n_open = c.take<int32_t>(S + 8);
+  unsigned long long* list = c.take<unsigned long long>((size_t)S * kRsMaxK);
+  PNX_CHECK_HIP(hipMemsetAsync(ovf, 0, (size_t)S * kRsBins * 4, st));
+  k_rs_init<<<(S + 255) / 256, 256, 0, st>>>(rs, S, pre_max);
+  for (int p = 0; p < 6; p++) {
+    if (nchunks > 0) k_rs_hist<<<nchunks, kRsThreads, 0, st>>>((const unsigned long long*)keys, n_keys, p, rs, slotseg, rows, ovf);
+    k_rs_select<<<S, 256, 0, st>>>(p, rs, slotseg, nchunks * kRsSlots, rows, ovf);
+  }
   const unsigned nb = (unsigned)((n_keys + 255) / 256);
-  if (nb > 0) k_topk_hist<<<nb, 256, 0, st>>>((const unsigned long long*)keys, n_keys, hist);
-  k_topk_select<<<num_segments, 256, 0, st>>>(hist, pre_max, tb, need);
-  k_topk_offsets<<<1, 256, 0, st>>>(need, num_segments, base, cursor);
-  if (nb > 0) k_topk_collect<<<nb, 256, 0, st>>>((const unsigned long long*)keys, n_keys, tb, base, cursor, list);
-  k_topk_sort<<<num_segments, 256, 0, st>>>(list, base, need, pre_max, (unsigned long long*)sorted_keys, order, seg_start, seg_len);
+  if (nb > 0) k_rs_collect<<<nb, 256, 0, st>>>((const unsigned long long*)keys, n_keys, rs, pre_max, list);
+  k_rs_sort<<<S, 256, 0, st>>>(list, rs, pre_max, (unsigned long long*)sorted_keys, order, seg_start, seg_len, seg_total);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

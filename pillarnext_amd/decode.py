@@ -51,7 +51,7 @@ class PackedDecoder:
         # selection (tests/test_gpu_decode.py), but OFF by default: with a freshly initialised head half of all cells pass the score
         # threshold and tens of thousands of them tie at one quantised score, so every segment sorts ~40 k candidates in LDS chunks --
         # measured 6.4 ms per 8-frame step against 1.06 ms for the sort; it pays once candidates are a few percent of the cells.
-        self.use_topk = os.environ.get("PNX_DECODE_TOPK", "0") == "1"
+        self.use_topk = os.environ.get("PNX_DECODE_TOPK", "1") == "1"
         self.use_torch_sort = os.environ.get("PNX_DECODE_TORCH_SORT", "0") == "1"   # the generic 64-bit torch.sort (cross-check)
         self._sort_ws = None
         self._tptr = {}
@@ -99,8 +99,8 @@ class PackedDecoder:
             self._dev[ck] = (tdesc, koff, seg_off, thr, bounds)
         tdesc, koff, seg_off, thr, bounds = self._dev[ck]
         if self.use_topk and self.pre_max <= 4096:
-            # segmented top-k in HIP (csrc/decode.hip): per-segment score histogram -> threshold bin -> collect -> LDS sort; the
-            # 6 M-key device sort (rocprim onesweep, ~0.5 ms per 8 frames) is gone
+            # segmented top-k in HIP (csrc/decode.hip): exact radix select on (score key, key index) -> collect -> LDS sort of the <= pre_max
+            # survivors of every list; no device sort of all keys, no searchsorted
             n_rows0 = S * self.pre_max
             skeys = torch.empty((n_rows0,), dtype=torch.int64, device=dev)
             order = torch.empty((n_rows0,), dtype=torch.int64, device=dev)
@@ -109,7 +109,7 @@ class PackedDecoder:
             wsb = int(L.pnx_decode_topk_workspace_bytes(offs[-1], S)) + 256
             if self._topk_ws is None or self._topk_ws.numel() < wsb or self._topk_ws.device != dev:
                 self._topk_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            check(L.pnx_decode_topk(ptr(keys), offs[-1], S, self.pre_max, ptr(skeys), ptr(order), ptr(seg_start), ptr(seg_len), ptr(self._topk_ws),
+            check(L.pnx_decode_topk(ptr(keys), offs[-1], S, self.pre_max, ptr(skeys), ptr(order), ptr(seg_start), ptr(seg_len), None, ptr(self._topk_ws),
                                     self._topk_ws.numel(), stream_ptr()), "pnx_decode_topk")
         elif self.use_torch_sort:
             # keys are non-negative when valid ... as int64 the all-ones key is -1: sort as unsigned by flipping the sign bit
@@ -227,19 +227,34 @@ class PackedDecoder:
             jj = torch.arange(self.pre_max, device=dev, dtype=torch.int64)
             self._dev[ck] = (tdesc, koff, seg_off, thr, bounds, segs, kofs, jj)
         tdesc, koff, seg_off, thr, bounds, segs, kofs, jj = self._dev[ck]
-        skeys = torch.empty_like(keys)
-        order = torch.empty_like(keys)
-        wsb = int(L.pnx_sort_keys_workspace_bytes(offs[-1]))
-        if self._sort_ws is None or self._sort_ws.numel() < wsb or self._sort_ws.device != dev:
-            self._sort_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        check(L.pnx_sort_keys(ptr(keys), offs[-1], S, ptr(skeys), ptr(order), ptr(self._sort_ws), self._sort_ws.numel(), stream_ptr()), "pnx_sort_keys")
-        seg_start = torch.searchsorted(skeys ^ (-0x8000000000000000), bounds)
-        seg_total = (seg_start[1:] - seg_start[:-1]).to(torch.int32)
-        seg_len = torch.clamp(seg_total, max=self.pre_max)
-        # candidate cells per slot (s, j): local index b*H*W + cell inside the slot's task
-        pos = torch.clamp(seg_start[:S, None] + jj[None, :], max=offs[-1] - 1)
-        valid = jj[None, :] < seg_len[:, None]
-        local = order[pos] - kofs[:, None]
+        if self.use_topk and self.pre_max <= 4096:
+            n_rows0 = S * self.pre_max
+            skeys = torch.empty((n_rows0,), dtype=torch.int64, device=dev)
+            order = torch.zeros((n_rows0,), dtype=torch.int64, device=dev)     # slots behind seg_len are read (and ignored) by the evaluator's glue
+            seg_start = torch.empty((S,), dtype=torch.int64, device=dev)
+            seg_len = torch.empty((S,), dtype=torch.int32, device=dev)
+            seg_total = torch.empty((S,), dtype=torch.int32, device=dev)
+            wsb = int(L.pnx_decode_topk_workspace_bytes(offs[-1], S)) + 256
+            if self._topk_ws is None or self._topk_ws.numel() < wsb or self._topk_ws.device != dev:
+                self._topk_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            check(L.pnx_decode_topk(ptr(keys), offs[-1], S, self.pre_max, ptr(skeys), ptr(order), ptr(seg_start), ptr(seg_len), ptr(seg_total),
+                                    ptr(self._topk_ws), self._topk_ws.numel(), stream_ptr()), "pnx_decode_topk")
+            valid = jj[None, :] < seg_len[:, None]
+            local = torch.where(valid, order.view(S, self.pre_max) - kofs[:, None], torch.zeros_like(kofs[:, None]))
+        else:
+            skeys = torch.empty_like(keys)
+            order = torch.empty_like(keys)
+            wsb = int(L.pnx_sort_keys_workspace_bytes(offs[-1]))
+            if self._sort_ws is None or self._sort_ws.numel() < wsb or self._sort_ws.device != dev:
+                self._sort_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            check(L.pnx_sort_keys(ptr(keys), offs[-1], S, ptr(skeys), ptr(order), ptr(self._sort_ws), self._sort_ws.numel(), stream_ptr()), "pnx_sort_keys")
+            seg_start = torch.searchsorted(skeys ^ (-0x8000000000000000), bounds)
+            seg_total = (seg_start[1:] - seg_start[:-1]).to(torch.int32)
+            seg_len = torch.clamp(seg_total, max=self.pre_max)
+            # candidate cells per slot (s, j): local index b*H*W + cell inside the slot's task
+            pos = torch.clamp(seg_start[:S, None] + jj[None, :], max=offs[-1] - 1)
+            valid = jj[None, :] < seg_len[:, None]
+            local = order[pos] - kofs[:, None]
         n_rows = S * self.pre_max
         cand = evaluator(local, seg_len, valid, segs)                          # (S, pre_max, 10) fp32
         boxes9 = torch.empty((n_rows, 9), dtype=torch.float32, device=dev)

@@ -236,24 +236,32 @@ def test_training_step_end_to_end():
     assert torch.isfinite(loss2)
 
 
-def test_segmented_topk_equals_the_full_stable_sort():
-    """pnx_decode_topk (score histogram -> threshold bin -> collect -> LDS sort) must select and order exactly what one stable sort of
-    all keys + the [:pre_max] cut gives, including ties (bf16 head outputs quantise the scores) and segments with fewer / far more
-    candidates than pre_max."""
-    import ctypes
-
+@pytest.mark.parametrize("layout,pre_max,n", [("mixed", 1000, 900_000), ("blocked", 1000, 900_000), ("blocked", 4096, 1_300_000), ("blocked", 83, 5_000),
+                                               ("all_equal", 1000, 400_000), ("all_valid", 500, 300_000)])
+def test_segmented_topk_equals_the_full_stable_sort(layout, pre_max, n):
+    """pnx_decode_topk (exact radix select on (score key, index) -> collect -> LDS sort) must select and order exactly what one stable sort of
+    all keys + the [:pre_max] cut gives, including ties (bf16 head outputs quantise the scores), segments with fewer / far more candidates
+    than pre_max, an empty segment and a segment whose scores are ALL equal.  layout "mixed": every chunk holds keys of all 23 segments (the
+    global-atomic overflow path of the histogram pass); "blocked": segments own contiguous key ranges, as pnx_decode_keys lays them out;
+    "all_equal": every valid key of every segment carries the same score (the index digits decide everything); "all_valid": a fresh head."""
     from pillarnext_amd._lib import check, lib, ptr, stream_ptr
 
     L = lib()
     g = torch.Generator(device="cuda").manual_seed(4)
-    S, pre_max, n = 23, 1000, 900_000
-    seg = torch.randint(0, S, (n,), device="cuda", generator=g)
+    S = 23
+    if layout == "mixed":
+        seg = torch.randint(0, S, (n,), device="cuda", generator=g)
+    else:                                                                    # (sample, task) blocks of two classes each, like the head's maps
+        blk = torch.arange(n, device="cuda") * 12 // n
+        seg = (blk * 2 + torch.randint(0, 2, (n,), device="cuda", generator=g)).clamp(max=S - 1)
     seg[seg == 5] = 6                                                        # an empty segment
     sc = torch.rand((n,), device="cuda", generator=g) * 0.9 + 0.1
     sc = sc.to(torch.bfloat16).float()                                       # heavy ties
     sc[seg == 7] = 0.5                                                       # one segment: ALL scores equal (tens of thousands of ties)
+    if layout == "all_equal":
+        sc[:] = 0.25
     few = (seg == 9).nonzero().flatten()
-    valid = torch.rand((n,), device="cuda", generator=g) < 0.08
+    valid = torch.rand((n,), device="cuda", generator=g) < (1.1 if layout in ("all_valid", "all_equal") else 0.08)
     valid[few[40:]] = False                                                  # a segment with fewer candidates than pre_max
     low = (0xFFFFFFFF - sc.view(torch.int32).to(torch.int64))
     keys = torch.where(valid, (seg.to(torch.int64) << 32) | low, torch.full_like(low, -1))
@@ -262,20 +270,25 @@ def test_segmented_topk_equals_the_full_stable_sort():
     skeys = skeys ^ (-0x8000000000000000)
     bounds = (torch.arange(S + 1, device="cuda", dtype=torch.int64) << 32) ^ (-0x8000000000000000)
     st = torch.searchsorted(skeys ^ (-0x8000000000000000), bounds)
-    ln = torch.clamp(st[1:] - st[:-1], max=pre_max)
+    tot = st[1:] - st[:-1]
+    ln = torch.clamp(tot, max=pre_max)
     out_k = torch.empty((S * pre_max,), dtype=torch.int64, device="cuda")
     out_o = torch.empty((S * pre_max,), dtype=torch.int64, device="cuda")
     out_s = torch.empty((S,), dtype=torch.int64, device="cuda")
     out_l = torch.empty((S,), dtype=torch.int32, device="cuda")
+    out_t = torch.empty((S,), dtype=torch.int32, device="cuda")
     ws = torch.empty(int(L.pnx_decode_topk_workspace_bytes(n, S)) + 256, dtype=torch.uint8, device="cuda")
-    check(L.pnx_decode_topk(ptr(keys), n, S, pre_max, ptr(out_k), ptr(out_o), ptr(out_s), ptr(out_l), ptr(ws), ws.numel(), stream_ptr()), "pnx_decode_topk")
-    assert torch.equal(out_l.long(), ln) and int(ln[5]) == 0 and int(ln[9]) <= 40
-    for s in range(S):
-        k = int(ln[s])
-        a0 = int(st[s])
-        assert torch.equal(out_o[s * pre_max: s * pre_max + k], order[a0: a0 + k]), s
-        assert torch.equal(out_k[s * pre_max: s * pre_max + k], skeys[a0: a0 + k]), s
-        assert int(out_s[s]) == s * pre_max
+    for rep in range(2):                                                     # the workspace is reused from call to call
+        check(L.pnx_decode_topk(ptr(keys), n, S, pre_max, ptr(out_k), ptr(out_o), ptr(out_s), ptr(out_l), ptr(out_t), ptr(ws), ws.numel(), stream_ptr()),
+              "pnx_decode_topk")
+        assert torch.equal(out_l.long(), ln) and int(ln[5]) == 0 and int(ln[9]) <= 40
+        assert torch.equal(out_t.long(), tot)
+        for s in range(S):
+            k = int(ln[s])
+            a0 = int(st[s])
+            assert torch.equal(out_o[s * pre_max: s * pre_max + k], order[a0: a0 + k]), (rep, s)
+            assert torch.equal(out_k[s * pre_max: s * pre_max + k], skeys[a0: a0 + k]), (rep, s)
+            assert int(out_s[s]) == s * pre_max
 
 
 @pytest.mark.parametrize("S", [23, 31, 32, 80])
