@@ -44,8 +44,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PNX_BENCH_BATCH", "8")),
-                    help="frames per GPU per step (measured on one MI355X: 4 -> 292, 8 -> 325, 16 -> 326 frames/s)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PNX_BENCH_BATCH", "12")),
+                    help="frames per GPU per step (round 3, one MI355X, same box: 8 -> 569, 12 -> 595, 16 -> 598 frames/s; the reader is at its best at 12)")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--dist", default="sweep", choices=["uniform", "sweep"],
                     help="sweep = ring-structured 10-sweep cloud (BASELINE configs[1]); uniform = worst case, ~1.2 points per pillar")
