@@ -355,6 +355,28 @@ int pnx_gather_kept(const float* boxes9, const float* scores, const int32_t* kee
                     int32_t pre_max, int32_t post_max, float* out, pnx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Train-mode BatchNorm over the ACTIVE sites of a dense NHWC map (the reference: BatchNorm1d on the features of a SparseConvTensor,
+ * det3d/models/utils/sparse_conv.py:31-37,57-60) fused with the residual add, ReLU and the active-site mask, forward and backward.
+ * x, residual, y, gy, dx, dresidual: (n_sites, channels) bf16 or fp32 (channels_last maps); mask fp32[n_sites], 0 = inactive (never read,
+ * written as zeros); channels in {8,16,32,64,128,256}.
+ *   stats      partials fp32 [pnx_masked_bn_blocks()][2*channels + 1]: per workgroup sum x | sum x^2 | active sites -- the caller adds the rows
+ *              (fp64), all-reduces them under SyncBatchNorm (tools/train.py:56), forms mean / invstd and
+ *              scale = gamma * invstd, shift = beta - mean * scale
+ *   apply      y = [relu](x * scale + shift [+ residual]) at the active sites
+ *   bwd_stats  partials fp32 [blocks][2*channels]: sum g | sum g * xhat with g = gy * [pre-activation > 0], xhat = (x - mean) * invstd
+ *   bwd_apply  dx = scale * (g - mean_g - xhat * mean_gx), dresidual (optional) = g; mean_g = sum g / count, mean_gx = sum g*xhat / count */
+int32_t pnx_masked_bn_blocks(void);
+int pnx_masked_bn_stats(const void* x, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels, float* partials, pnx_stream_t stream);
+int pnx_masked_bn_apply(const void* x, const void* residual, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels, const float* scale,
+                        const float* shift, int32_t relu, void* y, pnx_stream_t stream);
+int pnx_masked_bn_bwd_stats(const void* gy, const void* x, const void* residual, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels,
+                            const float* scale, const float* shift, const float* mean, const float* invstd, int32_t relu, float* partials,
+                            pnx_stream_t stream);
+int pnx_masked_bn_bwd_apply(const void* gy, const void* x, const void* residual, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels,
+                            const float* scale, const float* shift, const float* mean, const float* invstd, int32_t relu, const float* mean_g,
+                            const float* mean_gx, void* dx, void* dresidual, pnx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * CenterHead training losses over the (B, M) label lists of ONE task, forward and backward (csrc/center_loss.hip):
  * det3d/models/loss/centerloss.py FastFocalLoss :8-37, RegLoss :40-60 (NaN-target rule :55-56), IouLoss :63-87 (target 2*IoU3D-1 from the
  * aligned rotated IoU), IouRegLoss :90-110 + DIoU :139-176, as combined by det3d/models/heads/centerhead.py:142-229; labels in the format

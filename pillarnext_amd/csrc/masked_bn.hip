@@ -1,0 +1,253 @@
+// masked_bn.hip -- train-mode BatchNorm over the ACTIVE sites of a dense NHWC map + residual + ReLU + mask, forward and backward, gfx950.
+//
+// The reference normalises the features of a SparseConvTensor with BatchNorm1d (det3d/models/utils/sparse_conv.py:31-37, 57-60: statistics
+// over the active sites only); this package's masked-dense stand-in did that with ~12 PyTorch elementwise / reduction passes over full fp32
+// maps in the forward and as many in the backward (models._MaskedBNActFn): 212 of the 341 ms of a C2 x 4-frame bf16 training step, although
+// only 17-30 % of the cells are active.  Here:
+//   stats       one pass over the active sites: per channel sum x, sum x^2 (fp32 partials per workgroup, summed in fp64 by the caller), count
+//   apply       y = relu(x * a + b [+ residual]) at the active sites, zeros elsewhere          (a = gamma * invstd, b = beta - mean * a)
+//   bwd_stats   g = gy * [pre > 0] at the active sites (pre recomputed from x): per channel sum g, sum g * xhat
+//   bwd_apply   dx = a * (g - mean_g - xhat * mean_gx) at the active sites, zeros elsewhere; dresidual = g
+// Inactive sites are never read.  Between stats and apply the caller (models.py) all-reduces the sums under SyncBatchNorm
+// (tools/train.py:56) and updates the running statistics.  One thread = 8 consecutive channels of one site (16 bytes of bf16).
+#include "pnx_common.h"
+
+namespace {
+
+constexpr int kMbnBlocks = 1024;
+
+template <typename T>
+struct Ld8;
+template <>
+struct Ld8<uint16_t> {  // bf16
+  static __device__ __forceinline__ void load(const uint16_t* p, float (&v)[8]) {
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[2 * k] = __uint_as_float(w[k] << 16), v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+  }
+  static __device__ __forceinline__ uint32_t rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+  }
+  static __device__ __forceinline__ void store(uint16_t* p, const float (&v)[8]) {
+    uint4 q;
+    q.x = rne(v[0]) | (rne(v[1]) << 16), q.y = rne(v[2]) | (rne(v[3]) << 16), q.z = rne(v[4]) | (rne(v[5]) << 16), q.w = rne(v[6]) | (rne(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = q;
+  }
+};
+template <>
+struct Ld8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+
+// sums of NV vectors of 8 channels per thread -> partials[block][NV * C (+1: count)]: threads with equal channel chunk are added up
+template <int NV>
+__device__ __forceinline__ void block_reduce(const float (&acc)[NV][8], float cnt, bool with_cnt, int cvec, int C, float* __restrict__ out) {
+  __shared__ float s_red[256 * 8];
+  __shared__ float s_cnt[256];
+  const int t = threadIdx.x, chunk = t % cvec, rows = 256 / cvec;
+  for (int v = 0; v < NV; v++) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; k++) s_red[t * 8 + k] = acc[v][k];
+    if (v == 0) s_cnt[t] = cnt;
+    __syncthreads();
+    if (t < cvec * 8) {  // (chunk c, channel k) = t / 8, t % 8
+      const int c = t >> 3, k = t & 7;
+      float s = 0.f;
+      for (int r = 0; r < rows; r++) s += s_red[(r * cvec + c) * 8 + k];
+      out[v * C + c * 8 + k] = s;
+    }
+    if (v == 0 && with_cnt && t == 0) {
+      float s = 0.f;
+      for (int r = 0; r < rows; r++) s += s_cnt[r * cvec];  // chunk-0 threads counted the sites
+      out[NV * C] = s;
+    }
+  }
+  (void)chunk;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_mbn_stats(const T* __restrict__ x, const float* __restrict__ mask, int64_t n, int C, float* __restrict__ partials) {
+  const int cvec = C >> 3, t = threadIdx.x, chunk = t % cvec, rows = 256 / cvec;
+  float acc[2][8] = {};
+  float cnt = 0.f;
+  for (int64_t site = (int64_t)blockIdx.x * rows + t / cvec; site < n; site += (int64_t)gridDim.x * rows) {
+    if (mask[site] == 0.f) continue;
+    float v[8];
+    Ld8<T>::load(x + site * C + chunk * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[0][k] += v[k], acc[1][k] += v[k] * v[k];
+    if (chunk == 0) cnt += 1.f;
+  }
+  block_reduce<2>(acc, cnt, true, cvec, C, partials + (size_t)blockIdx.x * (2 * C + 1));
+}
+
+template <typename T, bool HAS_RES>
+__global__ __launch_bounds__(256) void k_mbn_apply(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ mask, int64_t n, int C,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift, int relu, T* __restrict__ y) {
+  const int cvec = C >> 3;
+  const int64_t nvec = n * cvec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t site = i / cvec;
+    const int c0 = (int)(i - site * cvec) * 8;
+    float o[8] = {};
+    if (mask[site] != 0.f) {
+      float v[8], r[8] = {};
+      Ld8<T>::load(x + site * C + c0, v);
+      if (HAS_RES) Ld8<T>::load(res + site * C + c0, r);
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        float p = v[k] * scale[c0 + k] + shift[c0 + k] + r[k];
+        o[k] = relu ? fmaxf(p, 0.f) : p;
+      }
+    }
+    Ld8<T>::store(y + site * C + c0, o);
+  }
+}
+
+// g of one (site, chunk): gy gated by the recomputed pre-activation; xh = (x - mean) * invstd
+template <typename T, bool HAS_RES>
+__device__ __forceinline__ void bwd_terms(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ res, int64_t off, int c0,
+                                          const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                                          const float* __restrict__ invstd, int relu, float (&g)[8], float (&xh)[8]) {
+  float v[8], r[8] = {};
+  Ld8<T>::load(gy + off, g);
+  Ld8<T>::load(x + off, v);
+  if (HAS_RES) Ld8<T>::load(res + off, r);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const float pre = v[k] * scale[c0 + k] + shift[c0 + k] + r[k];
+    if (relu && !(pre > 0.f)) g[k] = 0.f;
+    xh[k] = (v[k] - mean[c0 + k]) * invstd[c0 + k];
+  }
+}
+
+template <typename T, bool HAS_RES>
+__global__ __launch_bounds__(256) void k_mbn_bwd_stats(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ res,
+                                                       const float* __restrict__ mask, int64_t n, int C, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       int relu, float* __restrict__ partials) {
+  const int cvec = C >> 3, t = threadIdx.x, chunk = t % cvec, rows = 256 / cvec;
+  float acc[2][8] = {};
+  for (int64_t site = (int64_t)blockIdx.x * rows + t / cvec; site < n; site += (int64_t)gridDim.x * rows) {
+    if (mask[site] == 0.f) continue;
+    float g[8], xh[8];
+    bwd_terms<T, HAS_RES>(gy, x, res, site * C + chunk * 8, chunk * 8, scale, shift, mean, invstd, relu, g, xh);
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[0][k] += g[k], acc[1][k] += g[k] * xh[k];
+  }
+  block_reduce<2>(acc, 0.f, false, cvec, C, partials + (size_t)blockIdx.x * (2 * C));
+}
+
+template <typename T, bool HAS_RES>
+__global__ __launch_bounds__(256) void k_mbn_bwd_apply(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ res,
+                                                       const float* __restrict__ mask, int64_t n, int C, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       int relu, const float* __restrict__ mg, const float* __restrict__ mgx, T* __restrict__ dx,
+                                                       T* __restrict__ gres) {
+  const int cvec = C >> 3;
+  const int64_t nvec = n * cvec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t site = i / cvec;
+    const int c0 = (int)(i - site * cvec) * 8;
+    float d[8] = {}, g[8] = {};
+    if (mask[site] != 0.f) {
+      float xh[8];
+      bwd_terms<T, HAS_RES>(gy, x, res, site * C + c0, c0, scale, shift, mean, invstd, relu, g, xh);
+#pragma unroll
+      for (int k = 0; k < 8; k++) d[k] = scale[c0 + k] * (g[k] - mg[c0 + k] - xh[k] * mgx[c0 + k]);
+    }
+    Ld8<T>::store(dx + site * C + c0, d);
+    if (gres != nullptr) Ld8<T>::store(gres + site * C + c0, g);
+  }
+}
+
+bool mbn_shape_ok(int C) {
+  const int cvec = C >> 3;
+  return C % 8 == 0 && cvec >= 1 && cvec <= 32 && 256 % cvec == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t pnx_masked_bn_blocks(void) { return kMbnBlocks; }
+
+#define MBN_COMMON_CHECKS                                                                                                        \
+  PNX_REQUIRE(x && mask && n_sites > 0 && mbn_shape_ok(channels), PNX_ERR_INVALID, "bad arguments (channels %d: 8, 16, 32, 64, 128 or 256)", channels); \
+  PNX_REQUIRE(dtype == PNX_BF16 || dtype == PNX_F32, PNX_ERR_INVALID, "dtype %d: bf16 or fp32", dtype);                          \
+  PNX_REQUIRE(n_sites < ((int64_t)1 << 40), PNX_ERR_INVALID, "too many sites");                                                  \
+  hipStream_t st = (hipStream_t)stream;
+
+int pnx_masked_bn_stats(const void* x, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels, float* partials, pnx_stream_t stream) {
+  MBN_COMMON_CHECKS
+  PNX_REQUIRE(partials != nullptr, PNX_ERR_INVALID, "partials is NULL");
+  if (dtype == PNX_BF16) k_mbn_stats<uint16_t><<<kMbnBlocks, 256, 0, st>>>((const uint16_t*)x, mask, n_sites, channels, partials);
+  else k_mbn_stats<float><<<kMbnBlocks, 256, 0, st>>>((const float*)x, mask, n_sites, channels, partials);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+int pnx_masked_bn_apply(const void* x, const void* residual, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels, const float* scale,
+                        const float* shift, int32_t relu, void* y, pnx_stream_t stream) {
+  MBN_COMMON_CHECKS
+  PNX_REQUIRE(scale && shift && y, PNX_ERR_INVALID, "null pointer");
+  const int64_t nvec = n_sites * (channels / 8);
+  const unsigned nb = (unsigned)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+#define GO(T, R) k_mbn_apply<T, R><<<nb, 256, 0, st>>>((const T*)x, (const T*)residual, mask, n_sites, channels, scale, shift, relu, (T*)y)
+  if (dtype == PNX_BF16) {
+    if (residual) GO(uint16_t, true); else GO(uint16_t, false);
+  } else {
+    if (residual) GO(float, true); else GO(float, false);
+  }
+#undef GO
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+int pnx_masked_bn_bwd_stats(const void* gy, const void* x, const void* residual, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels,
+                            const float* scale, const float* shift, const float* mean, const float* invstd, int32_t relu, float* partials,
+                            pnx_stream_t stream) {
+  MBN_COMMON_CHECKS
+  PNX_REQUIRE(gy && scale && shift && mean && invstd && partials, PNX_ERR_INVALID, "null pointer");
+#define GO(T, R) k_mbn_bwd_stats<T, R><<<kMbnBlocks, 256, 0, st>>>((const T*)gy, (const T*)x, (const T*)residual, mask, n_sites, channels, scale, shift, mean, invstd, relu, partials)
+  if (dtype == PNX_BF16) {
+    if (residual) GO(uint16_t, true); else GO(uint16_t, false);
+  } else {
+    if (residual) GO(float, true); else GO(float, false);
+  }
+#undef GO
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+int pnx_masked_bn_bwd_apply(const void* gy, const void* x, const void* residual, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels,
+                            const float* scale, const float* shift, const float* mean, const float* invstd, int32_t relu, const float* mean_g,
+                            const float* mean_gx, void* dx, void* dresidual, pnx_stream_t stream) {
+  MBN_COMMON_CHECKS
+  PNX_REQUIRE(gy && scale && shift && mean && invstd && mean_g && mean_gx && dx, PNX_ERR_INVALID, "null pointer");
+  const int64_t nvec = n_sites * (channels / 8);
+  const unsigned nb = (unsigned)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+#define GO(T, R) k_mbn_bwd_apply<T, R><<<nb, 256, 0, st>>>((const T*)gy, (const T*)x, (const T*)residual, mask, n_sites, channels, scale, shift, mean, invstd, relu, mean_g, mean_gx, (T*)dx, (T*)dresidual)
+  if (dtype == PNX_BF16) {
+    if (residual) GO(uint16_t, true); else GO(uint16_t, false);
+  } else {
+    if (residual) GO(float, true); else GO(float, false);
+  }
+#undef GO
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+}  // extern "C"

@@ -98,8 +98,88 @@ class _MaskedBNActFn(torch.autograd.Function):
     forward and [sum g, sum g*xhat] backward over the ACTIVE sites of the global batch (dist_utils.all_reduce_sum)."""
 
     @staticmethod
+    def _hip_ok(x, residual):
+        """The fused HIP kernels (csrc/masked_bn.hip) take channels_last bf16 / fp32 CUDA maps with 8..256 channels."""
+        C = x.shape[1]
+        return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and C in (8, 16, 32, 64, 128, 256)
+                and x.is_contiguous(memory_format=torch.channels_last) and os.environ.get("PNX_MASKED_BN_HIP", "1") != "0"
+                and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
+                                          and residual.is_contiguous(memory_format=torch.channels_last))))
+
+    @staticmethod
+    def _forward_hip(ctx, x, m, weight, bias, residual, norm, relu):
+        from ._lib import check, lib, ptr, stream_ptr
+
+        L = lib()
+        B, C, H, W = x.shape
+        n = B * H * W
+        dt = ops._DT[x.dtype]
+        nblk = int(L.pnx_masked_bn_blocks())
+        part = torch.empty((nblk, 2 * C + 1), dtype=torch.float32, device=x.device)
+        mflat = m.reshape(-1)
+        check(L.pnx_masked_bn_stats(ptr(x), dt, ptr(mflat), n, C, ptr(part), stream_ptr()), "pnx_masked_bn_stats")
+        s = part.double().sum(0)                                            # [sum x | sum x^2 | count]
+        group = norm.sync_group if norm.sync else False
+        if group is not False:
+            from .dist_utils import all_reduce_sum
+
+            all_reduce_sum(s, group)
+        cnt = s[-1].clamp(min=1.0)
+        mean = s[:C] / cnt
+        var = (s[C:2 * C] / cnt - mean * mean).clamp(min=0.0)
+        invstd = torch.rsqrt(var + norm.eps)
+        with torch.no_grad():
+            mom = norm.momentum
+            norm.running_mean.mul_(1 - mom).add_(mean.to(norm.running_mean.dtype), alpha=mom)
+            norm.running_var.mul_(1 - mom).add_((var * cnt / (cnt - 1).clamp(min=1.0)).to(norm.running_var.dtype), alpha=mom)
+            norm.num_batches_tracked += 1
+        scale = (invstd * weight.double()).float().contiguous()
+        shift = (bias.double() - mean * invstd * weight.double()).float().contiguous()
+        mean32, invstd32, cnt32 = mean.float().contiguous(), invstd.float().contiguous(), cnt.float()
+        y = torch.empty_like(x)
+        check(L.pnx_masked_bn_apply(ptr(x), ptr(residual), dt, ptr(mflat), n, C, ptr(scale), ptr(shift), 1 if relu else 0, ptr(y), stream_ptr()),
+              "pnx_masked_bn_apply")
+        ctx.save_for_backward(x, m, weight, bias, residual, mean32, invstd32, cnt32, scale, shift)
+        ctx.group, ctx.relu, ctx.hip = group, relu, True
+        return y
+
+    @staticmethod
+    def _backward_hip(ctx, gy):
+        from ._lib import check, lib, ptr, stream_ptr
+
+        L = lib()
+        x, m, weight, bias, residual, mean, invstd, cnt, scale, shift = ctx.saved_tensors
+        B, C, H, W = x.shape
+        n = B * H * W
+        dt = ops._DT[x.dtype]
+        gy = gy.to(x.dtype)
+        if not gy.is_contiguous(memory_format=torch.channels_last):
+            gy = gy.contiguous(memory_format=torch.channels_last)
+        mflat = m.reshape(-1)
+        nblk = int(L.pnx_masked_bn_blocks())
+        part = torch.empty((nblk, 2 * C), dtype=torch.float32, device=x.device)
+        relu = 1 if ctx.relu else 0
+        check(L.pnx_masked_bn_bwd_stats(ptr(gy), ptr(x), ptr(residual), dt, ptr(mflat), n, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), relu, ptr(part),
+                                        stream_ptr()), "pnx_masked_bn_bwd_stats")
+        sg = part.double().sum(0)
+        dbeta, dgamma = sg[:C].clone(), sg[C:].clone()                      # parameter gradients: local sums (DDP averages them)
+        if ctx.group is not False:
+            from .dist_utils import all_reduce_sum
+
+            all_reduce_sum(sg, ctx.group)
+        mg, mgx = (sg[:C] / cnt.double()).float().contiguous(), (sg[C:] / cnt.double()).float().contiguous()
+        dx = torch.empty_like(x)
+        gres = torch.empty_like(residual) if residual is not None and ctx.needs_input_grad[4] else None
+        check(L.pnx_masked_bn_bwd_apply(ptr(gy), ptr(x), ptr(residual), dt, ptr(mflat), n, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), relu, ptr(mg),
+                                        ptr(mgx), ptr(dx), ptr(gres), stream_ptr()), "pnx_masked_bn_bwd_apply")
+        return dx, None, dgamma.to(weight.dtype), dbeta.to(bias.dtype), gres, None, None
+
+    @staticmethod
     def forward(ctx, x, mask, weight, bias, residual, norm, relu):
         m = mask if mask.dtype == torch.float32 else mask.float()
+        if _MaskedBNActFn._hip_ok(x, residual):
+            return _MaskedBNActFn._forward_hip(ctx, x, m.contiguous(), weight, bias, residual, norm, relu)
+        ctx.hip = False
         xf = x.float()
         s1 = torch.cat([(xf * m).sum(dim=(0, 2, 3)), m.sum().view(1)])
         group = norm.sync_group if norm.sync else False
@@ -132,6 +212,8 @@ class _MaskedBNActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if ctx.hip:
+            return _MaskedBNActFn._backward_hip(ctx, gy)
         x, m, weight, bias, residual, mean, invstd, cnt = ctx.saved_tensors
         xhat = (x.float() - mean.view(1, -1, 1, 1)).mul_(invstd.view(1, -1, 1, 1))
         g = gy.float() * m
