@@ -236,6 +236,78 @@ def test_training_step_end_to_end():
     assert torch.isfinite(loss2)
 
 
+def test_training_graph_on_the_fused_masked_bn_kernels(monkeypatch):
+    """The training graph with the masked BatchNorm + residual + ReLU node on the HIP kernels (csrc/masked_bn.hip; channels_last maps) against
+    the same detector with the node in its torch statement:
+      fp32:  channels_last + HIP kernels  vs  NCHW + torch node -- same loss to 1e-5, every parameter gradient within 4 % norm-wise (what is left
+             is MIOpen running other fp32 solvers for NHWC than for NCHW; measured 0.5-2 %)
+      bf16:  autocast + channels_last, HIP kernels  vs  the torch node in the same graph -- loss within 0.5 %, gradients within the run-to-run
+             spread of two bf16 graphs that round differently (measured values are printed with -s)
+    and, for the record, bf16 against fp32 (a freshly initialised 30-layer net with batch statistics over two frames amplifies bf16 rounding:
+    the loss agrees to 2 %, gradient directions to cos ~0.8; reported, bounded loosely).  Gradients whose norm is below 1e-3 of the largest one
+    (convolution biases in front of a BatchNorm: exactly zero in exact arithmetic) are skipped."""
+    import copy
+
+    from pillarnext_amd import synth
+    from pillarnext_amd.models import build_pillarnext_b
+
+    cfg = synth.CONFIGS["C1"]
+    torch.manual_seed(0)
+    tasks = [["car"], ["pedestrian", "cyclist"]]
+    ref = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"], tasks=tasks).cuda().train()
+    B, M = 2, 16
+    pts = torch.from_numpy(synth.make_batch("C1", B, "sweep", n=12000)).cuda()
+    H = W = 512 // 4
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    ex = {"points": pts, "batch_size": B, "hm": [], "ind": [], "mask": [], "cat": [], "anno_box": [], "gt_boxes": []}
+    for names in tasks:
+        ex["hm"].append(torch.rand((B, len(names), H, W), device="cuda", generator=gen) * 0.2)
+        ex["ind"].append(torch.randint(0, H * W, (B, M), device="cuda", generator=gen))
+        m = torch.zeros((B, M), dtype=torch.uint8, device="cuda")
+        m[:, :6] = 1
+        ex["mask"].append(m)
+        ex["cat"].append(torch.randint(0, len(names), (B, M), device="cuda", generator=gen))
+        ex["anno_box"].append(torch.randn((B, M, 10), device="cuda", generator=gen) * 0.3)
+        ex["gt_boxes"].append(torch.rand((B, M, 7), device="cuda", generator=gen) + torch.tensor([0, 0, -1, 1.5, 0.6, 1.2, 0], device="cuda"))
+
+    def run(model, amp):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            loss, _ = model(ex)
+        loss.backward()
+        return float(loss), {n: p.grad.double().flatten() for n, p in model.named_parameters() if p.grad is not None}
+
+    def compare(tag, ga, gb):
+        big = max(float(v.norm()) for v in ga.values())
+        worst_rel, worst_cos = 0.0, 1.0
+        for n, a in ga.items():
+            b = gb[n]
+            assert bool(torch.isfinite(b).all()), n
+            if float(a.norm()) < 1e-3 * big:
+                continue
+            rel = float((a - b).norm()) / float(a.norm())
+            cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+            worst_rel, worst_cos = max(worst_rel, rel), min(worst_cos, cos)
+        print(f"[train-graph] {tag}: worst relative L2 error of a gradient tensor {worst_rel:.4f}, worst cosine {worst_cos:.5f}")
+        return worst_rel, worst_cos
+
+    l_ref, g_ref = run(ref, False)                                            # fp32, NCHW: torch node
+    l_n, g_n = run(copy.deepcopy(ref).to(memory_format=torch.channels_last), False)   # fp32, channels_last: HIP kernels
+    print(f"[train-graph] loss fp32 NCHW {l_ref:.6f}, fp32 channels_last/HIP {l_n:.6f}")
+    assert abs(l_n - l_ref) <= 1e-5 * abs(l_ref)
+    r, c = compare("fp32 HIP vs fp32 torch", g_ref, g_n)
+    assert r <= 0.04 and c >= 0.999
+    l_a, g_a = run(copy.deepcopy(ref).to(memory_format=torch.channels_last), True)    # bf16 autocast: HIP kernels
+    monkeypatch.setenv("PNX_MASKED_BN_HIP", "0")
+    l_t, g_t = run(copy.deepcopy(ref).to(memory_format=torch.channels_last), True)    # bf16 autocast: torch node
+    monkeypatch.delenv("PNX_MASKED_BN_HIP")
+    print(f"[train-graph] loss bf16 HIP {l_a:.5f}, bf16 torch node {l_t:.5f}")
+    assert abs(l_a - l_t) <= 5e-3 * abs(l_t) and abs(l_a - l_ref) <= 2e-2 * abs(l_ref)
+    r, c = compare("bf16 HIP vs bf16 torch", g_t, g_a)
+    r2, c2 = compare("bf16 torch vs fp32", g_ref, g_t)
+    r3, c3 = compare("bf16 HIP vs fp32", g_ref, g_a)
+    assert r <= max(1.25 * r2, 0.1) and c3 >= min(c2 - 0.1, 0.9) and c3 >= 0.5
+
+
 @pytest.mark.parametrize("layout,pre_max,n", [("mixed", 1000, 900_000), ("blocked", 1000, 900_000), ("blocked", 4096, 1_300_000), ("blocked", 83, 5_000),
                                                ("all_equal", 1000, 400_000), ("all_valid", 500, 300_000)])
 def test_segmented_topk_equals_the_full_stable_sort(layout, pre_max, n):
