@@ -156,10 +156,18 @@ def serving_loop(model, examples, steps, upload=None):
     """`steps` frame batches through the fused graph; batch i+1 is enqueued before the host blocks on (and unpacks) the detections of
     batch i, and every batch's detections are on the host, as dicts, before this returns."""
     pending, out = None, None
+    # PNX_BENCH_PREFETCH=1: the reader of batch i+1 goes to a side stream before batch i's network is enqueued (FusedPillarNeXt.prefetch).
+    # Measured: 571-575 against 580-582 frames/s without it (the convolution workgroups hold the CUs' LDS, the reader's kernels are stretched
+    # over 4.5 ms instead of 0.87 and slow the convolutions down by more than they gain) -- off by default.
+    pre = upload is None and hasattr(model, "prefetch") and os.environ.get("PNX_BENCH_PREFETCH", "0") == "1"
+    if pre and steps > 0:
+        model.prefetch(examples[0])
     for i in range(steps):
         ex = examples[i % len(examples)]
         if upload is not None:
             ex = upload(i)
+        if pre and i + 1 < steps:
+            model.prefetch(examples[(i + 1) % len(examples)])
         nxt = model.forward_async(ex)
         if pending is not None:
             out = model.detections(pending.result())

@@ -827,6 +827,7 @@ class FusedPillarNeXt(nn.Module):
         if hip_conv is None:
             hip_conv = os.environ.get("PNX_HIP_CONV", "1") != "0"
         self._ws = {}
+        self._prefetched, self._rd_stream, self._rd_direct = {}, None, None   # prefetch(): readers enqueued on the side stream
         self.sparse_ws = os.environ.get("PNX_SPARSE_WS", "1") != "0"
         self.tile_lists = os.environ.get("PNX_TILE_LISTS", "1") != "0"
         self.reader = det.reader
@@ -968,6 +969,31 @@ class FusedPillarNeXt(nn.Module):
         self.lazy_head = self.lazy_head and all(self._lazy_ok)
 
     @torch.no_grad()
+    def prefetch(self, example, ready=None):
+        """Enqueue the READER of a later batch on a side stream, so that it runs beside the convolutions of the batch in flight (they are
+        latency-bound and leave HBM mostly idle; the reader is the opposite).  The following forward_async / forward_preds call with the
+        same `points` tensor picks the canvas up.  `ready`: a torch.cuda.Event after which the points are valid (None: they are resident)."""
+        pts, B = example["points"], int(example["batch_size"])
+        if self.sparse0 or not pts.is_cuda:
+            return
+        if self._rd_stream is None:
+            self._rd_stream = torch.cuda.Stream(device=pts.device)
+        side = self._rd_stream
+        if ready is not None:
+            side.wait_event(ready)
+        if self._rd_direct is not None:
+            side.wait_event(self._rd_direct)
+            self._rd_direct = None
+        ny, nx = (int(v) for v in self.reader.grid_size)
+        with torch.cuda.stream(side):
+            occ = torch.empty((B, ny, nx), dtype=torch.uint8, device=pts.device)
+            x = self.reader.forward_dense(pts, B, dtype=self.dtype, occupancy=occ)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        pts.record_stream(side)
+        self._prefetched[pts.data_ptr()] = (x, occ, ev)
+
+    @torch.no_grad()
     def forward_preds(self, points, batch_size, marks=None, packed_out=None, taps=None, lazy=None):
         """packed_out: a list that receives, per task, the packed NHWC head output -- or, with the lazy head (lazy=None: the model's
         setting), a LazyTask (dense [iou] hm map + deblocked features) for launch_decode()."""
@@ -982,11 +1008,24 @@ class FusedPillarNeXt(nn.Module):
         occ = torch.empty((batch_size, ny, nx), dtype=torch.uint8, device=points.device)
         sparse = self.sparse0 and taps is None
         sp = None
-        if sparse:
+        pf = self._prefetched.pop(points.data_ptr(), None) if self._prefetched else None
+        if pf is not None and not sparse:
+            # the reader of this batch was enqueued on the side stream by prefetch(): wait for it, hand its tensors to this stream
+            x, occ, ev = pf
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            x.record_stream(cur)
+            occ.record_stream(cur)
+        elif sparse:
             # the reader's sparse result (feature rows + occupancy words) feeds the first stage directly: no dense 1440 x 1440 x 64 canvas
             x, wfull, wpr = self.reader.forward_rows(points, batch_size, dtype=self.dtype, occupancy=occ)
         else:
+            if self._rd_stream is not None:       # the reader's workspace is shared with the side stream's calls: keep them in order
+                torch.cuda.current_stream().wait_stream(self._rd_stream)
             x = self.reader.forward_dense(points, batch_size, dtype=self.dtype, occupancy=occ)
+            if self._rd_stream is not None:
+                self._rd_direct = torch.cuda.Event()
+                self._rd_direct.record()
         mark("reader")
         mask = occ
         for si, (mods, (stride, subm)) in enumerate(zip(self.stages, self.stage_meta)):
