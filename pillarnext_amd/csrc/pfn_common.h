@@ -32,6 +32,7 @@ struct Pfn3Out {
   int64_t g1_rows;
   void* canvas;  // NHWC canvas or null
   int dt;        // PNX_F32 / PNX_BF16 / PNX_F16
+  const int32_t* row_of = nullptr;  // k_pfn3_tail behind pfn_spans.hip: feat_max row of a spill id (null: the pillar id is the row)
 };
 
 __device__ __forceinline__ uint32_t bf16_rne(float f) {

@@ -161,8 +161,9 @@ __device__ __forceinline__ void pfn3_big_pillar(const int r, const BigWeights<F>
       for (int half2 = 0; half2 < 2; half2++) {
         const float* v = half2 ? vb : va;
         const int chan0 = 32 * half2 + 8 * j + 4 * h;
-        if (out.g1 != nullptr && (int64_t)r < out.g1_rows)
-          *reinterpret_cast<float4*>(out.g1 + (int64_t)r * 64 + chan0) = make_float4(v[0], v[1], v[2], v[3]);
+        const int64_t grow = out.row_of != nullptr ? (int64_t)out.row_of[r] : (int64_t)r;
+        if (out.g1 != nullptr && grow < out.g1_rows)
+          *reinterpret_cast<float4*>(out.g1 + grow * 64 + chan0) = make_float4(v[0], v[1], v[2], v[3]);
         if (out.canvas != nullptr) {
           if (out.dt == PNX_F32) {
             *reinterpret_cast<float4*>(reinterpret_cast<float*>(out.canvas) + cell * 64 + chan0) = make_float4(v[0], v[1], v[2], v[3]);
@@ -593,12 +594,13 @@ int pnx_launch_pfn_v3(int F, const uint32_t* rec64, const uint32_t* pfirst, cons
 // points (biglist[0, bigcap), counters[3]) or a tile outside the fp16x3 range (biglist[bigcap, 2 bigcap), counters[4]).
 int pnx_launch_pfn3_tail(int F, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar, int32_t* counters,
                          const int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows, void* canvas, int canvas_dt, int blocks,
-                         hipStream_t st) {
+                         hipStream_t st, const int32_t* row_of) {
   Pfn3Out out;
   out.g1 = g1;
   out.g1_rows = g1_rows;
   out.canvas = canvas;
   out.dt = canvas_dt;
+  out.row_of = row_of;
   const uint4* rec = reinterpret_cast<const uint4*>(rec64);
   const int bc = (int)(bigcap > 0x7fffffff ? 0x7fffffff : bigcap);
   switch (F) {

@@ -95,3 +95,78 @@ __device__ __forceinline__ void pnx_fill_share(const PnxFillJob& j, const PnxGeo
   else if (j.dt == PNX_BF16) pnx_fill_share_dt<PNX_BF16>(j, g, s_word, t, nthreads);
   else pnx_fill_share_dt<PNX_F16>(j, g, s_word, t, nthreads);
 }
+
+// ---- the same tiles, read from an occupancy BYTE map in canvas order (cell = (b*gy + yi)*gx + xi, one byte per cell, 0 / 1): what
+// k_chunk_sort (chunk_sort.hip) leaves behind -- normally straight in the caller's occupancy output, so nothing is written here
+// beside the zeros.  `s_row` is 32 words of LDS: bit x of word y = cell (x0 + x, y0 + y) is occupied (or outside the grid).
+template <int DT, bool NT>
+__device__ __forceinline__ void pnx_fill_tile_bytes(const uint8_t* __restrict__ bytemap, const PnxGeomDev& g, void* __restrict__ canvas, int tile,
+                                                    uint32_t* s_row, int t, int nthreads) {
+  constexpr int ESZ = (DT == PNX_F32) ? 4 : 2;
+  constexpr int CH = 64 * ESZ / 16;  // 16-byte chunks per cell
+  const int tiles_x = (g.gx + 31) >> 5, tiles_y = (g.gy + 31) >> 5;
+  const int tx = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty = tile % tiles_y, b = tile / tiles_y;
+  const int x0 = tx << 5, y0 = ty << 5;
+  const int rows = min(32, g.gy - y0);
+  if (t < 256) {  // thread -> (row t >> 3, cells 4 (t & 7) .. + 3); the eight lanes of a row OR their nibbles together
+    const int yl = t >> 3, part = t & 7, xs = x0 + 4 * part;
+    uint32_t nib = 0xFu;
+    if (yl < rows) {
+      const int64_t at = ((int64_t)b * g.gy + (y0 + yl)) * g.gx + xs;
+      if (xs + 4 <= g.gx && ((reinterpret_cast<uintptr_t>(bytemap) + (uintptr_t)at) & 3) == 0) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(bytemap + at);
+        nib = ((v * 0x00204081u) >> 21) & 0xFu;  // 4 bytes (0/1) -> 4 bits
+      } else {
+        nib = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) nib |= ((xs + i < g.gx) ? (uint32_t)(bytemap[at + i] & 1u) : 1u) << i;
+      }
+    }
+    uint32_t w = nib << (4 * part);
+    w |= (uint32_t)__shfl_xor((int)w, 1);
+    w |= (uint32_t)__shfl_xor((int)w, 2);
+    w |= (uint32_t)__shfl_xor((int)w, 4);
+    if (part == 0) s_row[yl] = w;
+  }
+  __syncthreads();
+  uint4* out = reinterpret_cast<uint4*>(canvas);
+  for (int idx = t; idx < rows * 32 * CH; idx += nthreads) {
+    const int q = idx % CH;
+    const int xl = (idx / CH) & 31;
+    const int yl = idx / (CH * 32);
+    if ((s_row[yl] >> xl) & 1u) continue;
+    const int64_t cell = ((int64_t)b * g.gy + (y0 + yl)) * g.gx + (x0 + xl);
+    if (NT) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(u32x4{0u, 0u, 0u, 0u}, reinterpret_cast<u32x4*>(out + cell * CH + q));
+    } else {
+      out[cell * CH + q] = make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+
+static inline int pnx_fill_tiles_bytes(const PnxGeomDev& g) { return ((g.gx + 31) / 32) * ((g.gy + 31) / 32) * g.B; }
+
+struct PnxByteFillJob {
+  const uint8_t* bytemap;
+  void* canvas;
+  int32_t* counter;  // zero before the launch
+  int tiles, nt;
+};
+
+// persistent: tiles by ticket, in canvas order (a compact front of neighbouring tiles: 6.5-6.8 TB/s alone against 5.6 for one block
+// per tile or a static deal -- tools/microbench/fill_bw.hip)
+template <int DT>
+__device__ __forceinline__ void pnx_fill_bytes_share(const PnxByteFillJob& j, const PnxGeomDev& g, uint32_t* s_row /* 33 words */, int t, int nthreads) {
+  for (;;) {
+    if (t == 0) s_row[32] = (uint32_t)atomicAdd(j.counter, 1);
+    __syncthreads();
+    const int k = (int)s_row[32];
+    if (k >= j.tiles) break;  // block-uniform
+    if (j.nt) pnx_fill_tile_bytes<DT, true>(j.bytemap, g, j.canvas, k, s_row, t, nthreads);
+    else pnx_fill_tile_bytes<DT, false>(j.bytemap, g, j.canvas, k, s_row, t, nthreads);
+    __syncthreads();  // s_row is rewritten by the next tile
+  }
+}

@@ -25,6 +25,7 @@
 #include "pnx_common.h"
 #include "pnx_scan.h"
 #include "pnx_fill.h"
+#include "spans.h"
 
 namespace {
 
@@ -589,6 +590,40 @@ __global__ __launch_bounds__(kBlock) void k_scatter_list(const float* __restrict
     reinterpret_cast<uint16_t*>(canvas)[o] = (uint16_t)f32_to_f16_rne(v);
 }
 
+// ---- span path helpers (chunk_sort.hip + pfn_spans.hip)
+// zeroes the reader's counter block and the occupancy bytes in ONE launch (two hipMemsetAsync calls = two launches + their gap)
+__global__ __launch_bounds__(kBlock) void k_clear2(uint4* __restrict__ a, int64_t na16, uint8_t* __restrict__ b, int64_t nb) {
+  const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x, gsz = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = gid; i < na16; i += gsz) a[i] = make_uint4(0, 0, 0, 0);
+  if (nb <= 0) return;
+  int64_t head = (int64_t)((16 - (reinterpret_cast<uintptr_t>(b) & 15)) & 15);
+  head = head < nb ? head : nb;
+  for (int64_t i = gid; i < head; i += gsz) b[i] = 0;
+  uint4* bb = reinterpret_cast<uint4*>(b + head);
+  const int64_t n16 = (nb - head) >> 4;
+  for (int64_t i = gid; i < n16; i += gsz) bb[i] = make_uint4(0, 0, 0, 0);
+  for (int64_t i = head + (n16 << 4) + gid; i < nb; i += gsz) b[i] = 0;
+}
+
+// the zero-fill tiles of pnx_fill.h read from occupancy bytes, as a kernel of its own (a call without points; experiments)
+template <int DT>
+__global__ __launch_bounds__(kBlock) void k_canvas_fill_bytes(PnxByteFillJob fj, GeomDev g) {
+  __shared__ uint32_t s_row[36];
+  pnx_fill_bytes_share<DT>(fj, g, s_row, threadIdx.x, kBlock);
+}
+
+// rank outputs of the span path: pillar rank of every point (== unq_inv of the reference for kept points, pe:110-111)
+__global__ __launch_bounds__(kBlock) void k_point_rank(const int32_t* __restrict__ key, int64_t n, const uint2* __restrict__ wcomb,
+                                                       const uint32_t* __restrict__ wblk, int32_t* __restrict__ rank_out,
+                                                       int32_t* __restrict__ pillar_of_point) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int32_t k = key[i];
+  const int32_t r = k >= 0 ? cell_rank2(k, wcomb, wblk) : -1;
+  rank_out[i] = r;
+  if (pillar_of_point) pillar_of_point[i] = r;
+}
+
 // ------------------------------------------------------------------------------------------ host side
 // Optional event timing (pnx_profile_begin/end).
 constexpr int kEv = 8;
@@ -628,15 +663,29 @@ struct ReaderWs {
   uint32_t* rec64;               // pillar-sorted decorated records, 64 B per kept point
   uint32_t *pfirst, *pcnt;       // first sorted slot / number of points of every pillar
   uint2* wcomb;                  // {bitmap word, popcount prefix} pairs
+  // span path (chunk_sort.hip + pfn_spans.hip, PNX_READER_IMPL=4, default)
+  SpanGeom sg;
+  uint4* srecs;                  // chunk-sorted 32-byte records
+  uint16_t* stab;                // run table
+  int32_t* srowframe;
+  uint32_t* srowbase;
+  int32_t *frame_lo, *frame_hi;
+  uint32_t* slab_tot;
+  uint2* span_desc;
+  int32_t* nspan;
+  int32_t* row_of;               // feat_max row per spill id
+  uint8_t* cbytes;               // occupancy bytes in canvas order (when the caller passes no occupancy output)
+  size_t zero_bytes_span;        // counters | tick | frame_lo | frame_hi
   size_t bytes;
 };
 
 // PNX_READER_IMPL: 1 = round-1 pipeline, 2 = binned grouping + k_bin_sort + k_pfn3 (records through HBM), 3 (default) = binned grouping +
-// k_bin_pfn (pfn_bins.hip: sort and PFN in LDS).  Read on every call: the workspace layout follows it.
+// k_bin_pfn (pfn_bins.hip: sort and PFN in LDS), 4 (default) = chunk sort + span PFN (chunk_sort.hip, pfn_spans.hip).  Read on every call:
+// the workspace layout follows it.
 int reader_impl() {
   const char* e = getenv("PNX_READER_IMPL");
-  const int v = e ? atoi(e) : 3;
-  return v >= 1 && v <= 3 ? v : 3;
+  const int v = e ? atoi(e) : 4;
+  return v >= 1 && v <= 4 ? v : 4;
 }
 
 int64_t cells_padded(const pnx_geom* g, int32_t batch) {
@@ -657,6 +706,9 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   if (w.nblk_k < 1) w.nblk_k = 1;
   w.counters = c.take<int32_t>(64);
   w.tick = c.take<int32_t>(24 * 32);  // 16 window-ticket words (word 0: bin tickets of pfn_bins.hip) + 5 fill-share counters, one 128-byte line each
+  w.frame_lo = c.take<int32_t>(batch);
+  w.frame_hi = c.take<int32_t>(batch);
+  w.zero_bytes_span = c.used();
   w.bytemap = c.take<uint8_t>(cells + 64);
   w.zero_bytes2 = c.used();            // binned path: counters | tick | bytemap
   w.count = c.take<uint32_t>(w.pcap + 8);
@@ -685,7 +737,7 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   // 1024 threads) so that the (bin x workgroup) matrix stays ~2.5 M entries (measured: 256 chunks x 1024 threads 148 us of grouping at
   // C2 / 8 frames, 128 x 1024 165 us).
   const char* sh_env = getenv("PNX_BIN_SH");  // experiment: bins of 2^sh pillars
-  if (reader_impl() == 3) {
+  if (reader_impl() >= 3) {
     w.sh = 8;
     while (w.sh < 11 && ((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh) > 16384) w.sh++;
     if (sh_env && atoi(sh_env) >= 8 && atoi(sh_env) <= 11) w.sh = atoi(sh_env);
@@ -723,9 +775,34 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   w.pfirst = c.take<uint32_t>(w.pcap + 8);
   w.pcnt = c.take<uint32_t>(w.pcap + 8);
   w.wcomb = c.take<uint2>(w.nwords + 8);
+  // span path: chunks of kChunk points, one table row per chunk + a pool that covers the worst case (every chunk holds every frame)
+  {
+    const int64_t cpf = (int64_t)g->gx * g->gy;
+    w.sg.cpf = (int)cpf;
+    w.sg.nf = (int)((cpf + kSlabCells - 1) >> kSlabShift);
+    w.sg.tabw = (w.sg.nf + 2) & ~1;
+    w.sg.nchunks = (int)((n + kChunk - 1) / kChunk);
+    w.sg.ovf_cap = w.sg.nchunks * (batch - 1);
+    w.sg.B = batch;
+    const int q_env = getenv("PNX_SPAN_QUOTA") ? atoi(getenv("PNX_SPAN_QUOTA")) : 0, s_env = getenv("PNX_SPAN_SOLO") ? atoi(getenv("PNX_SPAN_SOLO")) : -1;
+    w.sg.quota = q_env >= 32 ? q_env : kSpanQuota;
+    w.sg.solo = s_env >= 0 ? s_env : kSpanSolo;
+    const int64_t rows = (int64_t)w.sg.nchunks + w.sg.ovf_cap;
+    w.srecs = c.take<uint4>(((int64_t)w.sg.nchunks * kChunk + 8) * 2);
+    w.stab = c.take<uint16_t>(rows * w.sg.tabw + 8);
+    w.srowframe = c.take<int32_t>(rows + 8);
+    w.srowbase = c.take<uint32_t>(rows + 8);
+    w.slab_tot = c.take<uint32_t>((int64_t)batch * w.sg.nf + 8);
+    w.span_desc = c.take<uint2>((int64_t)batch * (w.sg.nf + 1) + 8);
+    w.nspan = c.take<int32_t>(batch + 8);
+    w.row_of = c.take<int32_t>(w.pcap + 8);
+    w.cbytes = c.take<uint8_t>((int64_t)batch * cpf + 64);
+  }
   w.bytes = c.used();
   return w;
 }
+
+inline int64_t cells_of(const GeomDev& g) { return (int64_t)g.B * g.gx * g.gyp; }
 
 GeomDev make_geom(const pnx_geom* g, int32_t batch) {
   GeomDev d;
@@ -883,12 +960,138 @@ int pnx_launch_bin_pfn(int F, const uint32_t* binbuf, const uint32_t* hpre, cons
                        void* canvas, int canvas_dt, int64_t n_points, int n_fill, const PnxGeomDev& geom, const PnxFillJob& fj, hipStream_t st);
 int pnx_launch_pfn3_tail(int F, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar, int32_t* counters,
                          const int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows, void* canvas, int canvas_dt, int blocks,
-                         hipStream_t st);
+                         hipStream_t st, const int32_t* row_of = nullptr);
 
 // implemented in pfn_train.hip
 int pnx_launch_pfn_train(int F, int pass, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* counters,
                          const float* prm, float* part, const float* G, const float* out_saved, float* out, int64_t out_rows, hipStream_t st);
 int pnx_pfn_train_blocks(void);
+
+// implemented in chunk_sort.hip / pfn_spans.hip: the one-pass grouping front end and its consumer (spans.h)
+int pnx_launch_chunk_sort(const float* points, int64_t n, int stride, const PnxGeomDev& g, const SpanGeom& sg, uint4* recs, uint16_t* tab,
+                          int32_t* rowframe, uint32_t* rowbase, int32_t* counters, int32_t* frame_lo, int32_t* frame_hi, uint8_t* bytemap,
+                          uint32_t* slab_tot, uint2* span_desc, int32_t* nspan, hipStream_t st);
+int pnx_launch_span_pfn(int F, const SpanTables& T, const SpanGeom& sg, int32_t* counters, int32_t* tick, uint32_t* rec64,
+                        uint32_t* pfirst, uint32_t* pcnt, int32_t* cell_of_pillar, int32_t* row_of, int32_t* biglist, int64_t bigcap, int64_t idcap,
+                        const uint2* wcomb, const uint32_t* wblk, int32_t* coords, int64_t pillar_capacity, const float* folded, float* g1,
+                        int64_t g1_rows, void* canvas, int canvas_dt, int64_t n_points, int n_fill, const PnxByteFillJob& fj, const PnxGeomDev& geom,
+                        hipStream_t st);
+
+namespace {
+// PNX_READER_IMPL=4 (default): chunk sort -> span PFN (+ zero-fill tiles in the same launch) -> tail.  Canvas-only calls (the
+// detector's path) never build the key-order bitmap; the rank outputs (feat_max / coords / unq_inv / pillar_of_point, an NCHW canvas)
+// add the bitmap chain of the older pipelines beside it.
+int reader_forward_spans(const float* points, int64_t n, int32_t stride, const GeomDev& gd, const ReaderWs& w, const float* pfn_folded, void* canvas,
+                         int32_t canvas_dtype, int32_t canvas_layout, uint8_t* occupancy, float* feat_max, int32_t* coords, int64_t pillar_capacity,
+                         int64_t* unq_inv, int32_t* pillar_of_point, int32_t* counts, hipStream_t st) {
+  const int F = stride - 1;
+  const bool direct = canvas != nullptr && canvas_layout == PNX_NHWC;
+  const bool ranked = feat_max != nullptr || coords != nullptr || unq_inv != nullptr || pillar_of_point != nullptr || (canvas != nullptr && !direct);
+  float* g1 = nullptr;
+  int64_t g1_rows = 0;
+  if (feat_max != nullptr || (canvas != nullptr && !direct)) {
+    g1 = (feat_max && pillar_capacity >= w.pcap) ? feat_max : w.g1;
+    g1_rows = (g1 == feat_max) ? pillar_capacity : w.pcap;
+  }
+  const size_t canvas_bytes = (size_t)gd.B * gd.gx * gd.gy * 64 * (canvas_dtype == PNX_F32 ? 4 : 2);
+  const char* nt_env = getenv("PNX_FILL_NT");
+  const bool fill_nt = nt_env ? nt_env[0] == '1' : canvas_bytes >= ((size_t)3 << 29);
+  uint8_t* cbytes = direct ? (occupancy != nullptr ? occupancy : w.cbytes) : nullptr;
+  const int64_t ncb = cbytes != nullptr ? (int64_t)gd.B * w.sg.cpf : 0;
+  int rc;
+  prof_mark(0, st);
+  {
+    const int64_t work = (int64_t)(w.zero_bytes_span >> 4) + (ncb >> 4) + 64;
+    int blocks = (int)((work + kBlock * 8 - 1) / (kBlock * 8));
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    k_clear2<<<blocks, kBlock, 0, st>>>(reinterpret_cast<uint4*>(w.counters), (int64_t)(w.zero_bytes_span >> 4), cbytes, ncb);
+    PNX_LAUNCH_CHECK();
+  }
+  if (ranked) {  // the key-order bitmap and its popcount prefix: the pillar rank of a cell == torch.unique(dim=0) order (pe:110)
+    PNX_CHECK_HIP(hipMemsetAsync(w.bytemap, 0, (size_t)cells_of(gd) + 64, st));
+    if (n > 0) {
+      k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bytemap, nullptr);
+      PNX_LAUNCH_CHECK();
+    }
+    k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk, w.wcomb, nullptr, nullptr);
+    k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
+    PNX_LAUNCH_CHECK();
+  }
+  rc = pnx_launch_chunk_sort(points, n, stride, gd, w.sg, w.srecs, w.stab, w.srowframe, w.srowbase, w.counters, w.frame_lo, w.frame_hi, cbytes, w.slab_tot,
+                             w.span_desc, w.nspan, st);
+  if (rc != PNX_OK) return rc;
+  prof_mark(6, st);
+  PnxByteFillJob fj;
+  fj.bytemap = cbytes, fj.canvas = canvas, fj.counter = w.tick + 16 * 32, fj.tiles = direct ? pnx_fill_tiles_bytes(gd) : 0, fj.nt = fill_nt ? 1 : 0;
+  const char* fb_env = getenv("PNX_FILL_BLOCKS");
+  int n_fill = direct ? (fb_env ? atoi(fb_env) : 256) : 0;
+  // PNX_FILL_SIDE=1: the zero-fill as its own launch (a few hundred bytes of LDS per workgroup) on a second stream beside the span
+  // kernel, instead of blocks of the span launch that each hold the span kernel's 80 KB of LDS
+  static hipStream_t fside = nullptr;
+  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  const char* fs_env = getenv("PNX_FILL_SIDE");
+  const bool side = direct && n_fill > 0 && fs_env && fs_env[0] == '1';
+  if (side && fside == nullptr) {
+    int lo = 0, hi = 0;
+    PNX_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const char* pr_env = getenv("PNX_FILL_PRIO");
+    PNX_CHECK_HIP(hipStreamCreateWithPriority(&fside, hipStreamNonBlocking, pr_env && pr_env[0] == 'h' ? hi : (pr_env && pr_env[0] == 'l' ? lo : 0)));
+    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
+  SpanTables T;
+  T.recs = w.srecs, T.tab = w.stab, T.rowframe = w.srowframe, T.rowbase = w.srowbase, T.frame_lo = w.frame_lo, T.frame_hi = w.frame_hi;
+  T.span_desc = w.span_desc, T.nspan = w.nspan;
+  prof_mark(4, st);
+  prof_mark(1, st);
+  if (side) {
+    PNX_CHECK_HIP(hipEventRecord(ev_fork, st));
+    PNX_CHECK_HIP(hipStreamWaitEvent(fside, ev_fork, 0));
+    if (canvas_dtype == PNX_F32) k_canvas_fill_bytes<PNX_F32><<<n_fill, kBlock, 0, fside>>>(fj, gd);
+    else if (canvas_dtype == PNX_BF16) k_canvas_fill_bytes<PNX_BF16><<<n_fill, kBlock, 0, fside>>>(fj, gd);
+    else k_canvas_fill_bytes<PNX_F16><<<n_fill, kBlock, 0, fside>>>(fj, gd);
+    PNX_LAUNCH_CHECK();
+    PNX_CHECK_HIP(hipEventRecord(ev_join, fside));
+    n_fill = 0;
+  }
+  rc = pnx_launch_span_pfn(F, T, w.sg, w.counters, w.tick, w.rec64, w.pfirst, w.pcnt, w.cell, w.row_of, w.biglist, w.bigcap, w.pcap,
+                           ranked ? w.wcomb : nullptr, w.wblk, coords, pillar_capacity, pfn_folded, g1, g1_rows, direct ? canvas : nullptr, canvas_dtype, n,
+                           n_fill, fj, gd, st);
+  if (rc != PNX_OK) return rc;
+  if (side) PNX_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
+  if (n > 0) {
+    static const int tb = getenv("PNX_TAIL_BLOCKS") ? atoi(getenv("PNX_TAIL_BLOCKS")) : 128;
+    rc = pnx_launch_pfn3_tail(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.biglist, w.bigcap, pfn_folded, g1, g1_rows, direct ? canvas : nullptr,
+                              canvas_dtype, tb, st, ranked ? w.row_of : nullptr);
+    if (rc != PNX_OK) return rc;
+  }
+  prof_mark(5, st);
+  prof_mark(2, st);
+  if (feat_max && g1 != feat_max) {  // caller's buffer is smaller than the worst case: copy what fits (P is unknown on the host)
+    PNX_CHECK_HIP(hipMemcpyAsync(feat_max, g1, (size_t)(pillar_capacity < w.pcap ? pillar_capacity : w.pcap) * 64 * sizeof(float),
+                                 hipMemcpyDeviceToDevice, st));
+  }
+  if (canvas != nullptr && !direct) {
+    if (canvas_dtype == PNX_F32) rc = launch_canvas<PNX_F32>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
+    else if (canvas_dtype == PNX_BF16) rc = launch_canvas<PNX_BF16>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
+    else rc = launch_canvas<PNX_F16>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
+    if (rc != PNX_OK) return rc;
+  }
+  if (n > 0 && (unq_inv != nullptr || pillar_of_point != nullptr)) {
+    k_point_rank<<<nblocks(n), kBlock, 0, st>>>(w.key, n, w.wcomb, w.wblk, w.rank, pillar_of_point);
+    if (unq_inv) {
+      k_scan_local<SCAN_KEPT><<<w.nblk_k, kBlock, 0, st>>>(reinterpret_cast<const uint32_t*>(w.key), n, w.kpre, w.kblk);
+      k_scan_blocks<<<1, kBlock, 0, st>>>(w.kblk, w.nblk_k, nullptr);
+      k_write_inv<<<nblocks(n), kBlock, 0, st>>>(w.rank, n, w.kpre, w.kblk, unq_inv);
+    }
+    PNX_LAUNCH_CHECK();
+  }
+  if (counts) PNX_CHECK_HIP(hipMemcpyAsync(counts, w.counters, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  prof_mark(3, st);
+  if (g_prof.on && g_prof.n < g_prof.cap) g_prof.n++;
+  return PNX_OK;
+}
+}  // namespace
 
 namespace {
 // Sparse view of the voxelization for the backbone's first stage (conv3x3.hip: k_subm64_sparse, k_conv3x3_s2 with gathered input):
@@ -956,7 +1159,15 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   // default 3: binned grouping, then ONE launch sorts every bin in LDS and runs the PFN on it (pfn_bins.hip).
   const char* impl_env = getenv("PNX_PFN_IMPL");
   const int impl = impl_env ? atoi(impl_env) : 1;
-  const int rimpl = reader_impl();
+  {
+    const char* h16_env = getenv("PNX_PFN_F16X3");
+    const int64_t rows = (int64_t)w.sg.nchunks * batch;
+    if (reader_impl() == 4 && impl != 0 && stride - 1 <= 5 && !(h16_env && h16_env[0] == '0') && w.sg.nf <= 32768 && batch <= 1024 &&
+        rows < ((int64_t)1 << 30))
+      return reader_forward_spans(points, n, stride, gd, w, pfn_folded, canvas, canvas_dtype, canvas_layout, occupancy, feat_max, coords, pillar_capacity,
+                                  unq_inv, pillar_of_point, counts, st);
+  }
+  const int rimpl = reader_impl() == 4 ? 3 : reader_impl();
   const bool binned = rimpl != 1 && impl != 0 && w.K1 <= 16384;
   const int F = stride - 1;
   const char* h_env = getenv("PNX_PFN_F16X3");  // 0: plain fp32 MFMA layer 1 (pfn_v3.hip only)
@@ -1173,7 +1384,7 @@ int pnx_reader_forward_rows(const float* points, int64_t n, int32_t stride, int3
   const ReaderWs w = carve(workspace, n, batch, g);
   const GeomDev gd = make_geom(g, batch);
   const int F = stride - 1;
-  PNX_REQUIRE(reader_impl() == 3 && w.K1 <= 16384 && F <= 5 && w.sh <= 10, PNX_ERR_UNSUPPORTED, "the row output exists on the in-LDS bin path only");
+  PNX_REQUIRE(reader_impl() >= 3 && w.K1 <= 16384 && F <= 5 && w.sh <= 10, PNX_ERR_UNSUPPORTED, "the row output exists on the in-LDS bin path only");
   PNX_REQUIRE(row_capacity >= w.pcap, PNX_ERR_INVALID, "row_capacity %lld < worst-case pillar count %lld", (long long)row_capacity, (long long)w.pcap);
   PnxFillJob nofill[4] = {};
   rc = run_voxelize2(points, n, stride, gd, w, nullptr, 0, nullptr, nullptr, nofill, 0, st, nullptr, false);
@@ -1242,7 +1453,7 @@ int pnx_pfn_backward(int32_t pass, int64_t n, int32_t stride, int32_t batch, con
 }
 
 void pnx_reader_fill_split(int32_t* percent3) {
-  percent3[0] = 0, percent3[1] = 0, percent3[2] = reader_impl() == 3 ? 0 : 24;  // round-2 pipeline, measured on C2 / 8 frames (tools/reader_ab.py): only k_bin_sort's share pays
+  percent3[0] = 0, percent3[1] = 0, percent3[2] = reader_impl() >= 3 ? 0 : 24;  // round-2 pipeline, measured on C2 / 8 frames (tools/reader_ab.py): only k_bin_sort's share pays
   const char* sp_env = getenv("PNX_FILL_SPLIT");
   if (sp_env) sscanf(sp_env, "%d,%d,%d", &percent3[0], &percent3[1], &percent3[2]);
   for (int k = 0; k < 3; k++) percent3[k] = percent3[k] < 0 ? 0 : (percent3[k] > 100 ? 100 : percent3[k]);

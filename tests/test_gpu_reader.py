@@ -27,18 +27,20 @@ def make_net(pc_range, voxel_size, layers, F=5, num_filters=(64, 64)):
     return net.eval()
 
 
-@pytest.fixture(params=["ldsbins", "ldsbins_seg", "ldsbins_side", "binned", "binned_unfused", "round1", "pillar"])
+@pytest.fixture(params=["spans", "spans_seg", "ldsbins", "ldsbins_seg", "ldsbins_side", "binned", "binned_unfused", "round1", "pillar"])
 def pfn_impl(request, monkeypatch):
-    """ldsbins = default pipeline (reader_bins.h grouping, then pfn_bins.hip: every bin sorted and consumed in LDS, zero-fill tiles
+    """spans = default pipeline (chunk_sort.hip: every chunk of points sorted by canvas slab in LDS; pfn_spans.hip: every span of the canvas
+    grouped, ranked and consumed in LDS); spans_seg = the same with 96 LDS record slots, so that every span takes several segments;
+    ldsbins = round-3 pipeline (reader_bins.h grouping, then pfn_bins.hip: every bin sorted and consumed in LDS, zero-fill tiles
     carried by the same launch); ldsbins_seg = the same with 96 LDS record slots, so that every bin takes several segments;
     ldsbins_side = the zero-fill as a persistent kernel on a second stream; binned = round-2 pipeline (k_bin_sort + pfn_v3.hip,
     64-byte sorted records through HBM); binned_unfused = that with the fill as its own kernel; round1 = global-atomic slots +
     DPP-scan PFN; pillar = thread-per-pillar cross-check kernel."""
     p = request.param
     monkeypatch.setenv("PNX_PFN_IMPL", "0" if p == "pillar" else "1")
-    monkeypatch.setenv("PNX_READER_IMPL", "1" if p == "round1" else ("3" if p.startswith("ldsbins") else "2"))
+    monkeypatch.setenv("PNX_READER_IMPL", "1" if p == "round1" else ("4" if p.startswith("spans") else ("3" if p.startswith("ldsbins") else "2")))
     monkeypatch.setenv("PNX_READER_FUSE", "0" if p == "binned_unfused" else ("3" if p == "ldsbins_side" else "1"))
-    if p == "ldsbins_seg":
+    if p in ("ldsbins_seg", "spans_seg"):
         monkeypatch.setenv("PNX_BINS_CAP", "96")
     return p
 

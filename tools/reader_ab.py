@@ -4,7 +4,8 @@
 Variants are environment settings read by pnx_reader_forward on every call:
   PNX_READER_IMPL=1            round-1 pipeline (global-atomic slots, 32-byte records, DPP-scan PFN, separate fill kernel)
   PNX_READER_IMPL=2            round-2 pipeline: binned grouping (reader_bins.h) + k_bin_sort + PFN v3 (pfn_v3.hip), records through HBM
-  PNX_READER_IMPL=3            default: binned grouping + ONE launch that sorts every bin in LDS and runs the PFN on it (pfn_bins.hip)
+  PNX_READER_IMPL=4            default: chunk sort (chunk_sort.hip) + span PFN (pfn_spans.hip)
+  PNX_READER_IMPL=3            round 3: binned grouping + ONE launch that sorts every bin in LDS and runs the PFN on it (pfn_bins.hip)
     PNX_READER_FUSE=0|1|3      zero-fill as its own kernel | as extra blocks of the PFN launch and of the grouping kernels |
                                as a persistent grid-capped kernel on a second stream (PNX_FILL_SIDE percent, PNX_FILL_SIDE_BLOCKS)
     PNX_BIN_NWG, PNX_BIN_THREADS, PNX_BIN_SH   chunks / threads of k_bin_count and k_bin_scatter, pillars per bin (2^sh)
@@ -27,6 +28,24 @@ from pillarnext_amd.reader import PillarFeatureNet  # noqa: E402
 VARIANTS = [
     ("r2 binned default", {"PNX_READER_IMPL": "2"}),
     ("lds default", {"PNX_READER_IMPL": "3"}),
+    ("spans default", {"PNX_READER_IMPL": "4"}),
+    ("spans pfn768", {"PNX_READER_IMPL": "4", "PNX_PFN_BLOCKS": "768"}),
+    ("spans fill192", {"PNX_READER_IMPL": "4", "PNX_FILL_BLOCKS": "192"}),
+    ("spans fill128", {"PNX_READER_IMPL": "4", "PNX_FILL_BLOCKS": "128"}),
+    ("spans unfilled", {"PNX_READER_IMPL": "4", "PNX_FILL_BLOCKS": "0"}),
+    ("spans side", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1"}),
+    ("spans side lds78k", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1", "PNX_BINS_LDS": "78000"}),
+    ("spans side lds76k", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1", "PNX_BINS_LDS": "76000"}),
+    ("spans side lds72k", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1", "PNX_BINS_LDS": "72000"}),
+    ("spans side lds76k b512", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1", "PNX_BINS_LDS": "76000", "PNX_FILL_BLOCKS": "512"}),
+    ("spans side lds76k b128", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1", "PNX_BINS_LDS": "76000", "PNX_FILL_BLOCKS": "128"}),
+    ("spans lds76k", {"PNX_READER_IMPL": "4", "PNX_BINS_LDS": "76000"}),
+    ("spans q384 s128", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "384", "PNX_SPAN_SOLO": "128"}),
+    ("spans q512 s256", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "512", "PNX_SPAN_SOLO": "256"}),
+    ("spans q640", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640"}),
+    ("spans q768", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "768"}),
+    ("spans q640 unfilled", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_FILL_BLOCKS": "0"}),
+    ("spans q384 s128 unfilled", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "384", "PNX_SPAN_SOLO": "128", "PNX_FILL_BLOCKS": "0"}),
     ("lds fill384", {"PNX_READER_IMPL": "3", "PNX_FILL_BLOCKS": "384"}),
     ("lds fill192", {"PNX_READER_IMPL": "3", "PNX_FILL_BLOCKS": "192"}),
     ("lds pfnblocks768", {"PNX_READER_IMPL": "3", "PNX_PFN_BLOCKS": "768"}),
@@ -40,6 +59,14 @@ VARIANTS = [
     ("lds side100 atpfn", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn"}),
     ("lds side100 atpfn b512", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_FILL_SIDE_BLOCKS": "512"}),
     ("lds side50 atpfn", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_FILL_SIDE": "50"}),
+    ("lds sideat lds78k", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_BINS_LDS": "78000"}),
+    ("lds sideat lds76k", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_BINS_LDS": "76000"}),
+    ("lds sideat lds72k", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_BINS_LDS": "72000"}),
+    ("lds sideat lds64k", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_BINS_LDS": "64000"}),
+    ("lds sideat lds76k prio0", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_BINS_LDS": "76000", "PNX_FILL_PRIO": "0"}),
+    ("lds sideat lds76k b512", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_BINS_LDS": "76000", "PNX_FILL_SIDE_BLOCKS": "512"}),
+    ("lds sidebm lds76k", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_BINS_LDS": "76000"}),
+    ("lds fused lds76k", {"PNX_READER_IMPL": "3", "PNX_BINS_LDS": "76000"}),
     ("lds nwg256 t512", {"PNX_READER_IMPL": "3", "PNX_BIN_NWG": "256", "PNX_BIN_THREADS": "512"}),
     ("lds nwg256 t1024", {"PNX_READER_IMPL": "3", "PNX_BIN_NWG": "256", "PNX_BIN_THREADS": "1024"}),
     ("lds nwg128 t512", {"PNX_READER_IMPL": "3", "PNX_BIN_NWG": "128", "PNX_BIN_THREADS": "512"}),
@@ -50,7 +77,7 @@ VARIANTS = [
     ("round1", {"PNX_READER_IMPL": "1"}),
 ]
 KEYS = ["PNX_READER_IMPL", "PNX_READER_FUSE", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS", "PNX_FILL_SPLIT", "PNX_PFN_F16X3", "PNX_FILL_SIDE",
-        "PNX_FILL_SIDE_BLOCKS", "PNX_FILL_SIDE_AT", "PNX_BIN_NWG", "PNX_BIN_THREADS", "PNX_BIN_SH", "PNX_BINS_CAP", "PNX_BINS_LDS"]
+        "PNX_FILL_SIDE_BLOCKS", "PNX_FILL_SIDE_AT", "PNX_BIN_NWG", "PNX_BIN_THREADS", "PNX_BIN_SH", "PNX_BINS_CAP", "PNX_BINS_LDS", "PNX_FILL_PRIO", "PNX_SPAN_QUOTA", "PNX_SPAN_SOLO", "PNX_FILL_SIDE"]
 
 
 def main():
