@@ -1000,12 +1000,48 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
   const int64_t ncb = cbytes != nullptr ? (int64_t)gd.B * w.sg.cpf : 0;
   int rc;
   prof_mark(0, st);
+  // PNX_PREFILL=<percent> (experiment): the first tiles of the canvas are zeroed UNCONDITIONALLY by a launch of its own on a second stream
+  // while the grouping kernels run (they leave registers and LDS for a co-resident workgroup; the span kernel does not); the span
+  // launch's fill blocks take the rest from the occupancy bytes, and the pillars of the pre-filled part are simply stored over the zeros.
+  static hipStream_t fside = nullptr;
+  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  const char* pfl_env = getenv("PNX_PREFILL");
+  const int all_tiles = direct ? pnx_fill_tiles_bytes(gd) : 0;
+  int pre_tiles = (direct && pfl_env) ? (int)((int64_t)all_tiles * atoi(pfl_env) / 100) : 0;
+  pre_tiles = pre_tiles < 0 ? 0 : (pre_tiles > all_tiles ? all_tiles : pre_tiles);
+  const char* fs_env = getenv("PNX_FILL_SIDE");
+  const bool side = direct && fs_env && fs_env[0] == '1';
+  if ((side || pre_tiles > 0) && fside == nullptr) {
+    int lo = 0, hi = 0;
+    PNX_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const char* pr_env = getenv("PNX_FILL_PRIO");
+    PNX_CHECK_HIP(hipStreamCreateWithPriority(&fside, hipStreamNonBlocking, pr_env && pr_env[0] == 'h' ? hi : (pr_env && pr_env[0] == 'l' ? lo : 0)));
+    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
+  auto launch_fill_kernel = [&](const PnxByteFillJob& job, int blocks, hipStream_t fs) -> int {
+    if (canvas_dtype == PNX_F32) k_canvas_fill_bytes<PNX_F32><<<blocks, kBlock, 0, fs>>>(job, gd);
+    else if (canvas_dtype == PNX_BF16) k_canvas_fill_bytes<PNX_BF16><<<blocks, kBlock, 0, fs>>>(job, gd);
+    else k_canvas_fill_bytes<PNX_F16><<<blocks, kBlock, 0, fs>>>(job, gd);
+    PNX_LAUNCH_CHECK();
+    return PNX_OK;
+  };
   {
     const int64_t work = (int64_t)(w.zero_bytes_span >> 4) + (ncb >> 4) + 64;
     int blocks = (int)((work + kBlock * 8 - 1) / (kBlock * 8));
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     k_clear2<<<blocks, kBlock, 0, st>>>(reinterpret_cast<uint4*>(w.counters), (int64_t)(w.zero_bytes_span >> 4), cbytes, ncb);
     PNX_LAUNCH_CHECK();
+  }
+  if (pre_tiles > 0) {  // behind the clear (its ticket counter is zero), beside everything up to the span launch
+    PnxByteFillJob pj;
+    pj.bytemap = nullptr, pj.canvas = canvas, pj.counter = w.tick + 17 * 32, pj.tiles = pre_tiles, pj.nt = fill_nt ? 1 : 0, pj.base = 0;
+    PNX_CHECK_HIP(hipEventRecord(ev_fork, st));
+    PNX_CHECK_HIP(hipStreamWaitEvent(fside, ev_fork, 0));
+    static const int pb = getenv("PNX_PREFILL_BLOCKS") ? atoi(getenv("PNX_PREFILL_BLOCKS")) : 256;
+    rc = launch_fill_kernel(pj, pb, fside);
+    if (rc != PNX_OK) return rc;
+    PNX_CHECK_HIP(hipEventRecord(ev_join, fside));
   }
   if (ranked) {  // the key-order bitmap and its popcount prefix: the pillar rank of a cell == torch.unique(dim=0) order (pe:110)
     PNX_CHECK_HIP(hipMemsetAsync(w.bytemap, 0, (size_t)cells_of(gd) + 64, st));
@@ -1022,43 +1058,32 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
   if (rc != PNX_OK) return rc;
   prof_mark(6, st);
   PnxByteFillJob fj;
-  fj.bytemap = cbytes, fj.canvas = canvas, fj.counter = w.tick + 16 * 32, fj.tiles = direct ? pnx_fill_tiles_bytes(gd) : 0, fj.nt = fill_nt ? 1 : 0;
+  fj.bytemap = cbytes, fj.canvas = canvas, fj.counter = w.tick + 16 * 32, fj.tiles = all_tiles - pre_tiles, fj.nt = fill_nt ? 1 : 0, fj.base = pre_tiles;
   const char* fb_env = getenv("PNX_FILL_BLOCKS");
-  int n_fill = direct ? (fb_env ? atoi(fb_env) : 256) : 0;
-  // PNX_FILL_SIDE=1: the zero-fill as its own launch (a few hundred bytes of LDS per workgroup) on a second stream beside the span
-  // kernel, instead of blocks of the span launch that each hold the span kernel's 80 KB of LDS
-  static hipStream_t fside = nullptr;
-  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  const char* fs_env = getenv("PNX_FILL_SIDE");
-  const bool side = direct && n_fill > 0 && fs_env && fs_env[0] == '1';
-  if (side && fside == nullptr) {
-    int lo = 0, hi = 0;
-    PNX_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    const char* pr_env = getenv("PNX_FILL_PRIO");
-    PNX_CHECK_HIP(hipStreamCreateWithPriority(&fside, hipStreamNonBlocking, pr_env && pr_env[0] == 'h' ? hi : (pr_env && pr_env[0] == 'l' ? lo : 0)));
-    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-  }
+  int n_fill = (direct && fj.tiles > 0) ? (fb_env ? atoi(fb_env) : 256) : 0;
   SpanTables T;
   T.recs = w.srecs, T.tab = w.stab, T.rowframe = w.srowframe, T.rowbase = w.srowbase, T.frame_lo = w.frame_lo, T.frame_hi = w.frame_hi;
   T.span_desc = w.span_desc, T.nspan = w.nspan;
   prof_mark(4, st);
   prof_mark(1, st);
-  if (side) {
+  if (pre_tiles > 0) PNX_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));  // the pillars go over the zeros
+  if (side && n_fill > 0) {  // PNX_FILL_SIDE=1 (experiment): the rest of the fill as a launch of its own beside the span kernel
     PNX_CHECK_HIP(hipEventRecord(ev_fork, st));
     PNX_CHECK_HIP(hipStreamWaitEvent(fside, ev_fork, 0));
-    if (canvas_dtype == PNX_F32) k_canvas_fill_bytes<PNX_F32><<<n_fill, kBlock, 0, fside>>>(fj, gd);
-    else if (canvas_dtype == PNX_BF16) k_canvas_fill_bytes<PNX_BF16><<<n_fill, kBlock, 0, fside>>>(fj, gd);
-    else k_canvas_fill_bytes<PNX_F16><<<n_fill, kBlock, 0, fside>>>(fj, gd);
-    PNX_LAUNCH_CHECK();
+    rc = launch_fill_kernel(fj, n_fill, fside);
+    if (rc != PNX_OK) return rc;
     PNX_CHECK_HIP(hipEventRecord(ev_join, fside));
+    n_fill = 0;
+  } else if (n <= 0 && n_fill > 0) {
+    rc = launch_fill_kernel(fj, n_fill, st);
+    if (rc != PNX_OK) return rc;
     n_fill = 0;
   }
   rc = pnx_launch_span_pfn(F, T, w.sg, w.counters, w.tick, w.rec64, w.pfirst, w.pcnt, w.cell, w.row_of, w.biglist, w.bigcap, w.pcap,
                            ranked ? w.wcomb : nullptr, w.wblk, coords, pillar_capacity, pfn_folded, g1, g1_rows, direct ? canvas : nullptr, canvas_dtype, n,
                            n_fill, fj, gd, st);
   if (rc != PNX_OK) return rc;
-  if (side) PNX_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
+  if (side && fj.tiles > 0 && n_fill == 0 && n > 0) PNX_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
   if (n > 0) {
     static const int tb = getenv("PNX_TAIL_BLOCKS") ? atoi(getenv("PNX_TAIL_BLOCKS")) : 128;
     rc = pnx_launch_pfn3_tail(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.biglist, w.bigcap, pfn_folded, g1, g1_rows, direct ? canvas : nullptr,

@@ -33,6 +33,13 @@ VARIANTS = [
     ("spans fill192", {"PNX_READER_IMPL": "4", "PNX_FILL_BLOCKS": "192"}),
     ("spans fill128", {"PNX_READER_IMPL": "4", "PNX_FILL_BLOCKS": "128"}),
     ("spans unfilled", {"PNX_READER_IMPL": "4", "PNX_FILL_BLOCKS": "0"}),
+    ("spans pre10", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "10"}),
+    ("spans pre15", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "15"}),
+    ("spans pre20", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "20"}),
+    ("spans pre25", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "25"}),
+    ("spans pre30", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "30"}),
+    ("spans pre20 b128", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "20", "PNX_PREFILL_BLOCKS": "128"}),
+    ("spans pre100", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "100"}),
     ("spans side", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1"}),
     ("spans side lds78k", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1", "PNX_BINS_LDS": "78000"}),
     ("spans side lds76k", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1", "PNX_BINS_LDS": "76000"}),
@@ -77,7 +84,7 @@ VARIANTS = [
     ("round1", {"PNX_READER_IMPL": "1"}),
 ]
 KEYS = ["PNX_READER_IMPL", "PNX_READER_FUSE", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS", "PNX_FILL_SPLIT", "PNX_PFN_F16X3", "PNX_FILL_SIDE",
-        "PNX_FILL_SIDE_BLOCKS", "PNX_FILL_SIDE_AT", "PNX_BIN_NWG", "PNX_BIN_THREADS", "PNX_BIN_SH", "PNX_BINS_CAP", "PNX_BINS_LDS", "PNX_FILL_PRIO", "PNX_SPAN_QUOTA", "PNX_SPAN_SOLO", "PNX_FILL_SIDE"]
+        "PNX_FILL_SIDE_BLOCKS", "PNX_FILL_SIDE_AT", "PNX_BIN_NWG", "PNX_BIN_THREADS", "PNX_BIN_SH", "PNX_BINS_CAP", "PNX_BINS_LDS", "PNX_FILL_PRIO", "PNX_SPAN_QUOTA", "PNX_SPAN_SOLO", "PNX_FILL_SIDE", "PNX_PREFILL", "PNX_PREFILL_BLOCKS"]
 
 
 def main():
