@@ -444,8 +444,10 @@ def main():
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tj):
         try:
-            traffic = json.load(open(tj)).get(f"{a.config}_b{a.batch}_{a.dist}", {}).get("hbm_bytes_per_launch")
-            tsrc = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc_traffic.py, not measured in this run)"
+            ent = json.load(open(tj)).get(f"{a.config}_b{a.batch}_{a.dist}", {})
+            traffic = ent.get("hbm_bytes_per_launch") if ent.get("pipeline") == "spans" else None   # entries of older pipelines do not describe this one
+            tsrc = ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/profile_round.sh at this batch size, not measured in this run)" if traffic is not None
+                    else f"no PMC entry for {a.config} / {a.batch} frames / {a.dist} of the current pipeline: run tools/profile_round.sh with PNX_BENCH_BATCH={a.batch}")
         except Exception:
             traffic = None
     res = {
@@ -458,16 +460,16 @@ def main():
                    "frames_per_gpu_per_step": a.batch, "global_batch": a.batch * world, "parallelism": f"frame-sharded replicas x{world}",
                    "reader_dtype": "fp32 layer 0 + fp16x3 (22-bit) layer 1 on MFMA -> bf16 canvas", "pillars_per_launch": P,
                    "kept_points_per_launch": n_kept},
-        "roofline": {"bound": "hbm", "kernel": "reader, ALL of its kernels (keys, bitmap scan, bin count + scatter, in-LDS bin sort + PFN + canvas zero-fill, tail)",
+        "roofline": {"bound": "hbm", "kernel": "reader, ALL of its kernels (clear, chunk sort, slab totals, span carve, span grouping + PFN + canvas zero-fill in one launch, tail)",
                      "achieved": round(reader_gbs, 1) if reader_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(reader_gbs / HBM_PEAK_GBS, 4) if reader_gbs else None, "traffic": traffic, "traffic_source": tsrc,
                      "algorithmic_bytes_per_launch": reader_bytes, "kernel_us": round(r_us.value, 2), "samples": ns.value,
                      "voxelize_us": round(vox_us, 2)},
-        "roofline_fill": {"bound": "hbm", "kernel": "k_bin_pfn (bin sort + PFN blocks and zero-fill blocks in one launch: the pillar cells and this launch's share of the pillar-free tiles)",
+        "roofline_fill": {"bound": "hbm", "kernel": "k_span_pfn (span grouping + PFN blocks and zero-fill blocks in one launch: the pillar cells and every pillar-free tile)",
                           "achieved": round(fill_gbs, 1) if fill_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(fill_gbs / HBM_PEAK_GBS, 4) if fill_gbs else None, "algorithmic_bytes_per_launch": launch_bytes,
                           "kernel_us": round(c_us.value, 2), "zero_fill_percent_carried_by_grouping_kernels": [int(v) for v in split]},
-        "roofline_pfn": {"bound": "mfma", "kernel": "k_bin_pfn (same launch): fp32 v_mfma_f32_32x32x2_f32 layer 0 + 3 x v_mfma_f32_32x32x16_f16 layer 1",
+        "roofline_pfn": {"bound": "mfma", "kernel": "k_span_pfn (same launch): fp32 v_mfma_f32_32x32x2_f32 layer 0 + 3 x v_mfma_f32_32x32x16_f16 layer 1",
                          "achieved": round(pfn_tf, 2) if pfn_tf else None, "peak": 157.3, "unit": "TFLOP/s (reference fp32 FLOPs)",
                          "frac": round(pfn_tf / 157.3, 4) if pfn_tf else None, "kernel_us": round(pfn_us, 2), "algorithmic_flops_per_launch": pfn_flops},
     }

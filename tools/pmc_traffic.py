@@ -4,15 +4,15 @@
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide
 coalesced reads on gfx950; WRITE_SIZE is taken as reported.  Two kinds of entries:
   <key>            the WHOLE reader: every dispatch of every reader kernel (and the workspace memset) summed, divided by the number of
-                   reader calls (= dispatches of k_keys) -- what bench.py's `roofline.traffic` quotes
+                   reader calls (= dispatches of k_chunk_sort) -- what bench.py's `roofline.traffic` quotes
   <key>:<kernel>   one kernel, average per dispatch
 usage: pmc_traffic.py fetch.csv write.csv <key> <out.json>"""
 import csv
 import json
 import sys
 
-READER = ["k_keys", "k_pack_scan", "k_scan_blocks", "k_scan_local", "k_bin_count", "k_bin_scatter", "k_bin_sort", "k_bin_pfn", "k_pfn3", "k_canvas_fill",
-          "k_rank", "k_fill", "k_pfn_mfma", "k_pfn_big", "fillBufferAligned"]
+READER = ["k_clear2", "k_chunk_sort", "k_slab_totals", "k_span_carve", "k_span_pfn", "k_pfn3", "k_canvas_fill", "k_keys", "k_pack_scan", "k_scan_blocks",
+          "k_scan_local", "k_bin_count", "k_bin_scatter", "k_bin_sort", "k_bin_pfn", "k_rank", "k_fill", "k_pfn_mfma", "k_pfn_big", "fillBufferAligned"]
 
 
 def rows(path, counter):
@@ -28,10 +28,10 @@ def main():
         d = {}
     for k in [k for k in d if k.startswith(key + ":")]:   # per-kernel entries of an earlier pipeline
         del d[k]
-    calls = max(sum(1 for n, _ in f if "k_keys" in n), 1)
+    calls = max(sum(1 for n, _ in f if "k_chunk_sort" in n) or sum(1 for n, _ in f if "k_keys" in n), 1)
     tot_f = sum(v for n, v in f if any(k in n for k in READER))
     tot_w = sum(v for n, v in w if any(k in n for k in READER))
-    d[key] = {"kernel": "all reader kernels", "reader_calls": calls, "fetch_size_kib_raw_per_call": tot_f / calls, "write_size_kib_per_call": tot_w / calls,
+    d[key] = {"kernel": "all reader kernels", "pipeline": "spans" if any("k_chunk_sort" in n for n, _ in f) else "bins", "reader_calls": calls, "fetch_size_kib_raw_per_call": tot_f / calls, "write_size_kib_per_call": tot_w / calls,
               "hbm_bytes_per_launch": int((2 * tot_f + tot_w) / calls * 1024), "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as reported"}
     for k in READER:
         fv = [v for n, v in f if k in n]

@@ -3,16 +3,16 @@
 # (FETCH_SIZE / WRITE_SIZE, each in its own run with nothing but --kernel-trace) behind bench.py's roofline.traffic.
 # usage: tools/profile_round.sh <tag>      -> gpurun_out/<tag>/...
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 BATCH=${PNX_BENCH_BATCH:-12}   # frames per reader launch: what bench.py runs (profiles/pmc_traffic.json key C2_b<BATCH>_sweep)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/bench_trace -o p -- python $R/bench.py --steps 6 --warmup 4 --no-extras > $O/bench_trace.json 2> $O/bench_trace.err
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/reader_trace -o p -- python $R/tools/reader_ab.py --exact "lds default" --batch $BATCH --iters 20 > $O/reader_trace.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python $R/tools/reader_ab.py --exact "lds default" --batch $BATCH --iters 10 > $O/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python $R/tools/reader_ab.py --exact "lds default" --batch $BATCH --iters 10 > $O/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/reader_trace -o p -- python $R/tools/reader_ab.py --exact "spans default" --batch $BATCH --iters 20 > $O/reader_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python $R/tools/reader_ab.py --exact "spans default" --batch $BATCH --iters 10 > $O/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python $R/tools/reader_ab.py --exact "spans default" --batch $BATCH --iters 10 > $O/pmc_write.log 2>&1
 cd $R
 python tools/steady_trace.py $O/bench_trace 3 45 > $O/bench_steady_trace.md 2>&1
 python tools/prof_summary.py $(find $O/reader_trace -name "*.db" | head -1) 30 > $O/reader_kernels.md 2>&1

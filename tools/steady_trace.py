@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-step kernel breakdown of the steady state of a rocprofv3 --kernel-trace of bench.py (rocpd SQLite).
 
-Steps are delimited by the reader's first kernel (k_keys); the last `n` complete steps are averaged, which skips the
+Steps are delimited by the reader's grouping kernel (k_chunk_sort; k_keys for the older pipelines); the last `n` complete steps are averaged, which skips the
 MIOpen find-mode searches of the warm-up."""
 import glob
 import sqlite3
@@ -14,7 +14,9 @@ def main():
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
     db = path if path.endswith(".db") else glob.glob(path + "/**/*.db", recursive=True)[0]
     cur = sqlite3.connect(db).cursor()
-    starts = [r[0] for r in cur.execute("select start from kernels where name like '%k_keys%' order by start")]
+    starts = [r[0] for r in cur.execute("select start from kernels where name like '%k_chunk_sort%' order by start")]
+    if len(starts) <= nsteps:
+        starts = [r[0] for r in cur.execute("select start from kernels where name like '%k_keys%' order by start")]
     t0, t1 = starts[-nsteps - 1], starts[-1]
     rows = list(cur.execute("select name, count(*), avg(end-start)/1000.0, sum(end-start)/1000.0 from kernels where start >= ? and start < ? "
                             "group by name order by 4 desc", (t0, t1)))
