@@ -236,6 +236,83 @@ class _MaskedBNActFn(torch.autograd.Function):
         return dx.to(x.dtype), None, dgamma.to(weight.dtype), dbeta.to(bias.dtype), gres, None, None
 
 
+def _mask_u8(mask):
+    """(B,1,H,W) float occupancy -> (B,H,W) uint8 for the HIP convolution kernels; cached on the tensor object (one conversion per stage)."""
+    m = getattr(mask, "_pnx_u8", None)
+    if m is None:
+        m = (mask[:, 0] != 0).to(torch.uint8).contiguous()
+        try:
+            mask._pnx_u8 = m
+        except Exception:
+            pass
+    return m
+
+
+_ZERO_BIAS = {}
+
+
+def _zero_bias(c, device):
+    key = (c, str(device))
+    if key not in _ZERO_BIAS:
+        _ZERO_BIAS[key] = torch.zeros(c, dtype=torch.float32, device=device)
+    return _ZERO_BIAS[key]
+
+
+class _MaskedConv3x3Fn(torch.autograd.Function):
+    """y = mask_out * conv3x3(x, W) on the product's masked-convolution kernels (csrc/conv3x3.hip) in TRAINING, bf16 autocast
+    (sparse_conv.py:16-63: SubMConv2d / SparseConv2d compute only at the active sites, forward and backward).
+      forward   pnx_conv3x3_bf16 (no bias, no ReLU), row segments without an active site are skipped
+      dgrad     stride 1: the SAME kernel on the flipped, transposed weights with the INPUT's active set as its mask -- the upstream
+                gradient is zero outside mask_out (the BatchNorm node's backward writes zeros there), and what reaches an inactive input
+                site would be thrown away by that site's own mask; stride 2: MIOpen's dense dgrad
+      wgrad     MIOpen's dense wrw on (x, g): exact, because g is zero outside the active outputs
+    The fp32 training path (the reference's precision) stays on MIOpen: the kernels are bf16."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    def forward(ctx, x, weight, mask_out, mask_in, stride):
+        x = x.contiguous(memory_format=torch.channels_last)
+        co = weight.shape[0]
+        y = ops.conv3x3_masked(x, ops.conv3x3_pack_weights(weight), _zero_bias(co, x.device), co, stride=stride, mask=mask_out, relu=False)
+        ctx.save_for_backward(x, weight, mask_in)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x, weight, mask_in = ctx.saved_tensors
+        g = g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = dw = None
+        if ctx.stride == 1:
+            if need_x:
+                ci = weight.shape[1]
+                wt = weight.flip(2, 3).transpose(0, 1).contiguous()      # dgrad of a stride-1 'same' convolution = convolution with W^T flipped
+                dx = ops.conv3x3_masked(g, ops.conv3x3_pack_weights(wt), _zero_bias(ci, g.device), ci, stride=1, mask=mask_in, relu=False)
+            if need_w:
+                dw = torch.nn.grad.conv2d_weight(x, weight.shape, g, stride=1, padding=1)
+        else:
+            s = ctx.stride
+            dx, dw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, (s, s), (1, 1), (1, 1), False, (0, 0), 1, (need_x, need_w, False))
+        return dx, dw, None, None, None
+
+
+# (Cin, Cout, stride) served by the LDS-staged kernels of csrc/conv3x3.hip (every 3x3 layer of the PillarNeXt-B backbone)
+_HIP_TRAIN_CONVS = {(64, 64, 1), (128, 128, 1), (256, 256, 1), (64, 128, 2), (128, 256, 2), (256, 256, 2)}
+
+
+def masked_conv(conv, x, mask_out, mask_in):
+    """conv(x) of a backbone block; in bf16-autocast training the 3x3 layers run on the product's masked kernels (_MaskedConv3x3Fn).
+    PNX_TRAIN_HIPCONV=0 keeps every layer on MIOpen."""
+    if (conv.training and torch.is_grad_enabled() and x.is_cuda and conv.kernel_size == (3, 3) and conv.bias is None
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and os.environ.get("PNX_TRAIN_HIPCONV", "1") != "0"
+            and (conv.in_channels, conv.out_channels, conv.stride[0]) in _HIP_TRAIN_CONVS):
+        return _MaskedConv3x3Fn.apply(x, conv.weight, _mask_u8(mask_out), _mask_u8(mask_in), conv.stride[0])
+    return conv(x)
+
+
 def masked_bn_act(x, mask, norm, residual=None, relu=True):
     """relu(norm(x, mask) [+ residual]) * mask -- one fused autograd node in train mode, the plain modules otherwise."""
     if norm.training and mask is not None and torch.is_grad_enabled():
@@ -291,9 +368,10 @@ class SparseConvBlock(nn.Module):
         self.norm = MaskedBatchNorm(out_channels, eps=1e-3, momentum=0.01)
 
     def forward(self, x, mask):
+        mask_in = mask
         if not self.subm:
             mask = F.max_pool2d(mask, self.kernel_size, self.stride, self.kernel_size // 2)
-        out = masked_bn_act(self.conv(x), mask, self.norm)
+        out = masked_bn_act(masked_conv(self.conv, x, mask, mask_in), mask, self.norm)
         return out, mask
 
 
@@ -308,7 +386,7 @@ class SparseBasicBlock(nn.Module):
 
     def forward(self, x, mask):
         out, _ = self.block1(x, mask)
-        out = masked_bn_act(self.conv2(out), mask, self.norm2, residual=x)
+        out = masked_bn_act(masked_conv(self.conv2, out, mask, mask), mask, self.norm2, residual=x)
         return out, mask
 
 

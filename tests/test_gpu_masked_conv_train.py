@@ -1,0 +1,76 @@
+"""GPU: the training-mode masked 3x3 convolution node (models._MaskedConv3x3Fn: forward and dgrad on the product's HIP kernels, wgrad on
+MIOpen) against torch's own autograd of F.conv2d in FP32 on the same bf16-rounded operands, on LiDAR-like masks (sparse_conv.py:16-63:
+SubMConv2d / SparseConv2d compute at the active sites only).  bf16 tolerances: outputs and input gradients to 2 bf16 ulps of a K = 9*Cin
+fp32 sum, weight gradients relative to the largest entry."""
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _lidar_mask(B, H, W, gen, p=0.12):
+    """clustered occupancy: a few dense blobs + ring-like rows, ~p of the cells"""
+    m = torch.rand((B, 1, H, W), device="cuda", generator=gen) < p * 0.3
+    yy, xx = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
+    for b in range(B):
+        for _ in range(6):
+            cy, cx = (torch.rand(2, device="cuda", generator=gen) * torch.tensor([H, W], device="cuda")).tolist()
+            r = 3 + 0.12 * min(H, W) * float(torch.rand(1, device="cuda", generator=gen))
+            m[b, 0] |= ((yy - cy) ** 2 + (xx - cx) ** 2 < r * r) & (torch.rand((H, W), device="cuda", generator=gen) < 0.6)
+    return m.float()
+
+
+@pytest.mark.parametrize("cin,cout,stride,subm,shape", [(64, 64, 1, True, (2, 70, 97)), (64, 64, 1, False, (2, 48, 64)), (128, 128, 1, True, (2, 41, 70)),
+                                                       (256, 256, 1, True, (2, 23, 33)), (64, 128, 2, False, (2, 50, 66)), (128, 256, 2, False, (1, 37, 41))])
+def test_masked_conv_node_matches_fp32_autograd(cin, cout, stride, subm, shape):
+    import torch.nn.functional as F
+
+    from pillarnext_amd.models import _SpConv2d, masked_conv
+
+    B, H, W = shape
+    gen = torch.Generator(device="cuda").manual_seed(cin + cout + H)
+    mask_in = _lidar_mask(B, H, W, gen)
+    mask_out = mask_in if subm else F.max_pool2d(mask_in, 3, stride, 1)
+    conv = _SpConv2d(cin, cout, 3, stride=stride, padding=1, bias=False).cuda().train()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, device="cuda", generator=gen) * (2.0 / (9 * cin)) ** 0.5)
+    xb = (torch.randn((B, cin, H, W), device="cuda", generator=gen) * mask_in).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    Ho, Wo = mask_out.shape[2:]
+    gb = (torch.randn((B, cout, Ho, Wo), device="cuda", generator=gen) * mask_out).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    x = xb.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = masked_conv(conv, x, mask_out, mask_in)
+    assert y.dtype == torch.bfloat16 and type(y.grad_fn).__name__.startswith("_MaskedConv3x3Fn")   # the HIP node, not conv(x)
+    y.backward(gb)
+    dw, dx = conv.weight.grad.clone(), x.grad.float()
+    conv.weight.grad = None
+
+    # reference: fp32 autograd of mask_out * conv2d on the same bf16-rounded x, W and upstream gradient
+    xr = xb.float().contiguous().requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, 1) * mask_out
+    yr.backward(gb.float())
+    ulp = 2.0 ** -8
+    # stride 1: two bf16 ulps of the fp32 sum; the strided kernel sums its input slabs in another order: the bound of tests/test_gpu_dense_ops.py
+    tol_y = (2 * ulp * yr.detach().abs().clamp(min=1e-2) + 2e-3) if stride == 1 else (1.6e-2 * yr.detach().abs() + 2e-2)
+    err_y = (y.float() - yr.detach()).abs()
+    assert bool((err_y <= tol_y).all()), (float(err_y.max()), float((err_y / yr.detach().abs().clamp(min=1e-2)).max()))
+    assert bool((y.float()[(mask_out == 0).expand_as(y)] == 0).all())
+    dxr = xr.grad * mask_in          # an inactive input site is a constant zero: its gradient is thrown away by the previous layer's mask
+    dxm = dx * mask_in
+    assert bool(((dxm - dxr).abs() <= 2 * ulp * dxr.abs().clamp(min=1e-2) + 4e-3).all())
+    if stride == 1:
+        assert bool((dx[(mask_in == 0).expand_as(dx)] == 0).all())
+    scale = float(wr.grad.abs().max())
+    assert float((dw.float() - wr.grad).abs().max()) <= 2e-2 * scale
+
+
+def test_masked_conv_falls_back_outside_bf16_training():
+    from pillarnext_amd.models import _SpConv2d, masked_conv
+
+    conv = _SpConv2d(64, 64, 3, stride=1, padding=1, bias=False).cuda().train()
+    x = torch.randn((1, 64, 16, 16), device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    m = torch.ones((1, 1, 16, 16), device="cuda")
+    y = masked_conv(conv, x, m, m)             # fp32, no autocast: MIOpen
+    assert y.dtype == torch.float32 and not type(y.grad_fn).__name__.startswith("_MaskedConv3x3Fn")
