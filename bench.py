@@ -241,6 +241,81 @@ def sections(model, examples, batch):
     return {k: round(v, 1) for k, v in acc.items()}
 
 
+
+def train_leg(dev, rank, world, frames=4, steps=5, warmup=3):
+    """One data-parallel TRAINING step of PillarNeXt-B (reference: trainer/trainer/trainer.py:94-108 -- forward, loss, backward, clip 35,
+    AdamW, OneCycle) on synthetic C2 frames + labels, `frames` per GPU, under bf16 autocast in channels_last (the reference trains in
+    fp32; the bf16 step is what this repository optimises and is labelled as such).  DDP over the job's process group when world > 1
+    (gradient all-reduce over RCCL overlapped with backward; SyncBatchNorm over the active sites).  Returns the dict behind
+    value_train / train / roofline_train."""
+    import torch
+    import torch.distributed as dist
+
+    from pillarnext_amd import dist_utils, synth
+    from pillarnext_amd.models import NUSC_TASKS, build_pillarnext_b, convert_sync_batchnorm
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from train_step import synthetic_labels
+
+    for k in ("FWD", "BWD", "WRW"):   # MIOpen's naive reference solvers only lengthen the find step (tools/train_step.py)
+        os.environ.setdefault(f"MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_{k}", "0")
+    cfg = synth.CONFIGS["C2"]
+    torch.manual_seed(0)
+    model = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"]).to(dev).train().to(memory_format=torch.channels_last)
+    if world > 1:
+        model = convert_sync_batchnorm(model)
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=0.002, total_steps=1000, div_factor=10.0, pct_start=0.4)
+    pts = torch.from_numpy(synth.make_batch("C2", frames, "sweep", frame0=rank * frames)).to(dev)
+    net = model.module if hasattr(model, "module") else model
+    ny, nx = (int(v) for v in net.reader.grid_size)
+    ex = synthetic_labels(NUSC_TASKS, frames, ny // 4, nx // 4, 500, dev, 100 + rank)
+    ex.update(points=pts, batch_size=frames)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss, _ = model(ex)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 35)
+        opt.step()
+        sched.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.reset_peak_memory_stats(dev)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finite = bool(torch.isfinite(loss))
+    flops = 3 * 2.96e12 * frames                      # SURVEY 8d: 2.96 TFLOP per frame forward (dense-equivalent, 1440^2, 6 tasks); x 3 for dgrad + wgrad
+    tf = flops * steps / dt / 1e12
+    res = {"value_train": round(frames * world * steps / dt, 2),
+           "train": {"frames_per_gpu_per_step": frames, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
+                     "dtype": "bf16 autocast, channels_last (the reference trains fp32: tools/train_step.py --nhwc times that)",
+                     "step": "forward + CenterHead losses + backward + clip 35 + AdamW + OneCycle, DDP + SyncBN when n_gpus > 1",
+                     "loss_finite": finite, "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
+           "roofline_train": {"bound": "mfma", "kernel": "whole training step (backbone 3x3 layers: forward + dgrad on the masked HIP kernels, wgrad and the dense layers on MIOpen)",
+                              "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s (dense-equivalent bf16 FLOPs, 3 x forward)",
+                              "frac": round(tf / 2500.0, 4), "algorithmic_flops_per_step": flops}}
+    del model, opt, ex
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -418,6 +493,9 @@ def main():
                                                          "ms_per_step": round(wdt_s / wsteps * 1e3, 3)}
                     del wm, wex
                     torch.cuda.empty_cache()
+            # the training step (BASELINE configs[2]: 4 frames per GPU), timed by this run: value_train / roofline_train
+            if a.config == "C2" and not os.environ.get("PNX_BENCH_NO_TRAIN"):
+                extras.update(train_leg(dev, rank, world))
             if rank == 0:
                 extras["sections_us"] = sections(model, examples, a.batch)
                 extras["nms_us"] = nms_bench(dev)

@@ -280,7 +280,10 @@ def ns(**k):
     return types.SimpleNamespace(**k)
 
 
-def gen_decode():
+def gen_decode(name="decode_2task", bf16_reg=False):
+    """bf16_reg: the five regression maps are rounded to bf16 before the reference sees them -- the lazy head (decode.PackedDecoder.
+    launch_lazy + k_sephead_lazy) produces its regression values in bf16, so a test can reproduce these maps EXACTLY with identity
+    convolutions and compare its detections with the reference's on equal inputs."""
     from det3d.models.heads.centerhead import CenterHead
 
     torch.manual_seed(3)
@@ -305,6 +308,8 @@ def gen_decode():
                 a = rng.uniform(0, 1, (B, c, H, W)).astype(np.float32)
             if k == "iou":
                 a = np.clip(a * 0.7, -1.3, 1.3)
+            if bf16_reg and k not in ("hm", "iou"):
+                a = torch.from_numpy(a).to(torch.bfloat16).float().numpy()
             d[k] = a
         # make the grid spread over real-world metres: out_size_factor 56 -> 24*56*0.075 = 100.8 m
         preds.append(d)
@@ -332,7 +337,7 @@ def gen_decode():
     out["score_threshold"] = np.float32(0.1)
     out["pre_max"] = np.int64(1000)
     out["post_max"] = np.int64(83)
-    np.savez_compressed(os.path.join(OUT, "decode_2task.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
 def gen_loss():
@@ -403,6 +408,186 @@ def gen_loss():
     print(f"[golden] head_loss_2task: total {loss.item():.5f}")
 
 
+# --------------------------------------------------------------------------- voxel / multi-view readers
+def install_spconv_import_stub():
+    """det3d/models/readers/mvf_encoder.py imports spconv (third-party, absent from the image) at module level and derives SingleView's
+    blocks from it.  These stand-ins only let the FILE import; nothing of them is ever executed: the fixtures below come from
+    PillarVoxelNet, CylinderNet, PointNet and SingleView.bilinear_interpolate, which are torch + torch_scatter alone.  What needs spconv
+    (SingleView.forward, MVFFeatureNet.forward end to end) has no fixture -- unpinned, like the backbone."""
+    sp = types.ModuleType("spconv")
+    spt = types.ModuleType("spconv.pytorch")
+    core = types.ModuleType("spconv.core")
+
+    class _Never(torch.nn.Module):
+        def __init__(self, *a, **k):
+            raise RuntimeError("spconv stand-in: import only")
+
+    spt.SparseModule = torch.nn.Module
+    spt.SparseSequential = torch.nn.Sequential
+    spt.SubMConv2d = spt.SparseConv2d = spt.SubMConv3d = spt.SparseConv3d = spt.SparseConvTensor = _Never
+    core.ConvAlgo = types.SimpleNamespace(Native=0)
+    sp.pytorch, sp.core = spt, core
+    sys.modules["spconv"], sys.modules["spconv.pytorch"], sys.modules["spconv.core"] = sp, spt, core
+
+
+def gen_voxel():
+    from det3d.models.readers.voxel_encoder import VoxelFeatureNet
+
+    rng = np.random.default_rng(51)
+    pr, vs = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [0.2, 0.2, 0.4]
+    a = synth.sweep_cloud(3000, pr, 1020, 0)
+    b = synth.uniform_cloud(2000, pr, 1021, 2)          # sample 1 absent
+    b[:, 3] = rng.uniform(-6.0, 4.0, len(b))             # some rows outside the z range: this reader drops them (voxel_encoder.py:50-55)
+    e = edge_rows(pr, vs, 0)
+    e[:, 3] = np.where(np.arange(len(e)) % 3 == 0, -5.0, np.where(np.arange(len(e)) % 3 == 1, np.nextafter(np.float32(3.0), np.float32(-9)), 3.0))
+    pts = np.concatenate([a, b, e]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    net = VoxelFeatureNet(vs, pr)
+    with torch.no_grad():
+        f, c, g = net(torch.from_numpy(pts))
+        _, _, inv, _ = net.voxelization(torch.from_numpy(pts))
+    np.savez_compressed(os.path.join(OUT, "voxel_b3_gap.npz"), points=pts, pc_range=np.asarray(pr, np.float64), voxel_size=np.asarray(vs, np.float64),
+                        features=f.numpy(), coords=c.numpy().astype(np.int32), unq_inv=inv.numpy().astype(np.int64), grid=np.asarray(g, np.int64))
+    print(f"[golden] voxel_b3_gap: N={len(pts)} V={len(c)} grid={g}")
+
+
+def gen_mvf_parts():
+    install_spconv_import_stub()
+    from det3d.models.readers.mvf_encoder import CylinderNet, PillarVoxelNet, PointNet, SingleView
+
+    rng = np.random.default_rng(52)
+    pr, vs = [-76.8, -76.8, -10.0, 76.8, 76.8, 10.0], [0.075, 0.075, 20]
+    cr, cs = [-180, -10.0, 0, 180, 10.0, 107], [0.140625, 0.2, 107]
+    a = synth.sweep_cloud(2500, pr, 1030, 0, beams=64, sweeps=3)
+    b = synth.uniform_cloud(1500, pr, 1031, 1)
+    pts = np.concatenate([a, b]).astype(np.float32)
+    r = np.asarray(pr, np.float32)
+    keep = ((pts[:, 1] >= r[0]) & (pts[:, 1] < r[3]) & (pts[:, 2] >= r[1]) & (pts[:, 2] < r[4]) & (pts[:, 3] >= r[2]) & (pts[:, 3] < r[5]))
+    pts = pts[keep]                                      # MVFFeatureNet.forward masks first (mvf_encoder.py:292-299); the two nets then CLAMP
+    # rows on the clamp edges: x at the last cell's upper edge region, rho beyond the cylinder range, phi = +-180
+    extra = np.array([[0, 76.79999, 0.0, 0.0, 0.5, 0.0], [1, -76.8, -76.8, -10.0, 0.1, 0.0], [0, -50.0, 0.0, 1.0, 0.2, 0.0], [0, -50.0, -0.0, 1.0, 0.2, 0.0],
+                      [1, 76.0, 76.0, 9.99, 0.3, 0.0], [0, 0.0, 0.0, 0.0, 0.4, 0.0]], np.float32)
+    pts = np.concatenate([pts, extra])
+    pts = pts[rng.permutation(len(pts))]
+    tp = torch.from_numpy(pts)
+    out = dict(points=pts, pc_range=np.asarray(pr, np.float64), voxel_size=np.asarray(vs, np.float64), cylinder_range=np.asarray(cr, np.float64),
+               cylinder_size=np.asarray(cs, np.float64))
+    with torch.no_grad():
+        for tag, net in (("pillar", PillarVoxelNet(vs, pr)), ("cyl", CylinderNet(cs, cr))):
+            f, c, inv, g = net(tp)
+            out[f"{tag}_features"], out[f"{tag}_coords"], out[f"{tag}_unq_inv"], out[f"{tag}_grid"] = (f.numpy(), c.numpy().astype(np.int32),
+                                                                                                     inv.numpy().astype(np.int64), np.asarray(g, np.int64))
+            print(f"[golden] mvf {tag}: N={len(pts)} cells={len(c)} grid={g}")
+        pn = PointNet(20, 32).eval()
+        torch.manual_seed(5)
+        for prm in pn.parameters():
+            prm.copy_(torch.randn(prm.shape) * 0.3)
+        pn.norm.running_mean.copy_(torch.randn(32) * 0.2)
+        pn.norm.running_var.copy_(torch.rand(32) + 0.5)
+        x = torch.randn(300, 20)
+        out["pn_in"], out["pn_out"] = x.numpy(), pn(x).numpy()
+        for k, v in pn.state_dict().items():
+            out["pn_" + k] = v.numpy()
+        img = torch.randn(2, 6, 9, 11)
+        co = torch.stack([torch.randint(0, 2, (200,)).float(), torch.rand(200) * 13 - 1, torch.rand(200) * 11 - 1], 1)
+        out["bil_image"], out["bil_coords"] = img.numpy(), co.numpy()
+        out["bil_out"] = SingleView.bilinear_interpolate(None, img, co).numpy()
+    np.savez_compressed(os.path.join(OUT, "mvf_parts.npz"), **out)
+
+
+# --------------------------------------------------------------------------- multi-sweep merge (nusc.py:76-121, waymo.py:49-67)
+def install_devkit_import_stubs():
+    """The dataset modules import the nuScenes / Waymo devkits (and pyquaternion, fire) at module level for evaluation and label code
+    that is never called here; read_file / read_sweep / remove_close / load_pointcloud are pure numpy.  Import-only stand-ins, like numba."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    never = type("Never", (), {"__init__": lambda self, *a, **k: (_ for _ in ()).throw(RuntimeError("devkit stand-in: import only"))})
+    mod("nuscenes", NuScenes=never)
+    mod("nuscenes.utils", splits=types.SimpleNamespace())
+    mod("nuscenes.utils.data_classes", Box=never)
+    mod("nuscenes.eval")
+    mod("nuscenes.eval.detection")
+    mod("nuscenes.eval.detection.config", config_factory=lambda *a, **k: None)
+    mod("nuscenes.eval.detection.evaluate", NuScenesEval=never)
+    mod("pyquaternion", Quaternion=never)
+    mod("fire", Fire=lambda *a, **k: None)
+    mod("waymo_open_dataset", label_pb2=types.SimpleNamespace())
+    mod("waymo_open_dataset.protos", metrics_pb2=types.SimpleNamespace())
+
+
+def gen_merge():
+    """Fixtures for the sweep merge: the reference's NuScenesDataset.load_pointcloud / WaymoDataset.load_pointcloud run on raw sweep
+    files written to a temporary directory.  Inputs (raw sweeps, transforms / poses, time lags) and the merged (N, 5) result."""
+    import tempfile
+
+    install_devkit_import_stubs()
+    from det3d.datasets.nuscenes.nusc import NuScenesDataset
+    from det3d.datasets.waymo.waymo import WaymoDataset
+
+    rng = np.random.default_rng(61)
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        # ---- nuScenes: key frame + 3 past sweeps, (n, 5) fp32 files [x y z intensity ring], 4x4 fp64 transforms, time lags
+        ds = object.__new__(NuScenesDataset)
+        ds._root_path = root
+        sweeps = []
+        for k in range(4):
+            n = 900 + 37 * k
+            p = np.empty((n, 5), np.float32)
+            p[:, :2] = rng.uniform(-45, 45, (n, 2))
+            p[: n // 12, :2] = rng.uniform(-1.6, 1.6, (n // 12, 2))            # near the ego vehicle: removed from PAST sweeps (remove_close)
+            p[0, :2] = [1.0, 0.3]                                              # |x| == radius exactly: kept (strict <)
+            p[1, :2] = [0.999999, -0.999999]
+            p[:, 2] = rng.uniform(-3, 1, n)
+            p[:, 3] = rng.uniform(0, 255, n)
+            p[:, 4] = rng.integers(0, 32, n)
+            p.tofile(os.path.join(root, f"s{k}.bin"))
+            out[f"nusc_raw{k}"] = p
+            if k > 0:
+                a = 0.013 * k
+                T = np.eye(4)
+                T[:3, :3] = np.array([[np.cos(a), -np.sin(a), 0.002 * k], [np.sin(a), np.cos(a), -0.001 * k], [-0.002 * k, 0.001 * k, 1.0]])
+                T[:3, 3] = [0.43 * k, -0.11 * k, 0.02 * k]
+                out[f"nusc_T{k}"] = T
+                sweeps.append({"lidar_path": f"s{k}.bin", "transform_matrix": T, "time_lag": 0.05 * k})
+        out["nusc_time_lag"] = np.asarray([0.0, 0.05, 0.10, 0.15], np.float64)
+        res = ds.load_pointcloud({}, {"lidar_path": "s0.bin", "sweeps": sweeps})
+        out["nusc_points"] = res["points"]
+        print(f"[golden] merge nusc: {sum(len(out[f'nusc_raw{k}']) for k in range(4))} raw rows -> {len(res['points'])} merged, dtype {res['points'].dtype}")
+        # ---- Waymo: key frame + 2 past sweeps, (n, 6) fp32 files [x y z intensity elongation nlz], poses, timestamps; nlz != -1 rows are dropped
+        os.makedirs(os.path.join(root, "lidar_point"))
+        wd = object.__new__(WaymoDataset)
+        wd._root_path, wd.nsweeps, wd.drop_frames = root, 3, 0
+        poses, ts = [], [0.0, -0.1, -0.2]
+        for k in range(3):
+            n = 700 + 29 * k
+            p = np.empty((n, 6), np.float32)
+            p[:, :2] = rng.uniform(-70, 70, (n, 2))
+            p[:, 2] = rng.uniform(-2, 4, n)
+            p[:, 3] = rng.uniform(0, 1, n)
+            p[:, 4] = rng.uniform(0, 1, n)
+            p[:, 5] = np.where(rng.uniform(0, 1, n) < 0.9, -1.0, 1.0)
+            p.tofile(os.path.join(root, "lidar_point", f"w{k}.bin"))
+            out[f"waymo_raw{k}"] = p
+            a = 0.02 * k
+            P = np.eye(4)
+            P[:3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+            P[:3, 3] = [1.3 * k, 0.2 * k, 0.01 * k]
+            poses.append(P)
+            out[f"waymo_pose{k}"] = P
+        out["waymo_timestamp"] = np.asarray(ts, np.float64)
+        info = {"token": "w0", "pose": poses[0], "sweeps": [{"token": f"w{k}", "timestamp": ts[k], "pose": poses[k]} for k in (1, 2)]}
+        res = wd.load_pointcloud({}, info)
+        out["waymo_points"] = res["points"]
+        print(f"[golden] merge waymo: -> {len(res['points'])} merged rows")
+    np.savez_compressed(os.path.join(OUT, "merge_sweeps.npz"), **out)
+
+
 def main():
     assert os.path.isdir(REF), "gen_golden.py needs the reference tree"
     os.makedirs(OUT, exist_ok=True)
@@ -412,7 +597,7 @@ def main():
     install_numba_identity()
     install_iou3d_nms()
     sys.path.insert(0, REF)
-    what = sys.argv[1:] or ["reader", "train", "iou", "decode", "loss"]
+    what = sys.argv[1:] or ["reader", "train", "iou", "decode", "decode_lazy", "loss", "voxel", "mvf", "merge"]
     if "reader" in what:
         gen_reader()
     if "train" in what:
@@ -421,8 +606,16 @@ def main():
         gen_iou_nms()
     if "decode" in what:
         gen_decode()
+    if "decode_lazy" in what:
+        gen_decode("decode_2task_bf16reg", bf16_reg=True)
     if "loss" in what:
         gen_loss()
+    if "voxel" in what:
+        gen_voxel()
+    if "mvf" in what:
+        gen_mvf_parts()
+    if "merge" in what:
+        gen_merge()
 
 
 if __name__ == "__main__":

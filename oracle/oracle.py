@@ -279,8 +279,10 @@ def reader_forward(points, pc_range, voxel_size, num_filters, layers, eps=1e-3, 
 def merge_sweeps(sweeps, n_copy=4):
     """Restates det3d/datasets/nuscenes/nusc.py:76-121 (read_sweep: fp64 `transform.dot(vstack(xyz, 1))[:3]` stored back into the
     float32 array, remove_close :91-99 on past sweeps only, time-lag column), det3d/datasets/waymo/waymo.py:49-67 (same with
-    `xyz1 @ rel_pose.T`, timestamp column, no close-point filter) and collate.py:15-22 (batch index column).  The reference's dataset
-    modules import the nuscenes / waymo devkits at module level (absent here), so this restatement is pinned by reading only.
+    `xyz1 @ rel_pose.T`, timestamp column, no close-point filter) and collate.py:15-22 (batch index column).  PINNED: tests/golden/
+    merge_sweeps.npz holds the output of the reference's own NuScenesDataset.load_pointcloud / WaymoDataset.load_pointcloud on raw sweep
+    files (oracle/gen_golden.py merge: the devkit imports of those modules are stood in for at import only, their numpy code runs
+    unmodified); tests/test_merge_golden.py checks this function and the device merge against it.
     sweeps: list of dicts {points (n, C) fp32, batch, time, radius, transform (4x4 fp64 or None)} in concatenation order."""
     rows = []
     for s in sweeps:

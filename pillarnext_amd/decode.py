@@ -11,7 +11,7 @@ import weakref
 import torch
 
 from . import ops
-from ._lib import PNX_BF16, PNX_F16, PNX_F32, check, lib, ptr, stream_ptr
+from ._lib import PNX_BF16, PNX_F16, PNX_F32, PnxError, check, lib, ptr, stream_ptr
 
 
 def _get(cfg, name):
@@ -47,10 +47,10 @@ class PackedDecoder:
         self._topk_ws = None
         import os
 
-        # PNX_DECODE_TOPK=1: segmented top-k in HIP (pnx_decode_topk) instead of one stable device sort of all keys.  Exactly the same
-        # selection (tests/test_gpu_decode.py), but OFF by default: with a freshly initialised head half of all cells pass the score
-        # threshold and tens of thousands of them tie at one quantised score, so every segment sorts ~40 k candidates in LDS chunks --
-        # measured 6.4 ms per 8-frame step against 1.06 ms for the sort; it pays once candidates are a few percent of the cells.
+        # PNX_DECODE_TOPK=1 (default): exact radix-select top-k in HIP (pnx_decode_topk: most significant digit first over the composite
+        # (score key, key index), lists that hold fewer than pre_max valid keys finish after the first pass) -- exactly the selection of
+        # a stable sort + cut (tests/test_gpu_decode.py::test_segmented_topk_equals_the_full_stable_sort).  PNX_DECODE_TOPK=0 selects the
+        # bit-ranged stable key sort of all keys (pnx_sort_keys), PNX_DECODE_TORCH_SORT=1 the generic 64-bit torch.sort (cross-checks).
         self.use_topk = os.environ.get("PNX_DECODE_TOPK", "1") == "1"
         self.use_torch_sort = os.environ.get("PNX_DECODE_TORCH_SORT", "0") == "1"   # the generic 64-bit torch.sort (cross-check)
         self._sort_ws = None
@@ -283,10 +283,15 @@ class PendingDetections:
         if self._res is not None:
             return self._res
         self.event.synchronize()
-        if self.flag_h is not None and int(self.flag_h[0]) != 0 and self.fallback is not None:
+        if self.flag_h is not None and int(self.flag_h[0]) != 0:
+            if self.fallback is None:
+                raise PnxError("lazy head: a candidate list cut at pre_max lost a candidate to the centre range test and no dense fallback "
+                               "was supplied -- the selection may differ from CenterHead.post_processing (centerhead.py:341-363)")
             # a segment cut at pre_max lost a candidate to the centre range test: the dense path decides (exact, and rare)
-            self._res, self.done = self.fallback().result(), True
+            fb, self.fallback = self.fallback, None
+            self._res, self.done = fb().result(), True
             return self._res
+        self.fallback = None   # the closure holds every task's deblocked map (~1.2 GB at C2 x 12 frames): let the allocator have them back
         out_c, cnt_c = self.out_h, self.cnt_h.tolist()
         res = []
         for b in range(self.batch):

@@ -10,6 +10,8 @@ TARGETS = [
     "det3d.models.necks.aspp.ASPPNeck",
     "det3d.models.heads.centerhead.CenterHead",
     "det3d.models.detectors.single_stage.SingleStageDetector",
+    "det3d.models.readers.mvf_encoder.MVFFeatureNet",          # configs/models/reader/mvf_encoder.yaml
+    "det3d.models.readers.voxel_encoder.VoxelFeatureNet",      # configs/models/reader/voxel_encoder.yaml
 ]
 
 

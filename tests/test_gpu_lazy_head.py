@@ -130,3 +130,55 @@ def test_fallback_to_the_dense_path_when_the_range_test_cuts_a_full_list(monkeyp
         dd = dense(ex)["a"]
     got = lazy.detections(res)["a"]
     assert torch.equal(got["scores"], dd["scores"]) and torch.equal(got["box3d_lidar"], dd["box3d_lidar"])
+
+
+def test_lazy_launch_matches_the_reference_golden():
+    """The bench's DEFAULT decode path -- PackedDecoder.launch_lazy: keys and exact top-k from the dense [iou] hm maps, k_sephead_lazy at the
+    candidates, k_decode_boxes_lazy, batched NMS -- against the reference's CenterHead.predict (tests/golden/decode_2task_bf16reg.npz,
+    oracle/gen_golden.py decode_lazy: the regression maps are bf16-representable, so identity convolutions reproduce them EXACTLY through
+    the evaluator: `up` carries the positive and negative parts of the ten regression channels, conv 1 copies them (centre tap), conv 2
+    subtracts).  Same labels and counts, scores to 1e-5, boxes to 1e-4: the tolerances of the dense decoder's golden test."""
+    import numpy as np
+
+    from conftest import load_golden
+    from pillarnext_amd import ops
+    from pillarnext_amd.decode import PackedDecoder
+
+    g = load_golden("decode_2task_bf16reg")
+    test_cfg = dict(post_center_limit_range=list(g["post_center_limit_range"]), score_threshold=float(g["score_threshold"]),
+                    nms=dict(nms_pre_max_size=int(g["pre_max"]), nms_post_max_size=int(g["post_max"]), nms_iou_threshold=[[0.2], [0.2, 0.25]]),
+                    out_size_factor=[int(v) for v in g["out_size_factor"]], voxel_size=list(g["voxel_size"]), pc_range=list(g["pc_range"]))
+    W1 = torch.zeros((320, 64, 3, 3))
+    W2 = torch.zeros((10, 320, 3, 3))
+    for j in range(5):
+        for i in range(K[j]):
+            W1[64 * j + i, OFF[j] + i, 1, 1] = 1.0                  # positive part of regression channel OFF[j] + i
+            W1[64 * j + K[j] + i, 10 + OFF[j] + i, 1, 1] = 1.0      # negative part
+            W2[OFF[j] + i, 64 * j + i, 1, 1] = 1.0
+            W2[OFF[j] + i, 64 * j + K[j] + i, 1, 1] = -1.0
+    W1, W2 = W1.cuda(), W2.cuda()
+    zeros320, zeros10 = torch.zeros(320, device="cuda"), torch.zeros(10, device="cuda")
+    dense, tasks = [], []
+    for t, ncls in enumerate((1, 2)):
+        reg = np.concatenate([g[f"t{t}_{k}"] for k in ("reg", "height", "dim", "rot", "vel")], axis=1)       # (B, 10, H, W), bf16-representable
+        B, _, H, Wd = reg.shape
+        up = np.zeros((B, 64, H, Wd), np.float32)
+        up[:, :10], up[:, 10:20] = np.maximum(reg, 0), np.maximum(-reg, 0)
+        upt = torch.from_numpy(up).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        assert torch.equal(upt.float().cpu(), torch.from_numpy(up))                                             # nothing was rounded
+        tasks.append((upt, ops.conv3x3_pack_weights(W1), zeros320, ops.sephead_lazy_pack_w2(_w2m(W2)), zeros10))
+        hm = np.concatenate([g[f"t{t}_iou"], g[f"t{t}_hm"]], axis=1)                                          # [iou] hm, fp32
+        hm = np.concatenate([hm, np.zeros((B, 16 - hm.shape[1], H, Wd), np.float32)], axis=1)
+        dense.append(torch.from_numpy(hm).cuda().contiguous(memory_format=torch.channels_last))
+    dec = PackedDecoder([1, 2], [[0.5], [0.68, 0.2]], test_cfg, True, [16, 16])
+
+    def evaluator(local, seg_len, valid, segs):
+        return ops.sephead_lazy(tasks, [0, 1, 1], 2, local, seg_len, local.shape[1])
+
+    pend = dec.launch_lazy(dense, evaluator, ["a", "b"], None)
+    res = pend.result()
+    assert int(pend.flag_h[0]) == 0
+    for i, r in enumerate(res):
+        assert np.array_equal(r["label_preds"].numpy(), g[f"s{i}_labels"])
+        np.testing.assert_allclose(r["scores"].numpy(), g[f"s{i}_scores"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r["box3d_lidar"].numpy(), g[f"s{i}_boxes"], rtol=1e-4, atol=1e-4)
