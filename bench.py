@@ -274,7 +274,7 @@ def train_leg(dev, rank, world, frames=4, steps=5, warmup=3):
     ex.update(points=pts, batch_size=frames)
 
     def step():
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16):   # the inference legs around this run under no_grad
             loss, _ = model(ex)
         opt.zero_grad()
         loss.backward()
@@ -283,6 +283,10 @@ def train_leg(dev, rank, world, frames=4, steps=5, warmup=3):
         sched.step()
         return loss
 
+    # MIOpen's exhaustive find over the forward / dgrad / wgrad shapes of a 1440^2 training graph takes ~5 minutes (the inference legs
+    # run with cudnn.benchmark = True); the training leg takes MIOpen's immediate-mode choices instead, as tools/train_step.py does
+    bench_mode = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False
     for _ in range(warmup):
         step()
     torch.cuda.reset_peak_memory_stats(dev)
@@ -311,6 +315,7 @@ def train_leg(dev, rank, world, frames=4, steps=5, warmup=3):
            "roofline_train": {"bound": "mfma", "kernel": "whole training step (backbone 3x3 layers: forward + dgrad on the masked HIP kernels, wgrad and the dense layers on MIOpen)",
                               "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s (dense-equivalent bf16 FLOPs, 3 x forward)",
                               "frac": round(tf / 2500.0, 4), "algorithmic_flops_per_step": flops}}
+    torch.backends.cudnn.benchmark = bench_mode
     del model, opt, ex
     torch.cuda.empty_cache()
     return res

@@ -359,14 +359,17 @@ int pnx_gather_kept(const float* boxes9, const float* scores, const int32_t* kee
  * det3d/models/utils/sparse_conv.py:31-37,57-60) fused with the residual add, ReLU and the active-site mask, forward and backward.
  * x, residual, y, gy, dx, dresidual: (n_sites, channels) bf16 or fp32 (channels_last maps); mask fp32[n_sites], 0 = inactive (never read,
  * written as zeros); channels in {8,16,32,64,128,256}.
- *   stats      partials fp32 [pnx_masked_bn_blocks()][2*channels + 1]: per workgroup sum x | sum x^2 | active sites -- the caller adds the rows
- *              (fp64), all-reduces them under SyncBatchNorm (tools/train.py:56), forms mean / invstd and
+ *   stats      partials fp32 [pnx_masked_bn_blocks()][2*channels + 1]: per workgroup sum d | sum d^2 | active sites with d = x - center[c]
+ *              (center: fp32[channels] or NULL = 0; the running mean keeps the one-pass variance sum d^2 / n - (sum d / n)^2 from
+ *              cancelling when |mean| >> std; every rank of a SyncBatchNorm group must pass the same values) -- the caller adds the rows
+ *              (fp64), all-reduces them under SyncBatchNorm (tools/train.py:56), forms mean = center + sum d / n, invstd and
  *              scale = gamma * invstd, shift = beta - mean * scale
  *   apply      y = [relu](x * scale + shift [+ residual]) at the active sites
  *   bwd_stats  partials fp32 [blocks][2*channels]: sum g | sum g * xhat with g = gy * [pre-activation > 0], xhat = (x - mean) * invstd
  *   bwd_apply  dx = scale * (g - mean_g - xhat * mean_gx), dresidual (optional) = g; mean_g = sum g / count, mean_gx = sum g*xhat / count */
 int32_t pnx_masked_bn_blocks(void);
-int pnx_masked_bn_stats(const void* x, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels, float* partials, pnx_stream_t stream);
+int pnx_masked_bn_stats(const void* x, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels, const float* center, float* partials,
+                        pnx_stream_t stream);
 int pnx_masked_bn_apply(const void* x, const void* residual, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels, const float* scale,
                         const float* shift, int32_t relu, void* y, pnx_stream_t stream);
 int pnx_masked_bn_bwd_stats(const void* gy, const void* x, const void* residual, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels,

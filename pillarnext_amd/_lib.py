@@ -60,7 +60,7 @@ PROTOTYPES = {
     "pnx_subm64_sparse_bf16": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "pnx_conv3x3_s2_sparse_bf16": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "pnx_masked_bn_blocks": (_i32, []),
-    "pnx_masked_bn_stats": (ctypes.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _vp]),
+    "pnx_masked_bn_stats": (ctypes.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     "pnx_masked_bn_apply": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp]),
     "pnx_masked_bn_bwd_stats": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "pnx_masked_bn_bwd_apply": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),

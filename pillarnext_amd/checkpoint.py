@@ -27,7 +27,18 @@ def load_checkpoint(model, filename, map_location=None, strict=False):
         raise IOError(f"{filename} is not a checkpoint file")
     checkpoint = torch.load(filename, map_location=map_location, weights_only=False)
     target = model.module if hasattr(model, "module") else model
-    missing, unexpected = target.load_state_dict(extract_state_dict(checkpoint), strict=strict)
+    # files written by save_checkpoint say which layout their sparse-conv weights are in; the shapes alone cannot when Cin == kH == kW
+    layout = checkpoint.get("meta", {}).get("pnx_conv_layout") if isinstance(checkpoint, dict) and isinstance(checkpoint.get("meta"), dict) else None
+    from .models import _SpConv2d
+
+    convs = [m for m in target.modules() if isinstance(m, _SpConv2d)] if layout in ("spconv", "dense") else []
+    for m in convs:
+        m.assume_layout = layout
+    try:
+        missing, unexpected = target.load_state_dict(extract_state_dict(checkpoint), strict=strict)
+    finally:
+        for m in convs:
+            del m.assume_layout
     return checkpoint, missing, unexpected
 
 
@@ -48,7 +59,9 @@ def save_checkpoint(model, filename, optimizer=None, scheduler=None, meta=None, 
             if isinstance(m, _SpConv2d):
                 k = (name + "." if name else "") + "weight"
                 sd[k] = sd[k].permute(0, 2, 3, 1).contiguous()
-    ck = {"meta": meta or {}, "state_dict": sd}
+    meta = dict(meta or {})
+    meta["pnx_conv_layout"] = layout      # (Cout, kH, kW, Cin) and (Cout, Cin, kH, kW) cannot be told apart by shape when Cin == kH == kW
+    ck = {"meta": meta, "state_dict": sd}
     if optimizer is not None:
         ck["optimizer"] = optimizer.state_dict()
     if scheduler is not None:

@@ -167,14 +167,16 @@ __device__ __forceinline__ float diou_aa(const float* p, const float* q, float* 
 
 // losses[0] hm_loss, [1..10] per-element regression loss (before code weights), [11] iou_loss, [12] iou_reg_loss, [13] num_pos,
 // [14] the factor the hm gradient is scaled with (-1/num_pos or -1)
-__global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ gathered, const uint8_t* __restrict__ mask, const float* __restrict__ anno,
+// 256 threads: with 1024 (four waves per SIMD, 128 VGPRs each) the 14 fp64 accumulators beside the inlined DIoU spilled 1.3 KB per lane
+constexpr int kLossReduceThreads = 256;
+__global__ __launch_bounds__(kLossReduceThreads) void k_loss_reduce(const float* __restrict__ gathered, const uint8_t* __restrict__ mask, const float* __restrict__ anno,
                                                       const float* __restrict__ gt_boxes, const float* __restrict__ iou3d, const double* __restrict__ neg_part,
                                                       int n_neg_part, int n, int has_iou, int has_diou, float* __restrict__ losses) {
-  __shared__ double s_acc[16][16];
+  __shared__ double s_acc[kLossReduceThreads / 64][16];
   double acc[14];
 #pragma unroll
   for (int k = 0; k < 14; k++) acc[k] = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) {
+  for (int i = threadIdx.x; i < n; i += kLossReduceThreads) {
     if (!mask[i]) continue;  // every term carries the mask (a NaN target under a zero mask contributes nothing either, :55-58)
     const float* o = gathered + (int64_t)i * kGW;
     const float p = sigmoid_clamped(o[10]);
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ 
     if (has_diou) acc[13] += (double)(1.f - diou_aa(o + 12, gt_boxes + (int64_t)i * 7, nullptr));
   }
   double neg = 0.0;
-  for (int i = threadIdx.x; i < n_neg_part; i += 1024) neg += neg_part[i];
+  for (int i = threadIdx.x; i < n_neg_part; i += kLossReduceThreads) neg += neg_part[i];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 14; k++) {
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ 
     double t[15];
     for (int k = 0; k < 15; k++) {
       t[k] = 0.0;
-      for (int w = 0; w < 16; w++) t[k] += s_acc[w][k];
+      for (int w = 0; w < kLossReduceThreads / 64; w++) t[k] += s_acc[w][k];
     }
     const double npos = t[1];
     losses[0] = (float)(npos > 0.0 ? -(t[0] + t[14]) / npos : -t[14]);
@@ -315,7 +317,7 @@ int pnx_center_loss_forward(const void* const* maps7, const float* hm_target, co
     const int rc = pnx_boxes_aligned_iou3d(boxes7, gt_boxes, n, iou3d, stream);
     if (rc != PNX_OK) return rc;
   }
-  k_loss_reduce<<<1, 1024, 0, st>>>(gathered, mask, anno_box, gt_boxes, iou3d, part, kNegBlocks, n, has_iou, with_reg_iou != 0, losses15);
+  k_loss_reduce<<<1, kLossReduceThreads, 0, st>>>(gathered, mask, anno_box, gt_boxes, iou3d, part, kNegBlocks, n, has_iou, with_reg_iou != 0, losses15);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

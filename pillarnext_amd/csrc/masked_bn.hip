@@ -78,16 +78,27 @@ __device__ __forceinline__ void block_reduce(const float (&acc)[NV][8], float cn
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_mbn_stats(const T* __restrict__ x, const float* __restrict__ mask, int64_t n, int C, float* __restrict__ partials) {
+__global__ __launch_bounds__(256) void k_mbn_stats(const T* __restrict__ x, const float* __restrict__ mask, int64_t n, int C, const float* __restrict__ center,
+                                                   float* __restrict__ partials) {
   const int cvec = C >> 3, t = threadIdx.x, chunk = t % cvec, rows = 256 / cvec;
   float acc[2][8] = {};
   float cnt = 0.f;
+  // sums of (x - center) and (x - center)^2: with the running mean as the centre the one-pass variance E[d^2] - E[d]^2 does not cancel
+  // when |mean| >> std (the plain E[x^2] - mean^2 loses the variance's leading digits in fp32 there)
+  float ctr[8] = {};
+  if (center != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) ctr[k] = center[chunk * 8 + k];
+  }
   for (int64_t site = (int64_t)blockIdx.x * rows + t / cvec; site < n; site += (int64_t)gridDim.x * rows) {
     if (mask[site] == 0.f) continue;
     float v[8];
     Ld8<T>::load(x + site * C + chunk * 8, v);
 #pragma unroll
-    for (int k = 0; k < 8; k++) acc[0][k] += v[k], acc[1][k] += v[k] * v[k];
+    for (int k = 0; k < 8; k++) {
+      const float d = v[k] - ctr[k];
+      acc[0][k] += d, acc[1][k] += d * d;
+    }
     if (chunk == 0) cnt += 1.f;
   }
   block_reduce<2>(acc, cnt, true, cvec, C, partials + (size_t)blockIdx.x * (2 * C + 1));
@@ -190,11 +201,12 @@ int32_t pnx_masked_bn_blocks(void) { return kMbnBlocks; }
   PNX_REQUIRE(n_sites < ((int64_t)1 << 40), PNX_ERR_INVALID, "too many sites");                                                  \
   hipStream_t st = (hipStream_t)stream;
 
-int pnx_masked_bn_stats(const void* x, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels, float* partials, pnx_stream_t stream) {
+int pnx_masked_bn_stats(const void* x, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels, const float* center, float* partials,
+                        pnx_stream_t stream) {
   MBN_COMMON_CHECKS
   PNX_REQUIRE(partials != nullptr, PNX_ERR_INVALID, "partials is NULL");
-  if (dtype == PNX_BF16) k_mbn_stats<uint16_t><<<kMbnBlocks, 256, 0, st>>>((const uint16_t*)x, mask, n_sites, channels, partials);
-  else k_mbn_stats<float><<<kMbnBlocks, 256, 0, st>>>((const float*)x, mask, n_sites, channels, partials);
+  if (dtype == PNX_BF16) k_mbn_stats<uint16_t><<<kMbnBlocks, 256, 0, st>>>((const uint16_t*)x, mask, n_sites, channels, center, partials);
+  else k_mbn_stats<float><<<kMbnBlocks, 256, 0, st>>>((const float*)x, mask, n_sites, channels, center, partials);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

@@ -96,9 +96,15 @@ class _CenterLossFn(torch.autograd.Function):
                 raise ops.PnxError("fused center loss needs fp32 CUDA head maps")
         B, C, H, W = maps[0].shape
         M = ind.shape[1]
-        hm_t, ind, mask, cat = hm_t.contiguous().float(), ind.contiguous(), mask.contiguous().to(torch.uint8), cat.contiguous()
-        anno, gtb = anno.contiguous().float(), gtb.contiguous().float()
         dev = maps[0].device
+        # the kernels read the labels through raw pointers: int64 indices / classes, uint8 mask, fp32 targets, all on the maps' device
+        # (an int32 `ind` or a label batch left on the host would be misread or fault; the module path raises a torch error there)
+        hm_t, anno, gtb = (t.to(device=dev, dtype=torch.float32).contiguous() for t in (hm_t, anno, gtb))
+        ind, cat = ind.to(device=dev, dtype=torch.int64).contiguous(), cat.to(device=dev, dtype=torch.int64).contiguous()
+        mask = mask.to(device=dev, dtype=torch.uint8).contiguous()
+        if ind.shape != cat.shape or ind.shape != mask.shape or anno.shape[:2] != ind.shape or gtb.shape[:2] != ind.shape:
+            raise ops.PnxError(f"fused center loss: label shapes disagree (ind {tuple(ind.shape)}, cat {tuple(cat.shape)}, mask {tuple(mask.shape)}, "
+                               f"anno_box {tuple(anno.shape)}, gt_boxes {tuple(gtb.shape)})")
         losses = torch.empty(16, dtype=torch.float32, device=dev)
         ws = torch.empty(int(L.pnx_center_loss_workspace_bytes(B, M)) + 256, dtype=torch.uint8, device=dev)
         arr = (ctypes.c_void_p * 7)(*[t.data_ptr() if t is not None else None for t in maps])

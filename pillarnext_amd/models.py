@@ -28,9 +28,23 @@ from . import ops
 def _spconv_weight_to_conv2d(w, conv):
     """spconv >= 2.2 stores (Cout, kH, kW, Cin); older (kH, kW, Cin, Cout).  nn.Conv2d wants (Cout, Cin, kH, kW)."""
     want = tuple(conv.weight.shape)
-    if tuple(w.shape) == want:
-        return w
     co, ci, kh, kw = want
+    layout = getattr(conv, "assume_layout", None)           # checkpoint.load_checkpoint sets it from the file's meta for the duration of the load
+    if layout == "dense":
+        if tuple(w.shape) != want:
+            raise RuntimeError(f"dense-layout checkpoint holds {tuple(w.shape)} for Conv2d {want}")
+        return w
+    if layout == "spconv":
+        if tuple(w.shape) != (co, kh, kw, ci):
+            raise RuntimeError(f"spconv-layout checkpoint holds {tuple(w.shape)} for Conv2d {want}")
+        return w.permute(0, 3, 1, 2).contiguous()
+    if tuple(w.shape) == want:
+        if kh > 1 and ci == kh == kw:
+            # (Cout, Cin, kH, kW) and (Cout, kH, kW, Cin) have the same shape: a file that does not say which one it holds cannot be read safely
+            raise RuntimeError(f"sparse-conv weight {want}: the shape does not tell nn.Conv2d's layout from spconv's; load the file with "
+                               "checkpoint.load_checkpoint (files written by checkpoint.save_checkpoint record their layout) or set "
+                               "conv.assume_layout = 'dense' / 'spconv'")
+        return w
     if tuple(w.shape) == (co, kh, kw, ci):
         return w.permute(0, 3, 1, 2).contiguous()
     if tuple(w.shape) == (kh, kw, ci, co):
@@ -117,16 +131,19 @@ class _MaskedBNActFn(torch.autograd.Function):
         nblk = int(L.pnx_masked_bn_blocks())
         part = torch.empty((nblk, 2 * C + 1), dtype=torch.float32, device=x.device)
         mflat = m.reshape(-1)
-        check(L.pnx_masked_bn_stats(ptr(x), dt, ptr(mflat), n, C, ptr(part), stream_ptr()), "pnx_masked_bn_stats")
-        s = part.double().sum(0)                                            # [sum x | sum x^2 | count]
+        # statistics around the running mean (identical on every rank: DDP broadcasts the buffers): sum d, sum d^2 with d = x - centre
+        center = norm.running_mean.detach().float().contiguous().clone()
+        check(L.pnx_masked_bn_stats(ptr(x), dt, ptr(mflat), n, C, ptr(center), ptr(part), stream_ptr()), "pnx_masked_bn_stats")
+        s = part.double().sum(0)                                            # [sum d | sum d^2 | count]
         group = norm.sync_group if norm.sync else False
         if group is not False:
             from .dist_utils import all_reduce_sum
 
             all_reduce_sum(s, group)
         cnt = s[-1].clamp(min=1.0)
-        mean = s[:C] / cnt
-        var = (s[C:2 * C] / cnt - mean * mean).clamp(min=0.0)
+        dmean = s[:C] / cnt
+        var = (s[C:2 * C] / cnt - dmean * dmean).clamp(min=0.0)
+        mean = center.double() + dmean
         invstd = torch.rsqrt(var + norm.eps)
         with torch.no_grad():
             mom = norm.momentum

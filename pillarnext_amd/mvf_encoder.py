@@ -7,7 +7,7 @@ mvf18_aspp detectors (configs/models/reader/mvf_encoder.yaml, configs/experiment
 Same class names, constructor arguments and state-dict keys as the reference.  SURVEY 8f-4 row (after the PillarNeXt hot path):
 the two point-to-cell groupings (which CLAMP the cell index instead of dropping points, mvf:57-62, 111-116) are torch.unique over
 one int64 key per point, the PFN layers are reader.PFNLayer on the HIP scatter-max (pnx_scatter_max), the per-view sparse
-ResNets are the masked-dense blocks of models.py (spconv is absent from the image: like the backbone, that part has no oracle),
+ResNets are the masked-dense blocks of models.py (spconv is absent from the image: like the backbone, that part cannot be pinned),
 the rest is the reference's arithmetic restated on torch ops."""
 import numpy as np
 import torch

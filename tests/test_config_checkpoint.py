@@ -5,6 +5,8 @@
    num_batches_tracked) round-trips through pillarnext_amd.checkpoint."""
 import os
 
+import pytest
+
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -110,3 +112,30 @@ def test_waymo_yaml_instantiates_with_the_iou_head():
     for k in ("head.tasks.0.iou.0.weight", "head.tasks.1.iou.3.bias", "head.tasks.1.hm.3.weight"):
         assert k in keys, k
     assert det.state_dict()["head.tasks.1.hm.3.weight"].shape[0] == 2
+
+
+def test_checkpoint_records_its_conv_layout(tmp_path):
+    """A 3x3 sparse-conv layer over 3 input features: (Cout, Cin, kH, kW) and spconv's (Cout, kH, kW, Cin) have the same shape.  A file
+    written by save_checkpoint says which one it holds and loads back exactly in both layouts; a bare state_dict of that shape is refused."""
+    import torch
+
+    from pillarnext_amd import checkpoint
+    from pillarnext_amd.models import SparseResNet
+
+    torch.manual_seed(1)
+    bb = SparseResNet([1], [1], [8], 3)                       # blocks.0.0.conv.weight is (8, 3, 3, 3)
+    w = bb.state_dict()["blocks.0.0.conv.weight"].clone()
+    assert tuple(w.shape) == (8, 3, 3, 3) and not torch.equal(w, w.permute(0, 2, 3, 1))
+    for layout in ("spconv", "dense"):
+        f = str(tmp_path / f"{layout}.pth")
+        checkpoint.save_checkpoint(bb, f, layout=layout)
+        ck = torch.load(f, weights_only=False)
+        assert ck["meta"]["pnx_conv_layout"] == layout
+        stored = ck["state_dict"]["blocks.0.0.conv.weight"]
+        assert torch.equal(stored, w.permute(0, 2, 3, 1) if layout == "spconv" else w)
+        bb2 = SparseResNet([1], [1], [8], 3)
+        checkpoint.load_checkpoint(bb2, f)
+        assert torch.equal(bb2.state_dict()["blocks.0.0.conv.weight"], w)
+        assert not hasattr(bb2.blocks[0][0].conv, "assume_layout")
+    with pytest.raises(RuntimeError, match="layout"):
+        SparseResNet([1], [1], [8], 3).load_state_dict(bb.state_dict())

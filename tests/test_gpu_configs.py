@@ -126,6 +126,22 @@ def test_training_step_c2_geometry_4_frames():
         f.write(p.stdout)
 
 
+def test_waymo_training_step_full_size():
+    """BASELINE configs[3] as a TRAINING step: the Waymo detector of configs/pillarnext_b_waymo.yaml (2 tasks, iou head: IouLoss with the
+    aligned rotated 3-D IoU target on the fused loss kernel, waymo_det_pp18_aspp_iou_car_sp_f1.yaml) at C4 geometry (180 k points, 0.1 m,
+    1504 x 1504), 2 frames, bf16 autocast: two optimizer steps, finite loss, finite non-zero gradients."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.setdefault("MIOPEN_FIND_MODE", "2")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_step.py"), "--batch", "2", "--steps", "2", "--config", "C4", "--check", "--amp",
+                        "--yaml", os.path.join(ROOT, "configs", "pillarnext_b_waymo.yaml")], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("step ")]
+    assert len(lines) == 2 and "peak" in p.stdout
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "train_step_c4_b2_waymo.log"), "w") as f:
+        f.write(p.stdout)
+
+
 def test_two_rank_rccl_ddp_matches_single_process():
     """2 ranks over RCCL (backend "nccl"): SyncBN conversion + DDP through the real reader; averaged gradients == one process on
     the 2 x 2-frame batch.  Skipped on the 1-GPU box; the driver's 8-GPU node runs it."""

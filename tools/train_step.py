@@ -6,8 +6,11 @@
 Mirrors tools/train.py:26-67 + trainer/trainer/trainer.py:94-108 of the reference: SyncBatchNorm conversion, DDP wrap
 (bucketed gradient all-reduce overlapped with backward), AdamW(0.9,0.99,wd .01, configs/optimizer/adamW.yaml), OneCycleLR(max_lr .002,
 div_factor 10, pct_start .4, configs/scheduler/onecycle.yaml) stepped every iteration, clip 35.  --amp runs the dense graph under bf16
-autocast in channels_last (the reference trains fp32; its Waymo 3-frame config uses fp16 AMP).  The masked BatchNorm + ReLU + mask of
-every sparse block is one recomputing autograd node (models.masked_bn_act) either way."""
+autocast in channels_last -- narrower arithmetic than the reference, which trains in fp32 throughout (no autocast anywhere in its tree);
+--nhwc is the fp32 step in channels_last.  The masked BatchNorm + ReLU + mask of every sparse block is one recomputing autograd node
+(models.masked_bn_act) either way; under --amp the backbone's 3x3 layers run on the masked HIP kernels (models.masked_conv).
+--yaml configs/pillarnext_b_waymo.yaml builds the Waymo detector (2 tasks, iou head -> IouLoss on the fused loss kernel,
+configs/experiments/waymo_det_pp18_aspp_iou_car_sp_f1.yaml) at the geometry of --config (C4 / C5)."""
 import argparse
 import os
 import sys
@@ -47,13 +50,26 @@ def main():
     ap.add_argument("--amp", action="store_true", help="bf16 autocast + channels_last for the dense backbone / neck / head")
     ap.add_argument("--nhwc", action="store_true", help="channels_last without autocast (fp32): the fused masked-BatchNorm kernels need NHWC maps")
     ap.add_argument("--total-steps", type=int, default=1000, help="length of the OneCycle schedule the steps are taken from")
+    ap.add_argument("--yaml", default="", help="build the detector from this YAML (configs/pillarnext_b_waymo.yaml) instead of the nuScenes PillarNeXt-B")
     a = ap.parse_args()
     rank, world, local = dist_utils.init()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg = synth.CONFIGS[a.config]
     torch.manual_seed(0)
-    model = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"]).to(dev).train()
+    tasks = NUSC_TASKS
+    if a.yaml:
+        from pillarnext_amd import config as C
+
+        y = C.load(a.yaml)
+        y["model"]["reader"]["voxel_size"], y["model"]["reader"]["pc_range"] = list(cfg["voxel_size"]), list(cfg["pc_range"])
+        for blk in ("head", "post_processing"):
+            y["model"][blk]["voxel_size"], y["model"][blk]["pc_range"] = list(cfg["voxel_size"]), list(cfg["pc_range"])
+        model = C.instantiate(y["model"]).to(dev).train()
+        tasks = [list(t) for t in y["model"]["head"]["tasks"]]
+        assert model.head.with_iou, "the Waymo YAML carries the iou head"
+    else:
+        model = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"]).to(dev).train()
     if a.amp or a.nhwc:
         model = model.to(memory_format=torch.channels_last)
     model = dist_utils.wrap_ddp(model, device_ids=[local])
@@ -62,7 +78,7 @@ def main():
     pts = torch.from_numpy(synth.make_batch(a.config, a.batch, "sweep", frame0=rank * a.batch)).to(dev)
     net = model.module if hasattr(model, "module") else model
     ny, nx = (int(v) for v in net.reader.grid_size)
-    ex = synthetic_labels(NUSC_TASKS, a.batch, ny // 4, nx // 4, 500, dev, 100 + rank)
+    ex = synthetic_labels(tasks, a.batch, ny // 4, nx // 4, 500, dev, 100 + rank)
     ex.update(points=pts, batch_size=a.batch)
     for it in range(a.steps):
         torch.cuda.synchronize()
