@@ -96,21 +96,6 @@ int pnx_reader_forward(const float* points, int64_t n_points, int32_t row_stride
                        float* feat_max, int32_t* coords, int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point,
                        int32_t* counts, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
 
-/* PillarFeatureNet.forward with a SPARSE result (no dense canvas): what the reference's reader hands to spconv is exactly this -- features per
- * pillar + coordinates (pillar_encoder.py:180-182, sparse_resnet.py:63-66 builds the SparseConvTensor from them); the dense canvas of
- * pnx_reader_forward is this package's masked-dense stand-in, and the first backbone stage does not need it (pnx_subm64_sparse_bf16).
- *   rows        (row_capacity, 64) bf16/fp16: row r = PFN output of the pillar of rank r (torch.unique order over (b, xi, yi)); row_capacity must be
- *               >= min(n_points, batch*gx*gy) (the count is not known on the host)
- *   wfull       uint2[pnx_reader_sparse_words(batch, geom)]: word ((b*gx + xi)*wpr + (yi >> 5)), wpr = ceil(gy/32): {occupancy bits of cells
- *               yi = 32*(word % wpr) .. +31 of column xi, rank of the first of them}; rank(cell) = .y + popcount(.x & ((1 << (yi & 31)) - 1))
- *   occupancy   optional (batch, gy, gx) uint8 in canvas order, as pnx_reader_forward writes it
- *   counts      int32[2] = {P, N'}
- * Exists on the default reader pipeline only (in-LDS bins: PNX_READER_IMPL unset or 3, F <= 5). */
-int64_t pnx_reader_sparse_words(int32_t batch, const pnx_geom* geom_host);
-int pnx_reader_forward_rows(const float* points, int64_t n_points, int32_t row_stride, int32_t batch, const pnx_geom* geom_host, const float* pfn_folded,
-                            void* rows, int32_t rows_dtype, int64_t row_capacity, int32_t* counts, void* wfull, uint8_t* occupancy, void* workspace,
-                            size_t workspace_bytes, pnx_stream_t stream);
-
 /* Percent of the canvas zero-fill tiles that the fused reader hands to extra blocks of its three grouping kernels (the PFN launch
  * takes the rest); PNX_FILL_SPLIT="a,b,c" overrides the built-in split.  For reports only. */
 void pnx_reader_fill_split(int32_t* percent3_host);
@@ -236,20 +221,6 @@ int pnx_conv_tile_list(const uint8_t* mask, const uint8_t* const* row_dirty, int
  * (1/2: the dense [iou] hm branches of the lazy head). */
 int pnx_sephead_out_bf16(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t n_branch,
                          pnx_stream_t stream);
-/* Sparse first backbone stage (SubMConv2d 64 -> 64 + BN + ReLU [+ identity] of sparse_resnet.py's conv1 / SparseBasicBlock on the reader's
- * SparseConvTensor, spconv semantics: outputs at the input's active sites only).  Features are (P, 64) bf16 rows in the reader's rank order, the
- * geometry is wfull (pnx_reader_forward_rows); gx = rows of the bitmap (canvas columns), wpr = words per row.  The kernels work in the bitmap's
- * frame, the transpose of the canvas: pack the weights as ops.conv3x3_pack_weights(w.transpose(2, 3)).
- *   pnx_sparse_tile_list: the 16 (xi) x 32 (yi) tiles that hold an active cell -> tile_list int32[batch*ceil(gx/16)*wpr], tile_count int32[1]
- *   pnx_subm64_sparse_bf16: rows_out[r] = [relu](bias + residual[r] + sum_taps W_tap . rows_in[rank(neighbour)])  for every active cell
- *   pnx_conv3x3_s2_sparse_bf16: SparseConv2d(64, 128, 3, stride 2, padding 1) + BN + ReLU reading the sparse tensor and writing the DENSE
- *               (batch, ceil(h/2), ceil(w/2), 128) bf16 map of the next stage (canvas frame, weights packed as for pnx_conv3x3_bf16); h = gy, w = gx of
- *               the reader's grid; mask = active sites of the output (pnx_mask_pool3 of the occupancy), row_dirty as in pnx_conv3x3_bf16. */
-int pnx_sparse_tile_list(const void* wfull, int32_t batch, int32_t gx, int32_t wpr, int32_t* tile_list, int32_t* tile_count, pnx_stream_t stream);
-int pnx_subm64_sparse_bf16(const void* rows_in, const void* wfull, int32_t batch, int32_t gx, int32_t wpr, const void* wfrag, const float* bias,
-                           const void* residual, void* rows_out, int32_t relu, const int32_t* tile_list, const int32_t* tile_count, pnx_stream_t stream);
-int pnx_conv3x3_s2_sparse_bf16(const void* rows_in, const void* wfull, int32_t batch, int32_t h, int32_t w, int32_t wpr, const void* wfrag,
-                               const float* bias, const uint8_t* mask, void* y, int32_t cout, int32_t relu, uint8_t* row_dirty, pnx_stream_t stream);
 /* Lazy SepHead: the five regression branches of every task (reg 2, height 1, dim 3, rot 2, vel 2: centerhead.py:12-59, conv3x3 64->64 + BN + ReLU,
  * then conv3x3 64->k) evaluated only at the candidate cells CenterHead.post_processing keeps (centerhead.py:341-363) instead of over the map, all
  * tasks in one launch.  Candidate lists: batch*nc_total lists (list s = sample s / nc_total, class s % nc_total, task class_task[class]) of pre_max

@@ -54,11 +54,6 @@ PROTOTYPES = {
     "pnx_sum_bias_act": (ctypes.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "pnx_deconv2x2_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pnx_sephead_out_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "pnx_reader_sparse_words": (_i64, [_i32, ctypes.POINTER(PnxGeom)]),
-    "pnx_reader_forward_rows": (ctypes.c_int, [_vp, _i64, _i32, _i32, ctypes.POINTER(PnxGeom), _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "pnx_sparse_tile_list": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "pnx_subm64_sparse_bf16": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
-    "pnx_conv3x3_s2_sparse_bf16": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "pnx_masked_bn_blocks": (_i32, []),
     "pnx_masked_bn_stats": (ctypes.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     "pnx_masked_bn_apply": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp]),

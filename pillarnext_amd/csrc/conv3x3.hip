@@ -634,556 +634,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
   CT_FLUSH
 }
 
-// ---- 64 -> 64, stride 1, PIXEL-sparse (submanifold layers of stage 0): the N dimension of the implicit GEMM is not a 32-pixel row
-// segment but 32 ACTIVE pixels of the 16 x 32 tile, in row-major order.  On a LiDAR sweep 4.9 % of the stage-0 cells are active but
-// 26 % of the row segments hold one: per non-empty tile the row kernel above runs ~12 segments of MFMAs, this one ceil(72/32) = 3
-// (tools/occupancy_stats.py: 16 975 segments vs 3 977 pixel groups per frame).  Same staging, same tile list / depth-2 loop, same
-// accumulator start (bias + residual) and pack_tile; what changes is the addressing of the B fragments (per-lane halo cell instead of
-// row base + lane) and the epilogue: the packed lines go through LDS (the staged tile is dead by then) so that every row segment with
-// an active site is written as 32 complete 128-byte lines, zeros at its inactive pixels.
-// Work split: wave w computes output channels [32 (w & 1), +32) for the pixel groups (w >> 1), (w >> 1) + 2, ... -- four at a time -- so a
-// weight fragment (L1/L2) feeds up to four MFMAs and a tile costs 4 x 36 KiB of fragment reads instead of 4 x 72.
-template <int NR>
-__device__ __forceinline__ void conv_taps_g(v16f (&acc)[NR], const uint4* __restrict__ s_in, const uint4* __restrict__ wfrag, const int (&rb)[4],
-                                            const int (&col)[4], int m, int kb, int lane) {
-  constexpr int MTALL = 2, CB = 4;
-  const uint4* wp = wfrag + m * 64 + lane;
-  uint4 w[4];
-#pragma unroll
-  for (int cbl = 0; cbl < 4; cbl++) w[cbl] = wp[cbl * MTALL * 64];
-  uint4 qn[NR];
-  int cb[NR], swk[NR];  // current tap: halo cell base (uint4 index) and chunk swizzle ^ kb of this lane's pixel
-#pragma unroll
-  for (int j = 0; j < NR; j++) {
-    cb[j] = rb[j] + col[j] * 8;
-    swk[j] = lds_swz(col[j]) ^ kb;
-    qn[j] = s_in[cb[j] + swk[j]];
-  }
-#pragma unroll 1
-  for (int tap = 0; tap < 9; tap++) {
-    const int tn = tap + 1;
-    const int dyn = tn / 3, dxn = tn - 3 * dyn;
-    int cbn[NR], swkn[NR];
-#pragma unroll
-    for (int j = 0; j < NR; j++) {
-      const int c = col[j] + dxn;
-      cbn[j] = rb[j] + (dyn * LDS_HW + c) * 8;
-      swkn[j] = lds_swz(c) ^ kb;
-    }
-#pragma unroll
-    for (int cbl = 0; cbl < 4; cbl++) {
-      uint4 qc[NR];
-#pragma unroll
-      for (int j = 0; j < NR; j++) qc[j] = qn[j];
-      if (cbl < 3) {
-#pragma unroll
-        for (int j = 0; j < NR; j++) qn[j] = s_in[cb[j] + (((cbl + 1) * 2) ^ swk[j])];
-      } else if (tap < 8) {
-#pragma unroll
-        for (int j = 0; j < NR; j++) qn[j] = s_in[cbn[j] + swkn[j]];
-      }
-#pragma unroll
-      for (int j = 0; j < NR; j++)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[cbl]), __builtin_bit_cast(bf16x8, qc[j]), acc[j], 0, 0, 0);
-      if (tap < 8) w[cbl] = wp[(tn * CB + cbl) * MTALL * 64];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int j = 0; j < NR; j++) cb[j] = cbn[j], swk[j] = swkn[j];
-  }
-}
-
-// A wave's NR pixel groups, its 32 output channels: accumulators = bias (+ residual), taps, pack.  D[j][t]: chunk 4m + 2t + kb of the
-// lane's pixel (zeros if !valid).
-template <int NR, bool HAS_RES>
-__device__ __forceinline__ void conv_groups(const uint4* __restrict__ s_in, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
-                                            const uint4 (&rq)[4][2], const int (&rb)[4], const int (&col)[4], const bool (&valid)[4], int relu, int m,
-                                            int kb, int lane, uint4 (&D)[4][2]) {
-  v16f acc[NR];
-  const v16f bq = bias_tile(bias, m * 32, kb);
-#pragma unroll
-  for (int j = 0; j < NR; j++) acc[j] = bq;
-  if (HAS_RES) {
-#pragma unroll
-    for (int j = 0; j < NR; j++)
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const uint4 r = rq[j][t];
-        const uint32_t lo[4] = {r.x << 16, r.x & 0xffff0000u, r.y << 16, r.y & 0xffff0000u};
-        const uint32_t hi[4] = {r.z << 16, r.z & 0xffff0000u, r.w << 16, r.w & 0xffff0000u};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const u32x2 q = __builtin_amdgcn_permlane32_swap(lo[i], hi[i], false, false);
-          acc[j][8 * t + i] += __uint_as_float(q.x);
-          acc[j][8 * t + 4 + i] += __uint_as_float(q.y);
-        }
-      }
-  }
-  conv_taps_g<NR>(acc, s_in, wfrag, rb, col, m, kb, lane);
-#pragma unroll
-  for (int j = 0; j < NR; j++) pack_tile(acc[j], valid[j], relu, D[j]);
-}
-
-template <bool HAS_RES>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_gat(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
-                                                        const uint16_t* __restrict__ res, const uint8_t* __restrict__ mask, uint16_t* __restrict__ y,
-                                                        int B, int H, int W, int relu, uint8_t* __restrict__ row_dirty, int slot,
-                                                        const int32_t* __restrict__ tlist, const int32_t* __restrict__ tcount) {
-  constexpr int COUT = 64, TH = LDS_TH, HW_ = LDS_HW;
-  __shared__ uint4 s_in[LDS_NSTAGE];
-  __shared__ uint32_t s_rowmask2[2 * TH];
-  __shared__ unsigned int s_next[2];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int px = lane & 31, kb = lane >> 5;
-  const int mw = wv & 1, gsel = wv >> 1;
-  const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
-  const int64_t n_tiles = tlist != nullptr ? (int64_t)__builtin_amdgcn_readfirstlane(*tcount) : (int64_t)B * tiles_y * tiles_x;
-  auto load_mask = [&](int64_t t, bool (&a)[4], int (&wz)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) a[j] = false, wz[j] = 1;
-    if (t < 0) return;
-    const int tx = (int)(t % tiles_x);
-    const int ty = (int)((t / tiles_x) % tiles_y);
-    const int b = (int)(t / ((int64_t)tiles_x * tiles_y));
-    const int ox = tx * 32 + px;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int oy = ty * TH + wv * 4 + j;
-      a[j] = ox < W && oy < H && mask[((int64_t)b * H + oy) * W + ox] != 0;
-      if (row_dirty != nullptr && oy < H) wz[j] = (int)row_dirty[((int64_t)b * H + oy) * tiles_x + tx];
-    }
-  };
-  int64_t idxB = (int64_t)blockIdx.x + gridDim.x, idxC = 0;
-  int64_t tileA = tile_at(tlist, blockIdx.x, n_tiles), tileB = tile_at(tlist, idxB, n_tiles), tileC = -1;
-  bool aP[4], aN[4];
-  int wasP[4], wasN[4];
-  load_mask(tileA, aP, wasP);
-#pragma unroll
-  for (int j = 0; j < 4; j++) aN[j] = false, wasN[j] = 1;
-  int it = 0;
-  for (; tileA >= 0; tileA = tileB, tileB = tileC, idxB = idxC, it++) {
-    const int64_t tile = tileA;
-    sched_draw(s_next, it, slot);
-    uint32_t* const s_rowmask = s_rowmask2 + (it & 1) * TH;
-    const int tx = (int)(tile % tiles_x);
-    const int ty = (int)((tile / tiles_x) % tiles_y);
-    const int b = (int)(tile / ((int64_t)tiles_x * tiles_y));
-    const int x0 = tx * 32, y0 = ty * TH;
-    const int ox = x0 + px;
-    bool was[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      was[j] = __builtin_amdgcn_readfirstlane(wasP[j]) != 0;
-      const uint32_t bal = (uint32_t)__ballot(aP[j]);
-      if (lane == 0) s_rowmask[wv * 4 + j] = bal;
-    }
-    __syncthreads();  // row masks visible; everybody is done with the previous tile's LDS (staged input, then output lines)
-    idxC = sched_next2(s_next, it, slot, idxB);
-    tileC = tile_at(tlist, idxC, n_tiles);
-    load_mask(tileB, aN, wasN);
-#pragma unroll
-    for (int j = 0; j < 4; j++) aP[j] = aN[j], wasP[j] = wasN[j];
-    const uint32_t my_rm = s_rowmask[lane & 15];
-    const uint32_t am = (uint32_t)__ballot(my_rm != 0) & 0xffffu;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {  // rows without any active site: zero-fill if they held data one frame ago
-      const int rr = wv * 4 + j, oy = y0 + rr;
-      const bool active = (am >> rr) & 1u;
-      if (!active && was[j] && oy < H && ox < W) {
-        uint4* dst = reinterpret_cast<uint4*>(y + (((int64_t)b * H + oy) * W + ox) * COUT);
-#pragma unroll 1
-        for (int ch = kb; ch < COUT / 8; ch += 2) dst[ch] = make_uint4(0, 0, 0, 0);
-      }
-      if (row_dirty != nullptr && oy < H && lane == 0 && was[j] != active) row_dirty[((int64_t)b * H + oy) * tiles_x + tx] = active ? 1 : 0;
-    }
-    if (am == 0) continue;  // uniform over the workgroup
-    // ---- the tile's active pixels in row-major order, 32 per group
-    uint32_t rm[TH];
-    int P = 0;
-#pragma unroll
-    for (int r = 0; r < TH; r++) {
-      rm[r] = __builtin_amdgcn_readfirstlane(s_rowmask[r]);
-      P += __builtin_popcount(rm[r]);
-    }
-    const int ngroups = (P + 31) >> 5;
-    const uint32_t need = am | (am << 1) | (am << 2);
-    // this lane's pixel in group g: (row << 5 | col), or -1
-    auto locate = [&](int g) -> int {
-      int k = g * 32 + px;
-      if (k >= P) return -1;
-      int row = 0;
-      uint32_t m = 0;
-      bool found = false;
-#pragma unroll
-      for (int r = 0; r < TH; r++) {
-        const int c = __builtin_popcount(rm[r]);
-        if (!found) {
-          if (k < c) {
-            found = true, row = r, m = rm[r];
-          } else {
-            k -= c;
-          }
-        }
-      }
-      int pos = 0;  // the k-th set bit of m
-#pragma unroll
-      for (int wdt = 16; wdt >= 1; wdt >>= 1) {
-        const int c = __builtin_popcount(m & (((1u << wdt) - 1u) << pos));
-        if (k >= c) k -= c, pos += wdt;
-      }
-      return row << 5 | pos;
-    };
-    int pc[2][4];
-    uint4 rq[4][2];
-    auto load_res = [&](int rd) {  // residual lines of this wave's 32 channels
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int row = pc[rd][j] >> 5, c = pc[rd][j] & 31;
-        const uint16_t* rp = res + (((int64_t)b * H + (y0 + row)) * W + (x0 + c)) * COUT + mw * 32 + 8 * kb;
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          rq[j][t] = make_uint4(0, 0, 0, 0);
-          if (pc[rd][j] >= 0) rq[j][t] = *reinterpret_cast<const uint4*>(rp + 16 * t);
-        }
-      }
-    };
-#pragma unroll
-    for (int rd = 0; rd < 2; rd++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        pc[rd][j] = -1;
-        if (rd == 0 || ngroups > 8) pc[rd][j] = locate(gsel + 2 * (j + 4 * rd));
-      }
-    if (HAS_RES) load_res(0);  // requested before the tile is staged, consumed after
-    stage_tile64<64>(s_in, x, b, H, W, 0, y0, x0, need);
-    __syncthreads();
-    uint4 D[2][4][2];
-#pragma unroll
-    for (int rd = 0; rd < 2; rd++) {
-      const int g0 = gsel + 8 * rd;
-      const int nr = __builtin_amdgcn_readfirstlane(g0 < ngroups ? min(((ngroups - 1 - g0) >> 1) + 1, 4) : 0);
-      if (nr == 0) continue;
-      if (HAS_RES && rd == 1) load_res(1);  // more than 256 active pixels in the tile: rare, its residual latency is not hidden
-      int rb[4], col[4];
-      bool valid[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        valid[j] = pc[rd][j] >= 0;
-        rb[j] = valid[j] ? (pc[rd][j] >> 5) * HW_ * 8 : 0;
-        col[j] = valid[j] ? (pc[rd][j] & 31) : 0;
-      }
-      switch (nr) {  // wave-uniform
-        case 1: conv_groups<1, HAS_RES>(s_in, wfrag, bias, rq, rb, col, valid, relu, mw, kb, lane, D[rd]); break;
-        case 2: conv_groups<2, HAS_RES>(s_in, wfrag, bias, rq, rb, col, valid, relu, mw, kb, lane, D[rd]); break;
-        case 3: conv_groups<3, HAS_RES>(s_in, wfrag, bias, rq, rb, col, valid, relu, mw, kb, lane, D[rd]); break;
-        default: conv_groups<4, HAS_RES>(s_in, wfrag, bias, rq, rb, col, valid, relu, mw, kb, lane, D[rd]); break;
-      }
-    }
-    __syncthreads();  // every wave is done reading the staged tile: its LDS becomes the output lines [row][col][chunk ^ (col & 7)]
-#pragma unroll
-    for (int rd = 0; rd < 2; rd++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (pc[rd][j] >= 0 && gsel + 2 * (j + 4 * rd) < ngroups) {
-          uint4* o = s_in + pc[rd][j] * 8;  // (row * 32 + col) * 8
-          const int sw = pc[rd][j] & 7;
-#pragma unroll
-          for (int t = 0; t < 2; t++) o[(4 * mw + 2 * t + kb) ^ sw] = D[rd][j][t];
-        }
-      }
-    __syncthreads();
-    {  // every row segment with an active site: 32 complete lines, zeros at the inactive pixels (8 lanes per line)
-      const int p = threadIdx.x >> 3, q = threadIdx.x & 7;
-      uint32_t rest = am;
-      while (rest) {
-        const int r = __builtin_ctz(rest);
-        rest &= rest - 1;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if ((s_rowmask[r] >> p) & 1u) v = s_in[(r * 32 + p) * 8 + (q ^ (p & 7))];
-        if (x0 + p < W) *reinterpret_cast<uint4*>(y + (((int64_t)b * H + (y0 + r)) * W + x0 + p) * COUT + q * 8) = v;
-      }
-    }
-  }
-  sched_done(slot);
-}
-
-// ---- 64 -> 64 submanifold convolution on a SPARSE tensor: the features are (P, 64) rows in the reader's pillar order (rank = position
-// of the cell among the active cells in (b, xi, yi) order, pnx_reader_forward_rows) and the geometry is the reader's occupancy bitmap with
-// its rank prefix (SparseIdx).  No dense canvas exists: the kernel above moves 1.6 GB through HBM per stage-0 layer of an 8-frame batch --
-// the zeros of the 95 % empty cells, read and written -- and is bound by exactly that (its MFMA work fell 4.3x against the row kernel and
-// its time did not move: 494 vs 520 us); here a layer reads the active rows (+ halo) once and writes P rows: ~0.25 GB.
-// Frame of this kernel: tile ROWS run along xi and tile COLUMNS along yi (one bitmap word = the 32 columns of a tile row), i.e. the
-// transpose of the canvas; the 3 x 3 weights are packed transposed (ops.conv3x3_pack_weights(w.transpose(2, 3))).
-// The halo tile is expanded into the same LDS layout as the dense kernels' (zeros at inactive cells), so the tap loop is conv_taps_g.
-struct SparseIdx {
-  const uint2* wfull;  // [b][xi][word]: {bits, rank of the first active cell of the word}
-  int gx, wpr;         // rows per sample, words per row
-};
-
-__global__ __launch_bounds__(256) void k_sparse_tile_list(SparseIdx S, int B, int32_t* __restrict__ list, int32_t* __restrict__ count) {
-  __shared__ int s_n, s_base;
-  const int tiles_r = (S.gx + LDS_TH - 1) / LDS_TH;
-  const int64_t n_tiles = (int64_t)B * tiles_r * S.wpr;
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (threadIdx.x == 0) s_n = 0;
-  __syncthreads();
-  bool hit = false;
-  if (t < n_tiles) {
-    const int tc = (int)(t % S.wpr);
-    const int tr = (int)((t / S.wpr) % tiles_r);
-    const int b = (int)(t / ((int64_t)S.wpr * tiles_r));
-    for (int r = 0; r < LDS_TH && !hit; r++) {
-      const int xi = tr * LDS_TH + r;
-      if (xi < S.gx) hit = S.wfull[((int64_t)b * S.gx + xi) * S.wpr + tc].x != 0u;
-    }
-  }
-  int my = 0;
-  if (hit) my = atomicAdd(&s_n, 1);
-  __syncthreads();
-  if (threadIdx.x == 0 && s_n > 0) s_base = atomicAdd(count, s_n);
-  __syncthreads();
-  if (hit) list[s_base + my] = (int32_t)t;
-}
-
-// Weight-stationary form of the gather tap loop: a wave keeps the 36 fragments of ITS 32 output channels (9 taps x 4 k-steps, 144
-// registers) for the whole launch, so the loop has no global load at all and is straight-line code the scheduler can fill with the B
-// reads of later k-steps.  (With the fragments fetched per tile, one or two pixel groups per wave gave a tap 2-8 MFMAs -- 64-256 cycles --
-// to hide an L2 round trip of ~1500: in-kernel timers showed 62 % of the wave time in the tap loop at 450 cycles per 2-MFMA k-step.)
-template <int NR>
-__device__ __forceinline__ void conv_taps_ws(v16f (&acc)[NR], const uint4* __restrict__ s_in, const uint4 (&W)[36], const int (&rb)[2], const int (&col)[2],
-                                             int kb) {
-#pragma unroll
-  for (int tap = 0; tap < 9; tap++) {
-    const int dy = tap / 3, dx = tap - 3 * dy;
-    int cbj[NR], swk[NR];
-#pragma unroll
-    for (int j = 0; j < NR; j++) {
-      int c = col[j] + dx;
-      asm volatile("" : "+v"(c));  // recomputed per tap: hoisted out of the round loop, the 72 LDS addresses spill
-      cbj[j] = rb[j] + (dy * LDS_HW + c) * 8;
-      swk[j] = lds_swz(c) ^ kb;
-    }
-#pragma unroll
-    for (int cbl = 0; cbl < 4; cbl++) {
-#pragma unroll
-      for (int j = 0; j < NR; j++) {
-        const uint4 q = s_in[cbj[j] + ((cbl * 2) ^ swk[j])];
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W[tap * 4 + cbl]), __builtin_bit_cast(bf16x8, q), acc[j], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);  // B reads are hoisted within a tap, not across taps (registers)
-  }
-}
-
-template <int NR, bool HAS_RES>
-__device__ __forceinline__ void conv_groups_ws(const uint4* __restrict__ s_in, const uint4 (&W)[36], const float* __restrict__ s_bias, const uint4 (&rq)[2][2],
-                                               const int (&rb)[2], const int (&col)[2], const bool (&valid)[2], int relu, int kb, uint4 (&D)[2][2]) {
-  v16f acc[NR];
-  {
-    const v16f bq = bias_tile(s_bias, 0, kb);  // this wave's 32 biases, from LDS
-#pragma unroll
-    for (int j = 0; j < NR; j++) acc[j] = bq;
-  }
-  if (HAS_RES) {
-#pragma unroll
-    for (int j = 0; j < NR; j++)
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const uint4 r = rq[j][t];
-        const uint32_t lo[4] = {r.x << 16, r.x & 0xffff0000u, r.y << 16, r.y & 0xffff0000u};
-        const uint32_t hi[4] = {r.z << 16, r.z & 0xffff0000u, r.w << 16, r.w & 0xffff0000u};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const u32x2 q = __builtin_amdgcn_permlane32_swap(lo[i], hi[i], false, false);
-          acc[j][8 * t + i] += __uint_as_float(q.x);
-          acc[j][8 * t + 4 + i] += __uint_as_float(q.y);
-        }
-      }
-  }
-  conv_taps_ws<NR>(acc, s_in, W, rb, col, kb);
-#pragma unroll
-  for (int j = 0; j < NR; j++) pack_tile(acc[j], valid[j], relu, D[j]);
-}
-
-template <bool HAS_RES>
-__global__ __launch_bounds__(256, 2) void k_subm64_sparse(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
-                                                          const uint16_t* __restrict__ res, uint16_t* __restrict__ y, SparseIdx S, int B, int relu,
-                                                          int slot, const int32_t* __restrict__ tlist, const int32_t* __restrict__ tcount) {
-  constexpr int TH = LDS_TH, HW_ = LDS_HW, NW = (TH + 2) * 3;
-  constexpr int kNRS = 2;  // pixel groups per wave and round
-  __shared__ uint4 s_in[LDS_NSTAGE];
-  __shared__ uint2 s_w2[2][NW];  // the tile's 18 x 3 bitmap words {bits, rank}, double-buffered by iteration parity
-  __shared__ unsigned int s_next[2];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int px = lane & 31, kb = lane >> 5;
-  const int mw = wv & 1, gsel = wv >> 1;
-  const int tiles_r = (S.gx + TH - 1) / TH;
-  const int64_t n_tiles = tlist != nullptr ? (int64_t)__builtin_amdgcn_readfirstlane(*tcount) : (int64_t)B * tiles_r * S.wpr;
-  auto load_words = [&](int64_t t) -> uint2 {  // thread hr * 3 + wsel: word (tile column - 1 + wsel) of halo row hr
-    uint2 v = make_uint2(0u, 0u);
-    if (t >= 0 && tid < NW) {
-      const int tc = (int)(t % S.wpr);
-      const int tr = (int)((t / S.wpr) % tiles_r);
-      const int b = (int)(t / ((int64_t)S.wpr * tiles_r));
-      const int xi = tr * TH - 1 + tid / 3, wc = tc - 1 + tid % 3;
-      if ((unsigned)xi < (unsigned)S.gx && (unsigned)wc < (unsigned)S.wpr) v = S.wfull[((int64_t)b * S.gx + xi) * S.wpr + wc];
-    }
-    return v;
-  };
-  int64_t idxB = (int64_t)blockIdx.x + gridDim.x, idxC = 0;
-  int64_t tileA = tile_at(tlist, blockIdx.x, n_tiles), tileB = tile_at(tlist, idxB, n_tiles), tileC = -1;
-  uint2 wP = load_words(tileA);
-  int it = 0;
-  uint4 Wst[36];  // this wave's weight fragments, resident for the whole launch
-#pragma unroll
-  for (int q = 0; q < 36; q++) Wst[q] = wfrag[(q * 2 + mw) * 64 + lane];
-  __shared__ __align__(16) float s_bias[64];
-  if (tid < 64) s_bias[tid] = bias[tid];
-  CT_DECL
-  for (; tileA >= 0; tileA = tileB, tileB = tileC, idxB = idxC, it++) {
-    sched_draw(s_next, it, slot);
-    uint2* const sw = s_w2[it & 1];
-    if (tid < NW) sw[tid] = wP;
-    CT_TOCK(7)
-    __syncthreads();  // words visible; everybody is done with the previous tile's staged input
-    idxC = sched_next2(s_next, it, slot, idxB);
-    tileC = tile_at(tlist, idxC, n_tiles);
-    wP = load_words(tileB);  // consumed at the top of the next iteration
-    CT_TOCK(0)
-    uint32_t rm[TH];
-    int P = 0;
-    uint32_t am = 0;
-#pragma unroll
-    for (int r = 0; r < TH; r++) {
-      rm[r] = __builtin_amdgcn_readfirstlane(sw[(r + 1) * 3 + 1].x);
-      P += __builtin_popcount(rm[r]);
-      am |= rm[r] ? (1u << r) : 0u;
-    }
-    if (P == 0) continue;  // uniform over the workgroup
-    const int ngroups = (P + 31) >> 5;
-    const uint32_t need = am | (am << 1) | (am << 2);
-    // this lane's pixel in group g: (row << 5 | col), or -1
-    auto locate = [&](int g) -> int {
-      int k = g * 32 + px;
-      if (k >= P) return -1;
-      int row = 0;
-      uint32_t m = 0;
-      bool found = false;
-#pragma unroll
-      for (int r = 0; r < TH; r++) {
-        const int c = __builtin_popcount(rm[r]);
-        if (!found) {
-          if (k < c) {
-            found = true, row = r, m = rm[r];
-          } else {
-            k -= c;
-          }
-        }
-      }
-      int pos = 0;  // the k-th set bit of m
-#pragma unroll
-      for (int wdt = 16; wdt >= 1; wdt >>= 1) {
-        const int c = __builtin_popcount(m & (((1u << wdt) - 1u) << pos));
-        if (k >= c) k -= c, pos += wdt;
-      }
-      return row << 5 | pos;
-    };
-    auto rank_of = [&](int pc) -> uint32_t {  // row of the feature matrices that holds pixel pc
-      const uint2 w = sw[((pc >> 5) + 1) * 3 + 1];
-      return w.y + (uint32_t)__builtin_popcount(w.x & ((1u << (pc & 31)) - 1u));
-    };
-    int pc[2];
-    uint32_t rk[2];
-    uint4 rq[2][2];
-    auto prepare = [&](int rd) {  // this wave's (up to) four pixel groups of round rd: pixel, row of the feature matrices, residual lines
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        pc[j] = locate(gsel + 2 * (j + kNRS * rd));
-        rk[j] = pc[j] >= 0 ? rank_of(pc[j]) : 0u;
-        if (HAS_RES) {
-          const uint16_t* rp = res + (int64_t)rk[j] * 64 + mw * 32 + 8 * kb;
-#pragma unroll
-          for (int t = 0; t < 2; t++) {
-            rq[j][t] = make_uint4(0, 0, 0, 0);
-            if (pc[j] >= 0) rq[j][t] = *reinterpret_cast<const uint4*>(rp + 16 * t);
-          }
-        }
-      }
-    };
-    prepare(0);  // residual requested before the tile is staged, consumed after
-    CT_TOCK(1)
-    // ---- stage: every halo cell either gets its feature line (16 bytes per thread, 8 threads per cell) or zeros
-    {
-      constexpr int NSLOT = (TH + 2) * HW_ * 8, NB = (NSLOT + 255) / 256, HALF = (NB + 3) / 4;
-#pragma unroll 1
-      for (int part = 0; part < 4; part++) {
-        uint4 v[HALF];
-#pragma unroll
-        for (int k = 0; k < HALF; k++) {
-          const int e = tid + (part * HALF + k) * 256;
-          const int cell = e >> 3, q = e & 7;
-          const int hr = cell / HW_, hc = cell - hr * HW_;
-          v[k] = make_uint4(0, 0, 0, 0);
-          if (e < NSLOT && ((need >> hr) & 1u)) {
-            const int wsel = hc == 0 ? 0 : (hc == HW_ - 1 ? 2 : 1);
-            const int bit = hc == 0 ? 31 : (hc == HW_ - 1 ? 0 : hc - 1);
-            const uint2 w = sw[hr * 3 + wsel];
-            if ((w.x >> bit) & 1u) {
-              const uint32_t r = w.y + (uint32_t)__builtin_popcount(w.x & ((1u << bit) - 1u));
-              v[k] = *reinterpret_cast<const uint4*>(x + (int64_t)r * 64 + q * 8);
-            }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < HALF; k++) {
-          const int e = tid + (part * HALF + k) * 256;
-          const int cell = e >> 3, q = e & 7;
-          const int hr = cell / HW_, hc = cell - hr * HW_;
-          if (e < NSLOT && ((need >> hr) & 1u)) s_in[cell * 8 + (q ^ lds_swz(hc))] = v[k];
-        }
-      }
-    }
-    CT_TOCK(2)
-    __syncthreads();
-    CT_TOCK(3)
-#pragma unroll 1
-    for (int rd = 0; rd < 8 / kNRS; rd++) {
-      const int g0 = gsel + 2 * kNRS * rd;
-      const int nr = __builtin_amdgcn_readfirstlane(g0 < ngroups ? min(((ngroups - 1 - g0) >> 1) + 1, kNRS) : 0);
-      if (nr == 0) break;
-      if (rd > 0) {
-        prepare(rd);
-        CT_TOCK(1)
-      }  // later rounds (more than 64 kNRS active pixels in the tile): their residual latency is not hidden
-      int rb[2], col[2];
-      bool valid[2];
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        valid[j] = pc[j] >= 0;
-        rb[j] = valid[j] ? (pc[j] >> 5) * HW_ * 8 : 0;
-        col[j] = valid[j] ? (pc[j] & 31) : 0;
-      }
-      uint4 D[2][2];
-      if (nr == 1) conv_groups_ws<1, HAS_RES>(s_in, Wst, s_bias + mw * 32, rq, rb, col, valid, relu, kb, D);
-      else conv_groups_ws<2, HAS_RES>(s_in, Wst, s_bias + mw * 32, rq, rb, col, valid, relu, kb, D);
-      CT_TOCK(5)
-      // consecutive pixels of a group are consecutive rows of y: a store instruction covers 32 bytes of up to 32 adjacent lines
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        if (j < nr && valid[j]) {
-          uint16_t* o = y + (int64_t)rk[j] * 64 + (4 * mw + kb) * 8;
-#pragma unroll
-          for (int t = 0; t < 2; t++) *reinterpret_cast<uint4*>(o + 16 * t) = D[j][t];
-        }
-      }
-      CT_TOCK(6)
-    }
-    CT_TOCK(4)
-  }
-  sched_done(slot);
-  CT_FLUSH
-}
-
 // ---- CIN -> COUT channels in multiples of 64 / 128, stride 1: 8 x 32 pixel tiles, 64-channel input slabs through one LDS buffer
 constexpr int L128_TH = 8;
 constexpr int L128_NSTAGE = (L128_TH + 2) * LDS_HW * 8;
@@ -1436,57 +886,6 @@ __device__ __forceinline__ void stage_tile64_s2(uint4* __restrict__ s_in, const 
   }
 }
 
-// The same halo tile gathered from a sparse tensor (SparseIdx + (P, 64) feature rows, see k_subm64_sparse): cell (iy, ix) of the canvas
-// is bit iy & 31 of word (b, xi = ix, iy >> 5); the nine halo rows of a tile touch at most two words per column.
-__device__ __forceinline__ void stage_tile64_s2_sparse(uint4* __restrict__ s_in, const uint16_t* __restrict__ rows, const SparseIdx& S, int b, int H, int W,
-                                                       int iy0, int ix0, uint32_t need) {
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int slot = tid & 7, col = tid >> 3;
-  const int wiA = (iy0 < 0 ? 0 : iy0) >> 5, wiB = min(iy0 + S2_ROWS - 1, H - 1) >> 5;
-  auto fetch = [&](const uint2& wA, const uint2& wB, int iy, int chunk) -> uint4 {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if ((unsigned)iy < (unsigned)H) {
-      const uint2 w = (iy >> 5) == wiA ? wA : wB;
-      const int bit = iy & 31;
-      if ((w.x >> bit) & 1u) {
-        const uint32_t r = w.y + (uint32_t)__builtin_popcount(w.x & ((1u << bit) - 1u));
-        v = *reinterpret_cast<const uint4*>(rows + (int64_t)r * 64 + chunk * 8);
-      }
-    }
-    return v;
-  };
-#pragma unroll
-  for (int pl = 0; pl < 2; pl++) {        // pl 0: even plane (c = 2 col + 1), pl 1: odd plane (c = 2 col)
-    const int ls = pl * 32 + col;
-    const int ix = ix0 + 2 * col + (1 - pl);
-    const int chunk = slot ^ lds_swz(ls);
-    uint2 wA = make_uint2(0u, 0u), wB = wA;
-    if ((unsigned)ix < (unsigned)W) {
-      const uint2* wp = S.wfull + ((int64_t)b * S.gx + ix) * S.wpr;
-      wA = wp[wiA], wB = wp[wiB];
-    }
-    uint4 v[S2_ROWS];
-#pragma unroll
-    for (int r = 0; r < S2_ROWS; r++) v[r] = ((need >> r) & 1u) ? fetch(wA, wB, iy0 + r, chunk) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < S2_ROWS; r++)
-      if ((need >> r) & 1u) s_in[(r * S2_RS + ls) * 8 + slot] = v[r];
-  }
-  if (tid < S2_ROWS * 8) {  // slot 64: input column ix0 + 64
-    const int re = tid >> 3, ce = tid & 7;
-    if ((need >> re) & 1u) {
-      const int ix = ix0 + 64;
-      uint4 qe = make_uint4(0, 0, 0, 0);
-      if ((unsigned)ix < (unsigned)W) {
-        const uint2* wp = S.wfull + ((int64_t)b * S.gx + ix) * S.wpr;
-        qe = fetch(wp[wiA], wp[wiB], iy0 + re, ce);
-      }
-      s_in[(re * S2_RS + 64) * 8 + (ce ^ lds_swz(64))] = qe;
-    }
-  }
-}
-
 template <int NR, int CIN, int COUT>
 __device__ __forceinline__ void conv_rows_s2(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                              const float* __restrict__ bias, const int (&rbase)[4], const uint32_t (&rmask)[4],
@@ -1529,12 +928,11 @@ __device__ __forceinline__ void conv_rows_s2(uint4* __restrict__ s_in, const uin
 }
 
 // H, W: input; Ho, Wo: output.  The 4 waves are COUT/64 groups of 64 output channels x 4/(COUT/64) row groups.
-template <int CIN, int COUT, bool SPARSE = false>
+template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_s2(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
                                                     const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W, int Ho, int Wo,
-                                                    int relu, uint8_t* __restrict__ row_dirty, int slot, SparseIdx S = SparseIdx{nullptr, 0, 0}) {
+                                                    int relu, uint8_t* __restrict__ row_dirty, int slot) {
   static_assert(CIN % 64 == 0 && (COUT == 128 || COUT == 256), "64-channel input slabs; 2 or 4 groups of 64 output channels");
-  static_assert(!SPARSE || CIN == 64, "sparse input: one 64-channel slab (x = the (P, 64) feature rows)");
   constexpr int TH = S2_TH, NCG = COUT / 64, NRG = 4 / NCG, NRMAX = TH / NRG;
   extern __shared__ uint4 s_in[];  // S2_NSTAGE
   __shared__ uint32_t s_rowmask2[2 * TH];
@@ -1605,8 +1003,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_s2(const uint16_t* __restric
     for (int r = 0; r < TH; r++)
       if ((am >> r) & 1u) need |= 7u << (2 * r);
     const int iy0 = 2 * y0 - 1, ix0 = 2 * x0 - 1;
-    if constexpr (SPARSE) stage_tile64_s2_sparse(s_in, x, S, b, H, W, iy0, ix0, need);
-    else stage_tile64_s2<CIN>(s_in, x, b, H, W, 0, iy0, ix0, need);
+    stage_tile64_s2<CIN>(s_in, x, b, H, W, 0, iy0, ix0, need);
     __syncthreads();
 #define PNX_ROWS_S2(N_) conv_rows_s2<(N_ <= NRMAX ? N_ : NRMAX), CIN, COUT>(s_in, x, wfrag, bias, rbase, rmask, yrow, b, H, W, iy0, ix0, Wo - x0, need, mg, relu, px, kb, lane)
     switch (nr) {  // wave-uniform; every case runs the same barriers
@@ -1627,15 +1024,14 @@ int launch_s2(const void* x, const void* wfrag, const float* bias, const uint8_t
   const int slot = mask != nullptr ? next_sched_slot() : -1;
   int64_t nb = (int64_t)B * ((Ho + S2_TH - 1) / S2_TH) * ((Wo + 31) / 32);
   if (nb > 512) nb = 512;  // resident workgroups: 2 per CU (LDS and registers)
-  auto kern = k_conv3x3_s2<CIN, COUT, false>;
+  auto kern = k_conv3x3_s2<CIN, COUT>;
   constexpr int lds = S2_NSTAGE * 16;
   static bool attr_done = false;
   if (!attr_done) {
     PNX_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  kern<<<(unsigned)nb, 256, lds, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, mask, (uint16_t*)y, B, H, W, Ho, Wo, relu, row_dirty, slot,
-                                       SparseIdx{nullptr, 0, 0});
+  kern<<<(unsigned)nb, 256, lds, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, mask, (uint16_t*)y, B, H, W, Ho, Wo, relu, row_dirty, slot);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -1850,17 +1246,6 @@ int launch_lds(const void* x, const void* wfrag, const float* bias, const void* 
   if (nb > cap) nb = cap;
   const int slot = mask != nullptr ? next_sched_slot() : -1;
   if constexpr (COUT == 64) {
-    const bool gather = getenv("PNX_CONV_GATHER") && atoi(getenv("PNX_CONV_GATHER")) == 1;  // measured equal to the row kernel: opt-in
-    if (mask != nullptr && gather) {  // pixel-sparse variant (submanifold layers of stage 0)
-      if (res != nullptr)
-        k_conv3x3_gat<true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B, H, W,
-                                                         relu, row_dirty, slot, tlist, tcount);
-      else
-        k_conv3x3_gat<false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu,
-                                                          row_dirty, slot, tlist, tcount);
-      PNX_LAUNCH_CHECK();
-      return PNX_OK;
-    }
     if (res != nullptr) {
       k_conv3x3_lds<COUT, true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B,
                                                              H, W, relu, row_dirty, slot, tlist, tcount);
@@ -2008,68 +1393,6 @@ int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const 
 }
 
 }  // extern "C"
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// Sparse first stage: entry points (pnx.h)
-extern "C" int pnx_sparse_tile_list(const void* wfull, int32_t batch, int32_t gx, int32_t wpr, int32_t* tile_list, int32_t* tile_count, pnx_stream_t stream) {
-  PNX_REQUIRE(wfull && tile_list && tile_count && batch > 0 && gx > 0 && wpr > 0, PNX_ERR_INVALID, "bad arguments");
-  hipStream_t st = (hipStream_t)stream;
-  PNX_CHECK_HIP(hipMemsetAsync(tile_count, 0, sizeof(int32_t), st));
-  const SparseIdx S{(const uint2*)wfull, gx, wpr};
-  const int64_t n_tiles = (int64_t)batch * ((gx + LDS_TH - 1) / LDS_TH) * wpr;
-  k_sparse_tile_list<<<(unsigned)((n_tiles + 255) / 256), 256, 0, st>>>(S, batch, tile_list, tile_count);
-  PNX_LAUNCH_CHECK();
-  return PNX_OK;
-}
-
-extern "C" int pnx_subm64_sparse_bf16(const void* rows_in, const void* wfull, int32_t batch, int32_t gx, int32_t wpr, const void* wfrag, const float* bias,
-                                      const void* residual, void* rows_out, int32_t relu, const int32_t* tile_list, const int32_t* tile_count,
-                                      pnx_stream_t stream) {
-  PNX_REQUIRE(rows_in && wfull && wfrag && bias && rows_out && batch > 0 && gx > 0 && wpr > 0, PNX_ERR_INVALID, "bad arguments");
-  PNX_REQUIRE((tile_list == nullptr) == (tile_count == nullptr), PNX_ERR_INVALID, "tile_list and tile_count come together");
-  PNX_REQUIRE(rows_in != rows_out && residual != rows_out, PNX_ERR_INVALID, "the output rows must be a buffer of their own");
-  PNX_REQUIRE((((uintptr_t)rows_in | (uintptr_t)rows_out | (uintptr_t)wfrag | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)wfull) & 15) == 0,
-              PNX_ERR_INVALID, "16-byte alignment required");
-  hipStream_t st = (hipStream_t)stream;
-  const SparseIdx S{(const uint2*)wfull, gx, wpr};
-  const int64_t n_tiles = (int64_t)batch * ((gx + LDS_TH - 1) / LDS_TH) * wpr;
-  const unsigned nb = (unsigned)(n_tiles < 512 ? n_tiles : 512);  // resident workgroups: 2 per CU
-  const int slot = next_sched_slot();
-  if (residual != nullptr)
-    k_subm64_sparse<true><<<nb, 256, 0, st>>>((const uint16_t*)rows_in, (const uint4*)wfrag, bias, (const uint16_t*)residual, (uint16_t*)rows_out, S, batch,
-                                             relu, slot, tile_list, tile_count);
-  else
-    k_subm64_sparse<false><<<nb, 256, 0, st>>>((const uint16_t*)rows_in, (const uint4*)wfrag, bias, nullptr, (uint16_t*)rows_out, S, batch, relu, slot,
-                                              tile_list, tile_count);
-  PNX_LAUNCH_CHECK();
-  return PNX_OK;
-}
-
-extern "C" int pnx_conv3x3_s2_sparse_bf16(const void* rows_in, const void* wfull, int32_t batch, int32_t h, int32_t w, int32_t wpr, const void* wfrag,
-                                          const float* bias, const uint8_t* mask, void* y, int32_t cout, int32_t relu, uint8_t* row_dirty,
-                                          pnx_stream_t stream) {
-  PNX_REQUIRE(rows_in && wfull && wfrag && bias && y && batch > 0 && h > 0 && w > 0 && wpr * 32 >= h, PNX_ERR_INVALID, "bad arguments");
-  PNX_REQUIRE(cout == 128, PNX_ERR_UNSUPPORTED, "sparse strided entry convolution: 64 -> 128 only (got %d)", cout);
-  PNX_REQUIRE(row_dirty == nullptr || mask != nullptr, PNX_ERR_INVALID, "row_dirty needs an active-site mask");
-  PNX_REQUIRE((((uintptr_t)rows_in | (uintptr_t)y | (uintptr_t)wfrag | (uintptr_t)bias | (uintptr_t)wfull) & 15) == 0, PNX_ERR_INVALID,
-              "16-byte alignment required");
-  hipStream_t st = (hipStream_t)stream;
-  const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
-  const SparseIdx S{(const uint2*)wfull, w, wpr};  // canvas frame: rows of the bitmap are the canvas columns (xi)
-  const int slot = mask != nullptr ? next_sched_slot() : -1;
-  int64_t nb = (int64_t)batch * ((ho + S2_TH - 1) / S2_TH) * ((wo + 31) / 32);
-  if (nb > 512) nb = 512;
-  auto kern = k_conv3x3_s2<64, 128, true>;
-  constexpr int lds = S2_NSTAGE * 16;
-  static bool attr_done = false;
-  if (!attr_done) {
-    PNX_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_done = true;
-  }
-  kern<<<(unsigned)nb, 256, lds, st>>>((const uint16_t*)rows_in, (const uint4*)wfrag, bias, mask, (uint16_t*)y, batch, h, w, ho, wo, relu, row_dirty, slot, S);
-  PNX_LAUNCH_CHECK();
-  return PNX_OK;
-}
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Lazy SepHead (models.FusedPillarNeXt): the five regression branches of a task (reg, height, dim, rot, vel: conv3x3 64 -> 64 + BN +

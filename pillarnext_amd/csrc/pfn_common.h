@@ -1,4 +1,4 @@
-// pfn_common.h -- helpers shared by the PFN kernels over sorted records (pfn_v3.hip: records in HBM; pfn_bins.hip: records sorted
+// pfn_common.h -- helpers shared by the PFN kernels over sorted records (pfn_v3.hip: records in HBM; pfn_spans.hip: records sorted
 // in LDS by the same workgroup).  Reference arithmetic: pillar_encoder.py:35-50, :174-182.
 #pragma once
 #include "pnx_common.h"

@@ -1,7 +1,7 @@
 // pfn_v3.hip -- the PFN (pillar_encoder.py:35-50 x2, :174-182) over the pillar-sorted, pre-decorated 64-byte records that
 // reader_bins.h::k_bin_sort writes, fused with the zero-fill of the pillar-free canvas cells (pnx_fill.h).
 //
-// Same MFMA mapping as round 1 (pfn_mfma.hip): one wave = one tile of <= 32 points cut at pillar boundaries, lane = (point, h),
+// MFMA mapping: one wave = one tile of <= 32 points cut at pillar boundaries, lane = (point, h),
 // h = lane>>5 selecting the even/odd K element of v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain at the fp32 vector rate):
 //   layer 0   D0 = W0'(32ch x K) * F^T: the lane's six operand words ARE the six record words it loaded (no select, no decoration,
 //             no per-pillar mean here -- k_bin_sort did that once per point); D0 leaves 16 channels of the point in the lane,
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void k_pfn3_tail(const uint4* __restrict__ rec
   if (stat && wave >= nbig && wave >= novf) return;
   BigWeights<F> Wt;
   Wt.load(P, l);
-  if (stat) {  // nobody else draws tickets (pfn_bins.hip): a static deal, no atomic round trip per pillar
+  if (stat) {  // nobody else draws tickets (pfn_spans.hip): a static deal, no atomic round trip per pillar
     for (int bi = wave; bi < nbig; bi += nwaves) pfn3_big_pillar<F>(biglist[bi], Wt, rec, pfirst, pcnt, cell_of_pillar, out, l & 31, l >> 5);
   } else {
     pfn3_big_walk<F>(Wt, counters, biglist, nbig, -1, rec, pfirst, pcnt, cell_of_pillar, out, l);
@@ -590,7 +590,7 @@ int pnx_launch_pfn_v3(int F, const uint32_t* rec64, const uint32_t* pfirst, cons
   return PNX_ERR_UNSUPPORTED;
 }
 
-// k_pfn3_tail alone, for the LDS-sorted path (pfn_bins.hip): the pillars it spilled to the 64-byte record stream -- more than 32
+// k_pfn3_tail alone, for the LDS-sorted path (pfn_spans.hip): the pillars it spilled to the 64-byte record stream -- more than 32
 // points (biglist[0, bigcap), counters[3]) or a tile outside the fp16x3 range (biglist[bigcap, 2 bigcap), counters[4]).
 int pnx_launch_pfn3_tail(int F, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar, int32_t* counters,
                          const int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows, void* canvas, int canvas_dt, int blocks,

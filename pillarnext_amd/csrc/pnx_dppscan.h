@@ -1,5 +1,5 @@
 // pnx_dppscan.h -- segmented inclusive max across the 32 lanes of each wave half with DPP row shifts, for the PFN kernels
-// (pfn_mfma.hip, pfn_v3.hip): lane = point, the points of a pillar are adjacent lanes, idx = position inside the pillar.
+// (pfn_v3.hip): lane = point, the points of a pillar are adjacent lanes, idx = position inside the pillar.
 #pragma once
 #include "pnx_common.h"
 

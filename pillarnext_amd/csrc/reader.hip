@@ -278,14 +278,14 @@ __global__ void k_fold_bn(int C0, const float* w0, const float* g0, const float*
     const float a = __fmul_rn(__fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(v1[t], eps))), g1[t]);
     out[S1 + t] = __fsub_rn(b1[t], __fmul_rn(m1[t], a));
   }
-  // Fragment-ordered copy for k_pfn_mfma: register j of lane l at FR + j*64 + l.
+  // Fragment-ordered copy for the MFMA PFN kernels (pfn_v3.hip, pfn_spans.hip): register j of lane l at FR + j*64 + l.
   //   j 0..5   W0'[col][2j+h]            (A/B fragment of layer 0; column C0 = s0[col] for the constant-1 feature)
   //   j 6      s0[col]
   //   j 7..22  s0[ch(i,h)]               ch(i,h) = (i&3) + 8*(i>>2) + 4h  (accumulator-register channel order)
   //   j 23..54 W1'[col][k(i,h)]          k(i,h) = (i<16 ? ch(i,h) : 32 + ch(i-16,h))
   //   j 55..86 W1'[32+col][k(i,h)]
   //   j 87, 88 s1[col], s1[32+col]
-  //   then 64 x 32: s1[ch(i,h)] (i<16) | s1[32+ch(i-16,h)], contiguous per lane (tail-lane epilogue of k_pfn_mfma)
+  //   then 64 x 32: s1[ch(i,h)] (i<16) | s1[32+ch(i-16,h)], contiguous per lane (tail-lane epilogue)
   // Second fragment block (pfn_v3.hip, fp16x3 layer 1), register j of lane l at FR + 64*121 + j*64 + l:
   //   j 0..6   layer-0 fragments as j 0..6 above, times 2^PNX_PFN_SU (layer 0 then leaves h0 pre-scaled for the fp16 split)
   //   j 7..70  W1' * 2^PNX_PFN_SW as fp16 hi/lo pairs in the operand order of v_mfma_f32_32x32x16_f16:
@@ -356,72 +356,6 @@ __global__ void k_fold_bn(int C0, const float* w0, const float* g0, const float*
     }
     out[FR + idx] = v;
   }
-}
-
-// h0[c] = relu(W0'[c,:] . f + s0[c])
-template <int F>
-__device__ __forceinline__ void pfn_layer0(const float* f, const float* __restrict__ P, float* h0) {
-  using L = Folded<F>;
-#pragma unroll
-  for (int c = 0; c < 32; c++) {
-    float acc = 0.f;
-#pragma unroll
-    for (int k = 0; k < L::C0; k++) acc = __builtin_fmaf(f[k], P[L::W0 + c * L::C0 + k], acc);
-    const float y = acc + P[L::S0 + c];
-    h0[c] = y > 0.f ? y : 0.f;
-  }
-}
-
-// Reference kernel ("v0"): one thread per pillar walks its CSR list three times (mean, layer-0 max,
-// layer-1 max).  Simple and obviously right; kept as the cross-check for the wave-tiled kernel below and
-// selected with PNX_PFN_IMPL=0.
-template <int F>
-__global__ __launch_bounds__(kBlock) void k_pfn_pillar(const float* __restrict__ pts, GeomDev g, const int32_t* __restrict__ plist,
-                                                       const uint32_t* __restrict__ count, const uint32_t* __restrict__ cpre,
-                                                       const uint32_t* __restrict__ cblk, const int32_t* __restrict__ counters,
-                                                       const float* __restrict__ P, float* __restrict__ g1, int64_t g1_rows) {
-  using L = Folded<F>;
-  const int32_t r = blockIdx.x * kBlock + threadIdx.x;
-  if (r >= counters[0] || r >= g1_rows) return;
-  const uint32_t s = pillar_start(r, cpre, cblk), c = count[r] + 1u;  // count[] holds the non-owner points
-  double sx = 0, sy = 0, sz = 0;
-  for (uint32_t k = 0; k < c; k++) {
-    const float* p = pts + (int64_t)plist[s + k] * (F + 1);
-    sx += (double)p[1];
-    sy += (double)p[2];
-    sz += (double)p[3];
-  }
-  const float fc = (float)c;
-  const float mx = __fdiv_rn((float)sx, fc), my = __fdiv_rn((float)sy, fc), mz = __fdiv_rn((float)sz, fc);
-  float g0[32];
-#pragma unroll
-  for (int q = 0; q < 32; q++) g0[q] = 0.f;
-  for (uint32_t k = 0; k < c; k++) {
-    float f[F + 5], h0[32];
-    decorate<F>(pts + (int64_t)plist[s + k] * (F + 1), mx, my, mz, g, f);
-    pfn_layer0<F>(f, P, h0);
-#pragma unroll
-    for (int q = 0; q < 32; q++) g0[q] = fmaxf(g0[q], h0[q]);
-  }
-  float out[64];
-#pragma unroll
-  for (int q = 0; q < 64; q++) out[q] = 0.f;
-  for (uint32_t k = 0; k < c; k++) {
-    float f[F + 5], h0[32];
-    decorate<F>(pts + (int64_t)plist[s + k] * (F + 1), mx, my, mz, g, f);
-    pfn_layer0<F>(f, P, h0);
-    for (int q = 0; q < 64; q++) {
-      float acc = 0.f;
-#pragma unroll
-      for (int j = 0; j < 32; j++) acc = __builtin_fmaf(h0[j], P[L::W1 + q * 64 + j], acc);
-#pragma unroll
-      for (int j = 0; j < 32; j++) acc = __builtin_fmaf(g0[j], P[L::W1 + q * 64 + 32 + j], acc);
-      out[q] = fmaxf(out[q], acc + P[L::S1 + q]);  // relu folded into the 0 start value
-    }
-  }
-  float4* o = reinterpret_cast<float4*>(g1 + (int64_t)r * 64);
-#pragma unroll
-  for (int q = 0; q < 16; q++) o[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
 }
 
 // ------------------------------------------------------------------------------------------ canvas
@@ -497,24 +431,6 @@ __global__ __launch_bounds__(kBlock) void k_canvas_nhwc(const uint32_t* __restri
     }
     out[(((int64_t)b * g.gy + (y0 + yl)) * g.gx + xi) * CH + q] = v;
   }
-}
-
-// NHWC canvas, direct-write mode: the PFN kernel stores every pillar's 64 features straight into its cell; this kernel
-// writes the zeros of all OTHER cells (and the occupancy bytes) -- see pnx_fill.h (the fused PFN+fill launch of pfn_v3.hip
-// runs the same tile routine from its fill blocks).
-template <int DT, bool NT>
-__global__ __launch_bounds__(kBlock) void k_canvas_fill_nhwc(const uint32_t* __restrict__ bitmap, GeomDev g, void* __restrict__ canvas,
-                                                             uint8_t* __restrict__ occ) {
-  __shared__ uint32_t s_word[32];
-  pnx_fill_tile<DT, NT>(bitmap, g, canvas, occ, blockIdx.x, s_word, threadIdx.x, kBlock);
-}
-
-// The same tiles taken one by one from a ticket counter by a grid-capped launch (<= a few workgroups per CU): it can sit on a second
-// stream beside the latency-bound grouping kernels without flooding the dispatcher the way one block per tile does.
-template <int DT>
-__global__ __launch_bounds__(kBlock) void k_canvas_fill_persist(PnxFillJob fj, GeomDev g) {
-  __shared__ uint32_t s_word[36];
-  pnx_fill_share_dt<DT>(fj, g, s_word, threadIdx.x, kBlock);
 }
 
 // NCHW canvas (what .dense() returns).  Not the performance layout; same tile scheme, one element per store.
@@ -679,13 +595,12 @@ struct ReaderWs {
   size_t bytes;
 };
 
-// PNX_READER_IMPL: 1 = round-1 pipeline, 2 = binned grouping + k_bin_sort + k_pfn3 (records through HBM), 3 (default) = binned grouping +
-// k_bin_pfn (pfn_bins.hip: sort and PFN in LDS), 4 (default) = chunk sort + span PFN (chunk_sort.hip, pfn_spans.hip).  Read on every call:
-// the workspace layout follows it.
+// PNX_READER_IMPL: 4 (default) = chunk sort + span PFN (chunk_sort.hip, pfn_spans.hip); 2 = the round-2 pipeline kept as the one
+// cross-check: binned grouping (reader_bins.h) + k_bin_sort + k_pfn3 (64-byte pillar-sorted records through HBM, pfn_v3.hip) -- the
+// records the fused training passes (pfn_train.hip) consume, and the path of 6 point features / PNX_PFN_F16X3=0.
 int reader_impl() {
   const char* e = getenv("PNX_READER_IMPL");
-  const int v = e ? atoi(e) : 4;
-  return v >= 1 && v <= 4 ? v : 4;
+  return e && atoi(e) == 2 ? 2 : 4;
 }
 
 int64_t cells_padded(const pnx_geom* g, int32_t batch) {
@@ -705,7 +620,7 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   w.nblk_k = (int)((n + PNX_SCAN_ITEMS - 1) / PNX_SCAN_ITEMS);
   if (w.nblk_k < 1) w.nblk_k = 1;
   w.counters = c.take<int32_t>(64);
-  w.tick = c.take<int32_t>(24 * 32);  // 16 window-ticket words (word 0: bin tickets of pfn_bins.hip) + 5 fill-share counters, one 128-byte line each
+  w.tick = c.take<int32_t>(24 * 32);  // 16 window-ticket words (word 0: span tickets of pfn_spans.hip) + 5 fill-share counters, one 128-byte line each
   w.frame_lo = c.take<int32_t>(batch);
   w.frame_hi = c.take<int32_t>(batch);
   w.zero_bytes_span = c.used();
@@ -731,29 +646,10 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   w.kblk = c.take<uint32_t>(w.nblk_k + 8);
   w.mean = c.take<float>(w.pcap * 3 + 8);
   w.g1 = c.take<float>(w.pcap * 64 + 8);
-  // binned paths.  PNX_READER_IMPL=2 (round 2, k_bin_sort + k_pfn3): bins small enough for k_bin_sort's LDS (<= 2048 pillars), at most
-  // ~2400 of them, 512 chunks of points.  Default (3, pfn_bins.hip: the bin is sorted AND consumed in LDS): bins of 256 pillars
-  // (~770 points on a nuScenes sweep, one LDS segment), up to 16384 of them; the chunks grow (and the count/scatter workgroups get
-  // 1024 threads) so that the (bin x workgroup) matrix stays ~2.5 M entries (measured: 256 chunks x 1024 threads 148 us of grouping at
-  // C2 / 8 frames, 128 x 1024 165 us).
-  const char* sh_env = getenv("PNX_BIN_SH");  // experiment: bins of 2^sh pillars
-  if (reader_impl() >= 3) {
-    w.sh = 8;
-    while (w.sh < 11 && ((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh) > 16384) w.sh++;
-    if (sh_env && atoi(sh_env) >= 8 && atoi(sh_env) <= 11) w.sh = atoi(sh_env);
-    w.K1 = (int)((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh);
-    const int nwg_env = getenv("PNX_BIN_NWG") ? atoi(getenv("PNX_BIN_NWG")) : 0;
-    // one wave of workgroups: 1024-thread workgroups sit one per CU, and a 257th would run alone behind the other 256
-    // (measured: 261 chunks 194 us of grouping at C2 / 8 frames, 254 chunks 154 us)
-    int64_t nwg = nwg_env > 0 ? nwg_env : 2500000 / (w.K1 > 0 ? w.K1 : 1);
-    if (nwg > 256) nwg = 256;
-    if (nwg < 32) nwg = 32;
-    int64_t chunk = ((n + nwg - 1) / nwg + 255) / 256 * 256;
-    if (chunk < 2048) chunk = 2048;
-    w.chunk = (int)chunk;
-    const int thr_env = getenv("PNX_BIN_THREADS") ? atoi(getenv("PNX_BIN_THREADS")) : 0;
-    w.gthreads = thr_env > 0 ? thr_env : (chunk >= 8192 ? 1024 : (chunk >= 4096 ? 512 : 256));
-  } else {
+  // binned path (k_bin_count / k_bin_scatter / k_bin_sort): bins small enough for k_bin_sort's LDS (<= 2048 pillars), at most ~2400 of them,
+  // 512 chunks of points
+  {
+    const char* sh_env = getenv("PNX_BIN_SH");  // experiment: bins of 2^sh pillars
     w.sh = 8;
     static const int k1max = getenv("PNX_BIN_K1MAX") ? atoi(getenv("PNX_BIN_K1MAX")) : 2400;
     while (w.sh < 11 && ((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh) > k1max) w.sh++;
@@ -885,10 +781,8 @@ int launch_bin_sort(const GeomDev& gd, const ReaderWs& w, int32_t* coords, int64
 }
 
 // fill[0..2]: shares of the canvas zero-fill carried by extra blocks of k_bin_count / k_bin_scatter / k_bin_sort (quota 0 = none)
-// sort = false: stop behind k_bin_scatter (the LDS-sorted path consumes the bins itself, pfn_bins.hip)
 int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev& gd, const ReaderWs& w, int32_t* coords,
-                  int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, const PnxFillJob* fill, int fill_blocks, hipStream_t st,
-                  hipEvent_t bitmap_ready = nullptr, bool sort = true) {
+                  int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point, const PnxFillJob* fill, int fill_blocks, hipStream_t st) {
   PNX_CHECK_HIP(hipMemsetAsync(w.counters, 0, w.zero_bytes2, st));  // counters | tick | bytemap
   if (n > 0) {
     k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bytemap, nullptr);
@@ -899,7 +793,6 @@ int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev&
   // every block, and on this 8-XCD part that fence writes the XCD's dirty L2 lines back: measured +115 us on the 255 us voxelize.
   static const bool fuse_scan = getenv("PNX_SCAN_FUSE") != nullptr && getenv("PNX_SCAN_FUSE")[0] == '1';
   k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk, w.wcomb, w.counters + 0, fuse_scan ? w.counters + 8 : nullptr);
-  if (bitmap_ready != nullptr) PNX_CHECK_HIP(hipEventRecord(bitmap_ready, st));  // the zero-fill only needs the bitmap
   if (!fuse_scan) k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
   PNX_LAUNCH_CHECK();
   if (n <= 0) return PNX_OK;
@@ -914,7 +807,7 @@ int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev&
                                                                              w.rec, gd, f1);
   PNX_LAUNCH_CHECK();
   int rc = PNX_OK;
-  if (sort) switch (stride - 1) {
+  switch (stride - 1) {
     case 3: rc = launch_bin_sort<3>(gd, w, coords, pillar_capacity, f2, fill_blocks / 2, st); break;
     case 4: rc = launch_bin_sort<4>(gd, w, coords, pillar_capacity, f2, fill_blocks / 2, st); break;
     case 5: rc = launch_bin_sort<5>(gd, w, coords, pillar_capacity, f2, fill_blocks / 2, st); break;
@@ -943,21 +836,12 @@ int launch_canvas(const ReaderWs& w, const float* g1, int64_t g1_rows, const Geo
 
 }  // namespace
 
-// implemented in pfn_mfma.hip: the wave-tiled fp32-MFMA PFN kernel (PNX_PFN_IMPL=1, default)
-int pnx_launch_pfn_mfma(int F, const uint32_t* rec, const PnxGeomDev& geom, const uint32_t* count, const uint32_t* cpre,
-                        const uint32_t* cblk, int32_t* counters, int32_t* biglist, int64_t bigcap, const float* folded, float* g1,
-                        int64_t g1_rows, void* canvas, const int32_t* cell_of_pillar, int canvas_dt, int64_t n_points, hipStream_t st);
-
 // implemented in pfn_v3.hip: PFN over the pillar-sorted records of the binned path, optionally fused with the canvas zero-fill
 int pnx_launch_pfn_v3(int F, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar,
                       int32_t* counters, int32_t* tick, int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows,
                       void* canvas, int canvas_dt, int64_t n_points, int n_fill, const PnxGeomDev& geom, const PnxFillJob& fj, hipStream_t st);
 
-// implemented in pfn_bins.hip: in-LDS bin sort + PFN in one launch; pfn_v3.hip: the one-wave-per-pillar kernel for what it spills
-int pnx_launch_bin_pfn(int F, const uint32_t* binbuf, const uint32_t* hpre, const uint32_t* hblk, int64_t matlen, int sh, int nwg, int K1,
-                       int32_t* counters, int32_t* tick, uint32_t* rec64, uint32_t* pfirst, uint32_t* pcnt, int32_t* cell_of_pillar, int32_t* coords,
-                       int64_t pillar_capacity, int write_pillars, int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows,
-                       void* canvas, int canvas_dt, int64_t n_points, int n_fill, const PnxGeomDev& geom, const PnxFillJob& fj, hipStream_t st);
+// implemented in pfn_v3.hip: the one-wave-per-pillar kernel for what the span kernel (pfn_spans.hip) spills
 int pnx_launch_pfn3_tail(int F, const uint32_t* rec64, const uint32_t* pfirst, const uint32_t* pcnt, const int32_t* cell_of_pillar, int32_t* counters,
                          const int32_t* biglist, int64_t bigcap, const float* folded, float* g1, int64_t g1_rows, void* canvas, int canvas_dt, int blocks,
                          hipStream_t st, const int32_t* row_of = nullptr);
@@ -1000,25 +884,7 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
   const int64_t ncb = cbytes != nullptr ? (int64_t)gd.B * w.sg.cpf : 0;
   int rc;
   prof_mark(0, st);
-  // PNX_PREFILL=<percent> (experiment): the first tiles of the canvas are zeroed UNCONDITIONALLY by a launch of its own on a second stream
-  // while the grouping kernels run (they leave registers and LDS for a co-resident workgroup; the span kernel does not); the span
-  // launch's fill blocks take the rest from the occupancy bytes, and the pillars of the pre-filled part are simply stored over the zeros.
-  static hipStream_t fside = nullptr;
-  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  const char* pfl_env = getenv("PNX_PREFILL");
   const int all_tiles = direct ? pnx_fill_tiles_bytes(gd) : 0;
-  int pre_tiles = (direct && pfl_env) ? (int)((int64_t)all_tiles * atoi(pfl_env) / 100) : 0;
-  pre_tiles = pre_tiles < 0 ? 0 : (pre_tiles > all_tiles ? all_tiles : pre_tiles);
-  const char* fs_env = getenv("PNX_FILL_SIDE");
-  const bool side = direct && fs_env && fs_env[0] == '1';
-  if ((side || pre_tiles > 0) && fside == nullptr) {
-    int lo = 0, hi = 0;
-    PNX_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    const char* pr_env = getenv("PNX_FILL_PRIO");
-    PNX_CHECK_HIP(hipStreamCreateWithPriority(&fside, hipStreamNonBlocking, pr_env && pr_env[0] == 'h' ? hi : (pr_env && pr_env[0] == 'l' ? lo : 0)));
-    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-  }
   auto launch_fill_kernel = [&](const PnxByteFillJob& job, int blocks, hipStream_t fs) -> int {
     if (canvas_dtype == PNX_F32) k_canvas_fill_bytes<PNX_F32><<<blocks, kBlock, 0, fs>>>(job, gd);
     else if (canvas_dtype == PNX_BF16) k_canvas_fill_bytes<PNX_BF16><<<blocks, kBlock, 0, fs>>>(job, gd);
@@ -1032,16 +898,6 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     k_clear2<<<blocks, kBlock, 0, st>>>(reinterpret_cast<uint4*>(w.counters), (int64_t)(w.zero_bytes_span >> 4), cbytes, ncb);
     PNX_LAUNCH_CHECK();
-  }
-  if (pre_tiles > 0) {  // behind the clear (its ticket counter is zero), beside everything up to the span launch
-    PnxByteFillJob pj;
-    pj.bytemap = nullptr, pj.canvas = canvas, pj.counter = w.tick + 17 * 32, pj.tiles = pre_tiles, pj.nt = fill_nt ? 1 : 0, pj.base = 0;
-    PNX_CHECK_HIP(hipEventRecord(ev_fork, st));
-    PNX_CHECK_HIP(hipStreamWaitEvent(fside, ev_fork, 0));
-    static const int pb = getenv("PNX_PREFILL_BLOCKS") ? atoi(getenv("PNX_PREFILL_BLOCKS")) : 256;
-    rc = launch_fill_kernel(pj, pb, fside);
-    if (rc != PNX_OK) return rc;
-    PNX_CHECK_HIP(hipEventRecord(ev_join, fside));
   }
   if (ranked) {  // the key-order bitmap and its popcount prefix: the pillar rank of a cell == torch.unique(dim=0) order (pe:110)
     PNX_CHECK_HIP(hipMemsetAsync(w.bytemap, 0, (size_t)cells_of(gd) + 64, st));
@@ -1058,7 +914,7 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
   if (rc != PNX_OK) return rc;
   prof_mark(6, st);
   PnxByteFillJob fj;
-  fj.bytemap = cbytes, fj.canvas = canvas, fj.counter = w.tick + 16 * 32, fj.tiles = all_tiles - pre_tiles, fj.nt = fill_nt ? 1 : 0, fj.base = pre_tiles;
+  fj.bytemap = cbytes, fj.canvas = canvas, fj.counter = w.tick + 16 * 32, fj.tiles = all_tiles, fj.nt = fill_nt ? 1 : 0, fj.base = 0;
   const char* fb_env = getenv("PNX_FILL_BLOCKS");
   int n_fill = (direct && fj.tiles > 0) ? (fb_env ? atoi(fb_env) : 256) : 0;
   SpanTables T;
@@ -1066,15 +922,7 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
   T.span_desc = w.span_desc, T.nspan = w.nspan;
   prof_mark(4, st);
   prof_mark(1, st);
-  if (pre_tiles > 0) PNX_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));  // the pillars go over the zeros
-  if (side && n_fill > 0) {  // PNX_FILL_SIDE=1 (experiment): the rest of the fill as a launch of its own beside the span kernel
-    PNX_CHECK_HIP(hipEventRecord(ev_fork, st));
-    PNX_CHECK_HIP(hipStreamWaitEvent(fside, ev_fork, 0));
-    rc = launch_fill_kernel(fj, n_fill, fside);
-    if (rc != PNX_OK) return rc;
-    PNX_CHECK_HIP(hipEventRecord(ev_join, fside));
-    n_fill = 0;
-  } else if (n <= 0 && n_fill > 0) {
+  if (n <= 0 && n_fill > 0) {  // nothing to group: the span launch would have no PFN role
     rc = launch_fill_kernel(fj, n_fill, st);
     if (rc != PNX_OK) return rc;
     n_fill = 0;
@@ -1083,7 +931,6 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
                            ranked ? w.wcomb : nullptr, w.wblk, coords, pillar_capacity, pfn_folded, g1, g1_rows, direct ? canvas : nullptr, canvas_dtype, n,
                            n_fill, fj, gd, st);
   if (rc != PNX_OK) return rc;
-  if (side && fj.tiles > 0 && n_fill == 0 && n > 0) PNX_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
   if (n > 0) {
     static const int tb = getenv("PNX_TAIL_BLOCKS") ? atoi(getenv("PNX_TAIL_BLOCKS")) : 128;
     rc = pnx_launch_pfn3_tail(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.biglist, w.bigcap, pfn_folded, g1, g1_rows, direct ? canvas : nullptr,
@@ -1118,31 +965,6 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
 }
 }  // namespace
 
-namespace {
-// Sparse view of the voxelization for the backbone's first stage (conv3x3.hip: k_subm64_sparse, k_conv3x3_s2 with gathered input):
-// wfull[word] = {occupancy bits of the 32 cells yi = 32 (word % wpr) .. +31 of (b, xi) = word / wpr, rank of the word's first pillar};
-// the rank of cell (b, xi, yi) is wfull.y + popcount(bits below yi & 31) -- torch.unique order, the row of the pillar in the (P, 64)
-// feature rows.  occupancy (optional): the same bits as bytes in canvas order (b, yi, xi), what pnx_mask_pool3 consumes.
-__global__ __launch_bounds__(256) void k_sparse_index(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre, const uint32_t* __restrict__ wblk,
-                                                      GeomDev g, uint2* __restrict__ wfull, uint8_t* __restrict__ occ) {
-  const int wpr = g.gyp >> 5;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // lanes run over xi: the occupancy rows are written in 64-byte pieces
-  if (idx >= (int64_t)g.B * wpr * g.gx) return;
-  const int xi = (int)(idx % g.gx);
-  const int yw = (int)((idx / g.gx) % wpr);
-  const int b = (int)(idx / ((int64_t)g.gx * wpr));
-  const int64_t w = ((int64_t)b * g.gx + xi) * wpr + yw;
-  const uint32_t bits = bitmap[w];
-  wfull[w] = make_uint2(bits, wblk[w >> PNX_SCAN_SHIFT] + wpre[w]);
-  if (occ != nullptr) {
-#pragma unroll 4
-    for (int j = 0; j < 32; j++) {
-      const int yi = yw * 32 + j;
-      if (yi < g.gy) occ[((int64_t)b * g.gy + yi) * g.gx + xi] = (uint8_t)((bits >> j) & 1u);
-    }
-  }
-}
-}  // namespace
 
 extern "C" {
 
@@ -1179,254 +1001,69 @@ int pnx_reader_forward(const float* points, int64_t n, int32_t stride, int32_t b
   const ReaderWs w = carve(workspace, n, batch, g);
   const GeomDev gd = make_geom(g, batch);
 
-  // PNX_PFN_IMPL=0: per-pillar cross-check PFN kernel.  PNX_READER_IMPL=1: round-1 pipeline (global-atomic slots, 32-byte records,
-  // DPP-scan PFN); 2: binned pipeline (reader_bins.h) + k_bin_sort + k_pfn3 (64-byte sorted records through HBM, pfn_v3.hip);
-  // default 3: binned grouping, then ONE launch sorts every bin in LDS and runs the PFN on it (pfn_bins.hip).
-  const char* impl_env = getenv("PNX_PFN_IMPL");
-  const int impl = impl_env ? atoi(impl_env) : 1;
+  const int F = stride - 1;
   {
     const char* h16_env = getenv("PNX_PFN_F16X3");
     const int64_t rows = (int64_t)w.sg.nchunks * batch;
-    if (reader_impl() == 4 && impl != 0 && stride - 1 <= 5 && !(h16_env && h16_env[0] == '0') && w.sg.nf <= 32768 && batch <= 1024 &&
-        rows < ((int64_t)1 << 30))
+    if (reader_impl() == 4 && F <= 5 && !(h16_env && h16_env[0] == '0') && w.sg.nf <= 32768 && batch <= 1024 && rows < ((int64_t)1 << 30))
       return reader_forward_spans(points, n, stride, gd, w, pfn_folded, canvas, canvas_dtype, canvas_layout, occupancy, feat_max, coords, pillar_capacity,
                                   unq_inv, pillar_of_point, counts, st);
   }
-  const int rimpl = reader_impl() == 4 ? 3 : reader_impl();
-  const bool binned = rimpl != 1 && impl != 0 && w.K1 <= 16384;
-  const int F = stride - 1;
-  const char* h_env = getenv("PNX_PFN_F16X3");  // 0: plain fp32 MFMA layer 1 (pfn_v3.hip only)
-  const bool lds_sorted = binned && rimpl == 3 && F <= 5 && w.sh <= 10 && !(h_env && h_env[0] == '0');
-  // Direct mode (NHWC canvas, MFMA PFN): the PFN kernel stores each pillar straight into its canvas cell and fill blocks (or a fill
-  // kernel) write the zeros of every other cell -- no (P,64) fp32 intermediate, every canvas byte still written exactly once.
-  const bool direct = canvas != nullptr && canvas_layout == PNX_NHWC && impl != 0;
-  // feat_max doubles as the PFN output buffer when it can hold every possible pillar
-  float* g1 = (feat_max && pillar_capacity >= w.pcap) ? feat_max : w.g1;
+  // ---- the binned pipeline (PNX_READER_IMPL=2; 6 point features; PNX_PFN_F16X3=0): reader_bins.h + pfn_v3.hip
+  PNX_REQUIRE(w.K1 <= 16384, PNX_ERR_UNSUPPORTED, "too many points for the binned grouping");
+  // Direct mode (NHWC canvas): the PFN kernel stores each pillar straight into its canvas cell and fill blocks write the zeros of every
+  // other cell -- no (P,64) fp32 intermediate, every canvas byte written exactly once.
+  const bool direct = canvas != nullptr && canvas_layout == PNX_NHWC;
+  float* g1 = (feat_max && pillar_capacity >= w.pcap) ? feat_max : w.g1;  // feat_max doubles as the PFN output buffer when it can hold every possible pillar
   if (direct && feat_max == nullptr) g1 = nullptr;
   const int64_t g1_rows = (g1 == feat_max) ? pillar_capacity : w.pcap;
   const size_t canvas_bytes = (size_t)gd.B * gd.gx * gd.gy * 64 * (canvas_dtype == PNX_F32 ? 4 : 2);
   const char* nt_env = getenv("PNX_FILL_NT");
   const bool fill_nt = nt_env ? nt_env[0] == '1' : canvas_bytes >= ((size_t)3 << 29);  // >= 1.5 GiB: far beyond what the Infinity Cache absorbs
-  // PNX_READER_FUSE: 0 = zero-fill as its own kernel in front of the PFN; 1 = fill tiles carried by blocks of the reader's own
-  // launches; 2 = the stand-alone fill kernel (one block per tile) on a second stream; 3 = a PERSISTENT, grid-capped fill kernel on a
-  // second stream from the moment the bitmap exists (PNX_FILL_SIDE percent of the tiles, the reader's launches carry the rest).
-  const char* fuse_env = getenv("PNX_READER_FUSE");
-  const char* fb_env = getenv("PNX_FILL_BLOCKS");
-  const bool side_fill = binned && direct && fuse_env && fuse_env[0] == '2';
-  const bool fuse = binned && direct && !(fuse_env && (fuse_env[0] == '0' || fuse_env[0] == '2'));
-  const char* fs_env = getenv("PNX_FILL_SIDE");
-  int side_pct = (fuse && fuse_env && fuse_env[0] == '3') ? (fs_env ? atoi(fs_env) : 100) : 0;
-  side_pct = side_pct < 0 ? 0 : (side_pct > 100 ? 100 : side_pct);
   // The zero-fill's 32x32-cell tiles are dealt to the launches that leave HBM idle (pnx_fill.h): extra blocks of k_bin_count /
-  // k_bin_scatter / k_bin_sort take `split` percent each, the PFN launch the rest.  PNX_FILL_SPLIT="a,b,c".
-  PnxFillJob fjob[4], fside;
+  // k_bin_scatter / k_bin_sort take `split` percent each (PNX_FILL_SPLIT="a,b,c", default 0,0,24), the PFN launch the rest.
+  PnxFillJob fjob[4];
   {
     int split[3];
     pnx_reader_fill_split(split);
-    if (lds_sorted) split[2] = 0;  // no k_bin_sort launch on this path
     const int tiles = pnx_fill_tiles(gd);
-    int base = (fuse && n > 0) ? (int)((int64_t)tiles * side_pct / 100) : 0;
-    fside.bitmap = w.bitmap, fside.canvas = canvas, fside.occ = occupancy, fside.counter = w.tick + 20 * 32;
-    fside.base = 0, fside.quota = base, fside.dt = canvas_dtype, fside.nt = fill_nt ? 1 : 0, fside.n_main = 0;
-    const int rest = tiles - base;
+    int base = 0;
     for (int k = 0; k < 4; k++) {
-      int q = k < 3 ? (int)((int64_t)rest * split[k] / 100) : tiles - base;
-      if (!fuse || n <= 0) q = k < 3 ? 0 : (fuse ? tiles : 0);
+      int q = k < 3 ? (int)((int64_t)tiles * split[k] / 100) : tiles - base;
+      if (!direct || n <= 0) q = k < 3 ? 0 : (direct ? tiles : 0);
       if (q > tiles - base) q = tiles - base;
       fjob[k].bitmap = w.bitmap, fjob[k].canvas = canvas, fjob[k].occ = occupancy, fjob[k].counter = w.tick + (16 + k) * 32;
       fjob[k].base = base, fjob[k].quota = q, fjob[k].dt = canvas_dtype, fjob[k].nt = fill_nt ? 1 : 0, fjob[k].n_main = 0;
       base += q;
     }
   }
+  const char* fb_env = getenv("PNX_FILL_BLOCKS");
   const int fill_blocks = fb_env ? atoi(fb_env) : 256;
   prof_mark(0, st);
-  static hipStream_t side2 = nullptr;
-  static hipEvent_t ev_bitmap = nullptr, ev_filled = nullptr;
-  const bool side_any = side_fill || fside.quota > 0;
-  if (side_any && side2 == nullptr) {
-    int lo = 0, hi = 0;
-    PNX_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = lowest priority (numerically greatest)
-    const char* pr_env = getenv("PNX_FILL_PRIO");
-    PNX_CHECK_HIP(hipStreamCreateWithPriority(&side2, hipStreamNonBlocking, pr_env && pr_env[0] == '0' ? 0 : lo));
-    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_bitmap, hipEventDisableTiming));
-    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_filled, hipEventDisableTiming));
-  }
-  const char* sa_env = getenv("PNX_FILL_SIDE_AT");  // "pfn": the side-stream fill starts with the PFN launch instead of with the bitmap
-  const bool side_at_pfn = side_any && sa_env && sa_env[0] == 'p';
-  if (binned) {
-    rc = run_voxelize2(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, fjob, fill_blocks, st,
-                       (side_any && !side_at_pfn) ? ev_bitmap : nullptr, !lds_sorted);
-    if (rc == PNX_OK && side_at_pfn) PNX_CHECK_HIP(hipEventRecord(ev_bitmap, st));
-  }
-  else rc = run_voxelize(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, unq_inv != nullptr, st);
+  rc = run_voxelize2(points, n, stride, gd, w, coords, pillar_capacity, unq_inv, pillar_of_point, fjob, fill_blocks, st);
   if (rc != PNX_OK) return rc;
   prof_mark(6, st);
-
-  static hipStream_t side = nullptr;
-  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  const bool overlap = direct && !binned && getenv("PNX_READER_OVERLAP") != nullptr;  // round-1 path: zero-fill on a second stream
-  if (overlap && side == nullptr) {
-    PNX_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    PNX_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-  }
-  auto launch_fill = [&](hipStream_t fs) -> int {
-    const int tiles = ((gd.gx + 31) / 32) * (gd.gyp / 32) * gd.B;
-    const bool nt = fill_nt;
-#define PNX_FILL(DT)                                                                                    \
-  if (nt) k_canvas_fill_nhwc<DT, true><<<tiles, kBlock, 0, fs>>>(w.bitmap, gd, canvas, occupancy);      \
-  else k_canvas_fill_nhwc<DT, false><<<tiles, kBlock, 0, fs>>>(w.bitmap, gd, canvas, occupancy)
-    if (canvas_dtype == PNX_F32) {
-      PNX_FILL(PNX_F32);
-    } else if (canvas_dtype == PNX_BF16) {
-      PNX_FILL(PNX_BF16);
-    } else {
-      PNX_FILL(PNX_F16);
-    }
-#undef PNX_FILL
-    PNX_LAUNCH_CHECK();
-    return PNX_OK;
-  };
-  if (side_fill) {
-    PNX_CHECK_HIP(hipStreamWaitEvent(side2, ev_bitmap, 0));
-    rc = launch_fill(side2);
-    if (rc != PNX_OK) return rc;
-    PNX_CHECK_HIP(hipEventRecord(ev_filled, side2));
-  } else if (fside.quota > 0) {
-    const int sb = getenv("PNX_FILL_SIDE_BLOCKS") ? atoi(getenv("PNX_FILL_SIDE_BLOCKS")) : 256;
-    PNX_CHECK_HIP(hipStreamWaitEvent(side2, ev_bitmap, 0));
-    if (canvas_dtype == PNX_F32) k_canvas_fill_persist<PNX_F32><<<sb, kBlock, 0, side2>>>(fside, gd);
-    else if (canvas_dtype == PNX_BF16) k_canvas_fill_persist<PNX_BF16><<<sb, kBlock, 0, side2>>>(fside, gd);
-    else k_canvas_fill_persist<PNX_F16><<<sb, kBlock, 0, side2>>>(fside, gd);
-    PNX_LAUNCH_CHECK();
-    PNX_CHECK_HIP(hipEventRecord(ev_filled, side2));
-  } else if (direct && !fuse) {
-    if (overlap) {
-      PNX_CHECK_HIP(hipEventRecord(ev_fork, st));
-      PNX_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-      rc = launch_fill(side);
-      if (rc != PNX_OK) return rc;
-      PNX_CHECK_HIP(hipEventRecord(ev_join, side));
-    } else {
-      prof_mark(1, st);
-      rc = launch_fill(st);
-      if (rc != PNX_OK) return rc;
-      prof_mark(2, st);
-    }
-  }
-  if (lds_sorted) {
-    const int n_fill = (fuse && fjob[3].quota > 0) ? fill_blocks : 0;
-    prof_mark(4, st);
-    if (fuse) prof_mark(1, st);
-    // the pillar arrays (first slot / count / cell) are only written for spilled pillars; nothing downstream reads the others
-    rc = pnx_launch_bin_pfn(F, w.rec, w.hpre, w.hblk, w.matlen, w.sh, w.nwg, w.K1, w.counters, w.tick, w.rec64, w.pfirst, w.pcnt, w.cell, coords,
-                            pillar_capacity, 0, w.biglist, w.bigcap, pfn_folded, g1, g1_rows, direct ? canvas : nullptr, canvas_dtype, n, n_fill, gd,
-                            fjob[3], st);
-    if (rc != PNX_OK) return rc;
-    if (n > 0) {
-      static const int tb = getenv("PNX_TAIL_BLOCKS") ? atoi(getenv("PNX_TAIL_BLOCKS")) : 128;
-      rc = pnx_launch_pfn3_tail(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.biglist, w.bigcap, pfn_folded, g1, g1_rows, direct ? canvas : nullptr,
-                                canvas_dtype, tb, st);
-      if (rc != PNX_OK) return rc;
-    }
-    prof_mark(5, st);
-    if (fuse) prof_mark(2, st);
-  } else if (binned) {
-    const int n_fill = fuse ? fill_blocks : 0;
-    prof_mark(4, st);
-    if (fuse) prof_mark(1, st);
-    rc = pnx_launch_pfn_v3(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.tick, w.biglist, w.bigcap, pfn_folded, g1, g1_rows,
-                           direct ? canvas : nullptr, canvas_dtype, n, n_fill, gd, fjob[3], st);
-    if (rc != PNX_OK) return rc;
-    prof_mark(5, st);
-    if (fuse) prof_mark(2, st);
-  } else if (n > 0) {
-    if (impl == 0) {
-      const int nb = nblocks(w.pcap);
-      switch (F) {
-        case 3: k_pfn_pillar<3><<<nb, kBlock, 0, st>>>(points, gd, w.plist, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows); break;
-        case 4: k_pfn_pillar<4><<<nb, kBlock, 0, st>>>(points, gd, w.plist, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows); break;
-        case 5: k_pfn_pillar<5><<<nb, kBlock, 0, st>>>(points, gd, w.plist, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows); break;
-        default: k_pfn_pillar<6><<<nb, kBlock, 0, st>>>(points, gd, w.plist, w.count, w.cpre, w.cblk, w.counters, pfn_folded, g1, g1_rows); break;
-      }
-      PNX_LAUNCH_CHECK();
-    } else {
-      prof_mark(4, st);
-      rc = pnx_launch_pfn_mfma(F, w.rec, gd, w.count, w.cpre, w.cblk, w.counters, w.biglist, w.bigcap, pfn_folded, g1, g1_rows,
-                               direct ? canvas : nullptr, w.cell, canvas_dtype, n, st);
-      if (rc != PNX_OK) return rc;
-      prof_mark(5, st);
-    }
-  }
+  prof_mark(4, st);
+  prof_mark(1, st);
+  rc = pnx_launch_pfn_v3(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.tick, w.biglist, w.bigcap, pfn_folded, g1, g1_rows,
+                         direct ? canvas : nullptr, canvas_dtype, n, direct ? fill_blocks : 0, gd, fjob[3], st);
+  if (rc != PNX_OK) return rc;
+  prof_mark(5, st);
+  prof_mark(2, st);
   if (feat_max && g1 != feat_max) {
     // caller's buffer is smaller than the worst case: copy what fits (P is unknown on the host)
     PNX_CHECK_HIP(hipMemcpyAsync(feat_max, g1, (size_t)(pillar_capacity < w.pcap ? pillar_capacity : w.pcap) * 64 * sizeof(float),
                                  hipMemcpyDeviceToDevice, st));
   }
-  if (direct) {
-    if (overlap) {
-      PNX_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
-      prof_mark(1, st);
-      prof_mark(2, st);
-    }
-  } else {
-    prof_mark(1, st);
-    if (canvas) {
-      if (canvas_dtype == PNX_F32) rc = launch_canvas<PNX_F32>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
-      else if (canvas_dtype == PNX_BF16) rc = launch_canvas<PNX_BF16>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
-      else rc = launch_canvas<PNX_F16>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
-      if (rc != PNX_OK) return rc;
-    }
-    prof_mark(2, st);
-  }
-  if (side_any) {
-    PNX_CHECK_HIP(hipStreamWaitEvent(st, ev_filled, 0));
-    if (side_fill) {
-      prof_mark(1, st);
-      prof_mark(2, st);
-    }
+  if (canvas != nullptr && !direct) {
+    if (canvas_dtype == PNX_F32) rc = launch_canvas<PNX_F32>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
+    else if (canvas_dtype == PNX_BF16) rc = launch_canvas<PNX_BF16>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
+    else rc = launch_canvas<PNX_F16>(w, g1, g1_rows, gd, canvas, occupancy, canvas_layout, st);
+    if (rc != PNX_OK) return rc;
   }
   if (counts) PNX_CHECK_HIP(hipMemcpyAsync(counts, w.counters, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   prof_mark(3, st);
   if (g_prof.on && g_prof.n < g_prof.cap) g_prof.n++;
-  return PNX_OK;
-}
-
-int64_t pnx_reader_sparse_words(int32_t batch, const pnx_geom* g) {
-  if (!g || batch < 1) return 0;
-  return cells_padded(g, batch) / 32;
-}
-
-int pnx_reader_forward_rows(const float* points, int64_t n, int32_t stride, int32_t batch, const pnx_geom* g, const float* pfn_folded, void* rows,
-                            int32_t rows_dtype, int64_t row_capacity, int32_t* counts, void* wfull, uint8_t* occupancy, void* workspace,
-                            size_t workspace_bytes, pnx_stream_t stream) {
-  int rc = check_common(points, n, stride, batch, g, workspace, workspace_bytes);
-  if (rc != PNX_OK) return rc;
-  PNX_REQUIRE(pfn_folded != nullptr && rows != nullptr && wfull != nullptr, PNX_ERR_INVALID, "pfn_folded / rows / wfull is NULL");
-  PNX_REQUIRE(rows_dtype == PNX_BF16 || rows_dtype == PNX_F16, PNX_ERR_INVALID, "rows_dtype %d: bf16 or fp16", rows_dtype);
-  PNX_REQUIRE((((uintptr_t)rows | (uintptr_t)wfull) & 15) == 0, PNX_ERR_INVALID, "rows and wfull must be 16-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  const ReaderWs w = carve(workspace, n, batch, g);
-  const GeomDev gd = make_geom(g, batch);
-  const int F = stride - 1;
-  PNX_REQUIRE(reader_impl() >= 3 && w.K1 <= 16384 && F <= 5 && w.sh <= 10, PNX_ERR_UNSUPPORTED, "the row output exists on the in-LDS bin path only");
-  PNX_REQUIRE(row_capacity >= w.pcap, PNX_ERR_INVALID, "row_capacity %lld < worst-case pillar count %lld", (long long)row_capacity, (long long)w.pcap);
-  PnxFillJob nofill[4] = {};
-  rc = run_voxelize2(points, n, stride, gd, w, nullptr, 0, nullptr, nullptr, nofill, 0, st, nullptr, false);
-  if (rc != PNX_OK) return rc;
-  {
-    const int64_t items = (int64_t)gd.B * (gd.gyp >> 5) * gd.gx;
-    k_sparse_index<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(w.bitmap, w.wpre, w.wblk, gd, (uint2*)wfull, occupancy);
-    PNX_LAUNCH_CHECK();
-  }
-  rc = pnx_launch_bin_pfn(F, w.rec, w.hpre, w.hblk, w.matlen, w.sh, w.nwg, w.K1, w.counters, w.tick, w.rec64, w.pfirst, w.pcnt, w.cell, nullptr, 0, 2,
-                          w.biglist, w.bigcap, pfn_folded, nullptr, 0, rows, rows_dtype, n, 0, gd, nofill[3], st);
-  if (rc != PNX_OK) return rc;
-  if (n > 0) {
-    rc = pnx_launch_pfn3_tail(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.biglist, w.bigcap, pfn_folded, nullptr, 0, rows, rows_dtype, 128, st);
-    if (rc != PNX_OK) return rc;
-  }
-  if (counts) PNX_CHECK_HIP(hipMemcpyAsync(counts, w.counters, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   return PNX_OK;
 }
 
@@ -1478,7 +1115,7 @@ int pnx_pfn_backward(int32_t pass, int64_t n, int32_t stride, int32_t batch, con
 }
 
 void pnx_reader_fill_split(int32_t* percent3) {
-  percent3[0] = 0, percent3[1] = 0, percent3[2] = reader_impl() >= 3 ? 0 : 24;  // round-2 pipeline, measured on C2 / 8 frames (tools/reader_ab.py): only k_bin_sort's share pays
+  percent3[0] = 0, percent3[1] = 0, percent3[2] = reader_impl() == 4 ? 0 : 24;  // round-2 pipeline, measured on C2 / 8 frames (tools/reader_ab.py): only k_bin_sort's share pays
   const char* sp_env = getenv("PNX_FILL_SPLIT");
   if (sp_env) sscanf(sp_env, "%d,%d,%d", &percent3[0], &percent3[1], &percent3[2]);
   for (int k = 0; k < 3; k++) percent3[k] = percent3[k] < 0 ? 0 : (percent3[k] > 100 ? 100 : percent3[k]);

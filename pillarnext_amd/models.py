@@ -856,14 +856,6 @@ class _HipConv3x3(nn.Module):
         self.cout, self.cin, self.stride = weight.shape[0], weight.shape[1], int(stride)
         self.register_buffer("wfrag", ops.conv3x3_pack_weights(weight))
         self.register_buffer("bias", bias.float().contiguous())
-        if (self.cin, self.cout, self.stride) == (64, 64, 1):   # the sparse first stage works in the bitmap's frame: taps transposed
-            self.register_buffer("wfrag_t", ops.conv3x3_pack_weights(weight.transpose(2, 3)))
-
-    def forward_sparse(self, rows, sp, residual=None, out=None):
-        """The same layer on a sparse tensor: rows (P, 64) + sp = (wfull, batch, gx, wpr, tiles) -- ops.subm64_sparse."""
-        wfull, batch, gx, wpr, tiles = sp
-        return ops.subm64_sparse(rows, wfull, batch, gx, wpr, self.wfrag_t, self.bias, residual=residual, relu=True, out=out, tiles=tiles)
-
     def forward(self, x, mask=None, residual=None, out=None, tiles=None):
         return ops.conv3x3_masked(x, self.wfrag, self.bias, self.cout, self.stride, mask, residual, True, out=out,
                                   tiles=tiles if self.stride == 1 else None)
@@ -945,15 +937,6 @@ class FusedPillarNeXt(nn.Module):
                 mods.append(_backbone_conv(w2, b2, 1, rb.conv2.kernel_size[0] // 2, dtype, hip_conv))
             self.stages.append(mods)
             self.stage_meta.append((first.stride, first.subm))
-        # Sparse first stage (csrc/conv3x3.hip::k_subm64_sparse): the reader hands over feature rows + occupancy words instead of the dense
-        # canvas when stage 0 is 64 -> 64 SUBMANIFOLD layers throughout and stage 1 opens with the strided 64 -> 128 convolution.
-        # PillarNeXt-B itself does not qualify: its stage 0 opens with a SparseConv2d (sparse_resnet.py:53-54, use_subm=False), whose output
-        # set is the 3 x 3 dilation of the pillars (16.7 % of the cells on the C2 sweep cloud instead of 4.9 %) -- DESIGN.md, sparse stage 0.
-        s0, s1 = self.stages[0], (self.stages[1] if len(self.stages) > 1 else [])
-        self.sparse0 = (os.environ.get("PNX_SPARSE_STAGE0", "1") != "0" and dtype == torch.bfloat16 and self.stage_meta[0] == (1, True)
-                        and all(isinstance(m, _HipConv3x3) and (m.cin, m.cout, m.stride) == (64, 64, 1) for m in s0) and len(s1) > 0
-                        and isinstance(s1[0], _HipConv3x3) and (s1[0].cin, s1[0].cout, s1[0].stride) == (64, 128, 2)
-                        and os.environ.get("PNX_READER_IMPL", "3") == "3" and det.reader.num_point_features <= 5)
         w, b = _fold_bn(bb.mapping[0].weight, bb.mapping[1])
         self.mapping = _FusedConv(w, b, 1, 0, dtype=dtype)
         nk = det.neck
@@ -1069,7 +1052,7 @@ class FusedPillarNeXt(nn.Module):
         latency-bound and leave HBM mostly idle; the reader is the opposite).  The following forward_async / forward_preds call with the
         same `points` tensor picks the canvas up.  `ready`: a torch.cuda.Event after which the points are valid (None: they are resident)."""
         pts, B = example["points"], int(example["batch_size"])
-        if self.sparse0 or not pts.is_cuda:
+        if not pts.is_cuda:
             return
         if self._rd_stream is None:
             self._rd_stream = torch.cuda.Stream(device=pts.device)
@@ -1101,19 +1084,14 @@ class FusedPillarNeXt(nn.Module):
         mark("start")
         ny, nx = (int(v) for v in self.reader.grid_size)
         occ = torch.empty((batch_size, ny, nx), dtype=torch.uint8, device=points.device)
-        sparse = self.sparse0 and taps is None
-        sp = None
         pf = self._prefetched.pop(points.data_ptr(), None) if self._prefetched else None
-        if pf is not None and not sparse:
+        if pf is not None:
             # the reader of this batch was enqueued on the side stream by prefetch(): wait for it, hand its tensors to this stream
             x, occ, ev = pf
             cur = torch.cuda.current_stream()
             cur.wait_event(ev)
             x.record_stream(cur)
             occ.record_stream(cur)
-        elif sparse:
-            # the reader's sparse result (feature rows + occupancy words) feeds the first stage directly: no dense 1440 x 1440 x 64 canvas
-            x, wfull, wpr = self.reader.forward_rows(points, batch_size, dtype=self.dtype, occupancy=occ)
         else:
             if self._rd_stream is not None:       # the reader's workspace is shared with the side stream's calls: keep them in order
                 torch.cuda.current_stream().wait_stream(self._rd_stream)
@@ -1124,21 +1102,6 @@ class FusedPillarNeXt(nn.Module):
         mark("reader")
         mask = occ
         for si, (mods, (stride, subm)) in enumerate(zip(self.stages, self.stage_meta)):
-            if sparse and si == 0:
-                key = ("sp0", batch_size, x.shape[0], x.device)
-                bufs = self._ws.get(key)
-                if bufs is None:
-                    bufs = self._ws[key] = [torch.empty_like(x) for _ in range(3)]
-                tl = self._ws[("sp0_tiles",) + key[1:]] = ops.sparse_tile_list(wfull, batch_size, nx, wpr, out=self._ws.get(("sp0_tiles",) + key[1:]))
-                sp = (wfull, batch_size, nx, wpr, tl)
-                x = mods[0].forward_sparse(x, sp, out=bufs[0])
-                kk = 1
-                for j in range(1, len(mods), 2):
-                    y = mods[j].forward_sparse(x, sp, out=bufs[kk % 3])
-                    x = mods[j + 1].forward_sparse(y, sp, residual=x, out=bufs[(kk + 1) % 3])
-                    kk += 2
-                mark("backbone.stage0")
-                continue
             if not subm:
                 mask = ops.mask_pool3(mask, stride)
             ws, k = self._stage_workspace(si, mods, mask), 0
@@ -1151,12 +1114,7 @@ class FusedPillarNeXt(nn.Module):
                 k += 1                                  # x, y, out of a block sit in three different buffers
                 return m(inp, mask, residual=res, out=ws[(k - 1) % 3], tiles=tiles)
 
-            if sparse and si == 1:                      # the strided entry convolution gathers its input from the sparse tensor
-                k += 1
-                x = ops.conv3x3_s2_sparse(x, sp[0], batch_size, ny, nx, sp[3], mods[0].wfrag, mods[0].bias, mods[0].cout, mask=mask, relu=True,
-                                          out=ws[0] if ws is not None else None)
-            else:
-                x = run(mods[0], x)
+            x = run(mods[0], x)
             for j in range(1, len(mods), 2):
                 y = run(mods[j], x)
                 x = run(mods[j + 1], y, x)

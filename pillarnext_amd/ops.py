@@ -66,72 +66,6 @@ def reader_forward(points, batch, geom, folded, ws, canvas=None, canvas_layout=P
                                    buf.numel(), stream_ptr()), "pnx_reader_forward")
 
 
-def reader_sparse_words(batch, geom):
-    return int(lib().pnx_reader_sparse_words(batch, ctypes.byref(geom)))
-
-
-def reader_forward_rows(points, batch, geom, folded, ws, rows, wfull, occupancy=None, counts=None):
-    """Sparse reader output (include/pnx.h: pnx_reader_forward_rows): rows (cap, 64) bf16/fp16 by pillar rank, wfull (words, 2) int32."""
-    _need_cuda(points, "points")
-    if points.dtype != torch.float32 or points.dim() != 2:
-        raise PnxError("points must be (N, 1+F) fp32")
-    n, stride = points.shape
-    nbytes = lib().pnx_reader_workspace_bytes(n, batch, ctypes.byref(geom))
-    buf = ws.get(nbytes, points.device)
-    check(lib().pnx_reader_forward_rows(ptr(points), n, stride, batch, ctypes.byref(geom), ptr(folded), ptr(rows), _DT[rows.dtype], rows.shape[0],
-                                        ptr(counts), ptr(wfull), ptr(occupancy), ptr(buf), buf.numel(), stream_ptr()), "pnx_reader_forward_rows")
-
-
-def sparse_tile_list(wfull, batch, gx, wpr, out=None):
-    """Tiles (16 bitmap rows x one word) of the sparse tensor that hold an active cell -> (list int32, count int32[1])."""
-    n_tiles = batch * ((gx + 15) // 16) * wpr
-    if out is None or out[0].numel() < n_tiles:
-        out = (torch.empty((n_tiles,), dtype=torch.int32, device=wfull.device), torch.zeros((1,), dtype=torch.int32, device=wfull.device))
-    check(lib().pnx_sparse_tile_list(ptr(wfull), batch, gx, wpr, ptr(out[0]), ptr(out[1]), stream_ptr()), "pnx_sparse_tile_list")
-    return out
-
-
-def subm64_sparse(rows, wfull, batch, gx, wpr, wfrag_t, bias, residual=None, relu=True, out=None, tiles=None):
-    """SubMConv2d(64, 64, 3) + bias [+ residual] + ReLU on (P, 64) bf16 feature rows (csrc/conv3x3.hip::k_subm64_sparse).  wfrag_t: weights packed
-    TRANSPOSED, conv3x3_pack_weights(w.transpose(2, 3)) -- the bitmap's frame is the transpose of the canvas."""
-    if not (rows.is_cuda and rows.dtype == torch.bfloat16 and rows.dim() == 2 and rows.shape[1] == 64 and rows.is_contiguous()):
-        raise PnxError("subm64_sparse needs contiguous (P, 64) bf16 CUDA rows")
-    if out is None:
-        out = torch.empty_like(rows)
-    tl, tc = (tiles[0], tiles[1]) if tiles is not None else (None, None)
-    check(lib().pnx_subm64_sparse_bf16(ptr(rows), ptr(wfull), batch, gx, wpr, ptr(wfrag_t), ptr(bias), ptr(residual), ptr(out), 1 if relu else 0, ptr(tl),
-                                       ptr(tc), stream_ptr()), "pnx_subm64_sparse_bf16")
-    return out
-
-
-def conv3x3_s2_sparse(rows, wfull, batch, h, w, wpr, wfrag, bias, cout, mask=None, relu=True, out=None):
-    """SparseConv2d(64, cout, 3, stride 2, pad 1) + bias + ReLU + mask from sparse rows to the dense (B, cout, ceil(h/2), ceil(w/2)) channels_last map.
-    out = (buffer, row_dirty) workspace pair as for conv3x3_masked."""
-    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    row_dirty = None
-    if out is not None:
-        y, row_dirty = out
-    else:
-        y = torch.empty((batch, cout, ho, wo), dtype=torch.bfloat16, device=rows.device, memory_format=torch.channels_last)
-    check(lib().pnx_conv3x3_s2_sparse_bf16(ptr(rows), ptr(wfull), batch, h, w, wpr, ptr(wfrag), ptr(bias), ptr(mask), ptr(y), cout, 1 if relu else 0,
-                                           ptr(row_dirty), stream_ptr()), "pnx_conv3x3_s2_sparse_bf16")
-    return y
-
-
-def sparse_index_from_mask(mask_t):
-    """Test / tooling helper: wfull (words, 2) int32 of an occupancy given in the bitmap's frame, mask_t (B, gx, gy) uint8/bool -- what
-    pnx_reader_forward_rows produces from the points.  Plain torch."""
-    B, gx, gy = mask_t.shape
-    wpr = (gy + 31) // 32
-    m = torch.zeros((B, gx, wpr * 32), dtype=torch.int64, device=mask_t.device)
-    m[:, :, :gy] = (mask_t != 0).long()
-    bits = (m.view(B, gx, wpr, 32) << torch.arange(32, device=mask_t.device)).sum(-1)               # (B, gx, wpr) in [0, 2^32)
-    cnt = m.view(B, gx, wpr, 32).sum(-1).flatten()
-    pre = torch.cumsum(cnt, 0) - cnt
-    bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).flatten()
-    return torch.stack([bits, pre], 1).to(torch.int32).contiguous(), wpr
-
-
 def voxelize(points, batch, geom, ws, features=None, coords=None, unq_inv=None, pillar_of_point=None, counts=None):
     _need_cuda(points, "points")
     n, stride = points.shape

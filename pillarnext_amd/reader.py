@@ -175,27 +175,6 @@ class PillarFeatureNet(nn.Module):
         return feat_max, coords, grid_size
 
     # ------------------------------------------------------------------ MI355X dense path
-    def forward_rows(self, points, batch_size, dtype=torch.bfloat16, occupancy=None, counts=None):
-        """points -> the reader's SPARSE result: (rows (cap, 64) by pillar rank, wfull (words, 2) int32 occupancy words + rank prefix, wpr) --
-        include/pnx.h pnx_reader_forward_rows.  Eval mode, fused kernels only; the buffers are reused from call to call (a serving loop
-        consumes them before the next frame batch is read)."""
-        if self.training or not self._fused_supported():
-            raise PnxError("forward_rows: eval mode with the fused reader only")
-        points = points.contiguous().float()
-        ny, nx = int(self._geom.gy), int(self._geom.gx)
-        cap = min(points.shape[0], batch_size * ny * nx)
-        key = (batch_size, dtype, points.device)
-        buf = getattr(self, "_rows_buf", None)
-        if buf is None or buf[0] != key or buf[1].shape[0] < cap:
-            words = ops.reader_sparse_words(batch_size, self._geom)
-            rows = torch.empty((max(cap, 1), 64), dtype=dtype, device=points.device)
-            wfull = torch.empty((words, 2), dtype=torch.int32, device=points.device)
-            buf = self._rows_buf = (key, rows, wfull)
-        _, rows, wfull = buf
-        with torch.no_grad():
-            ops.reader_forward_rows(points, batch_size, self._geom, self.folded_params(), self._ws, rows, wfull, occupancy=occupancy, counts=counts)
-        return rows, wfull, (ny + 31) // 32
-
     def forward_dense(self, points, batch_size, dtype=torch.bfloat16, channels_last=True, out=None, counts=None, occupancy=None):
         """points -> dense BEV canvas (B, 64, ny, nx).  Eval mode: single fused call, no host sync, every canvas
         byte written exactly once.  Train mode: unfused path + scatter (gradients flow to the PFN parameters)."""

@@ -76,17 +76,9 @@ def test_point_uploader_roundtrip():
         assert np.array_equal(np.unique(ref[:, 0]), [0, 1, 2])
 
 
-@pytest.fixture(params=["rows", "gather"])
-def conv64_impl(request, monkeypatch):
-    """64 -> 64 masked stride-1 convolutions have two kernels: N = a 32-pixel row segment (default) or N = 32 active pixels of the tile
-    (k_conv3x3_gat, PNX_CONV_GATHER=1)."""
-    monkeypatch.setenv("PNX_CONV_GATHER", "1" if request.param == "gather" else "0")
-    return request.param
-
-
 @pytest.mark.parametrize("residual", [False, True])
-def test_conv3x3_64_both_kernels(conv64_impl, residual):
-    """The pixel-gather kernel and the row kernel on dense-ish, sparse and empty tiles, with a workspace that goes stale (row_dirty)."""
+def test_conv3x3_64_stale_workspace(residual):
+    """The 64 -> 64 row kernel on dense-ish, sparse and empty tiles, with a workspace that goes stale (row_dirty)."""
     from pillarnext_amd import ops
 
     g = torch.Generator(device="cuda").manual_seed(3)

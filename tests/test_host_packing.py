@@ -1,5 +1,5 @@
-"""CPU: host-side packing helpers added in round 3 (plain torch, no GPU): the occupancy words + rank prefix of the sparse tensor view, the
-second-convolution weight layout of the lazy SepHead evaluator, and the lazy flavour of the decoder's task descriptor."""
+"""CPU: host-side packing helpers (plain torch, no GPU): the second-convolution weight layout of the lazy SepHead evaluator and the lazy
+flavour of the decoder's task descriptor."""
 import struct
 
 import numpy as np
@@ -7,29 +7,6 @@ import torch
 
 from pillarnext_amd import ops
 from pillarnext_amd.decode import pack_task
-
-
-def test_sparse_index_from_mask_matches_a_numpy_statement():
-    rng = np.random.default_rng(3)
-    B, gx, gy = 2, 7, 70                                     # gy not a multiple of 32: the last word of a row is partly padding
-    m = rng.random((B, gx, gy)) < 0.3
-    w, wpr = ops.sparse_index_from_mask(torch.from_numpy(m))
-    assert wpr == 3 and w.shape == (B * gx * wpr, 2) and w.dtype == torch.int32
-    bits = w[:, 0].numpy().astype(np.int64) & 0xFFFFFFFF
-    pre = w[:, 1].numpy()
-    rank = 0
-    for b in range(B):
-        for xi in range(gx):
-            for k in range(wpr):
-                word = 0
-                for j in range(32):
-                    yi = 32 * k + j
-                    if yi < gy and m[b, xi, yi]:
-                        word |= 1 << j
-                i = (b * gx + xi) * wpr + k
-                assert bits[i] == word and pre[i] == rank    # rank of the word's first active cell = active cells before it in (b, xi, yi) order
-                rank += bin(word).count("1")
-    assert rank == int(m.sum())
 
 
 def test_lazy_second_conv_weight_layout():

@@ -12,7 +12,7 @@ import json
 import sys
 
 READER = ["k_clear2", "k_chunk_sort", "k_slab_totals", "k_span_carve", "k_span_pfn", "k_pfn3", "k_canvas_fill", "k_keys", "k_pack_scan", "k_scan_blocks",
-          "k_scan_local", "k_bin_count", "k_bin_scatter", "k_bin_sort", "k_bin_pfn", "k_rank", "k_fill", "k_pfn_mfma", "k_pfn_big", "fillBufferAligned"]
+          "k_scan_local", "k_bin_count", "k_bin_scatter", "k_bin_sort", "k_rank", "k_fill", "k_pfn_big", "fillBufferAligned"]
 
 
 def rows(path, counter):

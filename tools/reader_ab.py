@@ -2,16 +2,14 @@
 """A/B timing of the reader's pipelines on one GPU (points resident -> bf16 NHWC canvas + occupancy), HIP events from libpnx_hip.so.
 
 Variants are environment settings read by pnx_reader_forward on every call:
-  PNX_READER_IMPL=1            round-1 pipeline (global-atomic slots, 32-byte records, DPP-scan PFN, separate fill kernel)
-  PNX_READER_IMPL=2            round-2 pipeline: binned grouping (reader_bins.h) + k_bin_sort + PFN v3 (pfn_v3.hip), records through HBM
   PNX_READER_IMPL=4            default: chunk sort (chunk_sort.hip) + span PFN (pfn_spans.hip)
-  PNX_READER_IMPL=3            round 3: binned grouping + ONE launch that sorts every bin in LDS and runs the PFN on it (pfn_bins.hip)
-    PNX_READER_FUSE=0|1|3      zero-fill as its own kernel | as extra blocks of the PFN launch and of the grouping kernels |
-                               as a persistent grid-capped kernel on a second stream (PNX_FILL_SIDE percent, PNX_FILL_SIDE_BLOCKS)
+    PNX_SPAN_QUOTA, PNX_SPAN_SOLO     carve rule of the spans (spans.h)
+    PNX_BINS_LDS, PNX_BINS_CAP        LDS budget / record slots of a span workgroup
+    PNX_FILL_BLOCKS, PNX_PFN_BLOCKS   block counts of the two roles of the span launch (0 fill blocks: timing only, the canvas is wrong)
+  PNX_READER_IMPL=2            the general pipeline: binned grouping (reader_bins.h) + k_bin_sort + PFN v3 (pfn_v3.hip), records through HBM
     PNX_BIN_NWG, PNX_BIN_THREADS, PNX_BIN_SH   chunks / threads of k_bin_count and k_bin_scatter, pillars per bin (2^sh)
     PNX_FILL_SPLIT=a,b,c       percent of the fill tiles carried by k_bin_count / k_bin_scatter / k_bin_sort
-    PNX_PFN_F16X3=0|1          layer 1 as fp32 MFMA | fp16 hi/lo splits
-    PNX_FILL_BLOCKS, PNX_PFN_BLOCKS   block counts of the two roles
+  PNX_PFN_F16X3=0|1            layer 1 as fp32 MFMA | fp16 hi/lo splits (0 sends the call to the general pipeline)
 Every variant must equal the first variant's canvas bit for bit.
 """
 import argparse
@@ -26,65 +24,22 @@ from pillarnext_amd import _lib, synth  # noqa: E402
 from pillarnext_amd.reader import PillarFeatureNet  # noqa: E402
 
 VARIANTS = [
-    ("r2 binned default", {"PNX_READER_IMPL": "2"}),
-    ("lds default", {"PNX_READER_IMPL": "3"}),
-    ("spans default", {"PNX_READER_IMPL": "4"}),
-    ("spans pfn768", {"PNX_READER_IMPL": "4", "PNX_PFN_BLOCKS": "768"}),
-    ("spans fill192", {"PNX_READER_IMPL": "4", "PNX_FILL_BLOCKS": "192"}),
-    ("spans fill128", {"PNX_READER_IMPL": "4", "PNX_FILL_BLOCKS": "128"}),
-    ("spans unfilled", {"PNX_READER_IMPL": "4", "PNX_FILL_BLOCKS": "0"}),
-    ("spans pre10", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "10"}),
-    ("spans pre15", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "15"}),
-    ("spans pre20", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "20"}),
-    ("spans pre25", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "25"}),
-    ("spans pre30", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "30"}),
-    ("spans pre20 b128", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "20", "PNX_PREFILL_BLOCKS": "128"}),
-    ("spans pre100", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_PREFILL": "100"}),
-    ("spans side", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1"}),
-    ("spans side lds78k", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1", "PNX_BINS_LDS": "78000"}),
-    ("spans side lds76k", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1", "PNX_BINS_LDS": "76000"}),
-    ("spans side lds72k", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1", "PNX_BINS_LDS": "72000"}),
-    ("spans side lds76k b512", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1", "PNX_BINS_LDS": "76000", "PNX_FILL_BLOCKS": "512"}),
-    ("spans side lds76k b128", {"PNX_READER_IMPL": "4", "PNX_FILL_SIDE": "1", "PNX_BINS_LDS": "76000", "PNX_FILL_BLOCKS": "128"}),
-    ("spans lds76k", {"PNX_READER_IMPL": "4", "PNX_BINS_LDS": "76000"}),
-    ("spans q384 s128", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "384", "PNX_SPAN_SOLO": "128"}),
-    ("spans q512 s256", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "512", "PNX_SPAN_SOLO": "256"}),
-    ("spans q640", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640"}),
-    ("spans q768", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "768"}),
-    ("spans q640 unfilled", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "640", "PNX_FILL_BLOCKS": "0"}),
-    ("spans q384 s128 unfilled", {"PNX_READER_IMPL": "4", "PNX_SPAN_QUOTA": "384", "PNX_SPAN_SOLO": "128", "PNX_FILL_BLOCKS": "0"}),
-    ("lds fill384", {"PNX_READER_IMPL": "3", "PNX_FILL_BLOCKS": "384"}),
-    ("lds fill192", {"PNX_READER_IMPL": "3", "PNX_FILL_BLOCKS": "192"}),
-    ("lds pfnblocks768", {"PNX_READER_IMPL": "3", "PNX_PFN_BLOCKS": "768"}),
-    ("lds unfused", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "0"}),
-    ("lds side100", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3"}),
-    ("lds side100 b512", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_BLOCKS": "512"}),
-    ("lds side100 b128", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_BLOCKS": "128"}),
-    ("lds side60", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE": "60"}),
-    ("lds side40", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE": "40"}),
-    ("lds side25", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE": "25"}),
-    ("lds side100 atpfn", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn"}),
-    ("lds side100 atpfn b512", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_FILL_SIDE_BLOCKS": "512"}),
-    ("lds side50 atpfn", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_FILL_SIDE": "50"}),
-    ("lds sideat lds78k", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_BINS_LDS": "78000"}),
-    ("lds sideat lds76k", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_BINS_LDS": "76000"}),
-    ("lds sideat lds72k", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_BINS_LDS": "72000"}),
-    ("lds sideat lds64k", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_BINS_LDS": "64000"}),
-    ("lds sideat lds76k prio0", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_BINS_LDS": "76000", "PNX_FILL_PRIO": "0"}),
-    ("lds sideat lds76k b512", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_FILL_SIDE_AT": "pfn", "PNX_BINS_LDS": "76000", "PNX_FILL_SIDE_BLOCKS": "512"}),
-    ("lds sidebm lds76k", {"PNX_READER_IMPL": "3", "PNX_READER_FUSE": "3", "PNX_BINS_LDS": "76000"}),
-    ("lds fused lds76k", {"PNX_READER_IMPL": "3", "PNX_BINS_LDS": "76000"}),
-    ("lds nwg256 t512", {"PNX_READER_IMPL": "3", "PNX_BIN_NWG": "256", "PNX_BIN_THREADS": "512"}),
-    ("lds nwg256 t1024", {"PNX_READER_IMPL": "3", "PNX_BIN_NWG": "256", "PNX_BIN_THREADS": "1024"}),
-    ("lds nwg128 t512", {"PNX_READER_IMPL": "3", "PNX_BIN_NWG": "128", "PNX_BIN_THREADS": "512"}),
-    ("lds sh9", {"PNX_READER_IMPL": "3", "PNX_BIN_SH": "9"}),
-    ("lds split 10,10", {"PNX_READER_IMPL": "3", "PNX_FILL_SPLIT": "10,10,0"}),
-    ("r2 binned unfused", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "0"}),
-    ("r2 side-stream fill", {"PNX_READER_IMPL": "2", "PNX_READER_FUSE": "2"}),
-    ("round1", {"PNX_READER_IMPL": "1"}),
+    ("spans default", {}),
+    ("spans q512", {"PNX_SPAN_QUOTA": "512"}),
+    ("spans q768", {"PNX_SPAN_QUOTA": "768"}),
+    ("spans q384 s128", {"PNX_SPAN_QUOTA": "384", "PNX_SPAN_SOLO": "128"}),
+    ("spans pfn768", {"PNX_PFN_BLOCKS": "768"}),
+    ("spans fill192", {"PNX_FILL_BLOCKS": "192"}),
+    ("spans fill128", {"PNX_FILL_BLOCKS": "128"}),
+    ("spans lds76k", {"PNX_BINS_LDS": "76000"}),
+    ("spans seg96", {"PNX_BINS_CAP": "96"}),
+    ("spans unfilled (timing only)", {"PNX_FILL_BLOCKS": "0"}),
+    ("binned", {"PNX_READER_IMPL": "2"}),
+    ("binned split 10,10", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "10,10,0"}),
+    ("fp32 layer 1 (binned)", {"PNX_PFN_F16X3": "0"}),
 ]
-KEYS = ["PNX_READER_IMPL", "PNX_READER_FUSE", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS", "PNX_FILL_SPLIT", "PNX_PFN_F16X3", "PNX_FILL_SIDE",
-        "PNX_FILL_SIDE_BLOCKS", "PNX_FILL_SIDE_AT", "PNX_BIN_NWG", "PNX_BIN_THREADS", "PNX_BIN_SH", "PNX_BINS_CAP", "PNX_BINS_LDS", "PNX_FILL_PRIO", "PNX_SPAN_QUOTA", "PNX_SPAN_SOLO", "PNX_FILL_SIDE", "PNX_PREFILL", "PNX_PREFILL_BLOCKS"]
+KEYS = ["PNX_READER_IMPL", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS", "PNX_FILL_SPLIT", "PNX_PFN_F16X3", "PNX_BIN_NWG", "PNX_BIN_THREADS", "PNX_BIN_SH",
+        "PNX_BINS_CAP", "PNX_BINS_LDS", "PNX_SPAN_QUOTA", "PNX_SPAN_SOLO"]
 
 
 def main():

@@ -12,7 +12,7 @@ print("| source | kernel | VGPRs | AGPRs | SGPRs | scratch B/lane | occupancy wa
 print("|---|---|---|---|---|---|---|---|")
 for f in sorted(glob.glob("pillarnext_amd/csrc/*.hip")):
     extra = []
-    if os.path.basename(f) in ("pfn_mfma.hip", "pfn_v3.hip", "pfn_bins.hip", "pfn_spans.hip"):
+    if os.path.basename(f) in ("pfn_v3.hip", "pfn_spans.hip"):
         extra = ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
     elif os.path.basename(f) == "conv3x3.hip":
         extra = ["-fno-honor-nans"]
