@@ -156,24 +156,20 @@ def serving_loop(model, examples, steps, upload=None):
     """`steps` frame batches through the fused graph; batch i+1 is enqueued before the host blocks on (and unpacks) the detections of
     batch i, and every batch's detections are on the host, as dicts, before this returns."""
     pending, out = None, None
-    # PNX_BENCH_PREFETCH=1: the reader of batch i+1 goes to a side stream before batch i's network is enqueued (FusedPillarNeXt.prefetch).
-    # Measured: 571-575 against 580-582 frames/s without it (the convolution workgroups hold the CUs' LDS, the reader's kernels are stretched
-    # over 4.5 ms instead of 0.87 and slow the convolutions down by more than they gain) -- off by default.
-    pre = upload is None and hasattr(model, "prefetch") and os.environ.get("PNX_BENCH_PREFETCH", "0") == "1"
-    if pre and steps > 0:
-        model.prefetch(examples[0])
+    host = 0.0
     for i in range(steps):
         ex = examples[i % len(examples)]
         if upload is not None:
             ex = upload(i)
-        if pre and i + 1 < steps:
-            model.prefetch(examples[(i + 1) % len(examples)])
+        t0 = time.perf_counter()
         nxt = model.forward_async(ex)
+        host += time.perf_counter() - t0
         if pending is not None:
             out = model.detections(pending.result())
         pending = nxt
     if pending is not None:
         out = model.detections(pending.result())
+    serving_loop.host_enqueue_ms = 1e3 * host / max(steps, 1)   # launch-thread time per step: what the host must sustain for the GPU to stay busy
     return out
 
 
@@ -422,6 +418,7 @@ def main():
             model(examples[i % ROTATE])
         _lib.check(L.pnx_profile_begin(max(a.steps, 1)), "pnx_profile_begin")
         dt, out = timed(examples, a.steps)
+        host_ms = serving_loop.host_enqueue_ms
         r_us, c_us, ns = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
         _lib.check(L.pnx_profile_end(ctypes.byref(r_us), ctypes.byref(c_us), ctypes.byref(ns)), "pnx_profile_end")
         pfn_us, vox_us = float(L.pnx_profile_last_pfn_us()), float(L.pnx_profile_last_voxelize_us())
@@ -537,6 +534,7 @@ def main():
         "metric": "frames/s PillarNeXt-B nuScenes 300k-pt cloud (inference, end-to-end)", "value": round(frames / dt, 2), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "host_enqueue_ms_per_step": round(host_ms, 3),   # launch-thread time inside forward_async per step (launch plans: pnx_enqueue)
         "config": {"workload": f"{a.config}: PillarNeXt-B nuScenes inference, {cfg['n']} pts/frame, voxel {cfg['voxel_size'][0]} m, BEV {nx}x{ny}, "
                                f"6 tasks/10 classes, cloud={a.dist} (1.5 % of the rows outside the range), random-init weights, {ROTATE} distinct frame batches rotating, "
                                f"inputs resident in HBM (value_with_h2d_merge: raw sweeps uploaded from pinned memory + merged on the device every step)",

@@ -374,6 +374,65 @@ int pnx_center_loss_backward(const void* const* maps7, void* const* grads7, cons
                              int32_t max_objs, const float* geom4_host, int32_t with_reg_iou, const float* losses15, const float* upstream13,
                              float* coef_scratch, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * One-call enqueue of prebuilt launch tables (csrc/enqueue.hip).  The reference's step is a Python call tree
+ * (det3d/models/detectors/single_stage.py:22-33, then CenterHead.predict centerhead.py:231-384); the arguments of this library's calls for
+ * the backbone, the head and the decoder do not change between frame batches (persistent workspaces, weights, shapes), so a host
+ * integration freezes them once and replays the table per step -- the launch thread then paces the GPU from C, not from an interpreter.
+ * An entry forwards to the call it names: i[] = that call's integer arguments, p[] = its pointer arguments, both in signature order:
+ *   PNX_OP_MASK_POOL3   pnx_mask_pool3        p: mask_in, mask_out                     i: batch, h, w, stride
+ *   PNX_OP_TILE_LIST    pnx_conv_tile_list    p: mask, tile_list, tile_count, row_dirty[0..n_dirty)   i: n_dirty (<= 8), batch, h, w, tile_rows
+ *   PNX_OP_CONV3X3      pnx_conv3x3_bf16      p: x, wfrag, bias, residual, mask, y, row_dirty, tile_list, tile_count
+ *                                             i: batch, h, w, cin, cout, stride, relu
+ *   PNX_OP_DECONV2X2    pnx_deconv2x2_bf16    p: x, wfrag, bias, y                     i: batch, h, w, cin, cout, relu
+ *   PNX_OP_SEPHEAD_OUT  pnx_sephead_out_bf16  p: x, wfrag, bias, y                     i: batch, h, w, n_branch
+ * The table is HOST memory and is read during the call only.  On failure the status of the failing entry is returned and pnx_last_error()
+ * names its index. */
+enum { PNX_OP_MASK_POOL3 = 1, PNX_OP_TILE_LIST = 2, PNX_OP_CONV3X3 = 3, PNX_OP_DECONV2X2 = 4, PNX_OP_SEPHEAD_OUT = 5 };
+typedef struct pnx_op {
+  int32_t kind;
+  int32_t i[9];
+  const void* p[11];
+} pnx_op; /* 128 bytes */
+int pnx_enqueue(const pnx_op* ops_host, int32_t n_ops, pnx_stream_t stream);
+size_t pnx_op_bytes(void); /* sizeof(pnx_op), for bindings to check their mirror of the structure */
+
+/* The lazy-head decoder of a frame batch as ONE call: pnx_decode_keys per task -> pnx_decode_topk -> candidate cells -> pnx_sephead_lazy_bf16 ->
+ * pnx_decode_boxes_lazy -> pnx_nms_rotated_batched -> pnx_gather_kept [-> asynchronous copies into pinned host memory]; the clears that the
+ * individual calls expect of their caller (order, boxes7, flag, keep_count) are part of it.  S = batch * n_classes_total lists.
+ * Buffers (device, caller-owned): keys/sorted_keys uint64[n_keys] and [S*pre_max], order/local int64[S*pre_max], seg_start int64[S],
+ * seg_len/seg_total/keep_count int32[S], cand float[S*pre_max*10], boxes9/boxes7/scores float[S*pre_max*{9,7,1}], flag int32[1],
+ * keep int32[S*pre_max], out float[S*post_max*10]; workspaces sized by pnx_decode_topk_workspace_bytes / pnx_nms_workspace_bytes.
+ * flag != 0 after the call: the centre range test rejected a candidate, the selection has to be redone on the dense path (decode.py). */
+typedef struct pnx_lazy_decode {
+  int32_t n_tasks, n_classes_total, batch, pre_max, post_max, dtype;
+  const void* const* dense_host;     /* [n_tasks] device pointers: (batch, h_t, w_t, 16) maps holding [iou] hm */
+  const void* task_descs_host;       /* n_tasks * pnx_decode_task_desc_bytes() */
+  const void* task_descs_dev;
+  const int64_t* task_key_off_host;  /* [n_tasks + 1]: first key of every task, then n_keys */
+  const int64_t* task_key_off_dev;
+  const int64_t* list_key_off_dev;   /* [S]: task_key_off of the list's task */
+  const PnxLazyTask* lazy_tasks_host;
+  const int32_t* class_task_host;    /* [n_classes_total] */
+  const int32_t* seg_off_dev;        /* [S + 1] = s * pre_max */
+  const float* nms_thresh_dev;       /* [S] */
+  uint64_t *keys, *sorted_keys;
+  int64_t *order, *seg_start, *local;
+  int32_t *seg_len, *seg_total;
+  float *cand, *boxes9, *boxes7, *scores;
+  int32_t *flag, *keep, *keep_count;
+  void* topk_ws;
+  size_t topk_ws_bytes;
+  void* nms_ws;
+  size_t nms_ws_bytes;
+  float* out;
+  float* out_host;                   /* optional pinned copies */
+  int32_t* keep_count_host;
+  int32_t* flag_host;
+} pnx_lazy_decode;
+int pnx_decode_lazy_enqueue(const pnx_lazy_decode* desc_host, pnx_stream_t stream);
+size_t pnx_lazy_decode_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

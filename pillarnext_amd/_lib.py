@@ -73,6 +73,10 @@ PROTOTYPES = {
     "pnx_decode_boxes": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pnx_decode_boxes_lazy": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pnx_gather_kept": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "pnx_enqueue": (ctypes.c_int, [_vp, _i32, _vp]),
+    "pnx_decode_lazy_enqueue": (ctypes.c_int, [_vp, _vp]),
+    "pnx_op_bytes": (_sz, []),
+    "pnx_lazy_decode_bytes": (_sz, []),
     "pnx_center_loss_workspace_bytes": (_sz, [_i32, _i32]),
     "pnx_center_loss_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
     "pnx_center_loss_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),

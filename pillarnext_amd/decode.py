@@ -31,6 +31,17 @@ def pack_task(C, has_iou, ncls, cls_off, H, W, osf, vs, pc_range, score_thr, lim
     return blob
 
 
+class _PnxLazyDecode(ctypes.Structure):
+    """include/pnx.h: pnx_lazy_decode."""
+    _fields_ = ([(n, ctypes.c_int32) for n in ("n_tasks", "n_classes_total", "batch", "pre_max", "post_max", "dtype")]
+                + [(n, ctypes.c_void_p) for n in ("dense_host", "task_descs_host", "task_descs_dev", "task_key_off_host", "task_key_off_dev",
+                                                 "list_key_off_dev", "lazy_tasks_host", "class_task_host", "seg_off_dev", "nms_thresh_dev", "keys",
+                                                 "sorted_keys", "order", "seg_start", "local", "seg_len", "seg_total", "cand", "boxes9", "boxes7",
+                                                 "scores", "flag", "keep", "keep_count", "topk_ws")]
+                + [("topk_ws_bytes", ctypes.c_size_t), ("nms_ws", ctypes.c_void_p), ("nms_ws_bytes", ctypes.c_size_t)]
+                + [(n, ctypes.c_void_p) for n in ("out", "out_host", "keep_count_host", "flag_host")])
+
+
 class PackedDecoder:
     def __init__(self, num_classes, rectifier, test_cfg, has_iou, channels_per_task):
         self.num_classes = list(num_classes)
@@ -155,15 +166,7 @@ class PackedDecoder:
         check(L.pnx_gather_kept(ptr(boxes9), ptr(scores), ptr(keep), ptr(cnt), S, self.pre_max, self.post_max, ptr(out), stream_ptr()),
               "pnx_gather_kept")
         # the one device->host hand-off of the frame batch: asynchronous into pinned memory; PendingDetections.result() waits
-        # three rotating pinned result buffers per shape (a serving loop has at most two batches in flight: bench.py / forward_async)
-        # a slot is only reused once the PendingDetections that owns it was resolved (result()); otherwise the ring grows
-        pk2 = (tuple(out.shape), S)
-        ring = self._pin.setdefault(pk2, [])
-        slot = next((sl for sl in ring if sl["owner"] is None or sl["owner"]() is None or sl["owner"]().done), None)
-        if slot is None:
-            slot = {"out": torch.empty(out.shape, dtype=out.dtype, pin_memory=True), "cnt": torch.empty((S,), dtype=cnt.dtype, pin_memory=True),
-                    "owner": None}
-            ring.append(slot)
+        slot = self._pinned_slot(out.shape, S, out.dtype, cnt.dtype)
         out_h, cnt_h = slot["out"], slot["cnt"]
         out_h.copy_(out, non_blocking=True)
         cnt_h.copy_(cnt[:S], non_blocking=True)
@@ -264,6 +267,99 @@ class PackedDecoder:
         check(L.pnx_decode_boxes_lazy(ptr(tdesc), ptr(koff), T, self.nc_total, ptr(skeys), ptr(order), ptr(seg_start), ptr(seg_len), ptr(seg_total), S,
                                       self.pre_max, ptr(cand), ptr(boxes9), ptr(boxes7), ptr(scores), ptr(flag), stream_ptr()), "pnx_decode_boxes_lazy")
         return self._finish(boxes9, boxes7, scores, seg_off, thr, seg_len, S, B, dev, tokens, flag=flag, fallback=fallback)
+
+    @torch.no_grad()
+    def launch_lazy_fused(self, dense, lazy_tasks, class_task, tokens=None, fallback=None):
+        """launch_lazy with the HIP evaluator as ONE C call (include/pnx.h: pnx_decode_lazy_enqueue): keys per task, top-k, candidate cells,
+        regression branches at the candidates, boxes, batched NMS, gather and the copies into pinned memory are enqueued from C++ out of a
+        descriptor that is built once per (batch, map shapes); per step only the pointers of the dense maps, of the deblocked maps and of
+        the pinned result slot change.  lazy_tasks: per task (up, wfrag1, bias1, w2c, bias2) as ops.sephead_lazy takes them.
+        Every scratch buffer is persistent: the calls of consecutive steps are ordered by the stream."""
+        B, dev, T = dense[0].shape[0], dense[0].device, len(dense)
+        dt = {torch.float32: PNX_F32, torch.bfloat16: PNX_BF16, torch.float16: PNX_F16}[dense[0].dtype]
+        shapes = [(p.shape[2], p.shape[3]) for p in dense]
+        S = B * self.nc_total
+        L = lib()
+        ck = ("lazy_fused", B, T, dt, tuple(shapes), dev)
+        st = self._dev.get(ck)
+        if st is None:
+            cfg = self.cfg
+            descs, off, offs = [], 0, [0]
+            for t, (H, W) in enumerate(shapes):
+                descs.append(pack_task(dense[t].shape[1], self.has_iou, self.num_classes[t], off, H, W, _get(cfg, "out_size_factor")[t],
+                                       _get(cfg, "voxel_size"), _get(cfg, "pc_range"), _get(cfg, "score_threshold"),
+                                       _get(cfg, "post_center_limit_range"), self.rectifier[t], lazy=True))
+                off += self.num_classes[t]
+                offs.append(offs[-1] + B * H * W)
+            n_keys, n_rows = offs[-1], S * self.pre_max
+            kofs = torch.tensor([offs[class_task[s % self.nc_total]] for s in range(S)], dtype=torch.int64, device=dev)
+            i64, i32, f32 = torch.int64, torch.int32, torch.float32
+            bufs = {
+                "descs_host": ctypes.create_string_buffer(b"".join(descs)),
+                "tdesc": torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev),
+                "koff_host": (ctypes.c_int64 * (T + 1))(*offs),
+                "koff": torch.tensor(offs, dtype=i64, device=dev),
+                "kofs": kofs,
+                "seg_off": (torch.arange(S + 1, dtype=i32, device=dev) * self.pre_max).contiguous(),
+                "thr": torch.tensor(self.thr, dtype=f32, device=dev).repeat(B),
+                "dense_arr": (ctypes.c_void_p * T)(),
+                "tasks_arr": (ops._PnxLazyTask * T)(),
+                "class_task": (ctypes.c_int32 * self.nc_total)(*[int(v) for v in class_task]),
+                "keys": torch.empty((n_keys,), dtype=i64, device=dev), "skeys": torch.empty((n_rows,), dtype=i64, device=dev),
+                "order": torch.empty((n_rows,), dtype=i64, device=dev), "seg_start": torch.empty((S,), dtype=i64, device=dev),
+                "local": torch.empty((n_rows,), dtype=i64, device=dev), "seg_len": torch.empty((S,), dtype=i32, device=dev),
+                "seg_total": torch.empty((S,), dtype=i32, device=dev), "cand": torch.empty((n_rows, 10), dtype=f32, device=dev),
+                "boxes9": torch.empty((n_rows, 9), dtype=f32, device=dev), "boxes7": torch.empty((n_rows, 7), dtype=f32, device=dev),
+                "scores": torch.empty((n_rows,), dtype=f32, device=dev), "flag": torch.empty((1,), dtype=i32, device=dev),
+                "keep": torch.empty((n_rows,), dtype=i32, device=dev), "cnt": torch.empty((S,), dtype=i32, device=dev),
+                "out": torch.empty((S, self.post_max, 10), dtype=f32, device=dev),
+            }
+            bufs["topk_ws"] = torch.empty(int(L.pnx_decode_topk_workspace_bytes(n_keys, S)) + 256, dtype=torch.uint8, device=dev)
+            bufs["nms_ws"] = torch.empty(max(int(L.pnx_nms_workspace_bytes(n_rows, S, self.pre_max)), 1), dtype=torch.uint8, device=dev)
+            d = _PnxLazyDecode()
+            d.n_tasks, d.n_classes_total, d.batch, d.pre_max, d.post_max, d.dtype = T, self.nc_total, B, self.pre_max, self.post_max, dt
+            d.dense_host = ctypes.cast(bufs["dense_arr"], ctypes.c_void_p)
+            d.task_descs_host = ctypes.cast(bufs["descs_host"], ctypes.c_void_p)
+            d.task_key_off_host = ctypes.cast(bufs["koff_host"], ctypes.c_void_p)
+            d.lazy_tasks_host = ctypes.cast(bufs["tasks_arr"], ctypes.c_void_p)
+            d.class_task_host = ctypes.cast(bufs["class_task"], ctypes.c_void_p)
+            for f, k in (("task_descs_dev", "tdesc"), ("task_key_off_dev", "koff"), ("list_key_off_dev", "kofs"), ("seg_off_dev", "seg_off"),
+                         ("nms_thresh_dev", "thr"), ("keys", "keys"), ("sorted_keys", "skeys"), ("order", "order"), ("seg_start", "seg_start"),
+                         ("local", "local"), ("seg_len", "seg_len"), ("seg_total", "seg_total"), ("cand", "cand"), ("boxes9", "boxes9"),
+                         ("boxes7", "boxes7"), ("scores", "scores"), ("flag", "flag"), ("keep", "keep"), ("keep_count", "cnt"),
+                         ("topk_ws", "topk_ws"), ("nms_ws", "nms_ws"), ("out", "out")):
+                setattr(d, f, bufs[k].data_ptr())
+            d.topk_ws_bytes, d.nms_ws_bytes = bufs["topk_ws"].numel(), bufs["nms_ws"].numel()
+            st = self._dev[ck] = (d, bufs)
+        d, bufs = st
+        for t, (p, (up, wf, b1, w2c, b2)) in enumerate(zip(dense, lazy_tasks)):
+            if not (p.is_contiguous(memory_format=torch.channels_last) and up.is_contiguous(memory_format=torch.channels_last)
+                    and up.dtype == torch.bfloat16 and up.shape[1] == 64 and up.shape[0] == B and tuple(up.shape[2:]) == shapes[t]):
+                raise PnxError("lazy decode: dense maps and 64-channel deblocked maps must be channels_last bf16 of the task's shape")
+            bufs["dense_arr"][t] = p.data_ptr()
+            bufs["tasks_arr"][t] = ops._PnxLazyTask(up.data_ptr(), wf.data_ptr(), b1.data_ptr(), w2c.data_ptr(), b2.data_ptr(), up.shape[2], up.shape[3])
+        slot = self._pinned_slot((S, self.post_max, 10), S, torch.float32, torch.int32)
+        if "flag" not in slot:
+            slot["flag"] = torch.zeros((1,), dtype=torch.int32, pin_memory=True)
+        d.out_host, d.keep_count_host, d.flag_host = slot["out"].data_ptr(), slot["cnt"].data_ptr(), slot["flag"].data_ptr()
+        check(L.pnx_decode_lazy_enqueue(ctypes.byref(d), stream_ptr()), "pnx_decode_lazy_enqueue")
+        ev = torch.cuda.Event()
+        ev.record()
+        pend = PendingDetections(ev, slot["out"], slot["cnt"], B, self.nc_total, tokens if tokens else [None] * B)
+        pend.flag_h, pend.fallback = slot["flag"], fallback
+        slot["owner"] = weakref.ref(pend)
+        return pend
+
+    def _pinned_slot(self, out_shape, S, out_dtype, cnt_dtype):
+        """One of the rotating pinned result buffers of a shape (a serving loop has at most two batches in flight: bench.py / forward_async);
+        a slot is only reused once the PendingDetections that owns it was resolved (result()); otherwise the ring grows."""
+        ring = self._pin.setdefault((tuple(out_shape), S), [])
+        slot = next((sl for sl in ring if sl["owner"] is None or sl["owner"]() is None or sl["owner"]().done), None)
+        if slot is None:
+            slot = {"out": torch.empty(out_shape, dtype=out_dtype, pin_memory=True), "cnt": torch.empty((S,), dtype=cnt_dtype, pin_memory=True),
+                    "owner": None}
+            ring.append(slot)
+        return slot
 
     def __call__(self, packed, tokens=None):
         return self.launch(packed, tokens).result()

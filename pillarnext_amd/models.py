@@ -914,7 +914,8 @@ class FusedPillarNeXt(nn.Module):
         if hip_conv is None:
             hip_conv = os.environ.get("PNX_HIP_CONV", "1") != "0"
         self._ws = {}
-        self._prefetched, self._rd_stream, self._rd_direct = {}, None, None   # prefetch(): readers enqueued on the side stream
+        # launch plans (plan.py / pnx_enqueue): the backbone and the head as one C call each; PNX_PLAN=0 issues every launch from Python
+        self.use_plan = os.environ.get("PNX_PLAN", "1") != "0"
         self.sparse_ws = os.environ.get("PNX_SPARSE_WS", "1") != "0"
         self.tile_lists = os.environ.get("PNX_TILE_LISTS", "1") != "0"
         self.reader = det.reader
@@ -1047,31 +1048,6 @@ class FusedPillarNeXt(nn.Module):
         self.lazy_head = self.lazy_head and all(self._lazy_ok)
 
     @torch.no_grad()
-    def prefetch(self, example, ready=None):
-        """Enqueue the READER of a later batch on a side stream, so that it runs beside the convolutions of the batch in flight (they are
-        latency-bound and leave HBM mostly idle; the reader is the opposite).  The following forward_async / forward_preds call with the
-        same `points` tensor picks the canvas up.  `ready`: a torch.cuda.Event after which the points are valid (None: they are resident)."""
-        pts, B = example["points"], int(example["batch_size"])
-        if not pts.is_cuda:
-            return
-        if self._rd_stream is None:
-            self._rd_stream = torch.cuda.Stream(device=pts.device)
-        side = self._rd_stream
-        if ready is not None:
-            side.wait_event(ready)
-        if self._rd_direct is not None:
-            side.wait_event(self._rd_direct)
-            self._rd_direct = None
-        ny, nx = (int(v) for v in self.reader.grid_size)
-        with torch.cuda.stream(side):
-            occ = torch.empty((B, ny, nx), dtype=torch.uint8, device=pts.device)
-            x = self.reader.forward_dense(pts, B, dtype=self.dtype, occupancy=occ)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        pts.record_stream(side)
-        self._prefetched[pts.data_ptr()] = (x, occ, ev)
-
-    @torch.no_grad()
     def forward_preds(self, points, batch_size, marks=None, packed_out=None, taps=None, lazy=None):
         """packed_out: a list that receives, per task, the packed NHWC head output -- or, with the lazy head (lazy=None: the model's
         setting), a LazyTask (dense [iou] hm map + deblocked features) for launch_decode()."""
@@ -1083,25 +1059,18 @@ class FusedPillarNeXt(nn.Module):
 
         mark("start")
         ny, nx = (int(v) for v in self.reader.grid_size)
-        occ = torch.empty((batch_size, ny, nx), dtype=torch.uint8, device=points.device)
-        pf = self._prefetched.pop(points.data_ptr(), None) if self._prefetched else None
-        if pf is not None:
-            # the reader of this batch was enqueued on the side stream by prefetch(): wait for it, hand its tensors to this stream
-            x, occ, ev = pf
-            cur = torch.cuda.current_stream()
-            cur.wait_event(ev)
-            x.record_stream(cur)
-            occ.record_stream(cur)
+        planned = marks is None and taps is None and self._plan_ok()
+        if planned:
+            bb = self._backbone_plan(batch_size, points.device)
+            self.reader.forward_dense(points, batch_size, dtype=self.dtype, out=bb["canvas"], occupancy=bb["occ"])
+            bb["plan"].run()
+            x, mask = bb["out"], bb["mask"]
         else:
-            if self._rd_stream is not None:       # the reader's workspace is shared with the side stream's calls: keep them in order
-                torch.cuda.current_stream().wait_stream(self._rd_stream)
+            occ = torch.empty((batch_size, ny, nx), dtype=torch.uint8, device=points.device)
             x = self.reader.forward_dense(points, batch_size, dtype=self.dtype, occupancy=occ)
-            if self._rd_stream is not None:
-                self._rd_direct = torch.cuda.Event()
-                self._rd_direct.record()
+            mask = occ
         mark("reader")
-        mask = occ
-        for si, (mods, (stride, subm)) in enumerate(zip(self.stages, self.stage_meta)):
+        for si, (mods, (stride, subm)) in enumerate(zip(self.stages, self.stage_meta) if not planned else ()):
             if not subm:
                 mask = ops.mask_pool3(mask, stride)
             ws, k = self._stage_workspace(si, mods, mask), 0
@@ -1131,9 +1100,12 @@ class FusedPillarNeXt(nn.Module):
         mark("mapping+neck")
         if taps is not None:
             taps["neck"] = x
+        lazy = packed_out is not None and self.lazy_head and (lazy is None or lazy)
+        if planned and lazy and self._head_plan_ok():
+            packed_out.extend(self._run_head_plan(x))
+            return []
         x = self.shared(x)
         preds = []
-        lazy = packed_out is not None and self.lazy_head and (lazy is None or lazy)
         for ti, (db, c1, c2, (names, outs_n)) in enumerate(zip(self.task_deblock, self.task_conv1, self.task_conv2, self.task_split)):
             up = db(x)
             if lazy:
@@ -1150,6 +1122,105 @@ class FusedPillarNeXt(nn.Module):
             preds.append(d)
         mark("head")
         return preds
+
+    # ------------------------------------------------------------------ launch plans (plan.py, include/pnx.h: pnx_enqueue)
+    def _plan_ok(self):
+        return (self.use_plan and self.sparse_ws and self.tile_lists and self.dtype == torch.bfloat16 and not self.reader.training
+                and self.reader._fused_supported() and all(isinstance(m, _HipConv3x3) for mods in self.stages for m in mods))
+
+    def _head_plan_ok(self):
+        return isinstance(self.shared, _HipConv3x3) and all(isinstance(d, _HipDeconv2x2) for d in self.task_deblock)
+
+    def _backbone_plan(self, B, dev):
+        """The backbone of a B-frame batch as ONE pnx_enqueue call: per stage [mask_pool3,] tile list, convolutions -- the same calls, buffers
+        and order as the Python loop of forward_preds, frozen.  The reader writes the plan's persistent canvas / occupancy."""
+        from .plan import LaunchPlan
+
+        key = ("plan_bb", B, dev)
+        st = self._ws.get(key)
+        if st is not None:
+            return st
+        ny, nx = (int(v) for v in self.reader.grid_size)
+        canvas = torch.empty((B, 64, ny, nx), dtype=self.dtype, device=dev, memory_format=torch.channels_last)
+        occ = torch.empty((B, ny, nx), dtype=torch.uint8, device=dev)
+        plan = LaunchPlan()
+        x, mask = canvas, occ
+        for si, (mods, (stride, subm)) in enumerate(zip(self.stages, self.stage_meta)):
+            if not subm:
+                H, W = mask.shape[1:]
+                pooled = torch.empty((B, (H - 1) // stride + 1, (W - 1) // stride + 1), dtype=torch.uint8, device=dev)
+                plan.mask_pool3(mask, pooled, stride)
+                mask = pooled
+            ws = self._stage_workspace(si, mods, mask)
+            tiles, rows = self._stage_tile_buffers(si, mods, mask)
+            if tiles is not None:
+                plan.tile_list(mask, [w[1] for w in ws], rows, tiles)
+            k = 0
+
+            def run(m, inp, res=None):
+                nonlocal k
+                k += 1
+                out = ws[(k - 1) % 3]
+                plan.conv3x3(inp, m.wfrag, m.bias, m.cout, m.stride, mask, res, True, out=out, tiles=tiles if m.stride == 1 else None)
+                return out[0]
+
+            x = run(mods[0], x)
+            for j in range(1, len(mods), 2):
+                y = run(mods[j], x)
+                x = run(mods[j + 1], y, x)
+        st = self._ws[key] = {"canvas": canvas, "occ": occ, "plan": plan.freeze(), "out": x, "mask": mask}
+        return st
+
+    def _run_head_plan(self, x):
+        """shared conv + per task (deblock, dense [iou] hm branches) as ONE pnx_enqueue call.  The deblocked maps and the dense maps are fresh
+        tensors per step (the decoder's fallback may read them after later steps were enqueued); the intermediates are persistent."""
+        from .plan import Dyn, LaunchPlan
+
+        B, _, H, W = x.shape
+        dev = x.device
+        key = ("plan_head", B, H, W, dev)
+        st = self._ws.get(key)
+        T = len(self.task_deblock)
+
+        def fresh():
+            ups = [torch.empty((B, 64, 2 * H, 2 * W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last) for _ in range(T)]
+            dense = [torch.empty((B, 16, 2 * H, 2 * W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last) for _ in range(T)]
+            return ups, dense
+
+        ups, dense = fresh()
+        if st is None:
+            plan = LaunchPlan()
+            sh = torch.empty((B, self.shared.cout, H, W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+            plan.conv3x3(Dyn("x", x), self.shared.wfrag, self.shared.bias, self.shared.cout, 1, None, None, True, out=(sh, None))
+            mids = {}
+            for ti, db in enumerate(self.task_deblock):
+                c1, c2 = self.lazy_conv1[ti], self.lazy_conv2[ti]
+                plan.deconv2x2(sh, db.wfrag, db.bias, db.cout, Dyn(f"up{ti}", ups[ti]), db.relu)
+                if c1.cout not in mids:      # the tasks run one after the other on the stream: one intermediate per width serves them all
+                    mids[c1.cout] = torch.empty((B, c1.cout, 2 * H, 2 * W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+                plan.conv3x3(Dyn(f"up{ti}", ups[ti]), c1.wfrag, c1.bias, c1.cout, 1, None, None, True, out=(mids[c1.cout], None))
+                plan.sephead_out(mids[c1.cout], c2.wfrag, c2.bias, Dyn(f"dense{ti}", dense[ti]))
+            st = self._ws[key] = plan.freeze()
+        st.bind("x", x)
+        for ti in range(T):
+            st.bind(f"up{ti}", ups[ti])
+            st.bind(f"dense{ti}", dense[ti])
+        st.run()
+        return [LazyTask(d, u) for d, u in zip(dense, ups)]
+
+    def _stage_tile_buffers(self, si, mods, mask):
+        """(tile list, count) buffers of a stage and the tile rows of its kernels, without listing anything (see _stage_tiles)."""
+        m = next((m for m in mods if isinstance(m, _HipConv3x3) and m.stride == 1), None)
+        rows = ops.conv_tile_rows(m.cin, m.cout, 1) if m is not None else 0
+        if rows <= 0:
+            return None, 0
+        key = ("tiles", si) + tuple(mask.shape) + (mask.device,)
+        buf = self._ws.get(key)
+        if buf is None:
+            B, H, W = mask.shape
+            n_tiles = B * ((H + rows - 1) // rows) * ((W + 31) // 32)
+            buf = self._ws[key] = (torch.empty((n_tiles,), dtype=torch.int32, device=mask.device), torch.zeros((1,), dtype=torch.int32, device=mask.device))
+        return buf, rows
 
     def _stage_workspace(self, si, mods, mask):
         """Three persistent (activation, row_dirty) pairs per backbone stage for its HIP convolutions: they then touch only the row
@@ -1247,7 +1318,13 @@ class FusedPillarNeXt(nn.Module):
         def dense_path():  # the exact fallback (decode.PendingDetections.result): every branch over the whole map
             return self.decoder().launch([c2(c1(u)) for u, c1, c2 in zip(ups, self.task_conv1, self.task_conv2)], tokens)
 
-        return self.decoder().launch_lazy([p.dense for p in packed], lambda *a: self.lazy_eval(ups, *a), tokens, dense_path)
+        dec = self.decoder()
+        if self.use_plan and dec.use_topk and dec.pre_max <= 4096 and os.environ.get("PNX_HEAD_LAZY_TORCH", "0") != "1":
+            tasks = [(ups[ti], getattr(self, f"lazy_wf1_{ti}"), getattr(self, f"lazy_b1_{ti}"), getattr(self, f"lazy_w2c_{ti}"),
+                      getattr(self, f"lazy_b2_{ti}")) for ti in range(len(ups))]
+            class_task = [ti for ti, (names, outs) in enumerate(self.task_split) for _ in range(outs[-1])]
+            return dec.launch_lazy_fused([p.dense for p in packed], tasks, class_task, tokens, dense_path)
+        return dec.launch_lazy([p.dense for p in packed], lambda *a: self.lazy_eval(ups, *a), tokens, dense_path)
 
     @staticmethod
     def detections(outputs):

@@ -405,33 +405,38 @@ def test_decoder_sort_paths_agree(monkeypatch):
             assert torch.equal(a[k], b[k]), k
 
 
-def test_prefetched_reader_equals_the_inline_reader():
-    """FusedPillarNeXt.prefetch() runs the reader of a later batch on a side stream; the detections must equal the inline path bit for bit,
-    in a serving-loop order (prefetch i+1, launch i, read i-1), mixed with calls that were not prefetched."""
+def test_launch_plans_equal_the_python_launch_loop(monkeypatch):
+    """FusedPillarNeXt with launch plans (plan.py / pnx_enqueue: backbone and head as one C call each, pnx_decode_lazy_enqueue: the decoder as
+    one) against the same network issuing every launch from Python: detections bit for bit, in a serving-loop order (launch i + 1 before
+    the result of i is read), over batches whose active sets differ (the persistent workspaces go stale in between)."""
     from pillarnext_amd import synth
     from pillarnext_amd.models import FusedPillarNeXt, build_pillarnext_b
 
     cfg = synth.CONFIGS["C1"]
     torch.manual_seed(5)
     model = build_pillarnext_b(cfg["pc_range"], cfg["voxel_size"], tasks=[["car"], ["truck", "bus"]], with_iou_head=True).cuda().eval()
+    monkeypatch.setenv("PNX_PLAN", "0")
+    plain = FusedPillarNeXt(model).cuda().eval()
+    monkeypatch.setenv("PNX_PLAN", "1")
     fused = FusedPillarNeXt(model).cuda().eval()
+    assert fused.use_plan and not plain.use_plan and fused._plan_ok() and fused._head_plan_ok()
     B = 2
     exs = []
     for i, (d, n, f) in enumerate((("sweep", 30_000, 0), ("uniform", 20_000, 5), ("sweep", 25_000, 9), ("sweep", 30_000, 2))):
         exs.append({"points": torch.from_numpy(synth.make_batch("C1", B, d, n=n, frame0=f)).cuda(), "batch_size": B, "token": [f"f{i}a", f"f{i}b"]})
     with torch.no_grad():
-        want = [fused(e) for e in exs]
+        want = [plain(e) for e in exs]
         got, pend = [], None
-        fused.prefetch(exs[0])
-        for i, e in enumerate(exs):
-            if i + 1 < len(exs) and i != 1:            # batch 2 is NOT prefetched: inline reader between prefetched ones
-                fused.prefetch(exs[i + 1])
+        for e in exs:
             nxt = fused.forward_async(e)
             if pend is not None:
                 got.append(fused.detections(pend.result()))
             pend = nxt
         got.append(fused.detections(pend.result()))
+    assert ("plan_bb", B, exs[0]["points"].device) in fused._ws and any(k[0] == "lazy_fused" for k in fused.decoder()._dev)
+    assert sum(len(v["scores"]) for a in want for v in a.values()) > 0
     for a, b in zip(got, want):
         assert set(a) == set(b)
         for k in a:
             assert torch.equal(a[k]["scores"], b[k]["scores"]) and torch.equal(a[k]["box3d_lidar"], b[k]["box3d_lidar"]), k
+            assert torch.equal(a[k]["label_preds"], b[k]["label_preds"]), k

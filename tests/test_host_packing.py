@@ -35,3 +35,17 @@ def test_lazy_task_descriptor_points_at_the_class_map_only():
     d, z = struct.unpack("6i6f6fi4f3i", dense), struct.unpack("6i6f6fi4f3i", lazy)
     assert d[:23] == z[:23]                                  # geometry, thresholds, range, rectifier: the same
     assert d[-3:] == (11, 10, 0) and z[-3:] == (1, 0, 1)     # o_hm, o_iou, lazy: [reg .. vel | iou | hm] vs [iou | hm]
+
+
+def test_launch_table_structures_mirror_the_c_ones():
+    """plan.PnxOp / decode._PnxLazyDecode are ctypes mirrors of include/pnx.h's pnx_op / pnx_lazy_decode: same size as the compiled ones,
+    pointers 8-byte aligned behind the integer block."""
+    import ctypes
+
+    from pillarnext_amd import _lib, decode, plan
+
+    L = _lib.lib()
+    assert ctypes.sizeof(plan.PnxOp) == L.pnx_op_bytes() == 128
+    assert plan.PnxOp.p.offset == 40 and plan.PnxOp.i.offset == 4
+    assert ctypes.sizeof(decode._PnxLazyDecode) == L.pnx_lazy_decode_bytes()
+    assert decode._PnxLazyDecode.dense_host.offset == 24 and decode._PnxLazyDecode.flag_host.offset == L.pnx_lazy_decode_bytes() - 8
