@@ -36,6 +36,8 @@ def build(force=False, verbose=False):
         extra = []
         if src in ("pfn_v3.hip", "pfn_spans.hip"):  # fmaxf without canonicalising v_max pairs (-inf still honoured); MFMA accumulators in VGPRs (no v_accvgpr traffic)
             extra = ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + (["-DPNX_PFN_TIMERS"] if os.environ.get("PNX_PFN_TIMERS") else []) + (["-DPNX_BINS_TIMERS"] if os.environ.get("PNX_BINS_TIMERS") else [])
+            if src == "pfn_spans.hip" and os.environ.get("PNX_SPAN_NUM_VGPR"):
+                extra.append("-DPNX_SPAN_NUM_VGPR=" + os.environ["PNX_SPAN_NUM_VGPR"])
         elif src == "chunk_sort.hip":
             extra = ["-DPNX_BINS_TIMERS"] if os.environ.get("PNX_BINS_TIMERS") else []
         elif src == "conv3x3.hip":

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64 * kTotGroups) void k_slab_totals(const uint16_t*
                                                                 const int32_t* __restrict__ frame_lo, const int32_t* __restrict__ frame_hi,
                                                                 const int32_t* __restrict__ counters, SpanGeom sg, uint32_t* __restrict__ slab_tot) {
   __shared__ uint32_t s_part[kTotGroups][64];
+  __builtin_amdgcn_s_setprio(3);  // runs beside the canvas zero-fill (reader.hip): short and latency-bound, so first in line
   const int t = threadIdx.x, ls = t & 63, grp = t >> 6;
   const int b = blockIdx.y, sl0 = blockIdx.x * 64 + ls;
   const bool in = sl0 < sg.nf;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(64 * kTotGroups) void k_slab_totals(const uint16_t*
 __global__ __launch_bounds__(1024) void k_span_carve(const uint32_t* __restrict__ slab_tot, SpanGeom sg, uint2* __restrict__ span_desc,
                                                      int32_t* __restrict__ nspan) {
   __shared__ uint32_t s_wave[2][16];
+  __builtin_amdgcn_s_setprio(3);  // as k_slab_totals
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int b = blockIdx.x, nf = sg.nf;
   const uint32_t* T = slab_tot + (int64_t)b * nf;
@@ -311,7 +313,7 @@ size_t pnx_chunk_sort_lds(const SpanGeom& sg) { return (size_t)kChunk * 32 + (si
 // must be zero and receives a 1 for every occupied cell.
 int pnx_launch_chunk_sort(const float* points, int64_t n, int stride, const PnxGeomDev& g, const SpanGeom& sg, uint4* recs, uint16_t* tab,
                           int32_t* rowframe, uint32_t* rowbase, int32_t* counters, int32_t* frame_lo, int32_t* frame_hi, uint8_t* bytemap,
-                          uint32_t* slab_tot, uint2* span_desc, int32_t* nspan, hipStream_t st) {
+                          uint32_t* slab_tot, uint2* span_desc, int32_t* nspan, hipStream_t st, hipEvent_t sorted) {
   PNX_REQUIRE(sg.nf <= 32768 && sg.B <= 1024, PNX_ERR_UNSUPPORTED, "%d slabs per frame / %d frames exceed the span tables", sg.nf, sg.B);
   if (sg.nchunks > 0) {
     const size_t lds = pnx_chunk_sort_lds(sg);
@@ -346,6 +348,7 @@ int pnx_launch_chunk_sort(const float* points, int64_t n, int stride, const PnxG
             100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot);
   }
 #endif
+  if (sorted != nullptr) PNX_CHECK_HIP(hipEventRecord(sorted, st));  // the occupancy bytes are complete: the zero-fill may start
   k_slab_totals<<<dim3((unsigned)((sg.nf + 63) / 64), (unsigned)sg.B), 64 * kTotGroups, 0, st>>>(tab, rowframe, frame_lo, frame_hi, counters, sg, slab_tot);
   k_span_carve<<<sg.B, 1024, 0, st>>>(slab_tot, sg, span_desc, nspan);
   PNX_LAUNCH_CHECK();

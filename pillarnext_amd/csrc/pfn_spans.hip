@@ -22,7 +22,6 @@
 #include <type_traits>
 
 #include "pnx_common.h"
-#include "pnx_fill.h"
 #include "pfn_common.h"
 #include "spans.h"
 
@@ -75,7 +74,7 @@ struct SpanPfnArgs {
   int32_t* coords;
   int64_t pillar_capacity;
   const float* P;                // folded parameters (k_fold_bn)
-  int cap, n_fill;
+  int cap;
   unsigned long long* timers;
 };
 
@@ -132,18 +131,22 @@ __device__ __forceinline__ int32_t key_rank(int32_t key, const uint2* __restrict
   return (int32_t)(wblk[w >> PNX_SCAN_SHIFT] + c.y + __popc(c.x & ((1u << (key & 31)) - 1u)));
 }
 
+// Registers: the kernel is capped at 240 per lane (amdgpu_num_vgpr counts the arch half of gfx950's unified file: 120), 16-24 bytes of
+// scratch per lane instead of 256 registers and none -- so that the two workgroups of a CU leave 32 registers per SIMD lane, which is what
+// a wave of the zero-fill kernel (reader.hip: k_canvas_fill_bytes, 25 registers, no LDS to speak of) needs to be co-resident: the fill
+// runs on a second stream BESIDE this kernel, one workgroup per CU, instead of taking half of this kernel's workgroup slots
+// (PNX_SPAN_NUM_VGPR at build time for experiments; 128 = no cap).
+#ifndef PNX_SPAN_NUM_VGPR
+#define PNX_SPAN_NUM_VGPR 120
+#endif
 template <int F, int DT, bool PACK>
-__global__ __launch_bounds__(kSpBlock, 2) void k_span_pfn(SpanPfnArgs A, Pfn3Out out, PnxGeomDev g, PnxByteFillJob fj) {
+__global__ __launch_bounds__(kSpBlock, 2) __attribute__((amdgpu_num_vgpr(PNX_SPAN_NUM_VGPR))) void k_span_pfn(SpanPfnArgs A, Pfn3Out out, PnxGeomDev g) {
   constexpr int C0 = F + 5, KS = (C0 + 2) / 2;     // K = C0 features + the constant-1 column that carries the folded BN shift
   constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;  // start of the fragment-ordered block (k_fold_bn)
   constexpr int WL = wave_out_words<PACK>();
   constexpr int S = kS, E = kS >> 8;
   extern __shared__ __align__(16) uint32_t s_raw[];
   const int t = threadIdx.x;
-  if ((int)blockIdx.x < A.n_fill) {  // ---- fill role (block-uniform): the zero-fill tiles, by ticket (pnx_fill.h)
-    pnx_fill_bytes_share<DT>(fj, g, s_raw, t, kSpBlock);
-    return;
-  }
   uint32_t* s_cnt = s_raw;               // S + 1: points per pillar
   uint32_t* s_pst = s_cnt + (S + 4);     // S + 1: exclusive starts of the PADDED sizes of the pillars of <= 32 points
   uint32_t* s_slot = s_pst + (S + 4);    // S: first LDS slot of the pillar in the current segment (pillars of > 32 points: first slot of the spill stream)
@@ -855,12 +858,12 @@ __global__ __launch_bounds__(kSpBlock, 2) void k_span_pfn(SpanPfnArgs A, Pfn3Out
 }
 
 template <int F>
-int launch_spans(const SpanPfnArgs& A0, const Pfn3Out& out, const PnxGeomDev& g, const PnxByteFillJob& fj, int64_t n, hipStream_t st) {
+int launch_spans(const SpanPfnArgs& A0, const Pfn3Out& out, const PnxGeomDev& g, int64_t n, hipStream_t st) {
   SpanPfnArgs A = A0;
   const bool pack = out.g1 == nullptr && out.canvas != nullptr && out.dt != PNX_F32;
-  // two workgroups per CU (the kernel's ~216 VGPRs allow two waves per SIMD): 160 KiB / 2 minus a margin
+  // two workgroups per CU: 160 KiB / 2 minus a margin for the static arrays and for the zero-fill workgroup that shares the CU
   const char* l_env = getenv("PNX_BINS_LDS");
-  const size_t budget = l_env ? (size_t)atoi(l_env) : 80 * 1024 - 512;
+  const size_t budget = l_env ? (size_t)atoi(l_env) : 80000;
   const size_t fixed = span_pfn_lds_bytes(0, pack, A.sg.B);
   PNX_REQUIRE(fixed + (size_t)(kClassSlack + 64) * kRecW * 4 <= budget, PNX_ERR_UNSUPPORTED, "the span tables of %d frames do not fit the LDS budget", A.sg.B);
   int cap = (int)((budget - fixed) / (kRecW * 4));
@@ -870,7 +873,7 @@ int launch_spans(const SpanPfnArgs& A0, const Pfn3Out& out, const PnxGeomDev& g,
   const size_t lds = span_pfn_lds_bytes(cap, pack, A.sg.B);
   const char* b_env = getenv("PNX_PFN_BLOCKS");
   const int nb = n > 0 ? (b_env ? atoi(b_env) : 512) : 0;  // 256 CUs x 2 workgroups, persistent
-  const int grid = nb + A.n_fill;
+  const int grid = nb;
   if (grid <= 0) return PNX_OK;
 #define PNX_GO(DT_, PACK_)                                                                                                               \
   {                                                                                                                                     \
@@ -879,7 +882,7 @@ int launch_spans(const SpanPfnArgs& A0, const Pfn3Out& out, const PnxGeomDev& g,
       PNX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_span_pfn<F, DT_, PACK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       lds_set = lds;                                                                                                                    \
     }                                                                                                                                   \
-    k_span_pfn<F, DT_, PACK_><<<grid, kSpBlock, lds, st>>>(A, out, g, fj);                                                                  \
+    k_span_pfn<F, DT_, PACK_><<<grid, kSpBlock, lds, st>>>(A, out, g);                                                                      \
   }
   if (out.dt == PNX_F32) {
     PNX_GO(PNX_F32, false)
@@ -896,19 +899,17 @@ int launch_spans(const SpanPfnArgs& A0, const Pfn3Out& out, const PnxGeomDev& g,
 }  // namespace
 
 // The span grouping + PFN launch.  tick[0] must be zero (the reader's memset), tables as left by pnx_launch_chunk_sort.
-// n_fill > 0: blocks [0, n_fill) of the launch take the zero-fill tiles of `fj` (pnx_fill.h) concurrently.
 // wcomb / wblk (the reader's key-order bitmap prefix) select the rank outputs: g1 rows by global pillar rank, coords, row_of.
 int pnx_launch_span_pfn(int F, const SpanTables& T, const SpanGeom& sg, int32_t* counters, int32_t* tick, uint32_t* rec64,
                         uint32_t* pfirst, uint32_t* pcnt, int32_t* cell_of_pillar, int32_t* row_of, int32_t* biglist, int64_t bigcap, int64_t idcap,
                         const uint2* wcomb, const uint32_t* wblk, int32_t* coords, int64_t pillar_capacity, const float* folded, float* g1,
-                        int64_t g1_rows, void* canvas, int canvas_dt, int64_t n_points, int n_fill, const PnxByteFillJob& fj, const PnxGeomDev& geom,
-                        hipStream_t st) {
+                        int64_t g1_rows, void* canvas, int canvas_dt, int64_t n_points, const PnxGeomDev& geom, hipStream_t st) {
   SpanPfnArgs A;
   A.T = T, A.sg = sg, A.counters = counters, A.tick = tick, A.rec64 = rec64, A.pfirst = pfirst, A.pcnt = pcnt;
   A.cell_of_pillar = cell_of_pillar, A.row_of = row_of, A.biglist = biglist;
   A.bigcap = (int)(bigcap > 0x7fffffff ? 0x7fffffff : bigcap);
   A.idcap = (int)(idcap > 0x7fffffff ? 0x7fffffff : idcap);
-  A.wcomb = wcomb, A.wblk = wblk, A.coords = coords, A.pillar_capacity = pillar_capacity, A.P = folded, A.cap = 0, A.n_fill = n_fill;
+  A.wcomb = wcomb, A.wblk = wblk, A.coords = coords, A.pillar_capacity = pillar_capacity, A.P = folded, A.cap = 0;
   A.timers = nullptr;
 #ifdef PNX_BINS_TIMERS
   static unsigned long long* d_tim = nullptr;
@@ -921,9 +922,9 @@ int pnx_launch_span_pfn(int F, const SpanTables& T, const SpanGeom& sg, int32_t*
   out.row_of = nullptr;
   int rc;
   switch (F) {
-    case 3: rc = launch_spans<3>(A, out, geom, fj, n_points, st); break;
-    case 4: rc = launch_spans<4>(A, out, geom, fj, n_points, st); break;
-    case 5: rc = launch_spans<5>(A, out, geom, fj, n_points, st); break;
+    case 3: rc = launch_spans<3>(A, out, geom, n_points, st); break;
+    case 4: rc = launch_spans<4>(A, out, geom, n_points, st); break;
+    case 5: rc = launch_spans<5>(A, out, geom, n_points, st); break;
     default: pnx_set_error("the span PFN is built for 3..5 point features, got %d", F); return PNX_ERR_UNSUPPORTED;
   }
 #ifdef PNX_BINS_TIMERS

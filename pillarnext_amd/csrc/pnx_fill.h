@@ -170,7 +170,7 @@ __device__ __forceinline__ void pnx_fill_bytes_share(const PnxByteFillJob& j, co
     __syncthreads();
     const int k = (int)s_row[32];
     if (k >= j.tiles) break;  // block-uniform
-    if (j.nt) pnx_fill_tile_bytes<DT, true>(j.bytemap, g, j.canvas, j.base + k, s_row, t, nthreads);
+    if (j.nt & 1) pnx_fill_tile_bytes<DT, true>(j.bytemap, g, j.canvas, j.base + k, s_row, t, nthreads);
     else pnx_fill_tile_bytes<DT, false>(j.bytemap, g, j.canvas, j.base + k, s_row, t, nthreads);
     __syncthreads();  // s_row is rewritten by the next tile
   }

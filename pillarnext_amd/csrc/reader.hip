@@ -525,6 +525,7 @@ __global__ __launch_bounds__(kBlock) void k_clear2(uint4* __restrict__ a, int64_
 template <int DT>
 __global__ __launch_bounds__(kBlock) void k_canvas_fill_bytes(PnxByteFillJob fj, GeomDev g) {
   __shared__ uint32_t s_row[36];
+  if (fj.nt & 2) __builtin_amdgcn_s_setprio(3);  // beside the span kernel: few instructions, all of them stores -- issue them first
   pnx_fill_bytes_share<DT>(fj, g, s_row, threadIdx.x, kBlock);
 }
 
@@ -854,17 +855,40 @@ int pnx_pfn_train_blocks(void);
 // implemented in chunk_sort.hip / pfn_spans.hip: the one-pass grouping front end and its consumer (spans.h)
 int pnx_launch_chunk_sort(const float* points, int64_t n, int stride, const PnxGeomDev& g, const SpanGeom& sg, uint4* recs, uint16_t* tab,
                           int32_t* rowframe, uint32_t* rowbase, int32_t* counters, int32_t* frame_lo, int32_t* frame_hi, uint8_t* bytemap,
-                          uint32_t* slab_tot, uint2* span_desc, int32_t* nspan, hipStream_t st);
+                          uint32_t* slab_tot, uint2* span_desc, int32_t* nspan, hipStream_t st, hipEvent_t sorted);
 int pnx_launch_span_pfn(int F, const SpanTables& T, const SpanGeom& sg, int32_t* counters, int32_t* tick, uint32_t* rec64,
                         uint32_t* pfirst, uint32_t* pcnt, int32_t* cell_of_pillar, int32_t* row_of, int32_t* biglist, int64_t bigcap, int64_t idcap,
                         const uint2* wcomb, const uint32_t* wblk, int32_t* coords, int64_t pillar_capacity, const float* folded, float* g1,
-                        int64_t g1_rows, void* canvas, int canvas_dt, int64_t n_points, int n_fill, const PnxByteFillJob& fj, const PnxGeomDev& geom,
-                        hipStream_t st);
+                        int64_t g1_rows, void* canvas, int canvas_dt, int64_t n_points, const PnxGeomDev& geom, hipStream_t st);
 
 namespace {
-// PNX_READER_IMPL=4 (default): chunk sort -> span PFN (+ zero-fill tiles in the same launch) -> tail.  Canvas-only calls (the
+// The zero-fill's own stream and its fork / join events: one set per host thread and device (calls of a thread are issued in order, so
+// the record / wait pairs of consecutive calls cannot interleave).
+struct FillSide {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+int fill_side(FillSide** out) {
+  static thread_local FillSide sides[16];
+  int dev = 0;
+  PNX_CHECK_HIP(hipGetDevice(&dev));
+  PNX_REQUIRE(dev >= 0 && dev < 16, PNX_ERR_UNSUPPORTED, "device index %d", dev);
+  FillSide& f = sides[dev];
+  if (f.stream == nullptr) {
+    PNX_CHECK_HIP(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+    PNX_CHECK_HIP(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
+    PNX_CHECK_HIP(hipEventCreateWithFlags(&f.join, hipEventDisableTiming));
+  }
+  *out = &f;
+  return PNX_OK;
+}
+
+// PNX_READER_IMPL=4 (default): clear -> chunk sort -> [slab totals -> span carve -> span grouping + PFN -> tail] with the canvas zero-fill
+// BESIDE the bracketed part: a kernel of its own on a second stream, one workgroup per CU, from the moment the occupancy bytes exist
+// (the span kernel is built to leave it registers and LDS on every CU: pfn_spans.hip).  The fill has to be on the CUs BEFORE the span
+// kernel's workgroups arrive: started behind the carve it is 100 us slower (profiles/r04_reader_ab.txt).  Canvas-only calls (the
 // detector's path) never build the key-order bitmap; the rank outputs (feat_max / coords / unq_inv / pillar_of_point, an NCHW canvas)
-// add the bitmap chain of the older pipelines beside it.
+// add the bitmap chain of the binned pipeline beside it.
 int reader_forward_spans(const float* points, int64_t n, int32_t stride, const GeomDev& gd, const ReaderWs& w, const float* pfn_folded, void* canvas,
                          int32_t canvas_dtype, int32_t canvas_layout, uint8_t* occupancy, float* feat_max, int32_t* coords, int64_t pillar_capacity,
                          int64_t* unq_inv, int32_t* pillar_of_point, int32_t* counts, hipStream_t st) {
@@ -909,27 +933,36 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
     k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
     PNX_LAUNCH_CHECK();
   }
+  const char* fb_env = getenv("PNX_FILL_BLOCKS");
+  const int n_fill = all_tiles > 0 ? (fb_env ? atoi(fb_env) : 256) : 0;  // one workgroup per CU (0: timing experiments, the canvas is wrong)
+  const bool side = n > 0 && n_fill > 0;
+  FillSide* fs = nullptr;
+  if (side && (rc = fill_side(&fs)) != PNX_OK) return rc;
   rc = pnx_launch_chunk_sort(points, n, stride, gd, w.sg, w.srecs, w.stab, w.srowframe, w.srowbase, w.counters, w.frame_lo, w.frame_hi, cbytes, w.slab_tot,
-                             w.span_desc, w.nspan, st);
+                             w.span_desc, w.nspan, st, side ? fs->fork : nullptr);
   if (rc != PNX_OK) return rc;
   prof_mark(6, st);
   PnxByteFillJob fj;
   fj.bytemap = cbytes, fj.canvas = canvas, fj.counter = w.tick + 16 * 32, fj.tiles = all_tiles, fj.nt = fill_nt ? 1 : 0, fj.base = 0;
-  const char* fb_env = getenv("PNX_FILL_BLOCKS");
-  int n_fill = (direct && fj.tiles > 0) ? (fb_env ? atoi(fb_env) : 256) : 0;
   SpanTables T;
   T.recs = w.srecs, T.tab = w.stab, T.rowframe = w.srowframe, T.rowbase = w.srowbase, T.frame_lo = w.frame_lo, T.frame_hi = w.frame_hi;
   T.span_desc = w.span_desc, T.nspan = w.nspan;
   prof_mark(4, st);
   prof_mark(1, st);
-  if (n <= 0 && n_fill > 0) {  // nothing to group: the span launch would have no PFN role
+  if (side) {  // few instructions, all of them stores: the fill's waves issue ahead of the span kernel's (s_setprio in the kernel)
+    PnxByteFillJob sj = fj;
+    sj.nt |= 2;
+    PNX_CHECK_HIP(hipStreamWaitEvent(fs->stream, fs->fork, 0));
+    rc = launch_fill_kernel(sj, n_fill, fs->stream);
+    if (rc != PNX_OK) return rc;
+    PNX_CHECK_HIP(hipEventRecord(fs->join, fs->stream));
+  } else if (n_fill > 0) {  // nothing to group: the fill alone
     rc = launch_fill_kernel(fj, n_fill, st);
     if (rc != PNX_OK) return rc;
-    n_fill = 0;
   }
   rc = pnx_launch_span_pfn(F, T, w.sg, w.counters, w.tick, w.rec64, w.pfirst, w.pcnt, w.cell, w.row_of, w.biglist, w.bigcap, w.pcap,
                            ranked ? w.wcomb : nullptr, w.wblk, coords, pillar_capacity, pfn_folded, g1, g1_rows, direct ? canvas : nullptr, canvas_dtype, n,
-                           n_fill, fj, gd, st);
+                           gd, st);
   if (rc != PNX_OK) return rc;
   if (n > 0) {
     static const int tb = getenv("PNX_TAIL_BLOCKS") ? atoi(getenv("PNX_TAIL_BLOCKS")) : 128;
@@ -937,6 +970,7 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
                               canvas_dtype, tb, st, ranked ? w.row_of : nullptr);
     if (rc != PNX_OK) return rc;
   }
+  if (side) PNX_CHECK_HIP(hipStreamWaitEvent(st, fs->join, 0));
   prof_mark(5, st);
   prof_mark(2, st);
   if (feat_max && g1 != feat_max) {  // caller's buffer is smaller than the worst case: copy what fits (P is unknown on the host)

@@ -5,7 +5,8 @@ Variants are environment settings read by pnx_reader_forward on every call:
   PNX_READER_IMPL=4            default: chunk sort (chunk_sort.hip) + span PFN (pfn_spans.hip)
     PNX_SPAN_QUOTA, PNX_SPAN_SOLO     carve rule of the spans (spans.h)
     PNX_BINS_LDS, PNX_BINS_CAP        LDS budget / record slots of a span workgroup
-    PNX_FILL_BLOCKS, PNX_PFN_BLOCKS   block counts of the two roles of the span launch (0 fill blocks: timing only, the canvas is wrong)
+    PNX_FILL_BLOCKS, PNX_PFN_BLOCKS   workgroups of the zero-fill kernel (second stream) and of the span kernel (0 fill blocks: timing only,
+                                      the canvas is wrong); PNX_FILL_NT=0|1 plain / nontemporal fill stores
   PNX_READER_IMPL=2            the general pipeline: binned grouping (reader_bins.h) + k_bin_sort + PFN v3 (pfn_v3.hip), records through HBM
     PNX_BIN_NWG, PNX_BIN_THREADS, PNX_BIN_SH   chunks / threads of k_bin_count and k_bin_scatter, pillars per bin (2^sh)
     PNX_FILL_SPLIT=a,b,c       percent of the fill tiles carried by k_bin_count / k_bin_scatter / k_bin_sort
@@ -25,8 +26,19 @@ from pillarnext_amd.reader import PillarFeatureNet  # noqa: E402
 
 VARIANTS = [
     ("spans default", {}),
+    ("spans default again", {}),
     ("spans q512", {"PNX_SPAN_QUOTA": "512"}),
+    ("spans q704", {"PNX_SPAN_QUOTA": "704"}),
     ("spans q768", {"PNX_SPAN_QUOTA": "768"}),
+    ("spans q832", {"PNX_SPAN_QUOTA": "832"}),
+    ("spans q896", {"PNX_SPAN_QUOTA": "896"}),
+    ("spans q1024", {"PNX_SPAN_QUOTA": "1024"}),
+    ("spans q768 pfn768", {"PNX_SPAN_QUOTA": "768", "PNX_PFN_BLOCKS": "768"}),
+    ("spans q768 lds76k", {"PNX_SPAN_QUOTA": "768", "PNX_BINS_LDS": "76000"}),
+    ("spans q896 pfn768", {"PNX_SPAN_QUOTA": "896", "PNX_PFN_BLOCKS": "768"}),
+    ("spans pfn640", {"PNX_PFN_BLOCKS": "640"}),
+    ("spans pfn1024", {"PNX_PFN_BLOCKS": "1024"}),
+    ("spans default 3", {}),
     ("spans q384 s128", {"PNX_SPAN_QUOTA": "384", "PNX_SPAN_SOLO": "128"}),
     ("spans pfn768", {"PNX_PFN_BLOCKS": "768"}),
     ("spans fill192", {"PNX_FILL_BLOCKS": "192"}),
@@ -34,12 +46,14 @@ VARIANTS = [
     ("spans lds76k", {"PNX_BINS_LDS": "76000"}),
     ("spans seg96", {"PNX_BINS_CAP": "96"}),
     ("spans unfilled (timing only)", {"PNX_FILL_BLOCKS": "0"}),
+    ("spans lds78000", {"PNX_BINS_LDS": "78000"}),
+    ("spans fill nt off", {"PNX_FILL_NT": "0"}),
     ("binned", {"PNX_READER_IMPL": "2"}),
     ("binned split 10,10", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "10,10,0"}),
     ("fp32 layer 1 (binned)", {"PNX_PFN_F16X3": "0"}),
 ]
 KEYS = ["PNX_READER_IMPL", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS", "PNX_FILL_SPLIT", "PNX_PFN_F16X3", "PNX_BIN_NWG", "PNX_BIN_THREADS", "PNX_BIN_SH",
-        "PNX_BINS_CAP", "PNX_BINS_LDS", "PNX_SPAN_QUOTA", "PNX_SPAN_SOLO"]
+        "PNX_BINS_CAP", "PNX_BINS_LDS", "PNX_SPAN_QUOTA", "PNX_SPAN_SOLO", "PNX_FILL_NT"]
 
 
 def main():
