@@ -11,8 +11,12 @@ under a launcher (RANK/LOCAL_RANK/WORLD_SIZE set) it is one rank.  Frames are sh
 ("replicas only"); time = max over ranks between barriers.  Rank 0 prints ONE JSON line.  Extra objects:
   roofline        the READER (all of its kernels): algorithmic bytes (24*N + nx*ny*64*2) * frames per launch over the time
                   from the reader's first to its last kernel, HIP events recorded on the reader's own stream inside libpnx_hip.so
-  roofline_fill   its dominant launch (PFN + canvas zero-fill fused, HBM-write bound) with the canvas bytes it writes
-  roofline_pfn    the same launch read as MFMA work (8 832 FLOP per kept point)
+  roofline_fill   its dominant interval (span grouping + PFN kernel with the canvas zero-fill kernel beside it on a second stream, HBM-write
+                  bound) with the canvas bytes the two write
+  roofline_pfn    the same interval read as MFMA work (8 832 FLOP per kept point)
+  host_enqueue_ms_per_step   launch-thread time per step (the backbone, the head and the decoder are one C call each: pnx_enqueue)
+  value_train / train / roofline_train   the training step of BASELINE configs[2] (C2 x 4 frames per GPU: forward + CenterHead losses +
+                  backward + clip + AdamW + OneCycle, bf16 autocast, DDP + SyncBN when N > 1), frames/s and dense-equivalent MFMA FLOP rate
   value_with_h2d_merge   the same loop fed the way the reference's loader feeds it (collate.py:15-22, trainer.py:111, nusc.py:101-121):
                   every step the frames' RAW sweeps are copied into pinned memory, uploaded on a side stream (double-buffered) and merged
                   on the device (pnx_merge_sweeps: per-sweep transform, time lag, batch index) before the reader sees them
@@ -279,10 +283,14 @@ def train_leg(dev, rank, world, frames=4, steps=5, warmup=3):
         sched.step()
         return loss
 
-    # MIOpen's exhaustive find over the forward / dgrad / wgrad shapes of a 1440^2 training graph takes ~5 minutes (the inference legs
-    # run with cudnn.benchmark = True); the training leg takes MIOpen's immediate-mode choices instead, as tools/train_step.py does
+    # MIOpen's find pass over the forward / dgrad / wgrad shapes of a 1440^2 training graph (~50 problems: the dense neck / head layers and
+    # every weight gradient) takes ~3.5 minutes and buys a 2.2 x faster step (102 vs 227 ms) over MIOpen's immediate-mode choices.  A
+    # single-GPU run (what BENCH_rNN.json records) pays for it; the multi-GPU scaling runs take the immediate mode unless
+    # PNX_BENCH_TRAIN_FIND=1 -- `train.miopen` says which one a line was measured with.
     bench_mode = torch.backends.cudnn.benchmark
-    torch.backends.cudnn.benchmark = False
+    find = os.environ.get("PNX_BENCH_TRAIN_FIND", "1" if world == 1 else "0") == "1"
+    torch.backends.cudnn.benchmark = find
+    t_leg = time.perf_counter()
     for _ in range(warmup):
         step()
     torch.cuda.reset_peak_memory_stats(dev)
@@ -307,7 +315,8 @@ def train_leg(dev, rank, world, frames=4, steps=5, warmup=3):
            "train": {"frames_per_gpu_per_step": frames, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
                      "dtype": "bf16 autocast, channels_last (the reference trains fp32: tools/train_step.py --nhwc times that)",
                      "step": "forward + CenterHead losses + backward + clip 35 + AdamW + OneCycle, DDP + SyncBN when n_gpus > 1",
-                     "loss_finite": finite, "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
+                     "loss_finite": finite, "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                     "miopen": "find (cudnn.benchmark)" if find else "immediate mode", "leg_seconds": round(time.perf_counter() - t_leg, 1)},
            "roofline_train": {"bound": "mfma", "kernel": "whole training step (backbone 3x3 layers: forward + dgrad on the masked HIP kernels, wgrad and the dense layers on MIOpen)",
                               "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s (dense-equivalent bf16 FLOPs, 3 x forward)",
                               "frac": round(tf / 2500.0, 4), "algorithmic_flops_per_step": flops}}
@@ -422,6 +431,21 @@ def main():
         r_us, c_us, ns = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
         _lib.check(L.pnx_profile_end(ctypes.byref(r_us), ctypes.byref(c_us), ctypes.byref(ns)), "pnx_profile_end")
         pfn_us, vox_us = float(L.pnx_profile_last_pfn_us()), float(L.pnx_profile_last_voxelize_us())
+        # the same reader calls back to back, nothing else on the GPU between them: the convolutions of the detector leave the chip in a
+        # power / cache state in which the reader's kernels run 12-20 % slower (profiles/r04_reader_between.txt); `roofline` is the in-loop figure
+        ny_, nx_ = (int(v) for v in model.reader.grid_size)
+        cv = torch.empty((a.batch, 64, ny_, nx_), dtype=model.dtype, device=dev, memory_format=torch.channels_last)
+        oc = torch.empty((a.batch, ny_, nx_), dtype=torch.uint8, device=dev)
+        for i in range(3):
+            model.reader.forward_dense(examples[i % ROTATE]["points"], a.batch, dtype=model.dtype, out=cv, occupancy=oc)
+        torch.cuda.synchronize()
+        _lib.check(L.pnx_profile_begin(12), "pnx_profile_begin")
+        for i in range(12):
+            model.reader.forward_dense(examples[i % ROTATE]["points"], a.batch, dtype=model.dtype, out=cv, occupancy=oc)
+        torch.cuda.synchronize()
+        rb_us, cb_us, nb_ = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
+        _lib.check(L.pnx_profile_end(ctypes.byref(rb_us), ctypes.byref(cb_us), ctypes.byref(nb_)), "pnx_profile_end")
+        del cv, oc
 
         extras = {}
         if not a.no_extras:
@@ -541,16 +565,18 @@ def main():
                    "frames_per_gpu_per_step": a.batch, "global_batch": a.batch * world, "parallelism": f"frame-sharded replicas x{world}",
                    "reader_dtype": "fp32 layer 0 + fp16x3 (22-bit) layer 1 on MFMA -> bf16 canvas", "pillars_per_launch": P,
                    "kept_points_per_launch": n_kept},
-        "roofline": {"bound": "hbm", "kernel": "reader, ALL of its kernels (clear, chunk sort, slab totals, span carve, span grouping + PFN + canvas zero-fill in one launch, tail)",
+        "roofline": {"bound": "hbm", "kernel": "reader, ALL of its kernels (clear, chunk sort, then slab totals + span carve + span grouping/PFN + tail with the canvas zero-fill kernel beside them on a second stream)",
                      "achieved": round(reader_gbs, 1) if reader_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(reader_gbs / HBM_PEAK_GBS, 4) if reader_gbs else None, "traffic": traffic, "traffic_source": tsrc,
                      "algorithmic_bytes_per_launch": reader_bytes, "kernel_us": round(r_us.value, 2), "samples": ns.value,
-                     "voxelize_us": round(vox_us, 2)},
-        "roofline_fill": {"bound": "hbm", "kernel": "k_span_pfn (span grouping + PFN blocks and zero-fill blocks in one launch: the pillar cells and every pillar-free tile)",
+                     "voxelize_us": round(vox_us, 2),
+                     "back_to_back": {"kernel_us": round(rb_us.value, 2), "frac": round(reader_bytes / rb_us.value / 1e3 / HBM_PEAK_GBS, 4) if rb_us.value > 0 else None,
+                                      "note": "the same reader calls with nothing else on the GPU between them (12 calls); frac above is measured inside the detector's loop"}},
+        "roofline_fill": {"bound": "hbm", "kernel": "k_span_pfn (span grouping + PFN: the pillar cells) and k_canvas_fill_bytes (every pillar-free tile) running concurrently, fork to join",
                           "achieved": round(fill_gbs, 1) if fill_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(fill_gbs / HBM_PEAK_GBS, 4) if fill_gbs else None, "algorithmic_bytes_per_launch": launch_bytes,
                           "kernel_us": round(c_us.value, 2), "zero_fill_percent_carried_by_grouping_kernels": [int(v) for v in split]},
-        "roofline_pfn": {"bound": "mfma", "kernel": "k_span_pfn (same launch): fp32 v_mfma_f32_32x32x2_f32 layer 0 + 3 x v_mfma_f32_32x32x16_f16 layer 1",
+        "roofline_pfn": {"bound": "mfma", "kernel": "k_span_pfn (same interval, the zero-fill beside it): fp32 v_mfma_f32_32x32x2_f32 layer 0 + 3 x v_mfma_f32_32x32x16_f16 layer 1",
                          "achieved": round(pfn_tf, 2) if pfn_tf else None, "peak": 157.3, "unit": "TFLOP/s (reference fp32 FLOPs)",
                          "frac": round(pfn_tf / 157.3, 4) if pfn_tf else None, "kernel_us": round(pfn_us, 2), "algorithmic_flops_per_launch": pfn_flops},
     }

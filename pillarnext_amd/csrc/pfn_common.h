@@ -33,6 +33,7 @@ struct Pfn3Out {
   void* canvas;  // NHWC canvas or null
   int dt;        // PNX_F32 / PNX_BF16 / PNX_F16
   const int32_t* row_of = nullptr;  // k_pfn3_tail behind pfn_spans.hip: feat_max row of a spill id (null: the pillar id is the row)
+  int nt = 0;  // canvas rows as nontemporal stores (large canvases, reader.hip): nobody re-reads them before the caches have turned over
 };
 
 __device__ __forceinline__ uint32_t bf16_rne(float f) {
@@ -83,6 +84,19 @@ __device__ __forceinline__ uint32_t cvt_pk16(float a, float b) {
   return r;
 }
 
+// 16 bytes of a canvas line.  Nontemporal on large canvases: the pillar lines are scattered single lines that nothing re-reads soon,
+// and as plain stores they sit in L2 until evicted, between the zero-fill's streaming stores -- the reader's two writers then slow
+// each other down (C2 x 12 frames: 725 -> 627 us with the nontemporal form, profiles/r04_reader_ab.txt).
+__device__ __forceinline__ void canvas_store16(void* dst, const uint4& x, int nt) {
+  if (nt) {  // asm: as two builtin stores to one address the branches are merged into a plain store (the nontemporal flag is dropped)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = {x.x, x.y, x.z, x.w};
+    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
+  } else {
+    *reinterpret_cast<uint4*>(dst) = x;
+  }
+}
+
 // 8 consecutive channels (chan0 = 8q) of one pillar: canvas cell and/or feat_max row
 template <int DT>
 __device__ __forceinline__ void store_chunk(const Pfn3Out& o, int rank, int64_t cell, int q, const float* v) {
@@ -93,9 +107,9 @@ __device__ __forceinline__ void store_chunk(const Pfn3Out& o, int rank, int64_t 
   }
   if (o.canvas != nullptr) {
     if (DT == PNX_F32) {
-      float4* d = reinterpret_cast<float4*>(reinterpret_cast<float*>(o.canvas) + cell * 64 + 8 * q);
-      d[0] = make_float4(v[0], v[1], v[2], v[3]);
-      d[1] = make_float4(v[4], v[5], v[6], v[7]);
+      float* d = reinterpret_cast<float*>(o.canvas) + cell * 64 + 8 * q;
+      canvas_store16(d, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])), o.nt);
+      canvas_store16(d + 4, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])), o.nt);
     } else {
       uint4 p;
       if (DT == PNX_BF16) {
@@ -109,7 +123,7 @@ __device__ __forceinline__ void store_chunk(const Pfn3Out& o, int rank, int64_t 
         p.z = f16_rne(v[4]) | (f16_rne(v[5]) << 16);
         p.w = f16_rne(v[6]) | (f16_rne(v[7]) << 16);
       }
-      *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(o.canvas) + cell * 64 + 8 * q) = p;
+      canvas_store16(reinterpret_cast<uint16_t*>(o.canvas) + cell * 64 + 8 * q, p, o.nt);
     }
   }
 }

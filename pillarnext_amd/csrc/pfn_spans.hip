@@ -798,7 +798,7 @@ __global__ __launch_bounds__(kSpBlock, 2) __attribute__((amdgpu_num_vgpr(PNX_SPA
             for (int p = l >> 3; p < npl; p += 8) {
               const uint4 x = *reinterpret_cast<const uint4*>(s_out + p * kZSP + 4 * qq);
               const int32_t cl = (int32_t)s_cellrow[p];
-              if (cl >= 0) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(out.canvas) + (int64_t)cl * 64 + 8 * qq) = x;
+              if (cl >= 0) canvas_store16(reinterpret_cast<uint16_t*>(out.canvas) + (int64_t)cl * 64 + 8 * qq, x, out.nt);
             }
           } else {
             if (lead) {
@@ -903,7 +903,7 @@ int launch_spans(const SpanPfnArgs& A0, const Pfn3Out& out, const PnxGeomDev& g,
 int pnx_launch_span_pfn(int F, const SpanTables& T, const SpanGeom& sg, int32_t* counters, int32_t* tick, uint32_t* rec64,
                         uint32_t* pfirst, uint32_t* pcnt, int32_t* cell_of_pillar, int32_t* row_of, int32_t* biglist, int64_t bigcap, int64_t idcap,
                         const uint2* wcomb, const uint32_t* wblk, int32_t* coords, int64_t pillar_capacity, const float* folded, float* g1,
-                        int64_t g1_rows, void* canvas, int canvas_dt, int64_t n_points, const PnxGeomDev& geom, hipStream_t st) {
+                        int64_t g1_rows, void* canvas, int canvas_dt, int canvas_nt, int64_t n_points, const PnxGeomDev& geom, hipStream_t st) {
   SpanPfnArgs A;
   A.T = T, A.sg = sg, A.counters = counters, A.tick = tick, A.rec64 = rec64, A.pfirst = pfirst, A.pcnt = pcnt;
   A.cell_of_pillar = cell_of_pillar, A.row_of = row_of, A.biglist = biglist;
@@ -919,7 +919,7 @@ int pnx_launch_span_pfn(int F, const SpanTables& T, const SpanGeom& sg, int32_t*
 #endif
   Pfn3Out out;
   out.g1 = g1, out.g1_rows = g1_rows, out.canvas = canvas, out.dt = canvas_dt;
-  out.row_of = nullptr;
+  out.row_of = nullptr, out.nt = canvas_nt;
   int rc;
   switch (F) {
     case 3: rc = launch_spans<3>(A, out, geom, n_points, st); break;

@@ -157,7 +157,7 @@ struct PnxByteFillJob {
   const uint8_t* bytemap;  // null: every cell of the tile is zeroed
   void* canvas;
   int32_t* counter;  // zero before the launch
-  int tiles, nt;     // tiles [base, base + tiles)
+  int tiles, nt;     // tiles [base, base + tiles); nt bit 0: nontemporal stores, bit 1: raised wave priority (k_canvas_fill_bytes)
   int base;
 };
 

@@ -859,7 +859,7 @@ int pnx_launch_chunk_sort(const float* points, int64_t n, int stride, const PnxG
 int pnx_launch_span_pfn(int F, const SpanTables& T, const SpanGeom& sg, int32_t* counters, int32_t* tick, uint32_t* rec64,
                         uint32_t* pfirst, uint32_t* pcnt, int32_t* cell_of_pillar, int32_t* row_of, int32_t* biglist, int64_t bigcap, int64_t idcap,
                         const uint2* wcomb, const uint32_t* wblk, int32_t* coords, int64_t pillar_capacity, const float* folded, float* g1,
-                        int64_t g1_rows, void* canvas, int canvas_dt, int64_t n_points, const PnxGeomDev& geom, hipStream_t st);
+                        int64_t g1_rows, void* canvas, int canvas_dt, int canvas_nt, int64_t n_points, const PnxGeomDev& geom, hipStream_t st);
 
 namespace {
 // The zero-fill's own stream and its fork / join events: one set per host thread and device (calls of a thread are issued in order, so
@@ -961,8 +961,8 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
     if (rc != PNX_OK) return rc;
   }
   rc = pnx_launch_span_pfn(F, T, w.sg, w.counters, w.tick, w.rec64, w.pfirst, w.pcnt, w.cell, w.row_of, w.biglist, w.bigcap, w.pcap,
-                           ranked ? w.wcomb : nullptr, w.wblk, coords, pillar_capacity, pfn_folded, g1, g1_rows, direct ? canvas : nullptr, canvas_dtype, n,
-                           gd, st);
+                           ranked ? w.wcomb : nullptr, w.wblk, coords, pillar_capacity, pfn_folded, g1, g1_rows, direct ? canvas : nullptr, canvas_dtype,
+                           fill_nt ? 1 : 0, n, gd, st);
   if (rc != PNX_OK) return rc;
   if (n > 0) {
     static const int tb = getenv("PNX_TAIL_BLOCKS") ? atoi(getenv("PNX_TAIL_BLOCKS")) : 128;

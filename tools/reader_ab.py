@@ -27,6 +27,7 @@ from pillarnext_amd.reader import PillarFeatureNet  # noqa: E402
 VARIANTS = [
     ("spans default", {}),
     ("spans default again", {}),
+    ("spans default 4", {}),
     ("spans q512", {"PNX_SPAN_QUOTA": "512"}),
     ("spans q704", {"PNX_SPAN_QUOTA": "704"}),
     ("spans q768", {"PNX_SPAN_QUOTA": "768"}),
@@ -66,6 +67,9 @@ def main():
     ap.add_argument("--only", default="", help="run the variants whose name contains this string")
     ap.add_argument("--exact", default="", help="run exactly this variant")
     ap.add_argument("--no-occ", action="store_true", help="do not ask for the occupancy output")
+    ap.add_argument("--between", default="", choices=["", "mfma", "dirty", "both", "idle"],
+                    help="what the GPU does between two timed reader calls, as the detector's convolutions do in bench.py: mfma = ~12 ms of bf16 "
+                         "GEMMs (power state), dirty = 1 GiB of plain stores (dirty lines in L2 / Infinity Cache), idle = a 15 ms host sleep")
     a = ap.parse_args()
     cfg = synth.CONFIGS[a.config]
     net = PillarFeatureNet(5, [64, 64], list(cfg["voxel_size"]), list(cfg["pc_range"])).cuda().eval()
@@ -77,6 +81,11 @@ def main():
     counts = torch.zeros(2, dtype=torch.int32, device="cuda")
     L = _lib.lib()
     ref = None
+    if a.between in ("mfma", "both"):
+        ga = torch.randn((8192, 8192), device="cuda").to(torch.bfloat16)
+        gb, gc = ga.clone(), torch.empty_like(ga)
+    if a.between in ("dirty", "both"):
+        junk = torch.zeros((1 << 28,), dtype=torch.int32, device="cuda")
     alg = 24 * batches[0].shape[0] + out.numel() * 2
     print(f"# {a.config} {a.dist} B={a.batch}: algorithmic {alg/1e6:.1f} MB per launch (24*N + canvas)")
     for name, env in VARIANTS:
@@ -95,6 +104,15 @@ def main():
         same = torch.equal(out, ref_canvas) and (occ is None or torch.equal(occ, ref_occ))
         L.pnx_profile_begin(a.iters)
         for i in range(a.iters):
+            if a.between in ("mfma", "both"):
+                for _ in range(12):
+                    torch.mm(ga, gb, out=gc)
+            if a.between in ("dirty", "both"):
+                junk.add_(1)
+            if a.between == "idle":
+                torch.cuda.synchronize()
+                import time
+                time.sleep(0.015)
             net.forward_dense(batches[i % 4], a.batch, out=out, counts=counts, occupancy=occ)
         torch.cuda.synchronize()
         r_us, c_us, ns = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
