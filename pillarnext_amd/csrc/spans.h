@@ -19,7 +19,7 @@ constexpr int kSlabShift = 9;
 constexpr int kSlabCells = 1 << kSlabShift;   // 512 cells = 64 KiB of a 16-bit canvas
 constexpr int kSpanMaxSlabs = 16;             // 8192 cells: the span's occupancy bitmap is 256 words of LDS
 constexpr int kSpanPillars = 512;             // pillars one pass over a span handles (LDS arrays)
-constexpr int kChunk = 2048;                  // points per chunk: 64 KiB of records in LDS
+constexpr int kChunk = 2048;                  // points per chunk: 64 KiB of records in LDS (1536 = three workgroups per CU: same reader time)
 constexpr int kSpanQuota = 640;               // a span ends where the running total of points crosses a multiple of the quota ...
 constexpr int kSpanSolo = 0;                  // ... and (if > 0) a slab with more points than this is a span of its own
 
