@@ -204,6 +204,14 @@ int pnx_deconv2x2_bf16(const void* x, const void* wfrag, const float* bias, void
 int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, uint8_t* row_dirty, const int32_t* tile_list,
                      const int32_t* tile_count, pnx_stream_t stream);
+/* Weight gradient of the masked stride-1 3x3 convolution (training; det3d/models/utils/sparse_conv.py:16-63 under autograd: spconv accumulates
+ * over the active output sites):  dw[co][ci][ky][kx] = sum over the sites p with mask[p] != 0 of dy[p][co] * x[p + (ky-1, kx-1)][ci]
+ *   x (B,h,w,cin), dy (B,h,w,cout) bf16 NHWC (x zero at inactive sites, as every map of the masked-dense stand-in is), mask uint8 (B,h,w) of the
+ *   OUTPUT sites, dw fp32 (cout, cin, 3, 3); cin, cout multiples of 64 up to 512.  Deterministic (static tile deal + a fixed-order reduction of
+ *   per-workgroup partials in `workspace`, pnx_conv3x3_wgrad_workspace_bytes). */
+size_t pnx_conv3x3_wgrad_workspace_bytes(int32_t cin, int32_t cout);
+int pnx_conv3x3_wgrad_bf16(const void* x, const void* dy, const uint8_t* mask, float* dw, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                           void* workspace, size_t workspace_bytes, pnx_stream_t stream);
 /* Optional tile list for the stride-1 kernels: the submanifold blocks of a backbone stage share one active-site mask, so the
  * tiles that need any work (an active site, or a stale row in one of the persistent output buffers) are listed once per stage
  * and every convolution of the stage walks the list instead of all tiles.

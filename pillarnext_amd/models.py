@@ -282,7 +282,8 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
       dgrad     stride 1: the SAME kernel on the flipped, transposed weights with the INPUT's active set as its mask -- the upstream
                 gradient is zero outside mask_out (the BatchNorm node's backward writes zeros there), and what reaches an inactive input
                 site would be thrown away by that site's own mask; stride 2: MIOpen's dense dgrad
-      wgrad     MIOpen's dense wrw on (x, g): exact, because g is zero outside the active outputs
+      wgrad     stride 1: pnx_conv3x3_wgrad_bf16 (csrc/conv_wgrad.hip) over the 16-pixel row pieces that hold an active output, fp32 accumulation,
+                deterministic; stride 2 (and PNX_TRAIN_HIPWGRAD=0): MIOpen's dense wrw on (x, g), exact because g is zero outside the active outputs
     The fp32 training path (the reference's precision) stays on MIOpen: the kernels are bf16."""
 
     @staticmethod
@@ -291,14 +292,14 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
         x = x.contiguous(memory_format=torch.channels_last)
         co = weight.shape[0]
         y = ops.conv3x3_masked(x, ops.conv3x3_pack_weights(weight), _zero_bias(co, x.device), co, stride=stride, mask=mask_out, relu=False)
-        ctx.save_for_backward(x, weight, mask_in)
+        ctx.save_for_backward(x, weight, mask_in, mask_out)
         ctx.stride = stride
         return y
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
-        x, weight, mask_in = ctx.saved_tensors
+        x, weight, mask_in, mask_out = ctx.saved_tensors
         g = g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = None
@@ -308,7 +309,10 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
                 wt = weight.flip(2, 3).transpose(0, 1).contiguous()      # dgrad of a stride-1 'same' convolution = convolution with W^T flipped
                 dx = ops.conv3x3_masked(g, ops.conv3x3_pack_weights(wt), _zero_bias(ci, g.device), ci, stride=1, mask=mask_in, relu=False)
             if need_w:
-                dw = torch.nn.grad.conv2d_weight(x, weight.shape, g, stride=1, padding=1)
+                if os.environ.get("PNX_TRAIN_HIPWGRAD", "1") != "0":
+                    dw = ops.conv3x3_wgrad(x, g, mask_out).to(weight.dtype)
+                else:
+                    dw = torch.nn.grad.conv2d_weight(x, weight.shape, g, stride=1, padding=1)
         else:
             s = ctx.stride
             dx, dw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, (s, s), (1, 1), (1, 1), False, (0, 0), 1, (need_x, need_w, False))

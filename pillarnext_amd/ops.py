@@ -310,6 +310,31 @@ def sephead_lazy(tasks, class_task, batch, local, seg_len, pre_max):
     return out
 
 
+_WGRAD_WS = {}
+
+
+def conv3x3_wgrad(x, dy, mask):
+    """Weight gradient (Cout, Cin, 3, 3) fp32 of the masked stride-1 3x3 convolution: sum over the sites of `mask` (B,H,W uint8, the OUTPUT's
+    active set) of dy[p] (x) x[p + tap]; x, dy channels_last bf16 (csrc/conv_wgrad.hip).  Deterministic."""
+    for tns, what in ((x, "x"), (dy, "dy")):
+        if not (tns.is_cuda and tns.dtype == torch.bfloat16 and tns.dim() == 4 and tns.is_contiguous(memory_format=torch.channels_last)):
+            raise PnxError(f"conv3x3_wgrad: {what} must be a channels_last bf16 CUDA tensor")
+    B, ci, H, W = x.shape
+    co = dy.shape[1]
+    if tuple(dy.shape) != (B, co, H, W) or tuple(mask.shape) != (B, H, W) or mask.dtype != torch.uint8:
+        raise PnxError("conv3x3_wgrad: dy (B,Cout,H,W) and a uint8 (B,H,W) mask of the output sites")
+    nbytes = int(lib().pnx_conv3x3_wgrad_workspace_bytes(ci, co))
+    if nbytes == 0:
+        raise PnxError(f"conv3x3_wgrad: no kernel for {ci} -> {co} channels")
+    key = (nbytes, x.device)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=x.device)
+    check(lib().pnx_conv3x3_wgrad_bf16(ptr(x), ptr(dy), ptr(mask), ptr(dw), B, H, W, ci, co, ptr(ws), ws.numel(), stream_ptr()), "pnx_conv3x3_wgrad_bf16")
+    return dw
+
+
 def conv3x3_workspace(batch, cout, ho, wo, device):
     """A persistent (output buffer, row_dirty flags) pair for conv3x3_masked(out=...): both start zeroed (pnx.h: row_dirty)."""
     y = torch.zeros((batch, cout, ho, wo), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)

@@ -74,3 +74,27 @@ def test_masked_conv_falls_back_outside_bf16_training():
     m = torch.ones((1, 1, 16, 16), device="cuda")
     y = masked_conv(conv, x, m, m)             # fp32, no autocast: MIOpen
     assert y.dtype == torch.float32 and not type(y.grad_fn).__name__.startswith("_MaskedConv3x3Fn")
+
+
+@pytest.mark.parametrize("cin,cout,shape,p", [(64, 64, (2, 70, 97), 0.12), (64, 64, (1, 33, 31), 0.5), (128, 128, (2, 41, 70), 0.12), (256, 256, (2, 23, 33), 0.2),
+                                              (64, 128, (1, 19, 40), 0.3)])
+def test_wgrad_kernel_matches_fp32_conv2d_weight(cin, cout, shape, p):
+    """pnx_conv3x3_wgrad_bf16 (csrc/conv_wgrad.hip: K = pixels through the transposing LDS read, fp32 accumulation, fixed-order reduction)
+    against torch.nn.grad.conv2d_weight in fp32 on the same bf16 operands; bit-identical from call to call; an upstream gradient that is
+    NOT zero outside the mask must not contribute (the kernel applies the mask itself)."""
+    from pillarnext_amd import ops
+
+    B, H, W = shape
+    gen = torch.Generator(device="cuda").manual_seed(cin * 3 + cout + H)
+    m = _lidar_mask(B, H, W, gen, p)
+    x = (torch.randn((B, cin, H, W), device="cuda", generator=gen) * m).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    g_all = torch.randn((B, cout, H, W), device="cuda", generator=gen).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    mu8 = (m[:, 0] != 0).to(torch.uint8).contiguous()
+    dw = ops.conv3x3_wgrad(x, g_all, mu8)
+    ref = torch.nn.grad.conv2d_weight(x.float().contiguous(), (cout, cin, 3, 3), (g_all.float() * m).contiguous(), stride=1, padding=1)
+    scale = float(ref.abs().max())
+    assert dw.shape == ref.shape and dw.dtype == torch.float32
+    assert float((dw - ref).abs().max()) <= 2e-4 * scale, float((dw - ref).abs().max()) / scale
+    assert torch.equal(dw, ops.conv3x3_wgrad(x, g_all, mu8))
+    empty = torch.zeros_like(mu8)
+    assert float(ops.conv3x3_wgrad(x, g_all, empty).abs().max()) == 0.0
