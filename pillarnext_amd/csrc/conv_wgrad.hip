@@ -183,17 +183,30 @@ __global__ __launch_bounds__(256, 2) void k_wgrad64(const uint16_t* __restrict__
     }
 }
 
-// dW[co][ci][tap] = sum over the groups, in group order
+// dW[co][ci][tap] = sum over the groups in a FIXED order: 8 slices of the groups (g = slice, slice + 8, ...) are added up by 8 threads per
+// element and then combined slice 0..7 -- the same association for every launch; one thread per element walking all 512 partials left the
+// GPU at two waves per SIMD of dependent adds
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int cin, int cout, int G) {
-  const int e = blockIdx.x * 256 + threadIdx.x;  // ((pair * 9 + tap) * 64 + m) * 64 + n
+  __shared__ float s_sum[8][32];
+  const int t = threadIdx.x, el = t & 31, sl = t >> 5;
+  const int e = blockIdx.x * 32 + el;  // ((pair * 9 + tap) * 64 + m) * 64 + n
   const int nib = cin >> 6, n_pairs = (cout >> 6) * nib;
-  if (e >= n_pairs * 9 * 4096) return;
+  const bool live = e < n_pairs * 9 * 4096;
   const int n = e & 63, m = (e >> 6) & 63, tap = (e >> 12) % 9, pair = (e >> 12) / 9;
-  const float* p = part + (int64_t)pair * G * 9 * 4096 + tap * 4096 + m * 64 + n;
   float s = 0.f;
-  for (int g = 0; g < G; g++) s += p[(int64_t)g * 9 * 4096];
-  const int co = 64 * (pair / nib) + m, ci = 64 * (pair % nib) + n;
-  dw[((int64_t)co * cin + ci) * 9 + tap] = s;
+  if (live) {
+    const float* p = part + (int64_t)pair * G * 9 * 4096 + tap * 4096 + m * 64 + n;
+    for (int g = sl; g < G; g += 8) s += p[(int64_t)g * 9 * 4096];
+  }
+  s_sum[sl][el] = s;
+  __syncthreads();
+  if (sl == 0 && live) {
+    float r = s_sum[0][el];
+#pragma unroll
+    for (int k = 1; k < 8; k++) r += s_sum[k][el];
+    const int co = 64 * (pair / nib) + m, ci = 64 * (pair % nib) + n;
+    dw[((int64_t)co * cin + ci) * 9 + tap] = r;
+  }
 }
 
 int groups_per_pair(int cin, int cout) {
@@ -230,7 +243,7 @@ extern "C" int pnx_conv3x3_wgrad_bf16(const void* x, const void* dy, const uint8
   k_wgrad64<<<dim3((unsigned)G, (unsigned)n_pairs), 256, WG_LDS, st>>>((const uint16_t*)x, (const uint16_t*)dy, mask, (float*)workspace, batch, h, w, cin,
                                                                       cout, G);
   PNX_LAUNCH_CHECK();
-  k_wgrad_reduce<<<(unsigned)((n_pairs * 9 * 4096 + 255) / 256), 256, 0, st>>>((const float*)workspace, dw, cin, cout, G);
+  k_wgrad_reduce<<<(unsigned)((n_pairs * 9 * 4096 + 31) / 32), 256, 0, st>>>((const float*)workspace, dw, cin, cout, G);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

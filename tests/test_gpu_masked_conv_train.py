@@ -1,5 +1,5 @@
-"""GPU: the training-mode masked 3x3 convolution node (models._MaskedConv3x3Fn: forward and dgrad on the product's HIP kernels, wgrad on
-MIOpen) against torch's own autograd of F.conv2d in FP32 on the same bf16-rounded operands, on LiDAR-like masks (sparse_conv.py:16-63:
+"""GPU: the training-mode masked 3x3 convolution node (models._MaskedConv3x3Fn: forward, dgrad and the stride-1 wgrad on the product's HIP
+kernels, the stride-2 backward on MIOpen) against torch's own autograd of F.conv2d in FP32 on the same bf16-rounded operands, on LiDAR-like masks (sparse_conv.py:16-63:
 SubMConv2d / SparseConv2d compute at the active sites only).  bf16 tolerances: outputs and input gradients to 2 bf16 ulps of a K = 9*Cin
 fp32 sum, weight gradients relative to the largest entry."""
 import pytest

@@ -27,6 +27,7 @@ def timed(fn, n=10):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    with_miopen = not (len(sys.argv) > 2 and sys.argv[2] == "nomio")      # MIOpen's find pass over the four wrw problems takes ~2.5 minutes
     cfg = synth.CONFIGS["C2"]
     net = PillarFeatureNet(5, [64, 64], list(cfg["voxel_size"]), list(cfg["pc_range"])).cuda().eval()
     pts = torch.from_numpy(synth.make_batch("C2", B, "sweep")).cuda()
@@ -45,7 +46,7 @@ def main():
         mu8 = (m[:, 0] != 0).to(torch.uint8).contiguous()
         seg = float((F.max_pool2d(m, (1, 16), (1, 16), ceil_mode=True) > 0).float().mean())
         t_hip = timed(lambda: ops.conv3x3_wgrad(x, dy, mu8))
-        t_mio = timed(lambda: torch.nn.grad.conv2d_weight(x, (c, c, 3, 3), dy, stride=1, padding=1))
+        t_mio = timed(lambda: torch.nn.grad.conv2d_weight(x, (c, c, 3, 3), dy, stride=1, padding=1)) if with_miopen else float("nan")
         fl = 2.0 * c * c * 9 * B * H * W
         print(f"{c:3d} -> {c:3d} at {H}x{W} x {B}: active {float(m.mean()) * 100:4.1f} % of the cells, {seg * 100:4.1f} % of the 16-pixel pieces | "
               f"HIP {t_hip:7.1f} us ({fl / t_hip / 1e6:6.1f} dense-equivalent TFLOP/s)  MIOpen wrw {t_mio:7.1f} us ({fl / t_mio / 1e6:6.1f})", flush=True)
