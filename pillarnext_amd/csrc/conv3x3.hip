@@ -1166,17 +1166,10 @@ __global__ __launch_bounds__(256) void k_sephead_out(const uint16_t* __restrict_
 
 template <int NBR>
 int launch_sephead(const void* x, const void* wfrag, const float* bias, void* y, int B, int H, int W, hipStream_t st) {
-  static const int th = getenv("PNX_SEPHEAD_TH") ? atoi(getenv("PNX_SEPHEAD_TH")) : 8;
-  const int TH = th == 16 ? 16 : (th == 4 ? 4 : 8);
+  constexpr int TH = 8;  // 8-row tiles: 43.5 KiB of LDS, 3 workgroups per CU (4 and 16 rows measured slower in round 2)
   int64_t nb = (int64_t)B * ((H + TH - 1) / TH) * ((W + 31) / 32);
-  const int64_t cap = TH == 16 ? 512 : (TH == 4 ? 1280 : 768);  // resident workgroups: 2 (76.5 KiB), 3 (43.5 KiB) or 5 (26.1 KiB) per CU
-  if (nb > cap) nb = cap;
-  if (TH == 16)
-    k_sephead_out<NBR, 16><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (uint16_t*)y, B, H, W);
-  else if (TH == 4)
-    k_sephead_out<NBR, 4><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (uint16_t*)y, B, H, W);
-  else
-    k_sephead_out<NBR, 8><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (uint16_t*)y, B, H, W);
+  if (nb > 768) nb = 768;  // resident workgroups
+  k_sephead_out<NBR, TH><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (uint16_t*)y, B, H, W);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

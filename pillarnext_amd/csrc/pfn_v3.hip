@@ -207,7 +207,7 @@ template <int F, int R, int DT, bool PACK, bool H16>
 __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ pcnt,
                                              const int32_t* __restrict__ cell_of_pillar, int32_t* counters, int32_t* __restrict__ tick,
                                              int32_t* __restrict__ biglist, int bigcap, const float* __restrict__ P, Pfn3Out out, int n_fill, int n_bigb,
-                                             PnxGeomDev g, PnxFillJob fj, int dbg) {
+                                             PnxGeomDev g, PnxFillJob fj) {
   constexpr int C0 = F + 5, KS = (C0 + 2) / 2;     // K = C0 features + the constant-1 column that carries the folded BN shift
   constexpr int FR = 32 * C0 + 32 + 64 * 64 + 64;  // start of the fragment-ordered block (k_fold_bn)
   __shared__ __align__(16) uint32_t s_lds[4 * kWaveLds];
@@ -263,10 +263,6 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
 
   // Windows of R sorted slots are handed out by ticket counters: while the fill blocks occupy their share of every CU only part of
   // the PFN blocks is resident, and a static deal would leave the late blocks' share for after the fill.
-  // (experiment) phase offset between the two waves that share a SIMD (blocks b and b + resident/2): dbg bits 8.. = sleep units of 64 cycles
-  if ((dbg >> 8) != 0 && ((((int)blockIdx.x - n_fill - n_bigb) >> 8) & 1)) {
-    for (int k = 0; k < (dbg >> 8); k += 64) __builtin_amdgcn_s_sleep(64);
-  }
   const int64_t nwin = ((int64_t)n_kept + R - 1) / R;
   int shard = (int)(blockIdx.x & (kTickShards - 1)), tried = 0;
   int64_t pass = next_window(tick, shard, tried, ticket_wait(ticket_issue(tick + shard * kTickStride, l)), nwin, l);
@@ -355,12 +351,12 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
 #pragma unroll
         for (int tq = 0; tq < 8; tq++) split2_f16(u[2 * tq], u[2 * tq + 1], bh[tq], bl[tq]);
 #define PNX_L1H(S, PROD, I0, N)                                                                                         \
-  if (!(dbg & 4)) {                                                                                                     \
+  {                                                                                                     \
     da = PNX_MFMA16(as_v8h(&wq[((PROD) == 2 ? 32 : 0) + (0 * 4 + (S)) * 4]), as_v8h((PROD) == 1 ? &bl[4 * ((S) & 1)] : &bh[4 * ((S) & 1)]), da); \
     db = PNX_MFMA16(as_v8h(&wq[((PROD) == 2 ? 32 : 0) + (1 * 4 + (S)) * 4]), as_v8h((PROD) == 1 ? &bl[4 * ((S) & 1)] : &bh[4 * ((S) & 1)]), db); \
   }                                                                                                                     \
   __builtin_amdgcn_sched_barrier(0);                                                                                    \
-  if (!(dbg & 2) && (N) > 0) {                                                                                          \
+  if ((N) > 0) {                                                                                          \
     _Pragma("unroll") for (int pq_ = 0; pq_ < (N); pq_++) {                                                             \
       switch (((I0) + pq_) / 16) {                                                                                      \
         case 0: scan_pair_f32<0>(g0[((I0) + pq_) % 16], sm); break;                                                     \
@@ -389,12 +385,12 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
 #undef PNX_L1H
       } else {
 #define PNX_L1A(I)                                                                  \
-  if (!(dbg & 4)) {                                                                 \
+  {                                                                 \
     da = PNX_MFMA(w1a[I], u[I], da);                                                \
     db = PNX_MFMA(w1b[I], u[I], db);                                                \
   }                                                                                 \
   __builtin_amdgcn_sched_barrier(0);                                                \
-  if (!(dbg & 2)) {                                                                 \
+  {                                                                 \
     PNX_G0_PAIR(5 * (I) + 0) PNX_G0_PAIR(5 * (I) + 1) PNX_G0_PAIR(5 * (I) + 2) PNX_G0_PAIR(5 * (I) + 3) PNX_G0_PAIR(5 * (I) + 4) \
   }                                                                                 \
   __builtin_amdgcn_sched_barrier(0);
@@ -406,7 +402,7 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
           for (int i = 0; i < 16; i++)
             g0[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(tail_lane << 2, __builtin_bit_cast(int, g0[i])));
         }
-        if (!(dbg & 4)) {
+        {
 #pragma unroll
           for (int i = 0; i < 16; i++) {
             da = PNX_MFMA(w1a[16 + i], g0[i], da);
@@ -442,7 +438,7 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
           q[2 * j] = cvt_pk16<DT>(a0, a1), q[2 * j + 1] = cvt_pk16<DT>(a2, a3);
           q[8 + 2 * j] = cvt_pk16<DT>(b0, b1), q[8 + 2 * j + 1] = cvt_pk16<DT>(b2, b3);
         }
-        if (!(dbg & 2)) seg_max_pk16(q, sm, pl);
+        seg_max_pk16(q, sm, pl);
         // The record prefetch (issued a whole tile ago) is waited for HERE, before this tile's stores go out: otherwise the next
         // tile's first use of it waits behind those stores -- vmcnt is in-order and hipcc cannot count a data-dependent number of stores.
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -459,7 +455,7 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
         wave_lds_sync();
         // ---- stores: lane -> (pillar l>>3 + 8*it, 16 bytes = channels 8*(l&7) .. +7): one instruction writes 8 complete 128-byte lines
         const int qq = l & 7;
-        for (int p = l >> 3; p < ((dbg & 1) ? 0 : npil); p += 8) {
+        for (int p = l >> 3; p < npil; p += 8) {
           const uint4 x = *reinterpret_cast<const uint4*>(s_out + p * kZSP + 4 * qq);
           *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(out.canvas) + (int64_t)(int32_t)s_cell[p] * 64 + 8 * qq) = x;
         }
@@ -470,7 +466,7 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
           pa[i] = fmaxf(__builtin_fmaf(da[i], kDs, s1a[i]), 0.f);
           pb[i] = fmaxf(__builtin_fmaf(db[i], kDs, s1b[i]), 0.f);
         }
-        if (!(dbg & 2)) {
+        {
           seg_max_nn16(pa, idx, col, pl);
           seg_max_nn16(pb, idx, col, pl);
         }
@@ -490,7 +486,7 @@ __global__ __launch_bounds__(256) void k_pfn3(const uint4* __restrict__ rec, con
         wave_lds_sync();
         // ---- stores: lane -> (pillar l>>3 + 8*it, channels 8*(l&7) .. +7)
         const int qq = l & 7;
-        for (int p = l >> 3; p < ((dbg & 1) ? 0 : npil); p += 8) {
+        for (int p = l >> 3; p < npil; p += 8) {
           const uint4* src = reinterpret_cast<const uint4*>(s_out + p * kZS + 8 * qq);
           const uint4 x0 = src[0], x1 = src[1];
           const float v[8] = {__uint_as_float(x0.x), __uint_as_float(x0.y), __uint_as_float(x0.z), __uint_as_float(x0.w),
@@ -538,8 +534,6 @@ int launch3(const uint4* rec, const uint32_t* pfirst, const uint32_t* pcnt, cons
   if (nb > max_blocks) nb = max_blocks;
   if (n <= 0) nb = 0;
   const int bc = (int)(bigcap > 0x7fffffff ? 0x7fffffff : bigcap);
-  const char* d_env = getenv("PNX_PFN_DBG");  // timing ablations only (results are wrong): 1 no stores, 2 no scans, 4 no layer-1 MFMAs
-  const int dbg = d_env ? atoi(d_env) : 0;
   const int n_bigb = nb > 0 ? kBigBlocks : 0;
   if (nb + n_fill > 0) {
     const int grid = (int)(nb + n_fill + n_bigb);
@@ -548,8 +542,8 @@ int launch3(const uint4* rec, const uint32_t* pfirst, const uint32_t* pcnt, cons
     const bool h16 = !(h_env && h_env[0] == '0');
 #define PNX_GO(DT_, PACK_)                                                                                                                        \
   {                                                                                                                                               \
-    if (h16) k_pfn3<F, R, DT_, PACK_, true><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bc, folded, out, n_fill, n_bigb, g, fj, dbg); \
-    else k_pfn3<F, R, DT_, PACK_, false><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bc, folded, out, n_fill, n_bigb, g, fj, dbg);    \
+    if (h16) k_pfn3<F, R, DT_, PACK_, true><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bc, folded, out, n_fill, n_bigb, g, fj); \
+    else k_pfn3<F, R, DT_, PACK_, false><<<grid, 256, 0, st>>>(rec, pfirst, pcnt, cell_of_pillar, counters, tick, biglist, bc, folded, out, n_fill, n_bigb, g, fj);    \
   }
     if (out.dt == PNX_F32) {
       PNX_GO(PNX_F32, false)

@@ -20,8 +20,8 @@ __device__ __forceinline__ uint32_t scan_value(uint32_t v) {
 }
 
 // Level 2 as a device function: one block turns the per-block totals into exclusive offsets (in place) and publishes the grand
-// total (also stored at blk[nblk]).  Loads go to the device-coherent level: the caller may be the last block of the kernel that
-// produced the totals (scan_blocks_by_last).
+// total (also stored at blk[nblk]).  (Folding this into the last block of the level-1 kernel was measured in round 2: the device-scope
+// release fence it needs in every block writes the XCD's dirty L2 lines back, +115 us on a 255 us voxelize -- level 2 stays a launch.)
 __device__ __forceinline__ void scan_blocks_body(uint32_t* blk, int nblk, int32_t* total_out) {
   __shared__ uint32_t s_wave2[kBlock / 64];
   __shared__ uint32_t s_carry;
@@ -52,27 +52,11 @@ __device__ __forceinline__ void scan_blocks_body(uint32_t* blk, int nblk, int32_
   }
 }
 
-// Called by EVERY thread of EVERY block of a level-1 kernel after it wrote blk_tot[blockIdx.x] (gridDim.x == nblk): the block that
-// draws the last ticket of `done` (zero before the launch) runs level 2 right there -- a separate single-block launch costs
-// ~5 us of kernel + ~2 us of launch gap on an otherwise 600 us reader.  done == nullptr: level 2 is a separate k_scan_blocks launch.
-__device__ __forceinline__ void scan_blocks_by_last(uint32_t* blk, int32_t* total_out, int32_t* done) {
-  if (done == nullptr) return;  // kernel-uniform
-  __shared__ int s_last;
-  __threadfence();  // the total this block wrote is visible device-wide before its ticket
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(done, 1) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  scan_blocks_body(blk, (int)gridDim.x, total_out);
-}
-
 // Level 1: each block scans PNX_SCAN_ITEMS items; out_local = exclusive prefix inside the block.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_scan_local(const uint32_t* __restrict__ in, int64_t n,
                                                        uint32_t* __restrict__ out_local, uint32_t* blk_tot,
-                                                       const int32_t* __restrict__ limit = nullptr, int32_t* total_out = nullptr,
-                                                       int32_t* done = nullptr) {
+                                                       const int32_t* __restrict__ limit = nullptr) {
   __shared__ uint32_t s_wave[kBlock / 64];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -115,7 +99,6 @@ __global__ __launch_bounds__(kBlock) void k_scan_local(const uint32_t* __restric
       if (base + k < n) out_local[base + k] = excl + v[k];
   }
   if (t == kBlock - 1) blk_tot[blockIdx.x] = excl + sum;
-  scan_blocks_by_last(blk_tot, total_out, done);
 }
 
 // Level 2: one block turns the per-block totals into exclusive offsets (in place) and publishes the

@@ -61,8 +61,7 @@ __global__ __launch_bounds__(kBlock) void k_keys(const float* __restrict__ pts, 
 __device__ __forceinline__ uint32_t nib4(uint32_t v) { return ((v * 0x00204081u) >> 21) & 0xFu; }  // 4 bytes (0/1) -> 4 bits
 
 __global__ __launch_bounds__(kBlock) void k_pack_scan(const uint8_t* __restrict__ bytemap, int64_t nwords, uint32_t* __restrict__ bitmap,
-                                                      uint32_t* __restrict__ out_local, uint32_t* blk_tot, uint2* __restrict__ wcomb,
-                                                      int32_t* total_out = nullptr, int32_t* done = nullptr) {
+                                                      uint32_t* __restrict__ out_local, uint32_t* blk_tot, uint2* __restrict__ wcomb) {
   __shared__ uint32_t s_wave[kBlock / 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t base = (int64_t)blockIdx.x * PNX_SCAN_ITEMS + (int64_t)t * 8;
@@ -100,7 +99,6 @@ __global__ __launch_bounds__(kBlock) void k_pack_scan(const uint8_t* __restrict_
       if (wcomb != nullptr) wcomb[base + k] = make_uint2(w[k], excl + pre[k]);  // {bits, prefix} in one 8-byte load for the per-point rank
     }
   if (t == kBlock - 1) blk_tot[blockIdx.x] = excl + sum;
-  scan_blocks_by_last(blk_tot, total_out, done);  // binned path: the last block also turns the totals into offsets (pnx_scan.h)
 }
 
 __device__ __forceinline__ int32_t cell_rank(int32_t key, const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre,
@@ -650,11 +648,8 @@ ReaderWs carve(void* ws, int64_t n, int32_t batch, const pnx_geom* g) {
   // binned path (k_bin_count / k_bin_scatter / k_bin_sort): bins small enough for k_bin_sort's LDS (<= 2048 pillars), at most ~2400 of them,
   // 512 chunks of points
   {
-    const char* sh_env = getenv("PNX_BIN_SH");  // experiment: bins of 2^sh pillars
     w.sh = 8;
-    static const int k1max = getenv("PNX_BIN_K1MAX") ? atoi(getenv("PNX_BIN_K1MAX")) : 2400;
-    while (w.sh < 11 && ((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh) > k1max) w.sh++;
-    if (sh_env) w.sh = atoi(sh_env);
+    while (w.sh < 11 && ((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh) > 2400) w.sh++;
     w.K1 = (int)((w.pcap + ((int64_t)1 << w.sh) - 1) >> w.sh);
     int64_t chunk = (n / 512 + 255) / 256 * 256;
     if (chunk < 2048) chunk = 2048;
@@ -771,11 +766,9 @@ int launch_bin_sort(const GeomDev& gd, const ReaderWs& w, int32_t* coords, int64
     PNX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_sort<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set = lds;
   }
-  const char* d_env = getenv("PNX_SORT_DBG");  // timing ablations only (results are wrong): 1 no fp64 sums
-  const int sdbg = d_env ? atoi(d_env) : 0;
   const int bc = (int)(w.bigcap > 0x7fffffff ? 0x7fffffff : w.bigcap);
   k_bin_sort<F><<<w.K1 + (fj.quota > 0 ? fill_blocks : 0), kSortBlock, lds, st>>>(w.rec, gd, w.sh, w.nwg, w.matlen, w.hpre, w.hblk, w.counters, w.rec64,
-                                                                                 w.pfirst, w.pcnt, w.cell, coords, pillar_capacity, w.biglist, bc, sdbg,
+                                                                                 w.pfirst, w.pcnt, w.cell, coords, pillar_capacity, w.biglist, bc,
                                                                                  fj);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
@@ -789,12 +782,8 @@ int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev&
     k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bytemap, nullptr);
     PNX_LAUNCH_CHECK();
   }
-  // Level 2 of the two scans below stays a separate single-block launch (~5 us + ~2 us of launch gap each).  Folding it into the
-  // last block of the level-1 kernel (pnx_scan.h: scan_blocks_by_last, PNX_SCAN_FUSE=1) needs a device-scope release fence in
-  // every block, and on this 8-XCD part that fence writes the XCD's dirty L2 lines back: measured +115 us on the 255 us voxelize.
-  static const bool fuse_scan = getenv("PNX_SCAN_FUSE") != nullptr && getenv("PNX_SCAN_FUSE")[0] == '1';
-  k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk, w.wcomb, w.counters + 0, fuse_scan ? w.counters + 8 : nullptr);
-  if (!fuse_scan) k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
+  k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk, w.wcomb);
+  k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
   PNX_LAUNCH_CHECK();
   if (n <= 0) return PNX_OK;
   const size_t hl = (size_t)(w.K1 > 64 ? w.K1 : 64) * sizeof(uint32_t);
@@ -802,8 +791,8 @@ int run_voxelize2(const float* points, int64_t n, int32_t stride, const GeomDev&
   f0.n_main = w.nwg, f1.n_main = w.nwg, f2.n_main = w.K1;
   k_bin_count<<<w.nwg + (f0.quota > 0 ? fill_blocks : 0), w.gthreads, hl, st>>>(w.key, n, w.chunk, w.sh, w.K1, w.nwg, w.wcomb, w.wblk, w.rank, pillar_of_point,
                                                                            w.histmat, gd, f0);
-  k_scan_local<SCAN_IDENT><<<w.nblk_m, kBlock, 0, st>>>(w.histmat, w.matlen, w.hpre, w.hblk, nullptr, w.counters + 1, fuse_scan ? w.counters + 9 : nullptr);
-  if (!fuse_scan) k_scan_blocks<<<1, kBlock, 0, st>>>(w.hblk, w.nblk_m, w.counters + 1);
+  k_scan_local<SCAN_IDENT><<<w.nblk_m, kBlock, 0, st>>>(w.histmat, w.matlen, w.hpre, w.hblk);
+  k_scan_blocks<<<1, kBlock, 0, st>>>(w.hblk, w.nblk_m, w.counters + 1);
   k_bin_scatter<<<w.nwg + (f1.quota > 0 ? fill_blocks : 0), w.gthreads, hl, st>>>(points, stride, w.key, w.rank, n, w.chunk, w.sh, w.K1, w.nwg, w.hpre, w.hblk,
                                                                              w.rec, gd, f1);
   PNX_LAUNCH_CHECK();
@@ -929,7 +918,7 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
       k_keys<<<nblocks(n), kBlock, 0, st>>>(points, n, stride, gd, w.key, w.bytemap, nullptr);
       PNX_LAUNCH_CHECK();
     }
-    k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk, w.wcomb, nullptr, nullptr);
+    k_pack_scan<<<w.nblk_w, kBlock, 0, st>>>(w.bytemap, w.nwords, w.bitmap, w.wpre, w.wblk, w.wcomb);
     k_scan_blocks<<<1, kBlock, 0, st>>>(w.wblk, w.nblk_w, w.counters + 0);
     PNX_LAUNCH_CHECK();
   }
@@ -965,7 +954,7 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
                            fill_nt ? 1 : 0, n, gd, st);
   if (rc != PNX_OK) return rc;
   if (n > 0) {
-    static const int tb = getenv("PNX_TAIL_BLOCKS") ? atoi(getenv("PNX_TAIL_BLOCKS")) : 128;
+    const int tb = 128;
     rc = pnx_launch_pfn3_tail(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.biglist, w.bigcap, pfn_folded, g1, g1_rows, direct ? canvas : nullptr,
                               canvas_dtype, tb, st, ranked ? w.row_of : nullptr);
     if (rc != PNX_OK) return rc;

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_sort(const uint32_t* __restr
                                                          int32_t* counters, uint32_t* __restrict__ rec64,
                                                          uint32_t* __restrict__ pillar_first, uint32_t* __restrict__ pillar_cnt,
                                                          int32_t* __restrict__ cell_of_pillar, int32_t* __restrict__ coords,
-                                                         int64_t pillar_capacity, int32_t* __restrict__ biglist, int bigcap, int dbg,
+                                                         int64_t pillar_capacity, int32_t* __restrict__ biglist, int bigcap,
                                                          PnxFillJob fj) {
   constexpr int C0 = F + 5;
   extern __shared__ __align__(16) unsigned char s_raw[];
@@ -160,11 +160,9 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_sort(const uint32_t* __restr
     const uint32_t rl = c.w;
     atomicAdd(&s_start[rl], 1u);
     s_key[rl] = c.z;  // every point of the pillar stores the same key
-    if (!(dbg & 1)) {
-      atomicAdd(&s_sum[3 * rl + 0], (double)__uint_as_float(a.x));
-      atomicAdd(&s_sum[3 * rl + 1], (double)__uint_as_float(a.y));
-      atomicAdd(&s_sum[3 * rl + 2], (double)__uint_as_float(a.z));
-    }
+    atomicAdd(&s_sum[3 * rl + 0], (double)__uint_as_float(a.x));
+    atomicAdd(&s_sum[3 * rl + 1], (double)__uint_as_float(a.y));
+    atomicAdd(&s_sum[3 * rl + 2], (double)__uint_as_float(a.z));
   };
 #pragma unroll
   for (int it = 0; it < kKeep; it++) {

@@ -8,7 +8,6 @@ Variants are environment settings read by pnx_reader_forward on every call:
     PNX_FILL_BLOCKS, PNX_PFN_BLOCKS   workgroups of the zero-fill kernel (second stream) and of the span kernel (0 fill blocks: timing only,
                                       the canvas is wrong); PNX_FILL_NT=0|1 plain / nontemporal fill stores
   PNX_READER_IMPL=2            the general pipeline: binned grouping (reader_bins.h) + k_bin_sort + PFN v3 (pfn_v3.hip), records through HBM
-    PNX_BIN_NWG, PNX_BIN_THREADS, PNX_BIN_SH   chunks / threads of k_bin_count and k_bin_scatter, pillars per bin (2^sh)
     PNX_FILL_SPLIT=a,b,c       percent of the fill tiles carried by k_bin_count / k_bin_scatter / k_bin_sort
   PNX_PFN_F16X3=0|1            layer 1 as fp32 MFMA | fp16 hi/lo splits (0 sends the call to the general pipeline)
 Every variant must equal the first variant's canvas bit for bit.
@@ -53,8 +52,7 @@ VARIANTS = [
     ("binned split 10,10", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "10,10,0"}),
     ("fp32 layer 1 (binned)", {"PNX_PFN_F16X3": "0"}),
 ]
-KEYS = ["PNX_READER_IMPL", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS", "PNX_FILL_SPLIT", "PNX_PFN_F16X3", "PNX_BIN_NWG", "PNX_BIN_THREADS", "PNX_BIN_SH",
-        "PNX_BINS_CAP", "PNX_BINS_LDS", "PNX_SPAN_QUOTA", "PNX_SPAN_SOLO", "PNX_FILL_NT"]
+KEYS = ["PNX_READER_IMPL", "PNX_FILL_BLOCKS", "PNX_PFN_BLOCKS", "PNX_FILL_SPLIT", "PNX_PFN_F16X3", "PNX_BINS_CAP", "PNX_BINS_LDS", "PNX_SPAN_QUOTA", "PNX_SPAN_SOLO", "PNX_FILL_NT"]
 
 
 def main():
