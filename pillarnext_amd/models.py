@@ -1142,7 +1142,7 @@ class FusedPillarNeXt(nn.Module):
 
         key = ("plan_bb", B, dev)
         st = self._ws.get(key)
-        if st is not None:
+        if st is not None and st["weights_at"] == self.stages[0][0].wfrag.data_ptr():   # .to() / .cuda() after the plan was built moves the weights
             return st
         ny, nx = (int(v) for v in self.reader.grid_size)
         canvas = torch.empty((B, 64, ny, nx), dtype=self.dtype, device=dev, memory_format=torch.channels_last)
@@ -1172,7 +1172,7 @@ class FusedPillarNeXt(nn.Module):
             for j in range(1, len(mods), 2):
                 y = run(mods[j], x)
                 x = run(mods[j + 1], y, x)
-        st = self._ws[key] = {"canvas": canvas, "occ": occ, "plan": plan.freeze(), "out": x, "mask": mask}
+        st = self._ws[key] = {"canvas": canvas, "occ": occ, "plan": plan.freeze(), "out": x, "mask": mask, "weights_at": self.stages[0][0].wfrag.data_ptr()}
         return st
 
     def _run_head_plan(self, x):
@@ -1182,7 +1182,7 @@ class FusedPillarNeXt(nn.Module):
 
         B, _, H, W = x.shape
         dev = x.device
-        key = ("plan_head", B, H, W, dev)
+        key = ("plan_head", B, H, W, dev, self.shared.wfrag.data_ptr())   # the weights' address: .to() after the plan was built moves them
         st = self._ws.get(key)
         T = len(self.task_deblock)
 

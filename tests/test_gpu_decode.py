@@ -434,6 +434,7 @@ def test_launch_plans_equal_the_python_launch_loop(monkeypatch):
             pend = nxt
         got.append(fused.detections(pend.result()))
     assert ("plan_bb", B, exs[0]["points"].device) in fused._ws and any(k[0] == "lazy_fused" for k in fused.decoder()._dev)
+    assert any(isinstance(k, tuple) and k[0] == "plan_head" for k in fused._ws)
     assert sum(len(v["scores"]) for a in want for v in a.values()) > 0
     for a, b in zip(got, want):
         assert set(a) == set(b)
