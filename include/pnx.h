@@ -212,6 +212,9 @@ int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const 
 size_t pnx_conv3x3_wgrad_workspace_bytes(int32_t cin, int32_t cout);
 int pnx_conv3x3_wgrad_bf16(const void* x, const void* dy, const uint8_t* mask, float* dw, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
                            void* workspace, size_t workspace_bytes, pnx_stream_t stream);
+/* (cout, cin, 3, 3) fp32 / bf16 weights -> wfrag of pnx_conv3x3_bf16 (9*cout*cin bf16) in one launch; transposed != 0: the weights of the data
+ * gradient of a stride-1 layer, wt[ci][co][ky][kx] = w[co][ci][2-ky][2-kx], i.e. the wfrag of a cout -> cin convolution. */
+int pnx_conv3x3_pack_weights(const void* w, int32_t dtype, int32_t cout, int32_t cin, int32_t transposed, void* wfrag, pnx_stream_t stream);
 /* Optional tile list for the stride-1 kernels: the submanifold blocks of a backbone stage share one active-site mask, so the
  * tiles that need any work (an active site, or a stale row in one of the persistent output buffers) are listed once per stage
  * and every convolution of the stage walks the list instead of all tiles.

@@ -209,6 +209,30 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   }
 }
 
+// Weights (Cout, Cin, 3, 3) fp32 / bf16 -> the bf16 MFMA-fragment order of csrc/conv3x3.hip ([tap][cin/16][cout/32][lane = kb*32 + n][8]) in one
+// launch; transposed: the weights of the data gradient, wt[ci][co][ky][kx] = w[co][ci][2-ky][2-kx] (the kernel then maps ci -> co channels).
+// The host statement (ops.conv3x3_pack_weights: cast, permute, copy, cast; flip + transpose + copy in front for the gradient) is 3-6 launches
+// per layer and step of a training run.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_w3x3(const T* __restrict__ w, int cout, int cin, int transposed, uint16_t* __restrict__ out) {
+  const int M = transposed ? cin : cout, K = transposed ? cout : cin;  // output / input channels of the packed convolution
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 9 * M * K) return;
+  const int e = idx & 7, n = (idx >> 3) & 31, kb = (idx >> 8) & 1;
+  int r = idx >> 9;
+  const int MT = M >> 5, CB = K >> 4;
+  const int mt = r % MT;
+  r /= MT;
+  const int cb = r % CB, tap = r / CB;
+  const int o = mt * 32 + n, i = cb * 16 + kb * 8 + e, ky = tap / 3, kx = tap - 3 * ky;
+  float v;
+  if (transposed) v = (float)w[(((int64_t)i * cin + o) * 3 + (2 - ky)) * 3 + (2 - kx)];
+  else v = (float)w[(((int64_t)o * cin + i) * 3 + ky) * 3 + kx];
+  uint32_t u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite weights)
+  out[idx] = (uint16_t)(u >> 16);
+}
+
 int groups_per_pair(int cin, int cout) {
   const int n_pairs = (cin >> 6) * (cout >> 6);
   const int g = WG_GROUPS / n_pairs;
@@ -244,6 +268,18 @@ extern "C" int pnx_conv3x3_wgrad_bf16(const void* x, const void* dy, const uint8
                                                                       cout, G);
   PNX_LAUNCH_CHECK();
   k_wgrad_reduce<<<(unsigned)((n_pairs * 9 * 4096 + 31) / 32), 256, 0, st>>>((const float*)workspace, dw, cin, cout, G);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+extern "C" int pnx_conv3x3_pack_weights(const void* w, int32_t dtype, int32_t cout, int32_t cin, int32_t transposed, void* wfrag, pnx_stream_t stream) {
+  PNX_REQUIRE(w && wfrag && cout >= 32 && cin >= 16 && (cout & 31) == 0 && (cin & 15) == 0 && (!transposed || ((cin & 31) == 0 && (cout & 15) == 0)),
+              PNX_ERR_INVALID, "pnx_conv3x3_pack_weights: %d -> %d channels", cin, cout);
+  PNX_REQUIRE(dtype == PNX_F32 || dtype == PNX_BF16, PNX_ERR_UNSUPPORTED, "weights must be fp32 or bf16");
+  hipStream_t st = (hipStream_t)stream;
+  const int n = 9 * cout * cin;
+  if (dtype == PNX_F32) k_pack_w3x3<float><<<(n + 255) / 256, 256, 0, st>>>((const float*)w, cout, cin, transposed, (uint16_t*)wfrag);
+  else k_pack_w3x3<__bf16><<<(n + 255) / 256, 256, 0, st>>>((const __bf16*)w, cout, cin, transposed, (uint16_t*)wfrag);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

@@ -306,8 +306,8 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
         if ctx.stride == 1:
             if need_x:
                 ci = weight.shape[1]
-                wt = weight.flip(2, 3).transpose(0, 1).contiguous()      # dgrad of a stride-1 'same' convolution = convolution with W^T flipped
-                dx = ops.conv3x3_masked(g, ops.conv3x3_pack_weights(wt), _zero_bias(ci, g.device), ci, stride=1, mask=mask_in, relu=False)
+                # dgrad of a stride-1 'same' convolution = convolution with W^T flipped (packed in one launch)
+                dx = ops.conv3x3_masked(g, ops.conv3x3_pack_weights(weight, transposed=True), _zero_bias(ci, g.device), ci, stride=1, mask=mask_in, relu=False)
             if need_w:
                 if os.environ.get("PNX_TRAIN_HIPWGRAD", "1") != "0":
                     dw = ops.conv3x3_wgrad(x, g, mask_out).to(weight.dtype)

@@ -225,9 +225,19 @@ CONV3X3_SHAPES_S1 = {(64, 64), (64, 128), (128, 128), (256, 256), (256, 64), (64
 CONV3X3_SHAPES_S2 = {(64, 64), (64, 128), (128, 128), (128, 256), (256, 256)}
 
 
-def conv3x3_pack_weights(w):
-    """(Cout, Cin, 3, 3) -> bf16 MFMA-fragment order [tap][cin/16][cout/32][lane = kb*32 + n][8]  (csrc/conv3x3.hip)."""
+def conv3x3_pack_weights(w, transposed=False):
+    """(Cout, Cin, 3, 3) -> bf16 MFMA-fragment order [tap][cin/16][cout/32][lane = kb*32 + n][8]  (csrc/conv3x3.hip).  transposed: the weights of
+    the stride-1 data gradient instead, i.e. pack(w.flip(2, 3).transpose(0, 1)).  CUDA fp32 / bf16 weights take one HIP launch
+    (pnx_conv3x3_pack_weights); anything else the torch statement below, which is also what the tests compare the kernel with."""
     co, ci = w.shape[:2]
+    if w.is_cuda and w.dtype in (torch.float32, torch.bfloat16) and tuple(w.shape[2:]) == (3, 3) and co % 32 == 0 and ci % 32 == 0:
+        wc = w.detach().contiguous()
+        out = torch.empty((9 * co * ci,), dtype=torch.bfloat16, device=w.device)
+        check(lib().pnx_conv3x3_pack_weights(ptr(wc), _DT[wc.dtype], co, ci, 1 if transposed else 0, ptr(out), stream_ptr()), "pnx_conv3x3_pack_weights")
+        return out
+    if transposed:
+        w = w.flip(2, 3).transpose(0, 1)
+        co, ci = ci, co
     v = w.detach().float().reshape(co // 32, 32, ci // 16, 2, 8, 3, 3)         # (mt, n, cb, kb, e, ky, kx)
     v = v.permute(5, 6, 2, 0, 3, 1, 4).contiguous()                               # (ky, kx, cb, mt, kb, n, e)
     return v.reshape(-1).to(torch.bfloat16).contiguous()

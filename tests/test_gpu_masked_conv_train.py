@@ -98,3 +98,17 @@ def test_wgrad_kernel_matches_fp32_conv2d_weight(cin, cout, shape, p):
     assert torch.equal(dw, ops.conv3x3_wgrad(x, g_all, mu8))
     empty = torch.zeros_like(mu8)
     assert float(ops.conv3x3_wgrad(x, g_all, empty).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("co,ci", [(64, 64), (128, 64), (256, 256), (320, 64)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_weights_kernel_equals_the_torch_statement(co, ci, dtype):
+    """pnx_conv3x3_pack_weights (one launch, plain and transposed = data-gradient weights) bit for bit against the host statement of the layout."""
+    from pillarnext_amd import ops
+
+    w = torch.randn((co, ci, 3, 3), generator=torch.Generator().manual_seed(co + ci)).to(dtype)
+    for transposed in (False, True):
+        want = ops.conv3x3_pack_weights(w, transposed=transposed)              # CPU tensor: the torch statement
+        got = ops.conv3x3_pack_weights(w.cuda(), transposed=transposed)        # CUDA tensor: the kernel
+        assert want.dtype == got.dtype == torch.bfloat16 and want.shape == got.shape
+        assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16)), (transposed,)
