@@ -280,7 +280,7 @@ class PackedDecoder:
         shapes = [(p.shape[2], p.shape[3]) for p in dense]
         S = B * self.nc_total
         L = lib()
-        ck = ("lazy_fused", B, T, dt, tuple(shapes), dev)
+        ck = ("lazy_fused", B, T, dt, tuple(shapes), dev, torch.cuda.current_stream().cuda_stream)   # persistent scratch: one set per stream
         st = self._dev.get(ck)
         if st is None:
             cfg = self.cfg

@@ -909,7 +909,9 @@ class LazyTask:
 
 class FusedPillarNeXt(nn.Module):
     """Inference-only re-expression of SingleStageDetector (eval BN folded, epilogues fused, the 6-7 SepHead branches of a
-    task merged into two convolutions).  Mathematically the same network; weights come from the trained modules."""
+    task merged into two convolutions).  Mathematically the same network; weights come from the trained modules.
+    One instance drives ONE stream: the stage workspaces, the launch plans' canvas and the decoder's scratch are persistent and reused
+    from call to call in stream order (a second stream needs a second instance)."""
 
     def __init__(self, det, dtype=torch.bfloat16, hip_conv=None):
         super().__init__()

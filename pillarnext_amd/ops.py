@@ -336,7 +336,7 @@ def conv3x3_wgrad(x, dy, mask):
     nbytes = int(lib().pnx_conv3x3_wgrad_workspace_bytes(ci, co))
     if nbytes == 0:
         raise PnxError(f"conv3x3_wgrad: no kernel for {ci} -> {co} channels")
-    key = (nbytes, x.device)
+    key = (nbytes, x.device, torch.cuda.current_stream().cuda_stream)   # the partials of a call live until its reduction ran: one buffer per stream
     ws = _WGRAD_WS.get(key)
     if ws is None:
         ws = _WGRAD_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
