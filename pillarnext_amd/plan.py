@@ -31,8 +31,8 @@ def _t(a):
 
 def _nhwc_bf16(x, what):
     x = _t(x)
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
-        raise PnxError(f"{what} needs a channels_last bf16 CUDA tensor")
+    if not (x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise PnxError(f"{what} needs a channels_last bf16 tensor")
     return x
 
 
@@ -119,4 +119,6 @@ class LaunchPlan:
     def run(self):
         if self._arr is None:
             self.freeze()
+        if not all(a.is_cuda for a in self._keep) or not all(t.is_cuda for t in self._bound.values()):
+            raise PnxError("plan: every tensor of a launch table must live on the GPU")   # the library has no CPU path
         check(lib().pnx_enqueue(self._arr, len(self._ops), stream_ptr()), "pnx_enqueue")
