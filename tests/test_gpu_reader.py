@@ -400,3 +400,51 @@ def test_fp16x3_range_fallback_and_agreement(oracle):
         canvas = net.forward_dense(tp, 2)
         c = coords.long()
         assert torch.equal(canvas.permute(0, 2, 3, 1)[c[:, 0], c[:, 1], c[:, 2]], fm.to(torch.bfloat16))
+
+
+def test_reader_on_other_streams_and_from_two_threads():
+    """The span reader forks its zero-fill onto a stream of its own (one per host thread and device) and joins it before it returns to the
+    caller's stream: the canvas must not depend on which stream the call was enqueued on, and two host threads with their own readers and
+    streams must not disturb each other."""
+    import threading
+
+    from pillarnext_amd import synth
+
+    cfg = synth.CONFIGS["C1"]
+    layers = synth.pfn_params()
+    batches = [torch.from_numpy(synth.make_batch("C1", 2, "sweep", n=40_000, frame0=k)).cuda() for k in range(3)]
+    ref_net = make_net(cfg["pc_range"], cfg["voxel_size"], layers)
+    want = [ref_net.forward_dense(b, 2).clone() for b in batches]
+    torch.cuda.synchronize()
+    # a non-default stream, several calls back to back (the side stream's fork / join events are reused from call to call)
+    s1 = torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        got = [ref_net.forward_dense(b, 2).clone() for b in batches for _ in range(2)]
+    s1.synchronize()
+    for k, g in enumerate(got):
+        assert torch.equal(g, want[k // 2]), k
+    # two threads, each with its own reader, workspace and stream, 6 calls each
+    out, errs = {}, []
+
+    def worker(i):
+        try:
+            net = make_net(cfg["pc_range"], cfg["voxel_size"], layers)
+            st = torch.cuda.Stream()
+            res = []
+            with torch.cuda.stream(st):
+                for r in range(6):
+                    res.append(net.forward_dense(batches[(r + i) % 3], 2).clone())
+            st.synchronize()
+            out[i] = res
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        for r, g in enumerate(out[i]):
+            assert torch.equal(g, want[(r + i) % 3]), (i, r)
