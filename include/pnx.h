@@ -90,6 +90,9 @@ size_t pnx_reader_workspace_bytes(int64_t n_points, int32_t batch, const pnx_geo
  *   pillar_of_point (n_points) int32: pillar rank of input row i, -1 if the row was dropped
  *   counts      int32[2] = {P (number of pillars), N' (number of kept points)}
  * If P would exceed pillar_capacity the rows beyond it are not written (P is still reported).
+ * Streams: with an NHWC canvas the zero-fill of the pillar-free cells runs on an internal stream of the library (one per host thread and
+ * device) beside the grouping / PFN kernels; it is forked from and joined back into `stream` with events inside this call, so for the
+ * caller everything is ordered on `stream` as for any other call.
  */
 int pnx_reader_forward(const float* points, int64_t n_points, int32_t row_stride, int32_t batch, const pnx_geom* geom_host,
                        const float* pfn_folded, void* canvas, int32_t canvas_dtype, int32_t canvas_layout, uint8_t* occupancy,
