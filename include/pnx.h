@@ -208,13 +208,13 @@ int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const 
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, uint8_t* row_dirty, const int32_t* tile_list,
                      const int32_t* tile_count, pnx_stream_t stream);
 /* Weight gradient of the masked stride-1 3x3 convolution (training; det3d/models/utils/sparse_conv.py:16-63 under autograd: spconv accumulates
- * over the active output sites):  dw[co][ci][ky][kx] = sum over the sites p with mask[p] != 0 of dy[p][co] * x[p + (ky-1, kx-1)][ci]
- *   x (B,h,w,cin), dy (B,h,w,cout) bf16 NHWC (x zero at inactive sites, as every map of the masked-dense stand-in is), mask uint8 (B,h,w) of the
+ * over the active output sites):  dw[co][ci][ky][kx] = sum over the sites p with mask[p] != 0 of dy[p][co] * x[stride*p + (ky-1, kx-1)][ci]
+ *   stride 1 or 2 (pad 1); x (B,h,w,cin), dy (B,ho,wo,cout) bf16 NHWC with ho = (h-1)/stride + 1 (x zero at inactive sites, as every map of the masked-dense stand-in is), mask uint8 (B,ho,wo) of the
  *   OUTPUT sites, dw fp32 (cout, cin, 3, 3); cin, cout multiples of 64 up to 512.  Deterministic (static tile deal + a fixed-order reduction of
  *   per-workgroup partials in `workspace`, pnx_conv3x3_wgrad_workspace_bytes). */
 size_t pnx_conv3x3_wgrad_workspace_bytes(int32_t cin, int32_t cout);
 int pnx_conv3x3_wgrad_bf16(const void* x, const void* dy, const uint8_t* mask, float* dw, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
-                           void* workspace, size_t workspace_bytes, pnx_stream_t stream);
+                           int32_t stride, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
 /* (cout, cin, 3, 3) fp32 / bf16 weights -> wfrag of pnx_conv3x3_bf16 (9*cout*cin bf16) in one launch; transposed != 0: the weights of the data
  * gradient of a stride-1 layer, wt[ci][co][ky][kx] = w[co][ci][2-ky][2-kx], i.e. the wfrag of a cout -> cin convolution. */
 int pnx_conv3x3_pack_weights(const void* w, int32_t dtype, int32_t cout, int32_t cin, int32_t transposed, void* wfrag, pnx_stream_t stream);

@@ -64,7 +64,7 @@ PROTOTYPES = {
     "pnx_conv3x3_tile_rows": (ctypes.c_int, [_i32, _i32, _i32]),
     "pnx_conv3x3_pack_weights": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pnx_conv3x3_wgrad_workspace_bytes": (_sz, [_i32, _i32]),
-    "pnx_conv3x3_wgrad_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "pnx_conv3x3_wgrad_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "pnx_conv_tile_list": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pnx_mask_pool3": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pnx_decode_task_desc_bytes": (_sz, []),

@@ -11,7 +11,9 @@
 //   per lane, and every lane gets the 4 pixels of ONE channel back) -- two reads per operand and K step, straight from the staged NHWC tile
 //   a wave = one 32 x 32 channel block x all 9 taps (9 accumulators, 144 registers); per 16-pixel step 2 reads of dY serve 9 MFMAs,
 //   every tap reads its own shifted window of the X halo tile (immediate offsets from one base address)
-//   K steps without an active output are skipped (row masks by ballot); tiles are dealt to the workgroups STATICALLY and every workgroup
+//   stride 2 (the entry convolutions of stages 1-3): the same kernel on 2 x 32 output tiles, the X window of a tap strided by two pixels
+//   (a transposing read takes a free address per lane)
+//   K steps without an active output are skipped (row masks built while staging); tiles are dealt to the workgroups STATICALLY and every workgroup
 //   writes one fp32 partial, which a second kernel adds up in a fixed order: the result does not depend on timing (MIOpen's wrw adds
 //   with global atomics)
 // LDS: pixels 144 bytes apart (64 bf16 + 16 bytes): the four pixel rows of a transposing read then fall into disjoint banks.
@@ -24,42 +26,52 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int WG_TH = 4;                                   // tile: 4 rows x 32 pixels of the output
 constexpr int WG_PS = 144;                                 // bytes per staged pixel
-constexpr int WG_XW = 34;                                  // halo tile: 6 x 34 pixels
-constexpr int WG_XBYTES = (WG_TH + 2) * WG_XW * WG_PS;     // 29 376
-constexpr int WG_YBYTES = WG_TH * 32 * WG_PS;              // 18 432
 constexpr int WG_LIST_MAX = 2040;                          // non-empty tiles a workgroup lists (more tiles: PNX_ERR_UNSUPPORTED at launch)
-constexpr int WG_LDS = WG_XBYTES + WG_YBYTES + (WG_LIST_MAX + 16) * 4;  // 56 000: two workgroups per CU beside 9 x 16 accumulator registers per lane
 constexpr int WG_GROUPS = 512;                             // workgroups per launch (all block pairs together)
 
-// 8 pixels (k) of one channel for this lane: two transposing reads, 4 pixels each
-template <int OFF>
+// Tile geometry by stride S (1: the submanifold / stride-1 layers; 2: the entry convolutions of stages 1-3, iy = 2 oy + ky - 1):
+//   output tile TH rows x 32 pixels, input halo tile XH x XW pixels, 16-byte chunks per thread of the two operands
+template <int S>
+struct WgGeo {
+  static constexpr int TH = S == 1 ? 4 : 2;
+  static constexpr int XH = S * (TH - 1) + 3, XW = S * 31 + 3;  // 6 x 34 | 5 x 65
+  static constexpr int XBYTES = XH * XW * WG_PS, YBYTES = TH * 32 * WG_PS;
+  static constexpr int NY = TH, NX = (XH * XW * 8 + 255) / 256;  // 4 + 7 | 2 + 11
+  static constexpr int LDS = XBYTES + YBYTES + (WG_LIST_MAX + 16) * 4;  // 56 000 | 64 272: two workgroups per CU beside 9 x 16 accumulator registers
+};
+
+// 8 pixels (k) of one channel for this lane: two transposing reads, 4 pixels each (STEP pixels of the LDS image apart: 4 outputs = 4 S inputs)
+template <int OFF, int STEP>
 __device__ __forceinline__ bf16x8 tr_frag(const uint8_t* base) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + OFF));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + OFF + 4 * WG_PS));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + OFF + STEP * WG_PS));
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// One tile's operands on their way from HBM to LDS: 4 + 7 chunks of 16 bytes per thread, held in registers while the previous tile's K steps run.
+// One tile's operands on their way from HBM to LDS: NY + NX chunks of 16 bytes per thread, held in registers while the previous tile's K steps run.
+template <int S>
 struct TileRegs {
-  uint4 y[4], x[7];
+  uint4 y[WgGeo<S>::NY], x[WgGeo<S>::NX];
   uint32_t on;  // bit j: the thread's pixel of row j is an active output
 };
 
-__device__ __forceinline__ void tile_load(TileRegs& R, const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, const uint8_t* __restrict__ mask, int tile,
-                                          int tiles_x, int tiles_y, int B, int H, int W, int cin, int cout, int cb, int ib, int t) {
+// H, W: the INPUT map; Ho, Wo: the output map (= H, W at stride 1)
+template <int S>
+__device__ __forceinline__ void tile_load(TileRegs<S>& R, const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, const uint8_t* __restrict__ mask, int tile,
+                                          int tiles_x, int tiles_y, int H, int W, int Ho, int Wo, int cin, int cout, int cb, int ib, int t) {
+  using G = WgGeo<S>;
   const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-  const int x0 = tx << 5, y0 = ty * WG_TH;
+  const int x0 = tx << 5, y0 = ty * G::TH;
   R.on = 0u;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {  // dY: chunk c = t + 256 j -> row j, pixel (t >> 3), chunk t & 7; zero at inactive outputs
+  for (int j = 0; j < G::NY; j++) {  // dY: chunk c = t + 256 j -> row j, pixel (t >> 3), chunk t & 7; zero at inactive outputs
     const int q = t & 7, px = t >> 3, oy = y0 + j, ox = x0 + px;
     R.y[j] = make_uint4(0, 0, 0, 0);
-    if (oy < H && ox < W) {
-      const int64_t site = ((int64_t)b * H + oy) * W + ox;
+    if (oy < Ho && ox < Wo) {
+      const int64_t site = ((int64_t)b * Ho + oy) * Wo + ox;
       if (mask[site] != 0) {
         R.y[j] = *reinterpret_cast<const uint4*>(dy + site * cout + 64 * cb + 8 * q);
         R.on |= 1u << j;
@@ -67,50 +79,56 @@ __device__ __forceinline__ void tile_load(TileRegs& R, const uint16_t* __restric
     }
   }
 #pragma unroll
-  for (int j = 0; j < 7; j++) {  // X halo: chunk c = t + 256 j of 6 x 34 x 8; zero outside the image
-    const int c = t + 256 * j, q = c & 7, p = c >> 3, r = p / WG_XW, px = p - r * WG_XW;
-    const int iy = y0 - 1 + r, ix = x0 - 1 + px;
+  for (int j = 0; j < G::NX; j++) {  // X halo: chunk c = t + 256 j of XH x XW x 8; zero outside the image
+    const int c = t + 256 * j, q = c & 7, p = c >> 3, r = p / G::XW, px = p - r * G::XW;
+    const int iy = S * y0 - 1 + r, ix = S * x0 - 1 + px;
     R.x[j] = make_uint4(0, 0, 0, 0);
-    if (c < (WG_TH + 2) * WG_XW * 8 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+    if (c < G::XH * G::XW * 8 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
       R.x[j] = *reinterpret_cast<const uint4*>(x + (((int64_t)b * H + iy) * W + ix) * cin + 64 * ib + 8 * q);
   }
 }
 
-__device__ __forceinline__ void tile_store(const TileRegs& R, uint8_t* sx, uint8_t* sy, uint32_t* rowmask, int t) {
+template <int S>
+__device__ __forceinline__ void tile_store(const TileRegs<S>& R, uint8_t* sx, uint8_t* sy, uint32_t* rowmask, int t) {
+  using G = WgGeo<S>;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < G::NY; j++) {
     *reinterpret_cast<uint4*>(sy + (j * 32 + (t >> 3)) * WG_PS + 16 * (t & 7)) = R.y[j];
     if ((t & 7) == 0 && ((R.on >> j) & 1u)) atomicOr(&rowmask[j], 1u << (t >> 3));  // row masks of the tile: which 16-pixel pieces hold an active output
   }
 #pragma unroll
-  for (int j = 0; j < 7; j++) {
+  for (int j = 0; j < G::NX; j++) {
     const int c = t + 256 * j;
-    if (c < (WG_TH + 2) * WG_XW * 8) *reinterpret_cast<uint4*>(sx + (c >> 3) * WG_PS + 16 * (c & 7)) = R.x[j];
+    if (c < G::XH * G::XW * 8) *reinterpret_cast<uint4*>(sx + (c >> 3) * WG_PS + 16 * (c & 7)) = R.x[j];
   }
 }
 
+template <int S>
 __global__ __launch_bounds__(256, 2) void k_wgrad64(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, const uint8_t* __restrict__ mask,
-                                                    float* __restrict__ part, int B, int H, int W, int cin, int cout, int G) {
+                                                    float* __restrict__ part, int B, int H, int W, int Ho, int Wo, int cin, int cout, int G) {
+  using Geo = WgGeo<S>;
+  constexpr int TH = Geo::TH, XW = Geo::XW;
   extern __shared__ __align__(16) uint8_t s_tile[];  // X halo tile, the dY tile, the workgroup's list of non-empty tiles (no static LDS in front: the base stays 16-byte aligned)
   uint8_t* sx = s_tile;
-  uint8_t* sy = s_tile + WG_XBYTES;
-  int32_t* s_list = reinterpret_cast<int32_t*>(s_tile + WG_XBYTES + WG_YBYTES);   // [0] count, [1..] tiles in ascending order
-  uint32_t* s_rm = reinterpret_cast<uint32_t*>(s_list + WG_LIST_MAX + 8);         // two sets of 4 row masks (tile k uses set k & 1)
+  uint8_t* sy = s_tile + Geo::XBYTES;
+  int32_t* s_list = reinterpret_cast<int32_t*>(s_tile + Geo::XBYTES + Geo::YBYTES);   // [0] count, [1..] tiles in ascending order
+  uint32_t* s_rm = reinterpret_cast<uint32_t*>(s_list + WG_LIST_MAX + 8);              // two sets of 4 row masks (tile k uses set k & 1)
   const int t = threadIdx.x, l = t & 63, wv = t >> 6;
   const int nib = cin >> 6;
   const int pair = blockIdx.y, cb = pair / nib, ib = pair - cb * nib;  // 64-channel block of the outputs / of the inputs
   const int mb = wv & 1, nb = wv >> 1;                                 // this wave's 32-channel halves
   const int grp = l >> 4, i16 = l & 15;
-  // the lane's corner of the [4 pixels][16 channels] block its group hands to a transposing read: pixel 8 (grp >> 1) + i16 / 4, channels 4 (i16 % 4)..
+  // the lane's corner of the [4 pixels][16 channels] block its group hands to a transposing read: output pixel 8 (grp >> 1) + i16 / 4 of the
+  // 16-pixel piece (input pixel S times that), channels 4 (i16 % 4)..
   const int lane_px = 8 * (grp >> 1) + (i16 >> 2), lane_ch = 16 * (grp & 1) + 4 * (i16 & 3);
   const uint8_t* ay = sy + lane_px * WG_PS + (32 * mb + lane_ch) * 2;
-  const uint8_t* bx = sx + lane_px * WG_PS + (32 * nb + lane_ch) * 2;
+  const uint8_t* bx = sx + S * lane_px * WG_PS + (32 * nb + lane_ch) * 2;
   v16f acc[9];
 #pragma unroll
   for (int k = 0; k < 9; k++)
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[k][i] = 0.f;
-  const int tiles_x = (W + 31) >> 5, tiles_y = (H + WG_TH - 1) / WG_TH;
+  const int tiles_x = (Wo + 31) >> 5, tiles_y = (Ho + TH - 1) / TH;
   const int n_tiles = B * tiles_y * tiles_x;
   // ---- this workgroup's tiles (blockIdx.x, + G, ...) that hold an active output, in ascending order: one tile per thread and pass,
   // compacted with ballots (the order, and with it the fp32 sum, is fixed)
@@ -122,16 +140,16 @@ __global__ __launch_bounds__(256, 2) void k_wgrad64(const uint16_t* __restrict__
     bool any = false;
     if (tile < n_tiles) {
       const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-      const int x0 = tx << 5, y0 = ty * WG_TH;
-      const bool wide = (W & 15) == 0 && x0 + 32 <= W;
+      const int x0 = tx << 5, y0 = ty * TH;
+      const bool wide = (Wo & 15) == 0 && x0 + 32 <= Wo;
       uint32_t o = 0;
-      for (int r = 0; r < WG_TH && y0 + r < H; r++) {
-        const uint8_t* row = mask + ((int64_t)b * H + (y0 + r)) * W + x0;
+      for (int r = 0; r < TH && y0 + r < Ho; r++) {
+        const uint8_t* row = mask + ((int64_t)b * Ho + (y0 + r)) * Wo + x0;
         if (wide) {
           const uint4 a = reinterpret_cast<const uint4*>(row)[0], c = reinterpret_cast<const uint4*>(row)[1];
           o |= a.x | a.y | a.z | a.w | c.x | c.y | c.z | c.w;
         } else {
-          for (int k = 0; k < 32 && x0 + k < W; k++) o |= row[k];
+          for (int k = 0; k < 32 && x0 + k < Wo; k++) o |= row[k];
         }
       }
       any = o != 0;
@@ -152,21 +170,21 @@ __global__ __launch_bounds__(256, 2) void k_wgrad64(const uint16_t* __restrict__
   }
   const int n_mine = min(s_list[0], WG_LIST_MAX);
   // ---- software pipeline over the non-empty tiles: the operands of tile k + 1 travel HBM -> registers while the K steps of tile k run
-  TileRegs R;
-  if (n_mine > 0) tile_load(R, x, dy, mask, s_list[1], tiles_x, tiles_y, B, H, W, cin, cout, cb, ib, t);
+  TileRegs<S> R;
+  if (n_mine > 0) tile_load<S>(R, x, dy, mask, s_list[1], tiles_x, tiles_y, H, W, Ho, Wo, cin, cout, cb, ib, t);
   for (int k = 0; k < n_mine; k++) {
     uint32_t* rm = s_rm + 4 * (k & 1);
-    tile_store(R, sx, sy, rm, t);
+    tile_store<S>(R, sx, sy, rm, t);
     __syncthreads();
     if (t < 4) s_rm[4 * ((k + 1) & 1) + t] = 0u;  // the next tile's set: its writers come behind this iteration's last barrier
-    if (k + 1 < n_mine) tile_load(R, x, dy, mask, s_list[2 + k], tiles_x, tiles_y, B, H, W, cin, cout, cb, ib, t);
+    if (k + 1 < n_mine) tile_load<S>(R, x, dy, mask, s_list[2 + k], tiles_x, tiles_y, H, W, Ho, Wo, cin, cout, cb, ib, t);
 #pragma unroll 1
-    for (int ks = 0; ks < 2 * WG_TH; ks++) {  // rolled: unrolled, the 8 steps' 160 reads are hoisted and the accumulators spill
+    for (int ks = 0; ks < 2 * TH; ks++) {  // rolled: unrolled, the steps' reads are hoisted and the accumulators spill
       const int r = ks >> 1, hs = ks & 1;
       if (((rm[r] >> (16 * hs)) & 0xFFFFu) == 0u) continue;  // block-uniform: no active output among these 16 pixels
-      const bf16x8 a = tr_frag<0>(ay + (r * 32 + 16 * hs) * WG_PS);
-      const uint8_t* bb = bx + (r * WG_XW + 16 * hs) * WG_PS;
-#define PNX_WG_TAP(KY, KX) acc[(KY) * 3 + (KX)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tr_frag<((KY) * WG_XW + (KX)) * WG_PS>(bb), acc[(KY) * 3 + (KX)], 0, 0, 0);
+      const bf16x8 a = tr_frag<0, 4>(ay + (r * 32 + 16 * hs) * WG_PS);
+      const uint8_t* bb = bx + (S * r * XW + S * 16 * hs) * WG_PS;
+#define PNX_WG_TAP(KY, KX) acc[(KY) * 3 + (KX)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tr_frag<((KY) * XW + (KX)) * WG_PS, 4 * S>(bb), acc[(KY) * 3 + (KX)], 0, 0, 0);
       PNX_WG_TAP(0, 0) PNX_WG_TAP(0, 1) PNX_WG_TAP(0, 2) PNX_WG_TAP(1, 0) PNX_WG_TAP(1, 1) PNX_WG_TAP(1, 2) PNX_WG_TAP(2, 0) PNX_WG_TAP(2, 1) PNX_WG_TAP(2, 2)
 #undef PNX_WG_TAP
     }
@@ -246,30 +264,38 @@ extern "C" size_t pnx_conv3x3_wgrad_workspace_bytes(int32_t cin, int32_t cout) {
   return (size_t)(cin >> 6) * (cout >> 6) * groups_per_pair(cin, cout) * 9 * 4096 * sizeof(float) + 256;
 }
 
-extern "C" int pnx_conv3x3_wgrad_bf16(const void* x, const void* dy, const uint8_t* mask, float* dw, int32_t batch, int32_t h, int32_t w, int32_t cin,
-                                      int32_t cout, void* workspace, size_t workspace_bytes, pnx_stream_t stream) {
-  PNX_REQUIRE(x && dy && mask && dw && workspace && batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "pnx_conv3x3_wgrad_bf16: bad arguments");
-  PNX_REQUIRE(cin >= 64 && cout >= 64 && (cin & 63) == 0 && (cout & 63) == 0 && cin <= 512 && cout <= 512, PNX_ERR_UNSUPPORTED,
-              "weight gradient for %d -> %d channels (multiples of 64 up to 512)", cin, cout);
-  PNX_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)workspace) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
-  PNX_REQUIRE(workspace_bytes >= pnx_conv3x3_wgrad_workspace_bytes(cin, cout), PNX_ERR_WORKSPACE, "workspace too small");
-  PNX_REQUIRE((int64_t)batch * ((h + WG_TH - 1) / WG_TH) * ((w + 31) / 32) < 0x7fffffff, PNX_ERR_UNSUPPORTED, "too many tiles");
-  hipStream_t st = (hipStream_t)stream;
+template <int S>
+int launch_wgrad(const void* x, const void* dy, const uint8_t* mask, float* dw, int batch, int h, int w, int cin, int cout, void* workspace, hipStream_t st) {
+  using Geo = WgGeo<S>;
+  const int ho = (h - 1) / S + 1, wo = (w - 1) / S + 1;
   const int G = groups_per_pair(cin, cout), n_pairs = (cin >> 6) * (cout >> 6);
-  const int64_t n_tiles = (int64_t)batch * ((h + WG_TH - 1) / WG_TH) * ((w + 31) / 32);
-  PNX_REQUIRE((n_tiles + G - 1) / G <= WG_LIST_MAX, PNX_ERR_UNSUPPORTED, "%lld tiles over %d workgroups: more than %d per workgroup", (long long)n_tiles, G,
-              WG_LIST_MAX);
+  const int64_t n_tiles = (int64_t)batch * ((ho + Geo::TH - 1) / Geo::TH) * ((wo + 31) / 32);
+  PNX_REQUIRE(n_tiles < 0x7fffffff && (n_tiles + G - 1) / G <= WG_LIST_MAX, PNX_ERR_UNSUPPORTED, "%lld tiles over %d workgroups: more than %d per workgroup",
+              (long long)n_tiles, G, WG_LIST_MAX);
   static bool attr_done = false;
   if (!attr_done) {
-    PNX_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad64, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS));
+    PNX_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad64<S>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS));
     attr_done = true;
   }
-  k_wgrad64<<<dim3((unsigned)G, (unsigned)n_pairs), 256, WG_LDS, st>>>((const uint16_t*)x, (const uint16_t*)dy, mask, (float*)workspace, batch, h, w, cin,
-                                                                      cout, G);
+  k_wgrad64<S><<<dim3((unsigned)G, (unsigned)n_pairs), 256, Geo::LDS, st>>>((const uint16_t*)x, (const uint16_t*)dy, mask, (float*)workspace, batch, h, w, ho, wo,
+                                                                             cin, cout, G);
   PNX_LAUNCH_CHECK();
   k_wgrad_reduce<<<(unsigned)((n_pairs * 9 * 4096 + 31) / 32), 256, 0, st>>>((const float*)workspace, dw, cin, cout, G);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
+}
+
+extern "C" int pnx_conv3x3_wgrad_bf16(const void* x, const void* dy, const uint8_t* mask, float* dw, int32_t batch, int32_t h, int32_t w, int32_t cin,
+                                      int32_t cout, int32_t stride, void* workspace, size_t workspace_bytes, pnx_stream_t stream) {
+  PNX_REQUIRE(x && dy && mask && dw && workspace && batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "pnx_conv3x3_wgrad_bf16: bad arguments");
+  PNX_REQUIRE(stride == 1 || stride == 2, PNX_ERR_UNSUPPORTED, "stride %d", stride);
+  PNX_REQUIRE(cin >= 64 && cout >= 64 && (cin & 63) == 0 && (cout & 63) == 0 && cin <= 512 && cout <= 512, PNX_ERR_UNSUPPORTED,
+              "weight gradient for %d -> %d channels (multiples of 64 up to 512)", cin, cout);
+  PNX_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)workspace) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
+  PNX_REQUIRE(workspace_bytes >= pnx_conv3x3_wgrad_workspace_bytes(cin, cout), PNX_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1) return launch_wgrad<1>(x, dy, mask, dw, batch, h, w, cin, cout, workspace, st);
+  return launch_wgrad<2>(x, dy, mask, dw, batch, h, w, cin, cout, workspace, st);
 }
 
 extern "C" int pnx_conv3x3_pack_weights(const void* w, int32_t dtype, int32_t cout, int32_t cin, int32_t transposed, void* wfrag, pnx_stream_t stream) {

@@ -283,7 +283,7 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
                 gradient is zero outside mask_out (the BatchNorm node's backward writes zeros there), and what reaches an inactive input
                 site would be thrown away by that site's own mask; stride 2: MIOpen's dense dgrad
       wgrad     stride 1: pnx_conv3x3_wgrad_bf16 (csrc/conv_wgrad.hip) over the 16-pixel row pieces that hold an active output, fp32 accumulation,
-                deterministic; stride 2 (and PNX_TRAIN_HIPWGRAD=0): MIOpen's dense wrw on (x, g), exact because g is zero outside the active outputs
+                deterministic, stride 1 and 2 (PNX_TRAIN_HIPWGRAD=0: MIOpen's dense wrw on (x, g), exact because g is zero outside the active outputs)
     The fp32 training path (the reference's precision) stays on MIOpen: the kernels are bf16."""
 
     @staticmethod
@@ -315,7 +315,12 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
                     dw = torch.nn.grad.conv2d_weight(x, weight.shape, g, stride=1, padding=1)
         else:
             s = ctx.stride
-            dx, dw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, (s, s), (1, 1), (1, 1), False, (0, 0), 1, (need_x, need_w, False))
+            hip_w = need_w and os.environ.get("PNX_TRAIN_HIPWGRAD", "1") != "0"
+            if hip_w:
+                dw = ops.conv3x3_wgrad(x, g, mask_out, stride=s).to(weight.dtype)
+            if need_x or (need_w and not hip_w):
+                dx, dw2, _ = torch.ops.aten.convolution_backward(g, x, weight, None, (s, s), (1, 1), (1, 1), False, (0, 0), 1, (need_x, need_w and not hip_w, False))
+                dw = dw if hip_w else dw2
         return dx, dw, None, None, None
 
 

@@ -323,16 +323,17 @@ def sephead_lazy(tasks, class_task, batch, local, seg_len, pre_max):
 _WGRAD_WS = {}
 
 
-def conv3x3_wgrad(x, dy, mask):
-    """Weight gradient (Cout, Cin, 3, 3) fp32 of the masked stride-1 3x3 convolution: sum over the sites of `mask` (B,H,W uint8, the OUTPUT's
-    active set) of dy[p] (x) x[p + tap]; x, dy channels_last bf16 (csrc/conv_wgrad.hip).  Deterministic."""
+def conv3x3_wgrad(x, dy, mask, stride=1):
+    """Weight gradient (Cout, Cin, 3, 3) fp32 of the masked 3x3 convolution (pad 1, stride 1 or 2): sum over the sites of `mask` (B,Ho,Wo uint8,
+    the OUTPUT's active set) of dy[p] (x) x[stride * p + tap]; x, dy channels_last bf16 (csrc/conv_wgrad.hip).  Deterministic."""
     for tns, what in ((x, "x"), (dy, "dy")):
         if not (tns.is_cuda and tns.dtype == torch.bfloat16 and tns.dim() == 4 and tns.is_contiguous(memory_format=torch.channels_last)):
             raise PnxError(f"conv3x3_wgrad: {what} must be a channels_last bf16 CUDA tensor")
     B, ci, H, W = x.shape
     co = dy.shape[1]
-    if tuple(dy.shape) != (B, co, H, W) or tuple(mask.shape) != (B, H, W) or mask.dtype != torch.uint8:
-        raise PnxError("conv3x3_wgrad: dy (B,Cout,H,W) and a uint8 (B,H,W) mask of the output sites")
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if stride not in (1, 2) or tuple(dy.shape) != (B, co, Ho, Wo) or tuple(mask.shape) != (B, Ho, Wo) or mask.dtype != torch.uint8:
+        raise PnxError("conv3x3_wgrad: stride 1 or 2, dy (B,Cout,Ho,Wo) and a uint8 (B,Ho,Wo) mask of the output sites")
     nbytes = int(lib().pnx_conv3x3_wgrad_workspace_bytes(ci, co))
     if nbytes == 0:
         raise PnxError(f"conv3x3_wgrad: no kernel for {ci} -> {co} channels")
@@ -341,7 +342,7 @@ def conv3x3_wgrad(x, dy, mask):
     if ws is None:
         ws = _WGRAD_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=x.device)
-    check(lib().pnx_conv3x3_wgrad_bf16(ptr(x), ptr(dy), ptr(mask), ptr(dw), B, H, W, ci, co, ptr(ws), ws.numel(), stream_ptr()), "pnx_conv3x3_wgrad_bf16")
+    check(lib().pnx_conv3x3_wgrad_bf16(ptr(x), ptr(dy), ptr(mask), ptr(dw), B, H, W, ci, co, stride, ptr(ws), ws.numel(), stream_ptr()), "pnx_conv3x3_wgrad_bf16")
     return dw
 
 

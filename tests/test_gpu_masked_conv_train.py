@@ -76,28 +76,33 @@ def test_masked_conv_falls_back_outside_bf16_training():
     assert y.dtype == torch.float32 and not type(y.grad_fn).__name__.startswith("_MaskedConv3x3Fn")
 
 
-@pytest.mark.parametrize("cin,cout,shape,p", [(64, 64, (2, 70, 97), 0.12), (64, 64, (1, 33, 31), 0.5), (128, 128, (2, 41, 70), 0.12), (256, 256, (2, 23, 33), 0.2),
-                                              (64, 128, (1, 19, 40), 0.3)])
-def test_wgrad_kernel_matches_fp32_conv2d_weight(cin, cout, shape, p):
+@pytest.mark.parametrize("cin,cout,shape,p,stride", [(64, 64, (2, 70, 97), 0.12, 1), (64, 64, (1, 33, 31), 0.5, 1), (128, 128, (2, 41, 70), 0.12, 1),
+                                                     (256, 256, (2, 23, 33), 0.2, 1), (64, 128, (1, 19, 40), 0.3, 1), (64, 128, (2, 50, 66), 0.12, 2),
+                                                     (128, 256, (1, 37, 41), 0.3, 2), (256, 256, (2, 24, 64), 0.2, 2), (64, 64, (1, 9, 131), 0.4, 2)])
+def test_wgrad_kernel_matches_fp32_conv2d_weight(cin, cout, shape, p, stride):
     """pnx_conv3x3_wgrad_bf16 (csrc/conv_wgrad.hip: K = pixels through the transposing LDS read, fp32 accumulation, fixed-order reduction)
     against torch.nn.grad.conv2d_weight in fp32 on the same bf16 operands; bit-identical from call to call; an upstream gradient that is
     NOT zero outside the mask must not contribute (the kernel applies the mask itself)."""
     from pillarnext_amd import ops
 
+    import torch.nn.functional as F
+
     B, H, W = shape
     gen = torch.Generator(device="cuda").manual_seed(cin * 3 + cout + H)
-    m = _lidar_mask(B, H, W, gen, p)
-    x = (torch.randn((B, cin, H, W), device="cuda", generator=gen) * m).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    g_all = torch.randn((B, cout, H, W), device="cuda", generator=gen).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    m_in = _lidar_mask(B, H, W, gen, p)
+    m = m_in if stride == 1 else F.max_pool2d(m_in, 3, stride, 1)          # SparseConv2d: the output set is the pooled input set
+    Ho, Wo = m.shape[2:]
+    x = (torch.randn((B, cin, H, W), device="cuda", generator=gen) * m_in).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    g_all = torch.randn((B, cout, Ho, Wo), device="cuda", generator=gen).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     mu8 = (m[:, 0] != 0).to(torch.uint8).contiguous()
-    dw = ops.conv3x3_wgrad(x, g_all, mu8)
-    ref = torch.nn.grad.conv2d_weight(x.float().contiguous(), (cout, cin, 3, 3), (g_all.float() * m).contiguous(), stride=1, padding=1)
+    dw = ops.conv3x3_wgrad(x, g_all, mu8, stride=stride)
+    ref = torch.nn.grad.conv2d_weight(x.float().contiguous(), (cout, cin, 3, 3), (g_all.float() * m).contiguous(), stride=stride, padding=1)
     scale = float(ref.abs().max())
     assert dw.shape == ref.shape and dw.dtype == torch.float32
     assert float((dw - ref).abs().max()) <= 2e-4 * scale, float((dw - ref).abs().max()) / scale
-    assert torch.equal(dw, ops.conv3x3_wgrad(x, g_all, mu8))
+    assert torch.equal(dw, ops.conv3x3_wgrad(x, g_all, mu8, stride=stride))
     empty = torch.zeros_like(mu8)
-    assert float(ops.conv3x3_wgrad(x, g_all, empty).abs().max()) == 0.0
+    assert float(ops.conv3x3_wgrad(x, g_all, empty, stride=stride).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("co,ci", [(64, 64), (128, 64), (256, 256), (320, 64)])

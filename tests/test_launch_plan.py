@@ -81,5 +81,5 @@ def test_training_entry_points_validate_before_launching():
     assert L.pnx_conv3x3_wgrad_workspace_bytes(64, 64) == 512 * 9 * 4096 * 4 + 256          # 512 workgroups x one 64 x 64 x 9 fp32 partial
     assert L.pnx_conv3x3_wgrad_workspace_bytes(256, 256) == 16 * 32 * 9 * 4096 * 4 + 256      # 16 block pairs x 32 workgroups
     assert L.pnx_conv3x3_wgrad_workspace_bytes(48, 64) == 0 and L.pnx_conv3x3_wgrad_workspace_bytes(64, 100) == 0
-    assert L.pnx_conv3x3_wgrad_bf16(None, None, None, None, 1, 8, 8, 64, 64, None, 0, None) < 0
+    assert L.pnx_conv3x3_wgrad_bf16(None, None, None, None, 1, 8, 8, 64, 64, 1, None, 0, None) < 0
     assert L.pnx_conv3x3_pack_weights(None, 0, 64, 64, 0, None, None) < 0
