@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--amp", action="store_true", help="bf16 autocast + channels_last for the dense backbone / neck / head")
     ap.add_argument("--nhwc", action="store_true", help="channels_last without autocast (fp32): the fused masked-BatchNorm kernels need NHWC maps")
     ap.add_argument("--total-steps", type=int, default=1000, help="length of the OneCycle schedule the steps are taken from")
-    ap.add_argument("--find", action="store_true", help="let MIOpen time its solvers per conv problem (cudnn.benchmark): ~2 minutes in step 0, a ~10 % faster step")
+    ap.add_argument("--find", action="store_true", help="let MIOpen time its solvers per conv problem (cudnn.benchmark): ~2 minutes in step 0, a step about a tenth faster")
     ap.add_argument("--yaml", default="", help="build the detector from this YAML (configs/pillarnext_b_waymo.yaml) instead of the nuScenes PillarNeXt-B")
     a = ap.parse_args()
     torch.backends.cudnn.benchmark = bool(a.find)
