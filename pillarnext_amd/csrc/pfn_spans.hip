@@ -861,7 +861,8 @@ template <int F>
 int launch_spans(const SpanPfnArgs& A0, const Pfn3Out& out, const PnxGeomDev& g, int64_t n, hipStream_t st) {
   SpanPfnArgs A = A0;
   const bool pack = out.g1 == nullptr && out.canvas != nullptr && out.dt != PNX_F32;
-  // two workgroups per CU: 160 KiB / 2 minus a margin for the static arrays and for the zero-fill workgroup that shares the CU
+  // two workgroups per CU: 160 KiB / 2 minus room for the zero-fill workgroup that shares the CU -- LDS is handed out in 1280-byte granules:
+  // 2 x 63 granules (80 000 B) + 1 for the fill = 127 of 128; at 81 000 B (2 x 64) the fill no longer fits and the reader takes 840 instead of 620 us
   const char* l_env = getenv("PNX_BINS_LDS");
   const size_t budget = l_env ? (size_t)atoi(l_env) : 80000;
   const size_t fixed = span_pfn_lds_bytes(0, pack, A.sg.B);

@@ -47,6 +47,8 @@ VARIANTS = [
     ("spans seg96", {"PNX_BINS_CAP": "96"}),
     ("spans unfilled (timing only)", {"PNX_FILL_BLOCKS": "0"}),
     ("spans lds78000", {"PNX_BINS_LDS": "78000"}),
+    ("spans lds81000", {"PNX_BINS_LDS": "81000"}),
+    ("spans lds81400", {"PNX_BINS_LDS": "81400"}),
     ("spans fill nt off", {"PNX_FILL_NT": "0"}),
     ("binned", {"PNX_READER_IMPL": "2"}),
     ("binned split 10,10", {"PNX_READER_IMPL": "2", "PNX_FILL_SPLIT": "10,10,0"}),
