@@ -196,6 +196,8 @@ int pnx_sum_bias_act(const void* const* srcs, int32_t n_src, const float* bias, 
  * [ky*2+kx][cin/16][cout/32][lane][8] (pillarnext_amd/ops.py::deconv2x2_pack_weights); bias fp32[cout].  Kernels: 64 -> 64. */
 int pnx_deconv2x2_bf16(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
                        int32_t relu, pnx_stream_t stream);
+int pnx_deconv2x2_f16(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                       int32_t relu, pnx_stream_t stream); /* IEEE-half twin */
 /* Masked 3x3 convolution (pad 1, stride 1 or 2) with the same epilogue fused, bf16 NHWC, fp32 accumulation on MFMA:
  *   y = mask_out * [relu]( conv3x3(x, W) + bias [+ residual] ),  rows/tiles of the output without an active site are skipped.
  *   x (B,h,w,cin), y/residual (B,ho,wo,cout), mask uint8 (B,ho,wo) or NULL; wfrag = weights in MFMA-fragment order
@@ -207,6 +209,11 @@ int pnx_deconv2x2_bf16(const void* x, const void* wfrag, const float* bias, void
 int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, uint8_t* row_dirty, const int32_t* tile_list,
                      const int32_t* tile_count, pnx_stream_t stream);
+/* The same kernels on IEEE half (fp16 activations and wfrag; BASELINE configs[4], waymo_det_pp18_aspp_iou_car_sp.yaml in fp16): identical
+ * arguments and fp32 accumulation; only the MFMA opcode and the rounding of the stored result differ. */
+int pnx_conv3x3_f16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
+                    int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, uint8_t* row_dirty, const int32_t* tile_list,
+                    const int32_t* tile_count, pnx_stream_t stream);
 /* Weight gradient of the masked stride-1 3x3 convolution (training; det3d/models/utils/sparse_conv.py:16-63 under autograd: spconv accumulates
  * over the active output sites):  dw[co][ci][ky][kx] = sum over the sites p with mask[p] != 0 of dy[p][co] * x[stride*p + (ky-1, kx-1)][ci]
  *   stride 1 or 2 (pad 1); x (B,h,w,cin), dy (B,ho,wo,cout) bf16 NHWC with ho = (h-1)/stride + 1 (x zero at inactive sites, as every map of the masked-dense stand-in is), mask uint8 (B,ho,wo) of the
@@ -235,6 +242,8 @@ int pnx_conv_tile_list(const uint8_t* mask, const uint8_t* const* row_dirty, int
  * (1/2: the dense [iou] hm branches of the lazy head). */
 int pnx_sephead_out_bf16(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t n_branch,
                          pnx_stream_t stream);
+int pnx_sephead_out_f16(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t n_branch,
+                         pnx_stream_t stream); /* IEEE-half twin */
 /* Lazy SepHead: the five regression branches of every task (reg 2, height 1, dim 3, rot 2, vel 2: centerhead.py:12-59, conv3x3 64->64 + BN + ReLU,
  * then conv3x3 64->k) evaluated only at the candidate cells CenterHead.post_processing keeps (centerhead.py:341-363) instead of over the map, all
  * tasks in one launch.  Candidate lists: batch*nc_total lists (list s = sample s / nc_total, class s % nc_total, task class_task[class]) of pre_max
@@ -253,6 +262,8 @@ typedef struct {
 } PnxLazyTask;
 int pnx_sephead_lazy_bf16(const PnxLazyTask* tasks, int32_t n_tasks, const int32_t* class_task, int32_t nc_total, int32_t batch, const int64_t* local,
                           const int32_t* seg_len, int32_t pre_max, float* out, pnx_stream_t stream);
+int pnx_sephead_lazy_f16(const PnxLazyTask* tasks, int32_t n_tasks, const int32_t* class_task, int32_t nc_total, int32_t batch, const int64_t* local,
+                          const int32_t* seg_len, int32_t pre_max, float* out, pnx_stream_t stream); /* IEEE-half twin */
 /* Active-site rule of SparseConv2d(k=3, stride, pad=1): mask_out = maxpool3x3(mask_in, stride, 1); uint8 (B,h,w) -> (B,ho,wo). */
 int pnx_mask_pool3(const uint8_t* mask_in, int32_t batch, int32_t h, int32_t w, int32_t stride, uint8_t* mask_out, pnx_stream_t stream);
 
@@ -397,9 +408,11 @@ int pnx_center_loss_backward(const void* const* maps7, void* const* grads7, cons
  *   PNX_OP_MASK_POOL3   pnx_mask_pool3        p: mask_in, mask_out                     i: batch, h, w, stride
  *   PNX_OP_TILE_LIST    pnx_conv_tile_list    p: mask, tile_list, tile_count, row_dirty[0..n_dirty)   i: n_dirty (<= 8), batch, h, w, tile_rows
  *   PNX_OP_CONV3X3      pnx_conv3x3_bf16      p: x, wfrag, bias, residual, mask, y, row_dirty, tile_list, tile_count
- *                                             i: batch, h, w, cin, cout, stride, relu
- *   PNX_OP_DECONV2X2    pnx_deconv2x2_bf16    p: x, wfrag, bias, y                     i: batch, h, w, cin, cout, relu
- *   PNX_OP_SEPHEAD_OUT  pnx_sephead_out_bf16  p: x, wfrag, bias, y                     i: batch, h, w, n_branch
+ *                                             i: batch, h, w, cin, cout, stride, relu, dtype
+ *   PNX_OP_DECONV2X2    pnx_deconv2x2_bf16    p: x, wfrag, bias, y                     i: batch, h, w, cin, cout, relu, dtype
+ *   PNX_OP_SEPHEAD_OUT  pnx_sephead_out_bf16  p: x, wfrag, bias, y                     i: batch, h, w, n_branch, dtype
+ * dtype (the last integer of the three convolution entries): PNX_F16 selects the pnx_*_f16 twin, anything else (0 in tables built before the
+ * twins existed) the bf16 entry point.
  * The table is HOST memory and is read during the call only.  On failure the status of the failing entry is returned and pnx_last_error()
  * names its index. */
 enum { PNX_OP_MASK_POOL3 = 1, PNX_OP_TILE_LIST = 2, PNX_OP_CONV3X3 = 3, PNX_OP_DECONV2X2 = 4, PNX_OP_SEPHEAD_OUT = 5 };

@@ -53,14 +53,18 @@ PROTOTYPES = {
     "pnx_bias_act_mask": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "pnx_sum_bias_act": (ctypes.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "pnx_deconv2x2_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pnx_deconv2x2_f16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pnx_sephead_out_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pnx_sephead_out_f16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pnx_masked_bn_blocks": (_i32, []),
     "pnx_masked_bn_stats": (ctypes.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     "pnx_masked_bn_apply": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp]),
     "pnx_masked_bn_bwd_stats": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "pnx_masked_bn_bwd_apply": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pnx_sephead_lazy_bf16": (ctypes.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "pnx_sephead_lazy_f16": (ctypes.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "pnx_conv3x3_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pnx_conv3x3_f16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pnx_conv3x3_tile_rows": (ctypes.c_int, [_i32, _i32, _i32]),
     "pnx_conv3x3_pack_weights": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pnx_conv3x3_wgrad_workspace_bytes": (_sz, [_i32, _i32]),

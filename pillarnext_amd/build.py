@@ -31,8 +31,9 @@ def build(force=False, verbose=False):
         return LIB
     objs = []
     procs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + (os.environ.get("PNX_OBJ_SUFFIX") or "") + ".o")
+    # conv3x3.hip is compiled twice: bf16 (as is) and IEEE half (-DPNX_CONV_F16 -> the pnx_*_f16 entry points)
+    for src, variant in [(s, "") for s in SOURCES] + [("conv3x3.hip", "_f16")]:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + variant + (os.environ.get("PNX_OBJ_SUFFIX") or "") + ".o")
         extra = []
         if src in ("pfn_v3.hip", "pfn_spans.hip"):  # fmaxf without canonicalising v_max pairs (-inf still honoured); MFMA accumulators in VGPRs (no v_accvgpr traffic)
             extra = ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + (["-DPNX_PFN_TIMERS"] if os.environ.get("PNX_PFN_TIMERS") else []) + (["-DPNX_BINS_TIMERS"] if os.environ.get("PNX_BINS_TIMERS") else [])
@@ -41,11 +42,11 @@ def build(force=False, verbose=False):
         elif src == "chunk_sort.hip":
             extra = ["-DPNX_BINS_TIMERS"] if os.environ.get("PNX_BINS_TIMERS") else []
         elif src == "conv3x3.hip":
-            extra = ["-fno-honor-nans"] + (["-DPNX_CONV_TIMERS"] if os.environ.get("PNX_CONV_TIMERS") else [])
+            extra = ["-fno-honor-nans"] + (["-DPNX_CONV_TIMERS"] if os.environ.get("PNX_CONV_TIMERS") else []) + (["-DPNX_CONV_F16"] if variant else [])
         cmd = [_hipcc()] + FLAGS + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        procs.append((src + variant, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:
         out, _ = p.communicate()

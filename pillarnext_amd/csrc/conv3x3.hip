@@ -20,11 +20,38 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float bf2f_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf2f_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+// Element type of activations and weights.  This file is compiled TWICE (pillarnext_amd/build.py): as is for bf16 (entry points pnx_*_bf16,
+// plus the type-independent tile-list helpers) and with -DPNX_CONV_F16 for IEEE half (pnx_*_f16: BASELINE configs[4], the fp16 Waymo network).
+// Everything between the loads and the stores is fp32 either way; the type shows in exactly four places: the MFMA opcode, the pack of the
+// epilogue (round to nearest even), the widening of the residual, and the rounding of the lazy head's intermediate.
+#ifdef PNX_CONV_F16
+typedef _Float16 el8 __attribute__((ext_vector_type(8)));
+typedef _Float16 el2 __attribute__((ext_vector_type(2)));
+#define PNX_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define PNX_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define PNX_CONV_FN(name) name##_f16
+// fp32 bit patterns of the low / high element of a packed pair
+__device__ __forceinline__ uint32_t el_lo_bits(uint32_t w) { return __float_as_uint((float)__builtin_bit_cast(el2, w)[0]); }
+__device__ __forceinline__ uint32_t el_hi_bits(uint32_t w) { return __float_as_uint((float)__builtin_bit_cast(el2, w)[1]); }
+#else
+typedef __bf16 el8 __attribute__((ext_vector_type(8)));
+typedef __bf16 el2 __attribute__((ext_vector_type(2)));
+#define PNX_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define PNX_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define PNX_CONV_FN(name) name##_bf16
+__device__ __forceinline__ uint32_t el_lo_bits(uint32_t w) { return w << 16; }
+__device__ __forceinline__ uint32_t el_hi_bits(uint32_t w) { return w & 0xffff0000u; }
+#endif
+// two fp32 -> one packed pair, round to nearest even (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32: one instruction per channel pair)
+__device__ __forceinline__ uint32_t pack_el(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, el2));
+}
+// x rounded to the element type and back (what a value becomes when it goes through a stored intermediate)
+__device__ __forceinline__ float round_el(float x) { return __uint_as_float(el_lo_bits(pack_el(x, 0.f))); }
 
 // Epilogue.  The MFMA leaves lane (px, kb) with channels {8g + 4kb + i} of pixel px: four 8-byte pieces per 32-channel tile,
 // i.e. 32 scattered 8-byte stores per row of 32 pixels.  Measured, that store pattern -- not the MFMAs -- bounded the kernel
@@ -38,12 +65,6 @@ __device__ __forceinline__ float bf2f_hi(uint32_t w) { return __uint_as_float(w 
 //      store d of lane L is chunk L&7 of pixel 8d + (L>>3): every store instruction writes 8 complete 128-byte lines.
 // Both must be called by all 64 lanes.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-  const f32x2 v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
 __device__ __forceinline__ void pack_tile(const v16f& a, bool act, int relu, uint4 (&out)[2]) {
 #pragma unroll
   for (int t = 0; t < 2; t++) {
@@ -58,11 +79,11 @@ __device__ __forceinline__ void pack_tile(const v16f& a, bool act, int relu, uin
 #pragma unroll
       for (int i = 0; i < 8; i++) v[i] = fmaxf(v[i], 0.f);
     }
-    uint4 p;  // v_cvt_pk_bf16_f32: round-to-nearest-even, one instruction per channel pair
-    p.x = pack_bf16(v[0], v[1]);
-    p.y = pack_bf16(v[2], v[3]);
-    p.z = pack_bf16(v[4], v[5]);
-    p.w = pack_bf16(v[6], v[7]);
+    uint4 p;
+    p.x = pack_el(v[0], v[1]);
+    p.y = pack_el(v[2], v[3]);
+    p.z = pack_el(v[4], v[5]);
+    p.w = pack_el(v[6], v[7]);
     if (!act) p = make_uint4(0, 0, 0, 0);
     out[t] = p;
   }
@@ -143,8 +164,8 @@ __device__ __forceinline__ void add_residual(v16f (&acc2)[2], const uint4 (&rq)[
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       const uint4 r = rq[m][t];
-      const uint32_t lo[4] = {r.x << 16, r.x & 0xffff0000u, r.y << 16, r.y & 0xffff0000u};
-      const uint32_t hi[4] = {r.z << 16, r.z & 0xffff0000u, r.w << 16, r.w & 0xffff0000u};
+      const uint32_t lo[4] = {el_lo_bits(r.x), el_hi_bits(r.x), el_lo_bits(r.y), el_hi_bits(r.y)};
+      const uint32_t hi[4] = {el_lo_bits(r.z), el_hi_bits(r.z), el_lo_bits(r.w), el_hi_bits(r.w)};
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const u32x2 q = __builtin_amdgcn_permlane32_swap(lo[i], hi[i], false, false);
@@ -240,20 +261,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const uint16_t* __restrict__
 #pragma unroll
         for (int cb = 0; cb < CB; cb++) {
           const int ks = tap * CB + cb;
-          bf16x8 af[MT];
+          el8 af[MT];
 #pragma unroll
           for (int m = 0; m < MT; m++) {
             const uint4 wq = W_LDS ? s_w[(ks * MT + m) * 64 + lane] : wfrag[(ks * MT + m) * 64 + lane];
-            af[m] = __builtin_bit_cast(bf16x8, wq);
+            af[m] = __builtin_bit_cast(el8, wq);
           }
 #pragma unroll
           for (int j = 0; j < NT; j++) {
             if (!any_row[j]) continue;  // wave-uniform
             uint4 q = make_uint4(0, 0, 0, 0);
             if (ok[j]) q = *reinterpret_cast<const uint4*>(src[j] + cb * 16);
-            const bf16x8 bfr = __builtin_bit_cast(bf16x8, q);
+            const el8 bfr = __builtin_bit_cast(el8, q);
 #pragma unroll
-            for (int m = 0; m < MT; m++) acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr, acc[j][m], 0, 0, 0);
+            for (int m = 0; m < MT; m++) acc[j][m] = PNX_MFMA32(af[m], bfr, acc[j][m]);
           }
         }
       }
@@ -452,10 +473,10 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __res
       }
 #pragma unroll
       for (int j = 0; j < NR; j++) {
-        const bf16x8 bfr = __builtin_bit_cast(bf16x8, qc[j]);
+        const el8 bfr = __builtin_bit_cast(el8, qc[j]);
 #pragma unroll
         for (int m = 0; m < 2; m++)
-          acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[cbl][m]), bfr, acc[j][m], 0, 0, 0);
+          acc[j][m] = PNX_MFMA32(__builtin_bit_cast(el8, w[cbl][m]), bfr, acc[j][m]);
       }
       if (tap < 8) {
 #pragma unroll
@@ -1072,9 +1093,9 @@ __global__ __launch_bounds__(256, 2) void k_deconv2x2_64(const uint16_t* __restr
       v16f acc[2] = {bq[0], bq[1]};
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
-        const bf16x8 bfr = __builtin_bit_cast(bf16x8, q[ks]);
+        const el8 bfr = __builtin_bit_cast(el8, q[ks]);
 #pragma unroll
-        for (int m = 0; m < 2; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[p][ks][m]), bfr, acc[m], 0, 0, 0);
+        for (int m = 0; m < 2; m++) acc[m] = PNX_MFMA32(__builtin_bit_cast(el8, w[p][ks][m]), bfr, acc[m]);
       }
       uint4 D[4];
 #pragma unroll
@@ -1144,8 +1165,7 @@ __global__ __launch_bounds__(256) void k_sephead_out(const uint16_t* __restrict_
           for (int r = 0; r < RW; r++)
 #pragma unroll
             for (int h = 0; h < 2; h++)
-              acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[kc]), __builtin_bit_cast(bf16x8, bf[r][h]), acc[r][h], 0,
-                                                                  0, 0);
+              acc[r][h] = PNX_MFMA16(__builtin_bit_cast(el8, wc[kc]), __builtin_bit_cast(el8, bf[r][h]), acc[r][h]);
         }
       }
     }
@@ -1156,8 +1176,8 @@ __global__ __launch_bounds__(256) void k_sephead_out(const uint16_t* __restrict_
         const int oy = y0 + wv * RW + r, ox = x0 + 16 * h + n;
         if (oy < H && ox < W) {
           uint2 p;
-          p.x = pack_bf16(acc[r][h][0], acc[r][h][1]);
-          p.y = pack_bf16(acc[r][h][2], acc[r][h][3]);
+          p.x = pack_el(acc[r][h][0], acc[r][h][1]);
+          p.y = pack_el(acc[r][h][2], acc[r][h][3]);
           *reinterpret_cast<uint2*>(y + (((int64_t)b * H + oy) * W + ox) * 16 + 4 * q) = p;
         }
       }
@@ -1281,7 +1301,7 @@ int launch(const void* x, const void* wfrag, const float* bias, const void* res,
 
 extern "C" {
 
-#ifdef PNX_CONV_TIMERS
+#if defined(PNX_CONV_TIMERS) && !defined(PNX_CONV_F16)
 int pnx_debug_conv_timers(unsigned long long* out) {  // sums over waves of s_memtime ticks per section; resets the counters
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   PNX_CHECK_HIP(hipDeviceSynchronize());
@@ -1291,7 +1311,7 @@ int pnx_debug_conv_timers(unsigned long long* out) {  // sums over waves of s_me
 }
 #endif
 
-int pnx_sephead_out_bf16(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t n_branch,
+int PNX_CONV_FN(pnx_sephead_out)(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t n_branch,
                          pnx_stream_t stream) {
   PNX_REQUIRE(x && wfrag && bias && y && batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "bad arguments");
   PNX_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)wfrag | (uintptr_t)bias) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
@@ -1304,16 +1324,16 @@ int pnx_sephead_out_bf16(const void* x, const void* wfrag, const float* bias, vo
     case 7: return launch_sephead<7>(x, wfrag, bias, y, batch, h, w, st);
     default: break;
   }
-  pnx_set_error("pnx_sephead_out_bf16: no kernel for %d branches", n_branch);
+  pnx_set_error("pnx_sephead_out: no kernel for %d branches", n_branch);
   return PNX_ERR_UNSUPPORTED;
 }
 
-int pnx_deconv2x2_bf16(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+int PNX_CONV_FN(pnx_deconv2x2)(const void* x, const void* wfrag, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
                        int32_t relu, pnx_stream_t stream) {
   PNX_REQUIRE(x && wfrag && bias && y && batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "bad arguments");
   PNX_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)wfrag | (uintptr_t)bias) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
   if (cin != 64 || cout != 64) {
-    pnx_set_error("pnx_deconv2x2_bf16: no kernel for %d -> %d channels", cin, cout);
+    pnx_set_error("pnx_deconv2x2: no kernel for %d -> %d channels", cin, cout);
     return PNX_ERR_UNSUPPORTED;
   }
   const int64_t n_seg = (int64_t)batch * h * ((w + 31) / 32);
@@ -1324,6 +1344,7 @@ int pnx_deconv2x2_bf16(const void* x, const void* wfrag, const float* bias, void
   return PNX_OK;
 }
 
+#ifndef PNX_CONV_F16  // type-independent helpers: in the bf16 object only
 int pnx_conv3x3_tile_rows(int32_t cin, int32_t cout, int32_t stride) {
   if (stride != 1) return 0;
   if (cin == 64 && (cout == 64 || cout == 320 || cout == 384 || cout == 448)) return LDS_TH;
@@ -1345,7 +1366,9 @@ int pnx_conv_tile_list(const uint8_t* mask, const uint8_t* const* row_dirty, int
   return PNX_OK;
 }
 
-int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
+#endif
+
+int PNX_CONV_FN(pnx_conv3x3)(const void* x, const void* wfrag, const float* bias, const void* residual, const uint8_t* mask, void* y, int32_t batch,
                      int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, int32_t relu, uint8_t* row_dirty, const int32_t* tile_list,
                      const int32_t* tile_count, pnx_stream_t stream) {
   PNX_REQUIRE((tile_list == nullptr) == (tile_count == nullptr), PNX_ERR_INVALID, "tile_list and tile_count come together");
@@ -1381,7 +1404,7 @@ int pnx_conv3x3_bf16(const void* x, const void* wfrag, const float* bias, const 
   PNX_CONV_CASE(64, 128)
   PNX_CONV_CASE(128, 128)
 #undef PNX_CONV_CASE
-  pnx_set_error("pnx_conv3x3_bf16: no kernel for %d -> %d channels", cin, cout);
+  pnx_set_error("pnx_conv3x3: no kernel for %d -> %d channels", cin, cout);
   return PNX_ERR_UNSUPPORTED;
 }
 
@@ -1529,7 +1552,7 @@ __global__ __launch_bounds__(512) void k_sephead_lazy(const LazyArgs A, const in
           for (int j = 0; j < 3; j++) {
             const int cw = cwj[j];
             const uint4 bq4 = s_patch[pb[j] + cw * 8 + ((ks * 2 + kb) ^ (cw & 7))];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[tap][ks]), __builtin_bit_cast(bf16x8, bq4), acc[j], 0, 0, 0);
+            acc[j] = PNX_MFMA32(__builtin_bit_cast(el8, wq[tap][ks]), __builtin_bit_cast(el8, bq4), acc[j]);
           }
         }
         __builtin_amdgcn_sched_barrier(0);  // keeps the fragment loads where they are: kLzAhead taps ahead, not all at the top (registers)
@@ -1541,7 +1564,7 @@ __global__ __launch_bounds__(512) void k_sephead_lazy(const LazyArgs A, const in
         const float* w2p = s_w2 + ((mt * 9 + posv[j]) * 32 + 4 * kb) * 3;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-          const float tv = inside[j] ? bf2f_lo(pack_bf16(fmaxf(acc[j][i], 0.f), 0.f)) : 0.f;
+          const float tv = inside[j] ? round_el(fmaxf(acc[j][i], 0.f)) : 0.f;
           const float* w = w2p + (8 * (i >> 2) + (i & 3)) * 3;
           ps[j][0] = __builtin_fmaf(tv, w[0], ps[j][0]);
           ps[j][1] = __builtin_fmaf(tv, w[1], ps[j][1]);
@@ -1572,7 +1595,7 @@ __global__ __launch_bounds__(512) void k_sephead_lazy(const LazyArgs A, const in
     if (s_cell[cand] >= 0) {
       s = T.b2[o];
       for (int pos = 0; pos < 9; pos++) s += s_part[((cand * 9 + pos) * 5 + br) * 3 + q];
-      s = bf2f_lo(pack_bf16(s, 0.f));
+      s = round_el(s);
     }
     outp[e] = s;
   }
@@ -1585,7 +1608,7 @@ static_assert(kLzLds <= 160 * 1024, "k_sephead_lazy: LDS budget");
 
 }  // namespace
 
-extern "C" int pnx_sephead_lazy_bf16(const PnxLazyTask* tasks, int32_t n_tasks, const int32_t* class_task, int32_t nc_total, int32_t batch,
+extern "C" int PNX_CONV_FN(pnx_sephead_lazy)(const PnxLazyTask* tasks, int32_t n_tasks, const int32_t* class_task, int32_t nc_total, int32_t batch,
                                      const int64_t* local, const int32_t* seg_len, int32_t pre_max, float* out, pnx_stream_t stream) {
   PNX_REQUIRE(tasks && class_task && local && seg_len && out && batch > 0 && pre_max > 0, PNX_ERR_INVALID, "bad arguments");
   PNX_REQUIRE(n_tasks >= 1 && n_tasks <= kLzMaxTasks && nc_total >= 1 && nc_total <= kLzMaxClasses, PNX_ERR_UNSUPPORTED, "at most 8 tasks / 32 classes");

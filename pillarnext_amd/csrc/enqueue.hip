@@ -31,12 +31,12 @@ int run_op(const pnx_op& o, hipStream_t st) {
       PNX_REQUIRE(i[0] >= 0 && i[0] <= 8, PNX_ERR_INVALID, "tile list over %d row_dirty arrays (at most 8)", i[0]);
       return pnx_conv_tile_list((const uint8_t*)p[0], (const uint8_t* const*)&p[3], i[0], i[1], i[2], i[3], i[4], (int32_t*)p[1], (int32_t*)p[2], st);
     case PNX_OP_CONV3X3:
-      return pnx_conv3x3_bf16(p[0], p[1], (const float*)p[2], p[3], (const uint8_t*)p[4], (void*)p[5], i[0], i[1], i[2], i[3], i[4], i[5], i[6],
-                              (uint8_t*)p[6], (const int32_t*)p[7], (const int32_t*)p[8], st);
+      return (i[7] == PNX_F16 ? pnx_conv3x3_f16 : pnx_conv3x3_bf16)(p[0], p[1], (const float*)p[2], p[3], (const uint8_t*)p[4], (void*)p[5], i[0], i[1], i[2],
+                                                                    i[3], i[4], i[5], i[6], (uint8_t*)p[6], (const int32_t*)p[7], (const int32_t*)p[8], st);
     case PNX_OP_DECONV2X2:
-      return pnx_deconv2x2_bf16(p[0], p[1], (const float*)p[2], (void*)p[3], i[0], i[1], i[2], i[3], i[4], i[5], st);
+      return (i[6] == PNX_F16 ? pnx_deconv2x2_f16 : pnx_deconv2x2_bf16)(p[0], p[1], (const float*)p[2], (void*)p[3], i[0], i[1], i[2], i[3], i[4], i[5], st);
     case PNX_OP_SEPHEAD_OUT:
-      return pnx_sephead_out_bf16(p[0], p[1], (const float*)p[2], (void*)p[3], i[0], i[1], i[2], i[3], st);
+      return (i[4] == PNX_F16 ? pnx_sephead_out_f16 : pnx_sephead_out_bf16)(p[0], p[1], (const float*)p[2], (void*)p[3], i[0], i[1], i[2], i[3], st);
     default:
       pnx_set_error("unknown op kind %d", o.kind);
       return PNX_ERR_INVALID;
@@ -62,7 +62,7 @@ extern "C" int pnx_enqueue(const pnx_op* ops, int32_t n_ops, pnx_stream_t stream
 
 extern "C" int pnx_decode_lazy_enqueue(const pnx_lazy_decode* d, pnx_stream_t stream) {
   PNX_REQUIRE(d != nullptr, PNX_ERR_INVALID, "pnx_decode_lazy_enqueue: null descriptor");
-  PNX_REQUIRE(d->n_tasks > 0 && d->n_tasks <= 16 && d->n_classes_total > 0 && d->batch > 0 && d->pre_max > 0 && d->post_max > 0, PNX_ERR_INVALID,
+  PNX_REQUIRE(d->n_tasks > 0 && d->n_tasks <= 8 && d->n_classes_total > 0 && d->batch > 0 && d->pre_max > 0 && d->post_max > 0, PNX_ERR_INVALID,
               "pnx_decode_lazy_enqueue: bad sizes");
   PNX_REQUIRE(d->dense_host && d->task_descs_host && d->task_descs_dev && d->task_key_off_host && d->task_key_off_dev && d->list_key_off_dev &&
                   d->lazy_tasks_host && d->class_task_host && d->seg_off_dev && d->nms_thresh_dev,
@@ -89,7 +89,7 @@ extern "C" int pnx_decode_lazy_enqueue(const pnx_lazy_decode* d, pnx_stream_t st
   k_lazy_cells<<<(unsigned)((n_rows + 255) / 256), 256, 0, st>>>(d->order, d->seg_len, d->list_key_off_dev, d->pre_max, n_rows, d->local);
   PNX_LAUNCH_CHECK();
   // the regression branches at those cells only
-  rc = pnx_sephead_lazy_bf16(d->lazy_tasks_host, d->n_tasks, d->class_task_host, d->n_classes_total, d->batch, d->local, d->seg_len, d->pre_max, d->cand, st);
+  rc = (d->dtype == PNX_F16 ? pnx_sephead_lazy_f16 : pnx_sephead_lazy_bf16)(d->lazy_tasks_host, d->n_tasks, d->class_task_host, d->n_classes_total, d->batch, d->local, d->seg_len, d->pre_max, d->cand, st);
   if (rc != PNX_OK) return rc;
   PNX_CHECK_HIP(hipMemsetAsync(d->boxes7, 0, (size_t)n_rows * 7 * sizeof(float), st));
   PNX_CHECK_HIP(hipMemsetAsync(d->flag, 0, sizeof(int32_t), st));

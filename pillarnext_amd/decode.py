@@ -334,8 +334,8 @@ class PackedDecoder:
         d, bufs = st
         for t, (p, (up, wf, b1, w2c, b2)) in enumerate(zip(dense, lazy_tasks)):
             if not (p.is_contiguous(memory_format=torch.channels_last) and up.is_contiguous(memory_format=torch.channels_last)
-                    and up.dtype == torch.bfloat16 and up.shape[1] == 64 and up.shape[0] == B and tuple(up.shape[2:]) == shapes[t]):
-                raise PnxError("lazy decode: dense maps and 64-channel deblocked maps must be channels_last bf16 of the task's shape")
+                    and up.dtype == p.dtype and wf.dtype == p.dtype and up.shape[1] == 64 and up.shape[0] == B and tuple(up.shape[2:]) == shapes[t]):
+                raise PnxError("lazy decode: dense maps, 64-channel deblocked maps and packed weights must be channels_last bf16 / fp16 (one dtype) of the task's shape")
             bufs["dense_arr"][t] = p.data_ptr()
             bufs["tasks_arr"][t] = ops._PnxLazyTask(up.data_ptr(), wf.data_ptr(), b1.data_ptr(), w2c.data_ptr(), b2.data_ptr(), up.shape[2], up.shape[3])
         slot = self._pinned_slot((S, self.post_max, 10), S, torch.float32, torch.int32)

@@ -860,10 +860,10 @@ class _FusedConv(nn.Module):
 class _HipConv3x3(nn.Module):
     """3x3 masked conv + folded BN + [residual] + ReLU + mask in ONE HIP kernel (csrc/conv3x3.hip) -- no MIOpen, no epilogue pass."""
 
-    def __init__(self, weight, bias, stride=1):
+    def __init__(self, weight, bias, stride=1, dtype=torch.bfloat16):
         super().__init__()
         self.cout, self.cin, self.stride = weight.shape[0], weight.shape[1], int(stride)
-        self.register_buffer("wfrag", ops.conv3x3_pack_weights(weight))
+        self.register_buffer("wfrag", ops.conv3x3_pack_weights(weight, dtype=dtype))
         self.register_buffer("bias", bias.float().contiguous())
     def forward(self, x, mask=None, residual=None, out=None, tiles=None):
         return ops.conv3x3_masked(x, self.wfrag, self.bias, self.cout, self.stride, mask, residual, True, out=out,
@@ -873,10 +873,10 @@ class _HipConv3x3(nn.Module):
 class _HipDeconv2x2(nn.Module):
     """ConvTranspose2d(k=2, s=2) + folded BN + ReLU in ONE HIP kernel (csrc/conv3x3.hip::k_deconv2x2_64): the SepHead deblock."""
 
-    def __init__(self, weight, bias, relu=True):
+    def __init__(self, weight, bias, relu=True, dtype=torch.bfloat16):
         super().__init__()
         self.cout, self.relu = weight.shape[1], relu
-        self.register_buffer("wfrag", ops.deconv2x2_pack_weights(weight))
+        self.register_buffer("wfrag", ops.deconv2x2_pack_weights(weight, dtype=dtype))
         self.register_buffer("bias", bias.float().contiguous())
 
     def forward(self, x, mask=None, residual=None):
@@ -886,10 +886,10 @@ class _HipDeconv2x2(nn.Module):
 class _HipSepHeadOut(nn.Module):
     """Last 3x3 conv of all SepHead branches of a task as ONE HIP kernel over the block-diagonal weight (csrc/conv3x3.hip::k_sephead_out)."""
 
-    def __init__(self, weight, bias):
+    def __init__(self, weight, bias, dtype=torch.bfloat16):
         super().__init__()
         self.cout = weight.shape[0]
-        self.register_buffer("wfrag", ops.sephead_pack_weights(weight))
+        self.register_buffer("wfrag", ops.sephead_pack_weights(weight, dtype=dtype))
         self.register_buffer("bias", bias.float().contiguous())
 
     def forward(self, x, mask=None, residual=None):
@@ -899,8 +899,8 @@ class _HipSepHeadOut(nn.Module):
 def _backbone_conv(weight, bias, stride, padding, dtype, hip_conv):
     co, ci, kh, kw = weight.shape
     shapes = ops.CONV3X3_SHAPES_S1 if stride == 1 else ops.CONV3X3_SHAPES_S2
-    if hip_conv and dtype == torch.bfloat16 and (kh, kw) == (3, 3) and padding == 1 and (ci, co) in shapes and stride in (1, 2):
-        return _HipConv3x3(weight, bias, stride)
+    if hip_conv and dtype in ops._HALF and (kh, kw) == (3, 3) and padding == 1 and (ci, co) in shapes and stride in (1, 2):
+        return _HipConv3x3(weight, bias, stride, dtype=dtype)
     return _FusedConv(weight, bias, stride, padding, dtype=dtype)
 
 
@@ -976,15 +976,15 @@ class FusedPillarNeXt(nn.Module):
         # branches (reg, height, dim, rot, vel = 5/6 of the head's convolution work and its 9.6 GB/step intermediate) are evaluated
         # at the <= pre_max candidates per (sample, class) that the decoder selects -- what CenterHead.predict does after the fact
         # (centerhead.py:341-363) done before the fact.
-        self.lazy_head = bool(hip_conv) and dtype == torch.bfloat16 and os.environ.get("PNX_HEAD_LAZY", "1") != "0"
+        self.lazy_head = bool(hip_conv) and dtype in ops._HALF and os.environ.get("PNX_HEAD_LAZY", "1") != "0"
         self.lazy_conv1, self.lazy_conv2 = nn.ModuleList(), nn.ModuleList()
         self._lazy_ok = []
         for task in hd.tasks:
             db = task.deblock
             w, b = _fold_bn(db.conv.conv.weight, db.norm, transposed=True)
             dc = db.conv.conv
-            if hip_conv and dtype == torch.bfloat16 and tuple(w.shape) == (64, 64, 2, 2) and tuple(dc.stride) == (2, 2) and tuple(dc.padding) == (0, 0):
-                self.task_deblock.append(_HipDeconv2x2(w, b))
+            if hip_conv and dtype in ops._HALF and tuple(w.shape) == (64, 64, 2, 2) and tuple(dc.stride) == (2, 2) and tuple(dc.padding) == (0, 0):
+                self.task_deblock.append(_HipDeconv2x2(w, b, dtype=dtype))
             else:
                 self.task_deblock.append(_FusedConv(w, b, dc.stride, 0, transposed=True, dtype=dtype))
             names = list(task.heads.keys())
@@ -1002,7 +1002,7 @@ class FusedPillarNeXt(nn.Module):
             W1 = torch.cat(w1s, 0)                                   # (nh*hc, 64, 3, 3)
             tot = sum(outs)
             tot_p = (tot + 7) // 8 * 8                               # epilogue kernel wants channels % 8 == 0
-            hip_out = hip_conv and dtype == torch.bfloat16 and hc == 64 and tot <= 16 and len(names) in (5, 6, 7)
+            hip_out = hip_conv and dtype in ops._HALF and hc == 64 and tot <= 16 and len(names) in (5, 6, 7)
             if hip_out:
                 tot_p = 16                                           # k_sephead_out: 16 output channels (one MFMA M tile)
             W2 = torch.zeros((tot_p, hc * len(names), 3, 3), dtype=torch.float32, device=W1.device)
@@ -1012,11 +1012,11 @@ class FusedPillarNeXt(nn.Module):
                 W2[o:o + w2.shape[0], j * hc:(j + 1) * hc] = w2
                 B2[o:o + w2.shape[0]] = b2
                 o += w2.shape[0]
-            if hip_conv and dtype == torch.bfloat16 and (W1.shape[1], W1.shape[0]) in ops.CONV3X3_SHAPES_S1:
-                self.task_conv1.append(_HipConv3x3(W1, torch.cat(b1s), 1))   # input tile staged once, reused for all 64-channel passes
+            if hip_conv and dtype in ops._HALF and (W1.shape[1], W1.shape[0]) in ops.CONV3X3_SHAPES_S1:
+                self.task_conv1.append(_HipConv3x3(W1, torch.cat(b1s), 1, dtype=dtype))   # input tile staged once, reused for all 64-channel passes
             else:
                 self.task_conv1.append(_FusedConv(W1, torch.cat(b1s), 1, 1, dtype=dtype))
-            self.task_conv2.append(_HipSepHeadOut(W2, B2) if hip_out else _FusedConv(W2, B2, 1, 1, relu=False, dtype=dtype))
+            self.task_conv2.append(_HipSepHeadOut(W2, B2, dtype=dtype) if hip_out else _FusedConv(W2, B2, 1, 1, relu=False, dtype=dtype))
             self.task_chans.append(tot_p)
             self.task_split.append((names, outs))
             ti = len(self.task_split) - 1
@@ -1033,8 +1033,8 @@ class FusedPillarNeXt(nn.Module):
                     W2d[o:o + outs[j], q * hc:(q + 1) * hc] = w2s[j]
                     B2d[o:o + outs[j]] = b2s[j]
                     o += outs[j]
-                self.lazy_conv1.append(_HipConv3x3(W1d, b1d, 1))
-                self.lazy_conv2.append(_HipSepHeadOut(W2d, B2d))
+                self.lazy_conv1.append(_HipConv3x3(W1d, b1d, 1, dtype=dtype))
+                self.lazy_conv2.append(_HipSepHeadOut(W2d, B2d, dtype=dtype))
                 # regression branches as matrices over (tap, channel): conv1 (576 -> 320), conv2 (9 positions x 320 -> 10, block-diagonal)
                 W1z = torch.cat(w1s[:5], 0)                               # (320, 64, 3, 3)
                 w1m = W1z.permute(2, 3, 1, 0).reshape(9 * hc, 5 * hc)     # rows (ky, kx, cin)
@@ -1047,11 +1047,11 @@ class FusedPillarNeXt(nn.Module):
                         w2m[pos * 5 * hc + j * hc: pos * 5 * hc + (j + 1) * hc, o:o + outs[j]] = w2[:, :, pos // 3, pos % 3].t()
                     b2z[o:o + outs[j]] = b2s[j]
                     o += outs[j]
-                self.register_buffer(f"lazy_w1_{ti}", w1m.to(torch.bfloat16).contiguous())
+                self.register_buffer(f"lazy_w1_{ti}", w1m.to(dtype).contiguous())
                 self.register_buffer(f"lazy_b1_{ti}", torch.cat(b1s[:5]).float().contiguous())
-                self.register_buffer(f"lazy_w2_{ti}", w2m.to(torch.bfloat16).float().contiguous())   # the dense kernels hold W2 in bf16
+                self.register_buffer(f"lazy_w2_{ti}", w2m.to(dtype).float().contiguous())   # the dense kernels hold W2 in the element type
                 self.register_buffer(f"lazy_b2_{ti}", b2z)
-                self.register_buffer(f"lazy_wf1_{ti}", ops.conv3x3_pack_weights(W1z))
+                self.register_buffer(f"lazy_wf1_{ti}", ops.conv3x3_pack_weights(W1z, dtype=dtype))
                 self.register_buffer(f"lazy_w2c_{ti}", ops.sephead_lazy_pack_w2(getattr(self, f"lazy_w2_{ti}")))
             else:
                 self.lazy_conv1.append(nn.Identity())
@@ -1136,7 +1136,7 @@ class FusedPillarNeXt(nn.Module):
 
     # ------------------------------------------------------------------ launch plans (plan.py, include/pnx.h: pnx_enqueue)
     def _plan_ok(self):
-        return (self.use_plan and self.sparse_ws and self.tile_lists and self.dtype == torch.bfloat16 and not self.reader.training
+        return (self.use_plan and self.sparse_ws and self.tile_lists and self.dtype in ops._HALF and not self.reader.training
                 and self.reader._fused_supported() and all(isinstance(m, _HipConv3x3) for mods in self.stages for m in mods))
 
     def _head_plan_ok(self):
@@ -1149,7 +1149,8 @@ class FusedPillarNeXt(nn.Module):
 
         key = ("plan_bb", B, dev)
         st = self._ws.get(key)
-        if st is not None and st["weights_at"] == self.stages[0][0].wfrag.data_ptr():   # .to() / .cuda() after the plan was built moves the weights
+        wkey = tuple(t.data_ptr() for mods in self.stages for m in mods for t in (m.wfrag, m.bias))   # .to() / a reload / a re-fold moves or replaces them
+        if st is not None and st["weights_at"] == wkey:
             return st
         ny, nx = (int(v) for v in self.reader.grid_size)
         canvas = torch.empty((B, 64, ny, nx), dtype=self.dtype, device=dev, memory_format=torch.channels_last)
@@ -1179,7 +1180,7 @@ class FusedPillarNeXt(nn.Module):
             for j in range(1, len(mods), 2):
                 y = run(mods[j], x)
                 x = run(mods[j + 1], y, x)
-        st = self._ws[key] = {"canvas": canvas, "occ": occ, "plan": plan.freeze(), "out": x, "mask": mask, "weights_at": self.stages[0][0].wfrag.data_ptr()}
+        st = self._ws[key] = {"canvas": canvas, "occ": occ, "plan": plan.freeze(), "out": x, "mask": mask, "weights_at": wkey}
         return st
 
     def _run_head_plan(self, x):
@@ -1194,21 +1195,21 @@ class FusedPillarNeXt(nn.Module):
         T = len(self.task_deblock)
 
         def fresh():
-            ups = [torch.empty((B, 64, 2 * H, 2 * W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last) for _ in range(T)]
-            dense = [torch.empty((B, 16, 2 * H, 2 * W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last) for _ in range(T)]
+            ups = [torch.empty((B, 64, 2 * H, 2 * W), dtype=self.dtype, device=dev, memory_format=torch.channels_last) for _ in range(T)]
+            dense = [torch.empty((B, 16, 2 * H, 2 * W), dtype=self.dtype, device=dev, memory_format=torch.channels_last) for _ in range(T)]
             return ups, dense
 
         ups, dense = fresh()
         if st is None:
             plan = LaunchPlan()
-            sh = torch.empty((B, self.shared.cout, H, W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+            sh = torch.empty((B, self.shared.cout, H, W), dtype=self.dtype, device=dev, memory_format=torch.channels_last)
             plan.conv3x3(Dyn("x", x), self.shared.wfrag, self.shared.bias, self.shared.cout, 1, None, None, True, out=(sh, None))
             mids = {}
             for ti, db in enumerate(self.task_deblock):
                 c1, c2 = self.lazy_conv1[ti], self.lazy_conv2[ti]
                 plan.deconv2x2(sh, db.wfrag, db.bias, db.cout, Dyn(f"up{ti}", ups[ti]), db.relu)
                 if c1.cout not in mids:      # the tasks run one after the other on the stream: one intermediate per width serves them all
-                    mids[c1.cout] = torch.empty((B, c1.cout, 2 * H, 2 * W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+                    mids[c1.cout] = torch.empty((B, c1.cout, 2 * H, 2 * W), dtype=self.dtype, device=dev, memory_format=torch.channels_last)
                 plan.conv3x3(Dyn(f"up{ti}", ups[ti]), c1.wfrag, c1.bias, c1.cout, 1, None, None, True, out=(mids[c1.cout], None))
                 plan.sephead_out(mids[c1.cout], c2.wfrag, c2.bias, Dyn(f"dense{ti}", dense[ti]))
             st = self._ws[key] = plan.freeze()
@@ -1242,7 +1243,7 @@ class FusedPillarNeXt(nn.Module):
         key = (si, B, H, W, mask.device)
         if key not in self._ws:
             cout = next(m.cout for m in mods if isinstance(m, _HipConv3x3))
-            self._ws[key] = [ops.conv3x3_workspace(B, cout, H, W, mask.device) for _ in range(3)]
+            self._ws[key] = [ops.conv3x3_workspace(B, cout, H, W, mask.device, self.dtype) for _ in range(3)]
         return self._ws[key]
 
     def _stage_tiles(self, si, mods, mask, ws):
@@ -1310,9 +1311,9 @@ class FusedPillarNeXt(nn.Module):
         cols = patch.unfold(1, 3, 1).unfold(2, 3, 1).permute(0, 1, 2, 4, 5, 3).reshape(n * 9, 9 * C)
         t1 = torch.relu(cols.float() @ getattr(self, f"lazy_w1_{ti}").float() + getattr(self, f"lazy_b1_{ti}"))
         inside = (vy[:, 1:4, None] & vx[:, None, 1:4]).reshape(n * 9, 1)
-        t1 = (t1 * inside).to(torch.bfloat16).float().reshape(n, -1)
+        t1 = (t1 * inside).to(up.dtype).float().reshape(n, -1)
         out = t1 @ getattr(self, f"lazy_w2_{ti}") + getattr(self, f"lazy_b2_{ti}")
-        return out.to(torch.bfloat16).float() * valid[:, None]
+        return out.to(up.dtype).float() * valid[:, None]
 
     @torch.no_grad()
     def forward_async(self, example):

@@ -225,12 +225,20 @@ CONV3X3_SHAPES_S1 = {(64, 64), (64, 128), (128, 128), (256, 256), (256, 64), (64
 CONV3X3_SHAPES_S2 = {(64, 64), (64, 128), (128, 128), (128, 256), (256, 256)}
 
 
-def conv3x3_pack_weights(w, transposed=False):
-    """(Cout, Cin, 3, 3) -> bf16 MFMA-fragment order [tap][cin/16][cout/32][lane = kb*32 + n][8]  (csrc/conv3x3.hip).  transposed: the weights of
+_HALF = (torch.bfloat16, torch.float16)   # element types of the convolution kernels (csrc/conv3x3.hip is built for both)
+
+
+def _conv_fn(name, dtype):
+    """The bf16 or IEEE-half entry point of a convolution call (pnx_<name>_bf16 / pnx_<name>_f16)."""
+    return getattr(lib(), f"pnx_{name}_{'f16' if dtype == torch.float16 else 'bf16'}")
+
+
+def conv3x3_pack_weights(w, transposed=False, dtype=torch.bfloat16):
+    """(Cout, Cin, 3, 3) -> bf16 (or, dtype=torch.float16, fp16) MFMA-fragment order [tap][cin/16][cout/32][lane = kb*32 + n][8]  (csrc/conv3x3.hip).  transposed: the weights of
     the stride-1 data gradient instead, i.e. pack(w.flip(2, 3).transpose(0, 1)).  CUDA fp32 / bf16 weights take one HIP launch
     (pnx_conv3x3_pack_weights); anything else the torch statement below, which is also what the tests compare the kernel with."""
     co, ci = w.shape[:2]
-    if w.is_cuda and w.dtype in (torch.float32, torch.bfloat16) and tuple(w.shape[2:]) == (3, 3) and co % 32 == 0 and ci % 32 == 0:
+    if dtype == torch.bfloat16 and w.is_cuda and w.dtype in (torch.float32, torch.bfloat16) and tuple(w.shape[2:]) == (3, 3) and co % 32 == 0 and ci % 32 == 0:
         wc = w.detach().contiguous()
         out = torch.empty((9 * co * ci,), dtype=torch.bfloat16, device=w.device)
         check(lib().pnx_conv3x3_pack_weights(ptr(wc), _DT[wc.dtype], co, ci, 1 if transposed else 0, ptr(out), stream_ptr()), "pnx_conv3x3_pack_weights")
@@ -240,44 +248,45 @@ def conv3x3_pack_weights(w, transposed=False):
         co, ci = ci, co
     v = w.detach().float().reshape(co // 32, 32, ci // 16, 2, 8, 3, 3)         # (mt, n, cb, kb, e, ky, kx)
     v = v.permute(5, 6, 2, 0, 3, 1, 4).contiguous()                               # (ky, kx, cb, mt, kb, n, e)
-    return v.reshape(-1).to(torch.bfloat16).contiguous()
+    return v.reshape(-1).to(dtype).contiguous()
 
 
-def deconv2x2_pack_weights(w):
-    """ConvTranspose2d weight (Cin, Cout, 2, 2) -> bf16 MFMA-fragment order [ky*2+kx][cin/16][cout/32][lane = kb*32 + n][8]."""
+def deconv2x2_pack_weights(w, dtype=torch.bfloat16):
+    """ConvTranspose2d weight (Cin, Cout, 2, 2) -> bf16 / fp16 MFMA-fragment order [ky*2+kx][cin/16][cout/32][lane = kb*32 + n][8]."""
     ci, co = w.shape[:2]
     v = w.detach().float().permute(1, 0, 2, 3).reshape(co // 32, 32, ci // 16, 2, 8, 2, 2)   # (mt, n, cb, kb, e, ky, kx)
     v = v.permute(5, 6, 2, 0, 3, 1, 4).contiguous()                                          # (ky, kx, cb, mt, kb, n, e)
-    return v.reshape(-1).to(torch.bfloat16).contiguous()
+    return v.reshape(-1).to(dtype).contiguous()
 
 
 def deconv2x2(x, wfrag, bias, cout, relu=True):
-    """x (B,Cin,H,W) channels_last bf16 -> [relu](conv_transpose2d(x, W, stride 2) + bias) as (B,Cout,2H,2W) channels_last bf16."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):
-        raise PnxError("deconv2x2 needs a channels_last bf16 CUDA tensor")
+    """x (B,Cin,H,W) channels_last bf16 / fp16 -> [relu](conv_transpose2d(x, W, stride 2) + bias) as (B,Cout,2H,2W) channels_last, same dtype
+    (wfrag packed in that dtype)."""
+    if not (x.is_cuda and x.dtype in _HALF and x.is_contiguous(memory_format=torch.channels_last) and wfrag.dtype == x.dtype):
+        raise PnxError("deconv2x2 needs a channels_last bf16 / fp16 CUDA tensor and weights of the same dtype")
     B, ci, H, W = x.shape
-    y = torch.empty((B, cout, 2 * H, 2 * W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    check(lib().pnx_deconv2x2_bf16(ptr(x), ptr(wfrag), ptr(bias), ptr(y), B, H, W, ci, cout, 1 if relu else 0, stream_ptr()), "pnx_deconv2x2_bf16")
+    y = torch.empty((B, cout, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    check(_conv_fn("deconv2x2", x.dtype)(ptr(x), ptr(wfrag), ptr(bias), ptr(y), B, H, W, ci, cout, 1 if relu else 0, stream_ptr()), "pnx_deconv2x2_bf16")
     return y
 
 
-def sephead_pack_weights(w2):
-    """Block-diagonal (16, nb*64, 3, 3) -> bf16 fragment order [branch][tap][kc][lane = q*16 + o][8]  (csrc/conv3x3.hip::k_sephead_out)."""
+def sephead_pack_weights(w2, dtype=torch.bfloat16):
+    """Block-diagonal (16, nb*64, 3, 3) -> bf16 / fp16 fragment order [branch][tap][kc][lane = q*16 + o][8]  (csrc/conv3x3.hip::k_sephead_out)."""
     co, ci = w2.shape[:2]
     if co != 16 or ci % 64:
         raise PnxError("sephead_pack_weights wants a (16, nb*64, 3, 3) weight")
     v = w2.detach().float().reshape(16, ci // 64, 2, 4, 8, 3, 3)                # (o, j, kc, q, e, ky, kx)
     v = v.permute(1, 5, 6, 2, 3, 0, 4).contiguous()                               # (j, ky, kx, kc, q, o, e)
-    return v.reshape(-1).to(torch.bfloat16).contiguous()
+    return v.reshape(-1).to(dtype).contiguous()
 
 
 def sephead_out(x, wfrag, bias):
-    """x (B, nb*64, H, W) channels_last bf16 -> (B, 16, H, W) channels_last bf16: the last 3x3 conv of every SepHead branch of a task."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):
-        raise PnxError("sephead_out needs a channels_last bf16 CUDA tensor")
+    """x (B, nb*64, H, W) channels_last bf16 / fp16 -> (B, 16, H, W) channels_last, same dtype: the last 3x3 conv of every SepHead branch of a task."""
+    if not (x.is_cuda and x.dtype in _HALF and x.is_contiguous(memory_format=torch.channels_last) and wfrag.dtype == x.dtype):
+        raise PnxError("sephead_out needs a channels_last bf16 / fp16 CUDA tensor and weights of the same dtype")
     B, ci, H, W = x.shape
-    y = torch.empty((B, 16, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    check(lib().pnx_sephead_out_bf16(ptr(x), ptr(wfrag), ptr(bias), ptr(y), B, H, W, ci // 64, stream_ptr()), "pnx_sephead_out_bf16")
+    y = torch.empty((B, 16, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    check(_conv_fn("sephead_out", x.dtype)(ptr(x), ptr(wfrag), ptr(bias), ptr(y), B, H, W, ci // 64, stream_ptr()), "pnx_sephead_out_bf16")
     return y
 
 
@@ -300,14 +309,15 @@ class _PnxLazyTask(ctypes.Structure):
 
 def sephead_lazy(tasks, class_task, batch, local, seg_len, pre_max):
     """The regression branches of every task at the candidate cells (csrc/conv3x3.hip::k_sephead_lazy, one launch).
-    tasks: list of (up (B,64,H,W) channels_last bf16, wfrag1, bias1, w2c, bias2); class_task: task index of every class (host list);
+    tasks: list of (up (B,64,H,W) channels_last bf16 / fp16 (one dtype for all tasks), wfrag1 in that dtype, bias1, w2c, bias2); class_task: task index of every class (host list);
     local int64 (batch*len(class_task), pre_max) = b*H*W + cell per slot; seg_len int32 (batch*len(class_task),).  -> (lists, pre_max, 10) fp32,
     rows behind seg_len zero."""
     arr = (_PnxLazyTask * len(tasks))()
+    dt = tasks[0][0].dtype
     for i, (up, wf, b1, w2c, b2) in enumerate(tasks):
-        if not (up.is_cuda and up.dtype == torch.bfloat16 and up.shape[1] == 64 and up.is_contiguous(memory_format=torch.channels_last)
-                and up.shape[0] == batch):
-            raise PnxError("sephead_lazy needs 64-channel channels_last bf16 CUDA tensors")
+        if not (up.is_cuda and up.dtype in _HALF and up.dtype == dt and wf.dtype == dt and up.shape[1] == 64
+                and up.is_contiguous(memory_format=torch.channels_last) and up.shape[0] == batch):
+            raise PnxError("sephead_lazy needs 64-channel channels_last bf16 / fp16 CUDA tensors of one dtype (weights included)")
         arr[i] = _PnxLazyTask(up.data_ptr(), wf.data_ptr(), b1.data_ptr(), w2c.data_ptr(), b2.data_ptr(), up.shape[2], up.shape[3])
     nc = len(class_task)
     ct = (ctypes.c_int32 * nc)(*[int(v) for v in class_task])
@@ -316,7 +326,7 @@ def sephead_lazy(tasks, class_task, batch, local, seg_len, pre_max):
         raise PnxError("sephead_lazy: local must be int64 (lists*pre_max), seg_len int32 (lists)")
     local, seg_len = local.contiguous(), seg_len.contiguous()
     out = torch.empty((S, pre_max, 10), dtype=torch.float32, device=local.device)
-    check(lib().pnx_sephead_lazy_bf16(arr, len(tasks), ct, nc, batch, ptr(local), ptr(seg_len), pre_max, ptr(out), stream_ptr()), "pnx_sephead_lazy_bf16")
+    check(_conv_fn("sephead_lazy", dt)(arr, len(tasks), ct, nc, batch, ptr(local), ptr(seg_len), pre_max, ptr(out), stream_ptr()), "pnx_sephead_lazy_bf16")
     return out
 
 
@@ -346,9 +356,9 @@ def conv3x3_wgrad(x, dy, mask, stride=1):
     return dw
 
 
-def conv3x3_workspace(batch, cout, ho, wo, device):
+def conv3x3_workspace(batch, cout, ho, wo, device, dtype=torch.bfloat16):
     """A persistent (output buffer, row_dirty flags) pair for conv3x3_masked(out=...): both start zeroed (pnx.h: row_dirty)."""
-    y = torch.zeros((batch, cout, ho, wo), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
+    y = torch.zeros((batch, cout, ho, wo), dtype=dtype, device=device).contiguous(memory_format=torch.channels_last)
     return y, torch.zeros((batch, ho, (wo + 31) // 32), dtype=torch.uint8, device=device)
 
 
@@ -370,20 +380,21 @@ def conv_tile_list(mask, dirties, tile_rows, out=None):
 
 
 def conv3x3_masked(x, wfrag, bias, cout, stride=1, mask=None, residual=None, relu=True, out=None, tiles=None):
-    """x (B,Cin,H,W) channels_last bf16 -> (B,Cout,Ho,Wo) channels_last bf16; mask uint8 (B,Ho,Wo) of the OUTPUT sites.
+    """x (B,Cin,H,W) channels_last bf16 / fp16 -> (B,Cout,Ho,Wo) channels_last, same dtype (wfrag packed in it); mask uint8 (B,Ho,Wo) of the OUTPUT sites.
     out = (y, row_dirty) from conv3x3_workspace: write into the persistent buffer, touching only row segments that are or were active.
     tiles = conv_tile_list(mask, ...) of the same mask (stride 1 only): walk the listed tiles instead of all of them."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):
-        raise PnxError("conv3x3_masked needs a channels_last bf16 CUDA tensor")
+    if not (x.is_cuda and x.dtype in _HALF and x.is_contiguous(memory_format=torch.channels_last) and wfrag.dtype == x.dtype
+            and (residual is None or residual.dtype == x.dtype)):
+        raise PnxError("conv3x3_masked needs a channels_last bf16 / fp16 CUDA tensor, with weights and residual of the same dtype")
     B, ci, H, W = x.shape
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     if out is not None:
         y, dirty = out
-        if mask is None or tuple(y.shape) != (B, cout, Ho, Wo) or tuple(dirty.shape) != (B, Ho, (Wo + 31) // 32):
+        if mask is None or tuple(y.shape) != (B, cout, Ho, Wo) or tuple(dirty.shape) != (B, Ho, (Wo + 31) // 32) or y.dtype != x.dtype:
             raise PnxError("conv3x3_masked: out= needs a mask and a workspace of the output shape")
     else:
-        y, dirty = torch.empty((B, cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last), None
+        y, dirty = torch.empty((B, cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last), None
     tl, tc = tiles if tiles is not None else (None, None)
-    check(lib().pnx_conv3x3_bf16(ptr(x), ptr(wfrag), ptr(bias), ptr(residual), ptr(mask), ptr(y), B, H, W, ci, cout, stride, 1 if relu else 0,
-                                 ptr(dirty), ptr(tl), ptr(tc), stream_ptr()), "pnx_conv3x3_bf16")
+    check(_conv_fn("conv3x3", x.dtype)(ptr(x), ptr(wfrag), ptr(bias), ptr(residual), ptr(mask), ptr(y), B, H, W, ci, cout, stride, 1 if relu else 0,
+                                       ptr(dirty), ptr(tl), ptr(tc), stream_ptr()), "pnx_conv3x3")
     return y

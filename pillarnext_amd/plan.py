@@ -29,11 +29,18 @@ def _t(a):
     return a.like if isinstance(a, Dyn) else a
 
 
-def _nhwc_bf16(x, what):
+def _nhwc_half(x, what, like=None):
+    """channels_last bf16 / fp16 (and, with `like`, of like's dtype: a convolution call runs in one element type)."""
     x = _t(x)
-    if not (x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
-        raise PnxError(f"{what} needs a channels_last bf16 tensor")
+    if not (x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise PnxError(f"{what} needs a channels_last bf16 / fp16 tensor")
+    if like is not None and x.dtype != _t(like).dtype:
+        raise PnxError(f"{what}: dtype differs from the input's")
     return x
+
+
+def _dt(x):
+    return 2 if _t(x).dtype == torch.float16 else 1   # PNX_F16 / PNX_BF16: selects the pnx_*_f16 twin in csrc/enqueue.hip
 
 
 class LaunchPlan:
@@ -77,29 +84,31 @@ class LaunchPlan:
 
     def conv3x3(self, x, wfrag, bias, cout, stride=1, mask=None, residual=None, relu=True, out=None, tiles=None):
         """out = (y, row_dirty) workspace pair, or (y, None) for a plain output buffer."""
-        xs = _nhwc_bf16(x, "conv3x3")
+        xs = _nhwc_half(x, "conv3x3")
         B, ci, H, W = xs.shape
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
         y, dirty = out
-        ys = _nhwc_bf16(y, "conv3x3 output")
+        ys = _nhwc_half(y, "conv3x3 output", x)
+        if wfrag.dtype != xs.dtype or (residual is not None and _t(residual).dtype != xs.dtype):
+            raise PnxError("conv3x3: weights / residual of another dtype than the input")
         if tuple(ys.shape) != (B, cout, Ho, Wo) or (dirty is not None and (mask is None or tuple(dirty.shape) != (B, Ho, (Wo + 31) // 32))):
             raise PnxError("conv3x3: output / workspace of the wrong shape")
         tl, tc = tiles if tiles is not None else (None, None)
-        self._add(OP_CONV3X3, [B, H, W, ci, cout, stride, 1 if relu else 0], [x, wfrag, bias, residual, mask, y, dirty, tl, tc])
+        self._add(OP_CONV3X3, [B, H, W, ci, cout, stride, 1 if relu else 0, _dt(x)], [x, wfrag, bias, residual, mask, y, dirty, tl, tc])
 
     def deconv2x2(self, x, wfrag, bias, cout, y, relu=True):
-        xs = _nhwc_bf16(x, "deconv2x2")
+        xs = _nhwc_half(x, "deconv2x2")
         B, ci, H, W = xs.shape
-        if tuple(_nhwc_bf16(y, "deconv2x2 output").shape) != (B, cout, 2 * H, 2 * W):
-            raise PnxError("deconv2x2: output of the wrong shape")
-        self._add(OP_DECONV2X2, [B, H, W, ci, cout, 1 if relu else 0], [x, wfrag, bias, y])
+        if tuple(_nhwc_half(y, "deconv2x2 output", x).shape) != (B, cout, 2 * H, 2 * W) or wfrag.dtype != xs.dtype:
+            raise PnxError("deconv2x2: output of the wrong shape / weights of another dtype")
+        self._add(OP_DECONV2X2, [B, H, W, ci, cout, 1 if relu else 0, _dt(x)], [x, wfrag, bias, y])
 
     def sephead_out(self, x, wfrag, bias, y):
-        xs = _nhwc_bf16(x, "sephead_out")
+        xs = _nhwc_half(x, "sephead_out")
         B, ci, H, W = xs.shape
-        if tuple(_nhwc_bf16(y, "sephead_out output").shape) != (B, 16, H, W):
-            raise PnxError("sephead_out: output of the wrong shape")
-        self._add(OP_SEPHEAD_OUT, [B, H, W, ci // 64], [x, wfrag, bias, y])
+        if tuple(_nhwc_half(y, "sephead_out output", x).shape) != (B, 16, H, W) or wfrag.dtype != xs.dtype:
+            raise PnxError("sephead_out: output of the wrong shape / weights of another dtype")
+        self._add(OP_SEPHEAD_OUT, [B, H, W, ci // 64, _dt(x)], [x, wfrag, bias, y])
 
     # ---- replay
     def freeze(self):
@@ -108,6 +117,8 @@ class LaunchPlan:
         return self
 
     def bind(self, name, t):
+        if self._arr is None:
+            self.freeze()
         meta, where = self._dyn[name]
         if (t.shape, t.dtype, t.stride(), t.device) != meta:
             raise PnxError(f"plan: tensor bound to '{name}' differs from the one the plan was built for")
@@ -119,6 +130,9 @@ class LaunchPlan:
     def run(self):
         if self._arr is None:
             self.freeze()
+        missing = set(self._dyn) - set(self._bound)
+        if missing:   # an unbound slot would replay the build-time pointer, which nothing keeps alive
+            raise PnxError(f"plan: dynamic tensors never bound: {sorted(missing)}")
         if not all(a.is_cuda for a in self._keep) or not all(t.is_cuda for t in self._bound.values()):
             raise PnxError("plan: every tensor of a launch table must live on the GPU")   # the library has no CPU path
         check(lib().pnx_enqueue(self._arr, len(self._ops), stream_ptr()), "pnx_enqueue")
