@@ -143,6 +143,57 @@ int pnx_voxelize(const float* points, int64_t n_points, int32_t row_stride, int3
                  float* features, int32_t* coords, int64_t pillar_capacity, int64_t* unq_inv, int32_t* pillar_of_point,
                  int32_t* counts, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Voxel and multi-view readers: det3d/models/readers/voxel_encoder.py:25-87, det3d/models/readers/mvf_encoder.py:39-246.
+ *
+ * pnx_group_points = the point -> cell grouping of VoxelNet.forward (mode PNX_GROUP_VOXEL: 3-D cells, rows outside the range dropped by the
+ * float comparisons of voxel_encoder.py:53-58), PillarVoxelNet.forward (PNX_GROUP_PILLAR_CLAMP: 2-D cells over x, y; the cell index is
+ * CLAMPED, nothing is dropped, mvf_encoder.py:57-62) and CylinderNet.forward (PNX_GROUP_CYLINDER_CLAMP: the same over phi = atan2(y, x) / pi *
+ * 180 [deg], z; rho = sqrt(x^2 + y^2) is the third coordinate, :99-105), with torch.unique(dim=0)'s order and torch_scatter.scatter_mean:
+ *   points         (n_points, row_stride) fp32 rows [b, x, y, z, f..]
+ *   geom           min / voxel / grid of the three grouped axes IN THE ORDER OF THE YAML LISTS ((x, y, z) or (phi, z, rho)), mode, and an optional
+ *                  prefilter: rows whose raw x, y, z are outside [keep_min, keep_max) are dropped first (MVFFeatureNet.forward, :290-297);
+ *                  rows with b outside [0, batch) are always dropped
+ *   point_features (N', feature_ld) fp32, row j = the j-th KEPT point in input order:
+ *                    VOXEL            [x y z f..]                      (row_stride - 1 columns: points[mask][:, 1:], voxel_encoder.py:68)
+ *                    *_CLAMP          [u0 u1 u2 f.. | u - mean(cell) (3) | u[:2] - centre(cell) (2)]   (row_stride + 4 columns, :73-83 / :127-138)
+ *   coords         (group_capacity, 4) int32 [b, c2, c1, c0] for VOXEL (= unq[:, [0,3,2,1]], i.e. [b, z, y, x]); (group_capacity, 3) [b, c1, c0] for
+ *                  the 2-D modes (= unq[:, [0,2,1]]); rows in torch.unique order
+ *   unq_inv        (N') int64: cell rank of the j-th kept point
+ *   group_mean     (group_capacity, M) fp32: per-cell mean of the row's row_stride - 1 columns (VOXEL: DynamicVoxelEncoder.forward,
+ *                  voxel_encoder.py:19-22) or of the three grouped coordinates (2-D modes)
+ *   counts         int32[2] = {G cells, N' kept points}
+ * Each output may be NULL.  Deterministic: sums are fp64 atomics (exact here), mean = fp32(sum) / fp32(count).
+ * Indices are bit-exact with torch on the CPU for the Cartesian modes; in the cylinder mode atan2 is pnx_detmath.h's (the fp64 value
+ * rounded once), which differs from torch's CPU / CUDA atan2f by one ulp on a few percent of the points: phi within 2 ulp(180) = 3.1e-5 deg,
+ * rho within 1 ulp (torch's CPU sqrt is not correctly rounded), a point within that distance of a bin edge may fall into the neighbouring cell. */
+typedef enum pnx_group_mode { PNX_GROUP_VOXEL = 0, PNX_GROUP_PILLAR_CLAMP = 1, PNX_GROUP_CYLINDER_CLAMP = 2 } pnx_group_mode;
+typedef struct pnx_group_geom {
+  float min[3], voxel[3]; /* fp32 casts of pc_range[:3] / voxel_size, as the reference applies them */
+  int32_t grid[3];        /* np.round((max - min) / voxel) in fp64 */
+  int32_t mode;           /* pnx_group_mode */
+  int32_t prefilter;      /* != 0: drop rows with raw x, y, z outside [keep_min, keep_max) */
+  float keep_min[3], keep_max[3];
+} pnx_group_geom;
+size_t pnx_group_workspace_bytes(int64_t n_points, int32_t row_stride, int32_t batch, const pnx_group_geom* geom_host);
+int pnx_group_points(const float* points, int64_t n_points, int32_t row_stride, int32_t batch, const pnx_group_geom* geom_host, float* point_features,
+                     int32_t feature_ld, int32_t* coords, int64_t group_capacity, int64_t* unq_inv, float* group_mean, int32_t* counts, void* workspace,
+                     size_t workspace_bytes, pnx_stream_t stream);
+/* PFNLayer.forward in eval mode for any layer widths (pillar_encoder.py:35-50 as SingleView stacks it, mvf_encoder.py:150-163,187-188):
+ *   x = relu(W' [xa | gb[inv]] + shift)   with BatchNorm1d(eval) folded into W' / shift (pnx_pfn_fold_bn's algebra);
+ *   xa (n, lda) fp32: the first ca input columns; gb (num_groups, cb) fp32: the per-cell maximum of the PREVIOUS layer, read through inv -- the
+ *   torch.cat([x, x_max[unq_inv]]) of a non-last layer is never materialised; wt = W' transposed, (ca + cb, cout) fp32; shift (cout);
+ *   y (n, ldy) = x per point (may be NULL: the last layer), gmax (num_groups, cout) = scatter_max(x, inv) (may be NULL), fully written
+ *   (cells without a point hold 0).  ca + cb <= 128, cout <= 256.  The maximum is order-free: deterministic. */
+int pnx_pfn_layer_eval(const float* xa, int32_t lda, int32_t ca, const float* gb, int32_t cb, const int64_t* inv, const float* wt, const float* shift,
+                       int32_t cout, int64_t n, int64_t num_groups, float* y, int32_t ldy, float* gmax, pnx_stream_t stream);
+/* SingleView.bilinear_interpolate (mvf_encoder.py:208-246) on a channels-last map: image (batch, h, w, channels) fp32 / bf16;
+ *   sample position of point p = ((pos[p, 0:2] - pos_min) / pos_voxel) / ds_rate in (w, h) order (:184,:204), sample image = cell_coords[unq_inv[p]][0]
+ *   (:203); corners clamped to the map, weights from the CLAMPED corners (:227-240); out (n, out_ld) fp32.  ds_rate must be a power of two. */
+int pnx_bilinear_gather(const void* image, int32_t dtype, int32_t batch, int32_t h, int32_t w, int32_t channels, const float* pos, int32_t pos_ld,
+                        const float* pos_min2_host, const float* pos_voxel2_host, const int32_t* cell_coords, const int64_t* unq_inv, int32_t ds_rate,
+                        int64_t n, float* out, int32_t out_ld, pnx_stream_t stream);
+
 /* torch_scatter.scatter_max(x, unq_inv, dim=0) over pillars (call sites :43,:180), fp32, values of
  * any sign.  x (n, channels); index (n) int64 in [0,P); out (P, channels); argmax (P, channels) int64 =
  * row of the maximum (lowest row index wins ties) or n for an empty pillar.  Deterministic. */

@@ -18,6 +18,14 @@ class PnxGeom(ctypes.Structure):
     _fields_ = [("pc_min", ctypes.c_float * 3), ("voxel", ctypes.c_float * 3), ("gx", ctypes.c_int32), ("gy", ctypes.c_int32)]
 
 
+PNX_GROUP_VOXEL, PNX_GROUP_PILLAR_CLAMP, PNX_GROUP_CYLINDER_CLAMP = 0, 1, 2
+
+
+class PnxGroupGeom(ctypes.Structure):   # include/pnx.h: pnx_group_geom
+    _fields_ = [("min", ctypes.c_float * 3), ("voxel", ctypes.c_float * 3), ("grid", ctypes.c_int32 * 3), ("mode", ctypes.c_int32),
+                ("prefilter", ctypes.c_int32), ("keep_min", ctypes.c_float * 3), ("keep_max", ctypes.c_float * 3)]
+
+
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
 _i32 = ctypes.c_int32
@@ -43,6 +51,11 @@ PROTOTYPES = {
     "pnx_pfn_forward_train": (ctypes.c_int, [_i32, _vp, _i64, _i32, _i32, ctypes.POINTER(PnxGeom), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pnx_pfn_backward": (ctypes.c_int, [_i32, _i64, _i32, _i32, ctypes.POINTER(PnxGeom), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pnx_voxelize": (ctypes.c_int, [_vp, _i64, _i32, _i32, ctypes.POINTER(PnxGeom), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pnx_group_workspace_bytes": (_sz, [_i64, _i32, _i32, ctypes.POINTER(PnxGroupGeom)]),
+    "pnx_group_points": (ctypes.c_int, [_vp, _i64, _i32, _i32, ctypes.POINTER(PnxGroupGeom), _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pnx_pfn_layer_eval": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i64, _vp, _i32, _vp, _vp]),
+    "pnx_bilinear_gather": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _vp,
+                                           _vp, _i32, _i64, _vp, _i32, _vp]),
     "pnx_scatter_max_workspace_bytes": (_sz, [_i64, _i64]),
     "pnx_scatter_max": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "pnx_scatter_max_backward": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),

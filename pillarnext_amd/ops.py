@@ -118,6 +118,101 @@ def scatter_max(x, index, num_pillars):
     return ScatterMax.apply(x.contiguous(), index.contiguous(), int(num_pillars))
 
 
+# --------------------------------------------------------------------------------------------- voxel / multi-view readers (csrc/group.hip)
+def group_geom(pc_range, voxel_size, mode, keep_range=None):
+    """pnx_group_geom from the YAML lists: fp32 casts of min / voxel (what the reference applies, voxel_encoder.py:43-45), grid = np.round((max - min) /
+    voxel) in fp64 (:40-41); keep_range (6 values) = MVFFeatureNet.forward's range mask on the raw x, y, z (mvf_encoder.py:290-297)."""
+    import numpy as np
+
+    pr, vs = np.asarray(pc_range, np.float64), np.asarray(voxel_size, np.float64)
+    gs = (pr[3:] - pr[:3]) / vs
+    gs = np.round(gs, 0, gs).astype(np.int64)
+    g = _lib.PnxGroupGeom()
+    for k in range(3):
+        g.min[k], g.voxel[k], g.grid[k] = float(np.float32(pr[k])), float(np.float32(vs[k])), int(gs[k])
+    g.mode, g.prefilter = int(mode), 0
+    if keep_range is not None:
+        g.prefilter = 1
+        kr = torch.tensor([float(v) for v in keep_range], dtype=torch.float32)   # torch.tensor(self.pc_range, dtype=points.dtype): fp32 casts
+        for k in range(3):
+            g.keep_min[k], g.keep_max[k] = float(kr[k]), float(kr[3 + k])
+    return g
+
+
+_GROUP_WS = Workspace()
+
+
+def group_points(points, batch, geom, want_features=True, want_mean=False, features_out=None):
+    """pnx_group_points.  points (N, 1+F) fp32 CUDA.  Returns dict(features (N', C) or None, coords (G, 3|4) int32, unq_inv (N') int64,
+    mean (G, M) or None, G, Nk) -- ONE host sync for the two counts (the reference's torch.unique syncs as well).  features_out = (buffer (>= N, ld)
+    fp32, column offset): write the feature rows into columns [off, off + C) of an existing buffer (the concat of the two MVF views)."""
+    _need_cuda(points, "points")
+    if points.dtype != torch.float32 or points.dim() != 2:
+        raise PnxError("points must be (N, 1+F) fp32")
+    n, stride = points.shape
+    dev = points.device
+    voxel = geom.mode == _lib.PNX_GROUP_VOXEL
+    C = stride - 1 if voxel else stride + 4
+    M = stride - 1 if voxel else 3
+    cells = batch * geom.grid[0] * geom.grid[1] * (geom.grid[2] if voxel else 1)
+    cap = max(min(n, cells), 1)
+    feats, ld, fptr = None, 0, None
+    if features_out is not None:
+        buf, off = features_out
+        if not (buf.is_cuda and buf.dtype == torch.float32 and buf.dim() == 2 and buf.is_contiguous() and buf.shape[0] >= n and off + C <= buf.shape[1]):
+            raise PnxError("group_points: features_out must be a contiguous fp32 (>= N, ld) buffer with room for the columns")
+        feats, ld, fptr = buf, buf.shape[1], ctypes.c_void_p(buf.data_ptr() + 4 * off)
+    elif want_features:
+        feats = torch.empty((max(n, 1), C), dtype=torch.float32, device=dev)
+        ld, fptr = C, ptr(feats)
+    coords = torch.empty((cap, 4 if voxel else 3), dtype=torch.int32, device=dev)
+    inv = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
+    mean = torch.empty((cap, M), dtype=torch.float32, device=dev) if want_mean else None
+    counts = torch.zeros((2,), dtype=torch.int32, device=dev)
+    nbytes = lib().pnx_group_workspace_bytes(n, stride, batch, ctypes.byref(geom))
+    if nbytes == 0:
+        raise PnxError("group_points: bad geometry")
+    ws = _GROUP_WS.get(nbytes, dev)
+    check(lib().pnx_group_points(ptr(points), n, stride, batch, ctypes.byref(geom), fptr, ld, ptr(coords), cap, ptr(inv), ptr(mean), ptr(counts), ptr(ws),
+                                 ws.numel(), stream_ptr()), "pnx_group_points")
+    G, Nk = (int(v) for v in counts.tolist())
+    return {"features": None if feats is None else (feats if features_out is not None else feats[:Nk]), "coords": coords[:G], "unq_inv": inv[:Nk],
+            "mean": None if mean is None else mean[:G], "G": G, "Nk": Nk}
+
+
+def pfn_layer_eval(xa, gb, inv, wt, shift, num_groups, store=True, want_max=True):
+    """pnx_pfn_layer_eval: relu(W' [xa | gb[inv]] + shift) per point (returned when store) and its per-cell maximum (num_groups, cout) (when want_max).
+    xa (N, ca) fp32 -- may be a column slice of a wider contiguous buffer; gb (G, cb) fp32 or None; wt (ca + cb, cout) = W' transposed."""
+    _need_cuda(wt, "wt")
+    n = xa.shape[0]
+    ca, cb, cout = xa.shape[1], 0 if gb is None else gb.shape[1], wt.shape[1]
+    if not (xa.is_cuda and xa.dtype == torch.float32 and xa.stride(1) == 1 and wt.shape[0] == ca + cb and wt.dtype == torch.float32 and shift.numel() == cout):
+        raise PnxError("pfn_layer_eval: xa (N, ca) fp32 with unit column stride, wt (ca + cb, cout) fp32, shift (cout)")
+    if gb is not None:
+        _need_cuda(gb, "gb")
+    y = torch.empty((n, cout), dtype=torch.float32, device=xa.device) if store else None
+    gmax = torch.empty((num_groups, cout), dtype=torch.float32, device=xa.device) if want_max else None
+    check(lib().pnx_pfn_layer_eval(ptr(xa), xa.stride(0) if n > 1 else max(ca, 1), ca, ptr(gb), cb, ptr(inv), ptr(wt), ptr(shift), cout, n, num_groups, ptr(y), cout,
+                                   ptr(gmax), stream_ptr()), "pnx_pfn_layer_eval")
+    return y, gmax
+
+
+def bilinear_gather(image, pos, pos_min, pos_voxel, cell_coords, unq_inv, ds_rate):
+    """pnx_bilinear_gather: image (B, C, H, W) channels_last fp32 / bf16; pos (N, >= 2) fp32 columns (may be a slice of a wider buffer); -> (N, C) fp32."""
+    if not (image.is_cuda and image.dim() == 4 and image.is_contiguous(memory_format=torch.channels_last) and image.dtype in (torch.float32, torch.bfloat16)):
+        raise PnxError("bilinear_gather needs a channels_last fp32 / bf16 CUDA map")
+    if not (pos.is_cuda and pos.dtype == torch.float32 and pos.stride(1) == 1 and cell_coords.dtype == torch.int32 and unq_inv.dtype == torch.int64):
+        raise PnxError("bilinear_gather: pos fp32 rows, int32 coords, int64 unq_inv")
+    B, C, H, W = image.shape
+    n = pos.shape[0]
+    out = torch.empty((n, C), dtype=torch.float32, device=image.device)
+    mn = (ctypes.c_float * 2)(float(pos_min[0]), float(pos_min[1]))
+    vs = (ctypes.c_float * 2)(float(pos_voxel[0]), float(pos_voxel[1]))
+    check(lib().pnx_bilinear_gather(ptr(image), _DT[image.dtype], B, H, W, C, ptr(pos), pos.stride(0) if n > 1 else 2, mn, vs, ptr(cell_coords.contiguous()),
+                                    ptr(unq_inv), int(ds_rate), n, ptr(out), C, stream_ptr()), "pnx_bilinear_gather")
+    return out
+
+
 # --------------------------------------------------------------------------------------------- IoU / NMS
 def _boxes(t, name):
     _need_cuda(t, name)
