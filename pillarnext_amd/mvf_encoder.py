@@ -1,22 +1,28 @@
-"""Host-side mirror of det3d/models/readers/mvf_encoder.py ("mvf:" below): the multi-view (pillar + cylinder) reader of the
-mvf18_aspp detectors (configs/models/reader/mvf_encoder.yaml, configs/experiments/waymo_det_mvf18_aspp_iou_car.yaml).
+"""Host-side mirror of det3d/models/readers/mvf_encoder.py ("mvf:" below): the multi-view (pillar + cylinder) reader of the mvf18_aspp detectors
+(configs/models/reader/mvf_encoder.yaml, configs/experiments/waymo_det_mvf18_aspp_iou_car.yaml), on the kernels of csrc/group.hip.
 
     MVFFeatureNet(in_channels, voxel_size, pc_range, cylinder_size, cylinder_range, num_filters, layer_nums, ds_layer_strides,
                   ds_num_filters, kernel_size, out_channels).forward(points) -> dense (B, out_channels, gy / ds, gx / ds) map    # mvf:257-327
 
-Same class names, constructor arguments and state-dict keys as the reference.  SURVEY 8f-4 row (after the PillarNeXt hot path):
-the two point-to-cell groupings (which CLAMP the cell index instead of dropping points, mvf:57-62, 111-116) are torch.unique over
-one int64 key per point, the PFN layers are reader.PFNLayer on the HIP scatter-max (pnx_scatter_max), the per-view sparse
-ResNets are the masked-dense blocks of models.py (spconv is absent from the image: like the backbone, that part cannot be pinned),
-the rest is the reference's arithmetic restated on torch ops."""
+Same class names, constructor arguments and state-dict keys as the reference.  What runs where:
+  * the two point -> cell groupings, which CLAMP the cell index instead of dropping points (mvf:57-62, 111-116), the cylinder transform, the
+    per-cell means and the 10-column decoration: ONE C call each (pnx_group_points, modes PILLAR_CLAMP / CYLINDER_CLAMP); MVFFeatureNet's range
+    mask (mvf:290-297) is the call's prefilter and both views write their columns into one (N', 20) buffer -- the torch.cat of mvf:304 never runs;
+  * the PFN layers of a view in eval mode: pnx_pfn_layer_eval (Linear + folded BatchNorm + ReLU + per-cell max; the concat [x, max[inv]] of a
+    non-last layer is read in place by the next one); in training they are reader.PFNLayer on the HIP scatter-max (autograd);
+  * sampling the view's map back at the points: pnx_bilinear_gather (eval) / its torch statement over flat indices (training: needs autograd);
+  * the per-view sparse ResNets: the masked-dense blocks of models.py (spconv is absent from the image; like the backbone that part is
+    unpinned), the two PointNets: torch Linear (rocBLAS) + BatchNorm + ReLU.
+CUDA tensors only: there is no CPU path."""
 import numpy as np
 import torch
 from torch import nn
 from torch.nn import functional as F
 
 from . import ops
+from ._lib import PNX_GROUP_CYLINDER_CLAMP, PNX_GROUP_PILLAR_CLAMP
 from .reader import PFNLayer
-from .voxel_encoder import grid_of, scatter_mean
+from .voxel_encoder import _device_points, batch_of, grid_of
 
 
 class PointNet(nn.Module):
@@ -31,82 +37,67 @@ class PointNet(nn.Module):
         return F.relu(self.norm(self.linear(points)))
 
 
-def _cells(points3, b, pc_range, voxel_size, grid):
-    """(x - min) / voxel in fp32, CLAMPED to the grid (mvf:57-62), truncated; cell rows [b, c0, c1] made unique (mvf:67-69)."""
-    vs = torch.from_numpy(voxel_size).type_as(points3).to(points3.device)
-    pr = torch.from_numpy(pc_range).type_as(points3).to(points3.device)
-    pc = (points3 - pr[:3].view(-1, 3)) / vs.view(-1, 3)
-    for k in range(3):
-        pc[:, k] = torch.clamp(pc[:, k], 0, int(grid[k]) - 1)
-    pc = pc.long()
-    key = (b * int(grid[0]) + pc[:, 0]) * int(grid[1]) + pc[:, 1]
-    unq, unq_inv = torch.unique(key, return_inverse=True)
-    c1 = unq % int(grid[1])
-    t = unq // int(grid[1])
-    c0 = t % int(grid[0])
-    bb = t // int(grid[0])
-    return pc, torch.stack([bb, c1, c0], 1).int(), unq_inv, vs, pr            # coords = unq[:, [0, 2, 1]]
+class _ClampView(nn.Module):
+    """Shared body of PillarVoxelNet / CylinderNet: returns (features (N, F + 5), coords (P, 3) int32 [b, c1, c0], unq_inv, grid [g1, g0])."""
 
-
-def _decorate(points_rest, p3, pc, unq_inv, num, vs, pr):
-    """[rest | xyz - cell mean | xy - cell centre] (mvf:71-83), evaluated left to right in fp32 like the reference."""
-    mean = scatter_mean(p3, unq_inv, num)
-    f_cluster = p3 - mean[unq_inv]
-    f_center = p3[:, :2] - (pc[:, :2].to(p3.dtype) * vs[:2].unsqueeze(0) + vs[:2].unsqueeze(0) / 2 + pr[:2].unsqueeze(0))
-    return torch.cat([points_rest, f_cluster, f_center], dim=-1)
-
-
-class PillarVoxelNet(nn.Module):
-    """mvf:39-86: returns (features (N, F + 5), coords (P, 3) int32 [b, y, x], unq_inv, grid [gy, gx])."""
+    mode = PNX_GROUP_PILLAR_CLAMP
 
     def __init__(self, voxel_size, pc_range):
         super().__init__()
         self.voxel_size = np.array(voxel_size)
         self.pc_range = np.array(pc_range)
+        self._geoms = {}
 
-    def forward(self, points):
-        grid = grid_of(self.pc_range, self.voxel_size)
-        pc, coords, unq_inv, vs, pr = _cells(points[:, 1:4], points[:, 0].long(), self.pc_range, self.voxel_size, grid)
-        feats = _decorate(points[:, 1:], points[:, 1:4], pc, unq_inv, coords.shape[0], vs, pr)
-        return feats, coords, unq_inv, grid[[1, 0]]
+    def geom(self, keep_range=None):
+        key = None if keep_range is None else tuple(float(v) for v in keep_range)
+        if key not in self._geoms:
+            self._geoms[key] = ops.group_geom(self.pc_range, self.voxel_size, self.mode, keep_range)
+        return self._geoms[key]
+
+    def group(self, points, batch_size=None, keep_range=None, features_out=None):
+        points = _device_points(points, type(self).__name__)
+        return ops.group_points(points, batch_of(points, batch_size), self.geom(keep_range), want_features=True, features_out=features_out)
+
+    def forward(self, points, batch_size=None):
+        r = self.group(points, batch_size)
+        return r["features"], r["coords"], r["unq_inv"], grid_of(self.pc_range, self.voxel_size)[[1, 0]]
 
 
-class CylinderNet(nn.Module):
-    """mvf:88-141: the same grouping in (phi [deg], z, rho) coordinates."""
+class PillarVoxelNet(_ClampView):
+    """mvf:39-86: cells over (x, y)."""
 
-    def __init__(self, voxel_size, pc_range):
-        super().__init__()
-        self.voxel_size = np.array(voxel_size)
-        self.pc_range = np.array(pc_range)
 
-    def forward(self, points):
-        x, y, z = points[:, 1:2], points[:, 2:3], points[:, 3:4]
-        phi = torch.atan2(y, x) / np.pi * 180
-        rho = torch.sqrt(x ** 2 + y ** 2)
-        cyl = torch.cat((points[:, 0:1], phi, z, rho, points[:, 4:]), dim=-1)
-        grid = grid_of(self.pc_range, self.voxel_size)
-        pc, coords, unq_inv, vs, pr = _cells(cyl[:, 1:4], cyl[:, 0].long(), self.pc_range, self.voxel_size, grid)
-        feats = _decorate(cyl[:, 1:], cyl[:, 1:4], pc, unq_inv, coords.shape[0], vs, pr)
-        return feats, coords, unq_inv, grid[[1, 0]]
+class CylinderNet(_ClampView):
+    """mvf:88-141: the same grouping over (phi [deg], z); features [phi z rho f.. | cluster | centre]."""
+
+    mode = PNX_GROUP_CYLINDER_CLAMP
 
 
 def bilinear_interpolate(image, coords):
-    """mvf:208-246: image (B, C, H, W), coords (N, 3) = [b, x, y] in cell units -> (N, C); corners clamped to the map."""
-    x, y = coords[:, 1], coords[:, 2]
-    x0 = torch.floor(x).long()
-    y0 = torch.floor(y).long()
-    x1, y1 = x0 + 1, y0 + 1
-    B = coords[:, 0].long()
-    x0 = torch.clamp(x0, 0, image.shape[3] - 1)
-    x1 = torch.clamp(x1, 0, image.shape[3] - 1)
-    y0 = torch.clamp(y0, 0, image.shape[2] - 1)
-    y1 = torch.clamp(y1, 0, image.shape[2] - 1)
-    Ia, Ib, Ic, Id = image[B, :, y0, x0], image[B, :, y1, x0], image[B, :, y0, x1], image[B, :, y1, x1]
-    wa = ((x1.float() - x) * (y1.float() - y)).unsqueeze(-1)
-    wb = ((x1.float() - x) * (y - y0.float())).unsqueeze(-1)
-    wc = ((x - x0.float()) * (y1.float() - y)).unsqueeze(-1)
-    wd = ((x - x0.float()) * (y - y0.float())).unsqueeze(-1)
-    return Ia * wa + Ib * wb + Ic * wc + Id * wd
+    """mvf:208-246 as autograd-capable torch ops over flat indices (the training path; eval runs pnx_bilinear_gather): image (B, C, H, W),
+    coords (N, 3) = [b, x, y] in cell units -> (N, C).  Corner (kx, ky) = (floor(x) + kx, floor(y) + ky) clamped to the map; its weight is the product
+    of the distances to the OTHER clamped corner along each axis, as the reference computes it after clamping."""
+    B, C, H, W = image.shape
+    flat = image.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    b = coords[:, 0].long()
+    px, py = coords[:, 1], coords[:, 2]
+    fx, fy = torch.floor(px).long(), torch.floor(py).long()
+    xs = torch.stack([fx.clamp(0, W - 1), (fx + 1).clamp(0, W - 1)], 1)
+    ys = torch.stack([fy.clamp(0, H - 1), (fy + 1).clamp(0, H - 1)], 1)
+    wx = torch.stack([xs[:, 1].to(px.dtype) - px, px - xs[:, 0].to(px.dtype)], 1)
+    wy = torch.stack([ys[:, 1].to(py.dtype) - py, py - ys[:, 0].to(py.dtype)], 1)
+    out = None
+    for kx, ky in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        term = flat[(b * H + ys[:, ky]) * W + xs[:, kx]] * (wx[:, kx] * wy[:, ky]).unsqueeze(-1).to(flat.dtype)
+        out = term if out is None else out + term
+    return out
+
+
+def _fold_pfn(pfn):
+    """(W' transposed (cin, cout), shift (cout)): BatchNorm1d(eval) folded into the Linear, fp32 (pnx_pfn_fold_bn's algebra)."""
+    a = pfn.norm.weight.detach().float() / torch.sqrt(pfn.norm.running_var.float() + pfn.norm.eps)
+    wt = (pfn.linear.weight.detach().float() * a[:, None]).t().contiguous()
+    return wt, (pfn.norm.bias.detach().float() - pfn.norm.running_mean.float() * a).contiguous()
 
 
 class SingleView(nn.Module):
@@ -128,15 +119,28 @@ class SingleView(nn.Module):
                                           + [SparseBasicBlock(ds_num_filters[i], kernel_size[i]) for _ in range(n)]) for i, n in enumerate(layer_nums)])
         self.ds_rate = np.prod(np.array(ds_layer_strides))
 
+    def _pos_columns(self, features):
+        return features[:, 0:2] if self.mode == "pillar" else features[:, 10:12]
+
+    def cell_features(self, features, unq_inv, num_cells):
+        """(P, C) = scatter_max over the cells of the PFN stack's output (mvf:187-188)."""
+        if self.training or torch.is_grad_enabled() and any(p.requires_grad for p in self.pfn_layers.parameters()):
+            for pfn in self.pfn_layers:
+                features = pfn(features, unq_inv, num_cells)
+            return ops.scatter_max(features, unq_inv, num_cells)[0]
+        x, g = features, None
+        for k, pfn in enumerate(self.pfn_layers):     # eval: one fused launch per layer; [x, max[inv]] is read in place by the next layer
+            wt, shift = _fold_pfn(pfn)
+            last = k == len(self.pfn_layers) - 1
+            if pfn.last_vfe != last:
+                raise ops.PnxError("SingleView: only the final PFN layer may be a last_layer")
+            x, g = ops.pfn_layer_eval(x, g, unq_inv, wt, shift, num_cells, store=not last, want_max=True)
+        return g
+
     def forward(self, features, unq, unq_inv, grid_size, batch_size=None):
-        pos = features[:, 0:2] if self.mode == "pillar" else features[:, 10:12]
-        vs = torch.from_numpy(self.voxel_size).type_as(pos).to(pos.device)
-        bias = torch.from_numpy(self.bias).type_as(pos).to(pos.device)
-        pos = (pos - bias) / vs
+        pos = self._pos_columns(features)
         P = unq.shape[0]
-        for pfn in self.pfn_layers:
-            features = pfn(features, unq_inv, P)
-        fv = ops.scatter_max(features, unq_inv, P)[0]
+        fv = self.cell_features(features, unq_inv, P)
         if batch_size is None:
             batch_size = len(torch.unique(unq[:, 0]))                          # the reference's rule (mvf:190)
         H, W = int(grid_size[0]), int(grid_size[1])
@@ -145,11 +149,16 @@ class SingleView(nn.Module):
         u = unq.long()
         canvas[u[:, 0], u[:, 1], u[:, 2]] = fv
         mask[u[:, 0], 0, u[:, 1], u[:, 2]] = 1
-        x = canvas.permute(0, 3, 1, 2)
+        x = canvas.permute(0, 3, 1, 2)                                         # channels_last view of the NHWC canvas
         for blk in self.blocks:
             x, mask = blk(x, mask)
-        pos = torch.cat((unq[unq_inv][:, 0:1].to(pos.dtype), pos / float(self.ds_rate)), dim=-1)
-        return bilinear_interpolate(x, pos)
+        if not (self.training or torch.is_grad_enabled() and x.requires_grad) and x.dtype in (torch.float32, torch.bfloat16):
+            return ops.bilinear_gather(x.contiguous(memory_format=torch.channels_last), pos, self.bias, self.voxel_size, unq, unq_inv, int(self.ds_rate))
+        vs = torch.from_numpy(self.voxel_size).type_as(pos).to(pos.device)
+        bias = torch.from_numpy(self.bias).type_as(pos).to(pos.device)
+        cell = (pos - bias) / vs
+        cell = torch.cat((unq[unq_inv][:, 0:1].to(cell.dtype), cell / float(self.ds_rate)), dim=-1)
+        return bilinear_interpolate(x, cell)
 
     bilinear_interpolate = staticmethod(bilinear_interpolate)
 
@@ -173,26 +182,32 @@ class MVFFeatureNet(nn.Module):
         self.pointnet1 = PointNet(c, ds_num_filters[-1])
         self.pointnet2 = PointNet(ds_num_filters[-1] * 3, out_channels)
 
+    def group_views(self, points, batch_size=None):
+        """Both groupings of the range-masked points (mvf:290-304): (feat (N', 2 (F + 5)), pillar result, cylinder result)."""
+        points = _device_points(points, "MVFFeatureNet")
+        B = batch_of(points, batch_size)
+        c = points.shape[1] + 4
+        feat = torch.empty((max(points.shape[0], 1), 2 * c), dtype=torch.float32, device=points.device)
+        pr = self.voxelization.group(points, B, keep_range=self.pc_range, features_out=(feat, 0))
+        cr = self.cylinderlization.group(points, B, keep_range=self.pc_range, features_out=(feat, c))
+        return feat[:pr["Nk"]], pr, cr, B
+
     def forward(self, points, batch_size=None):
-        r = torch.tensor(self.pc_range, dtype=points.dtype, device=points.device)
-        mask = ((points[:, 1] >= r[0]) & (points[:, 1] < r[3]) & (points[:, 2] >= r[1]) & (points[:, 2] < r[4]) & (points[:, 3] >= r[2])
-                & (points[:, 3] < r[5]))
-        points = points[mask]
-        pf, pcoords, pinv, psize = self.voxelization(points)
-        cf, ccoords, cinv, csize = self.cylinderlization(points)
-        feat = torch.cat((pf, cf), dim=-1)
+        feat, pr, cr, B = self.group_views(points, batch_size)
+        pcoords, pinv, ccoords, cinv = pr["coords"], pr["unq_inv"], cr["coords"], cr["unq_inv"]
+        psize = grid_of(self.voxelization.pc_range, self.voxelization.voxel_size)[[1, 0]]
+        csize = grid_of(self.cylinderlization.pc_range, self.cylinderlization.voxel_size)[[1, 0]]
+        if batch_size is None:
+            batch_size = len(torch.unique(pcoords[:, 0]))                      # the reference's rule (mvf:320)
         pv = self.pillarview(feat, pcoords, pinv, psize, batch_size)
         cv = self.cylinderview(feat, ccoords, cinv, csize, batch_size)
-        feat = torch.cat((self.pointnet1(feat), pv, cv), dim=-1)
-        pillar = ops.scatter_max(self.pointnet2(feat), pinv, pcoords.shape[0])[0]
-        if batch_size is None:
-            batch_size = len(torch.unique(pcoords[:, 0]))
+        x = torch.cat((self.pointnet1(feat), pv, cv), dim=-1)
+        pillar = ops.scatter_max(self.pointnet2(x), pinv, pcoords.shape[0])[0]
         ds = int(self.ds_rate)
         u = pcoords.long()
         H, W = int(psize[0]) // ds, int(psize[1]) // ds
-        # SparseConvTensor(features, coords // ds, ...).dense() (mvf:322-327): several pillars fall into one coarse cell; spconv's dense()
-        # scatters them in index order, the last one wins -- the same rule here (index_put with accumulate=False keeps the last write on
-        # the CPU; on the GPU the winner among equal cells is unspecified, as it is in spconv's scatter kernel)
+        # SparseConvTensor(features, coords // ds, ...).dense() (mvf:322-327): several pillars fall into one coarse cell; spconv's dense() scatters them
+        # in index order -- which one stays is unspecified there and here (index_put without accumulate)
         out = torch.zeros((batch_size, H, W, pillar.shape[1]), dtype=pillar.dtype, device=pillar.device)
         out[u[:, 0], u[:, 1] // ds, u[:, 2] // ds] = pillar
         return out.permute(0, 3, 1, 2)

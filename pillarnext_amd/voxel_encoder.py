@@ -1,29 +1,18 @@
-"""Host-side mirror of det3d/models/readers/voxel_encoder.py ("ve:" below): dynamic 3-D voxelisation + per-voxel mean.
+"""Host-side mirror of det3d/models/readers/voxel_encoder.py ("ve:" below): dynamic 3-D voxelisation + per-voxel mean, on the HIP grouping
+kernel of csrc/group.hip (include/pnx.h: pnx_group_points, mode PNX_GROUP_VOXEL).
 
-    VoxelFeatureNet(voxel_size, pc_range).forward(points (N, 1+F) [b,x,y,z,..]) -> (features (V, F) = mean of the voxel's rows [x y z f..],
+    VoxelFeatureNet(voxel_size, pc_range).forward(points (N, 1+F) [b,x,y,z,..]) -> (features (V, F+3) = mean of the voxel's rows [x y z f..],
                                                                                   coords (V, 4) int32 [b, z, y, x], grid [gz, gy, gx])   # ve:75-87
 
-SURVEY 8f-4 row (after the PillarNeXt hot path): grouping by torch.unique on one int64 voxel key per kept point -- ascending key ==
-the reference's lexicographic torch.unique(dim=0) over [b, x, y, z] rows (ve:63) -- and index_add sums; no kernel of its own."""
+Same class names, constructor arguments and return values as the reference.  The voxel of a point follows from the reference's fp32 arithmetic
+((x - min) / voxel with an IEEE divide, float range test, truncation); the rank of a voxel in torch.unique(dim=0)'s order comes from a key-order
+occupancy bitmap + popcount prefix instead of a sort; the mean is an exact fp64 sum divided in fp32.  CUDA tensors only: there is no CPU path."""
 import numpy as np
 import torch
 from torch import nn
 
-
-def scatter_mean(src, index, num):
-    """torch_scatter.scatter_mean(src, index, dim=0) (ve:20): per-index sum, then true divide by the count."""
-    s = torch.zeros((num, src.shape[1]), dtype=src.dtype, device=src.device).index_add_(0, index, src)
-    cnt = torch.zeros((num,), dtype=src.dtype, device=src.device).index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
-    return s / cnt.clamp(min=1).unsqueeze(1)
-
-
-class DynamicVoxelEncoder(nn.Module):
-    """ve:12-22."""
-
-    def forward(self, inputs, unq_inv, num_voxels=None):
-        if num_voxels is None:
-            num_voxels = int(unq_inv.max().item()) + 1 if unq_inv.numel() else 0
-        return scatter_mean(inputs, unq_inv, num_voxels)
+from . import ops
+from ._lib import PNX_GROUP_VOXEL, PnxError
 
 
 def grid_of(pc_range, voxel_size):
@@ -32,32 +21,46 @@ def grid_of(pc_range, voxel_size):
     return np.round(g, 0, g).astype(np.int64)
 
 
+def batch_of(points, batch_size=None):
+    """Number of samples: the caller's, else what the reference's index arithmetic implies (largest batch index + 1; one host sync)."""
+    if batch_size is not None:
+        return int(batch_size)
+    return int(points[:, 0].max().item()) + 1 if points.shape[0] else 1
+
+
+def _device_points(points, who):
+    if not points.is_cuda:
+        raise PnxError(f"{who}: points must be a CUDA (ROCm) tensor; the readers have no CPU implementation")
+    return points.contiguous().float()
+
+
+class DynamicVoxelEncoder(nn.Module):
+    """ve:12-22: scatter_mean of arbitrary per-point rows (differentiable; VoxelFeatureNet itself takes the means the grouping kernel produces)."""
+
+    def forward(self, inputs, unq_inv, num_voxels=None):
+        if num_voxels is None:
+            num_voxels = int(unq_inv.max().item()) + 1 if unq_inv.numel() else 0
+        s = torch.zeros((num_voxels, inputs.shape[1]), dtype=inputs.dtype, device=inputs.device).index_add_(0, unq_inv, inputs)
+        cnt = torch.zeros((num_voxels,), dtype=inputs.dtype, device=inputs.device).index_add_(0, unq_inv, torch.ones_like(unq_inv, dtype=inputs.dtype))
+        return s / cnt.clamp(min=1).unsqueeze(1)
+
+
 class VoxelNet(nn.Module):
-    """ve:25-72: fp32 (x - min) / voxel with an IEEE divide, float range test on all three axes, truncation, unique voxel rows."""
+    """ve:25-72: returns (features (N', F+3) = the kept rows, coords (V, 4) int32 [b, z, y, x], unq_inv (N'), grid [gz, gy, gx])."""
 
     def __init__(self, voxel_size, pc_range):
         super().__init__()
         self.voxel_size = np.array(voxel_size)
         self.pc_range = np.array(pc_range)
+        self._geom = ops.group_geom(self.pc_range, self.voxel_size, PNX_GROUP_VOXEL)
 
-    def forward(self, points):
-        g = grid_of(self.pc_range, self.voxel_size)                                            # x, y, z
-        vs = torch.from_numpy(self.voxel_size).type_as(points).to(points.device)
-        pr = torch.from_numpy(self.pc_range).type_as(points).to(points.device)
-        pc = (points[:, 1:4] - pr[:3].view(-1, 3)) / vs.view(-1, 3)
-        mask = ((pc[:, 0] >= 0) & (pc[:, 0] < g[0]) & (pc[:, 1] >= 0) & (pc[:, 1] < g[1]) & (pc[:, 2] >= 0) & (pc[:, 2] < g[2]))
-        points, pc = points[mask], pc[mask].long()
-        b = points[:, 0].long()
-        key = ((b * int(g[0]) + pc[:, 0]) * int(g[1]) + pc[:, 1]) * int(g[2]) + pc[:, 2]          # ascending key == sorted [b, x, y, z] rows
-        unq, unq_inv = torch.unique(key, return_inverse=True)
-        z = unq % int(g[2])
-        t = unq // int(g[2])
-        y = t % int(g[1])
-        t = t // int(g[1])
-        x = t % int(g[0])
-        bb = t // int(g[0])
-        coords = torch.stack([bb, z, y, x], 1).int()                                              # ve:70: unq[:, [0, 3, 2, 1]]
-        return points[:, 1:], coords, unq_inv, g[[2, 1, 0]]
+    def group(self, points, batch_size=None, want_mean=False):
+        points = _device_points(points, "VoxelNet")
+        return ops.group_points(points, batch_of(points, batch_size), self._geom, want_features=True, want_mean=want_mean)
+
+    def forward(self, points, batch_size=None):
+        r = self.group(points, batch_size)
+        return r["features"], r["coords"], r["unq_inv"], grid_of(self.pc_range, self.voxel_size)[[2, 1, 0]]
 
 
 class VoxelFeatureNet(nn.Module):
@@ -68,6 +71,6 @@ class VoxelFeatureNet(nn.Module):
         self.voxelization = VoxelNet(voxel_size, pc_range)
         self.voxel_encoder = DynamicVoxelEncoder()
 
-    def forward(self, points):
-        features, coords, unq_inv, grid_size = self.voxelization(points)
-        return self.voxel_encoder(features, unq_inv, coords.shape[0]), coords, grid_size
+    def forward(self, points, batch_size=None):
+        r = self.voxelization.group(points, batch_size, want_mean=True)
+        return r["mean"], r["coords"], grid_of(self.voxelization.pc_range, self.voxelization.voxel_size)[[2, 1, 0]]

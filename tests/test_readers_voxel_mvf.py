@@ -1,7 +1,9 @@
-"""CPU: the voxel and multi-view readers (pillarnext_amd/voxel_encoder.py, mvf_encoder.py) against fixtures made by RUNNING the
-reference (oracle/gen_golden.py voxel / mvf: det3d/models/readers/voxel_encoder.py and mvf_encoder.py imported unmodified; torch_scatter
-restated, spconv stood in for at import only).  Indices bit-exact, features within 1e-5 (scatter_mean's summation order).  What needs spconv
--- SingleView.forward and MVFFeatureNet.forward end to end -- has no fixture (unpinned, like the backbone)."""
+"""CPU: the torch-CPU statement of the voxel and multi-view readers (oracle/torch_readers.py, test infrastructure) against fixtures made by RUNNING
+the reference (oracle/gen_golden.py voxel / mvf: det3d/models/readers/voxel_encoder.py and mvf_encoder.py imported unmodified; torch_scatter restated,
+spconv stood in for at import only) -- this pins the statement the HIP kernels of csrc/group.hip are compared with on the GPU
+(tests/test_gpu_readers_voxel_mvf.py, which also checks the kernels against these fixtures directly).  Indices bit-exact, features within 1e-5
+(scatter_mean's summation order).  Plus the host logic of the product modules: state-dict keys, YAML constructor, and that they refuse CPU tensors.
+What needs spconv -- SingleView.forward and MVFFeatureNet.forward end to end -- has no fixture (unpinned, like the backbone)."""
 import numpy as np
 import pytest
 
@@ -10,28 +12,28 @@ from conftest import load_golden
 torch = pytest.importorskip("torch")
 
 
-def test_voxel_feature_net_matches_the_reference():
-    from det3d.models.readers.voxel_encoder import VoxelFeatureNet
+def test_voxel_statement_matches_the_reference():
+    from oracle import torch_readers as R
 
     g = load_golden("voxel_b3_gap")
-    net = VoxelFeatureNet(list(g["voxel_size"]), list(g["pc_range"]))
-    pts = torch.from_numpy(g["points"])
-    f, c, grid = net(pts)
-    _, _, inv, _ = net.voxelization(pts)
+    rows, c, inv, grid, mean = R.voxel_net(torch.from_numpy(g["points"]), list(g["voxel_size"]), list(g["pc_range"]))
     assert np.array_equal(c.numpy(), g["coords"]) and c.dtype == torch.int32          # [b, z, y, x]
     assert np.array_equal(inv.numpy(), g["unq_inv"])
     assert np.array_equal(np.asarray(grid), g["grid"])                                  # [gz, gy, gx]
-    np.testing.assert_allclose(f.numpy(), g["features"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(mean.numpy(), g["features"], rtol=0, atol=1e-5)
     assert set(np.unique(g["coords"][:, 0])) == {0, 2}                                  # the fixture has an empty middle sample
 
 
 @pytest.mark.parametrize("tag", ["pillar", "cyl"])
-def test_mvf_groupings_match_the_reference(tag):
-    from det3d.models.readers.mvf_encoder import CylinderNet, PillarVoxelNet
+def test_mvf_grouping_statements_match_the_reference(tag):
+    from oracle import torch_readers as R
 
     g = load_golden("mvf_parts")
-    net = PillarVoxelNet(list(g["voxel_size"]), list(g["pc_range"])) if tag == "pillar" else CylinderNet(list(g["cylinder_size"]), list(g["cylinder_range"]))
-    f, c, inv, grid = net(torch.from_numpy(g["points"]))
+    pts = torch.from_numpy(g["points"])
+    if tag == "pillar":
+        f, c, inv, grid = R.clamp_view(pts, list(g["voxel_size"]), list(g["pc_range"]))
+    else:
+        f, c, inv, grid = R.clamp_view(R.cylinder_rows(pts), list(g["cylinder_size"]), list(g["cylinder_range"]))
     assert np.array_equal(c.numpy(), g[f"{tag}_coords"]) and np.array_equal(inv.numpy(), g[f"{tag}_unq_inv"])
     assert np.array_equal(np.asarray(grid), g[f"{tag}_grid"])
     ref = g[f"{tag}_features"]
@@ -43,14 +45,31 @@ def test_mvf_groupings_match_the_reference(tag):
 
 def test_pointnet_and_bilinear_match_the_reference():
     from det3d.models.readers.mvf_encoder import PointNet, SingleView
+    from oracle import torch_readers as R
 
     g = load_golden("mvf_parts")
     pn = PointNet(20, 32).eval()
     pn.load_state_dict({k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("pn_") and k not in ("pn_in", "pn_out")})
     with torch.no_grad():
         np.testing.assert_allclose(pn(torch.from_numpy(g["pn_in"])).numpy(), g["pn_out"], rtol=1e-6, atol=1e-6)
-    out = SingleView.bilinear_interpolate(torch.from_numpy(g["bil_image"]), torch.from_numpy(g["bil_coords"]))
-    np.testing.assert_allclose(out.numpy(), g["bil_out"], rtol=1e-6, atol=1e-6)
+    img, co = torch.from_numpy(g["bil_image"]), torch.from_numpy(g["bil_coords"])
+    np.testing.assert_allclose(R.bilinear(img, co).numpy(), g["bil_out"], rtol=1e-6, atol=1e-6)
+    # the training-path statement of the product (torch ops over flat indices, differentiable) is the same function
+    np.testing.assert_allclose(SingleView.bilinear_interpolate(img, co).numpy(), g["bil_out"], rtol=1e-6, atol=1e-6)
+
+
+def test_readers_refuse_cpu_tensors():
+    """The product modules run on the HIP kernels only: a CPU tensor is an error, not a fallback."""
+    from det3d.models.readers.mvf_encoder import CylinderNet, PillarVoxelNet
+    from det3d.models.readers.voxel_encoder import VoxelFeatureNet
+    from pillarnext_amd._lib import PnxError
+
+    g = load_golden("mvf_parts")
+    pts = torch.from_numpy(g["points"])
+    for net in (VoxelFeatureNet([0.2, 0.2, 0.4], [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]), PillarVoxelNet(list(g["voxel_size"]), list(g["pc_range"])),
+                CylinderNet(list(g["cylinder_size"]), list(g["cylinder_range"]))):
+        with pytest.raises(PnxError):
+            net(pts)
 
 
 def test_mvf_net_has_the_reference_keys_and_yaml_constructor():
@@ -64,22 +83,3 @@ def test_mvf_net_has_the_reference_keys_and_yaml_constructor():
             "cylinderview.blocks.3.2.block1.conv.weight", "pillarview.blocks.1.1.norm2.weight", "pointnet1.linear.weight", "pointnet2.norm.bias"} <= keys
     assert m.pointnet1.linear.weight.shape == (192, 20) and m.pointnet2.linear.weight.shape == (256, 576)
     assert m.pillarview.pfn_layers[0].linear.weight.shape == (24, 20) and m.pillarview.pfn_layers[1].linear.weight.shape == (48, 48)
-
-
-@pytest.mark.gpu
-def test_mvf_net_forward_on_the_gpu():
-    """End to end on the device (HIP scatter-max in the PFN layers): shape of SparseConvTensor(...).dense() (mvf_encoder.py:322-327), finite,
-    zero where no pillar falls, and equal to the same net on the torch CPU statement of scatter_max within fp32 noise."""
-    from pillarnext_amd import synth
-    from pillarnext_amd.mvf_encoder import MVFFeatureNet
-
-    torch.manual_seed(0)
-    pr, vs = [-25.6, -25.6, -10.0, 25.6, 25.6, 10.0], [0.2, 0.2, 20]
-    m = MVFFeatureNet(in_channels=5, voxel_size=vs, pc_range=pr, cylinder_size=[1.40625, 0.4, 40], cylinder_range=[-180, -10.0, 0, 180, 10.0, 40],
-                      num_filters=[16, 16], layer_nums=[1, 1], ds_layer_strides=[1, 2], ds_num_filters=[16, 32], kernel_size=[3, 3], out_channels=64).cuda().eval()
-    pts = torch.from_numpy(synth.make_batch("C1", 2, "sweep", n=4000)).cuda()
-    with torch.no_grad():
-        y = m(pts, batch_size=2)
-    assert y.shape == (2, 64, 128, 128) and bool(torch.isfinite(y).all())
-    occ = (y != 0).any(1)
-    assert 0 < int(occ.sum()) < occ.numel() // 2
