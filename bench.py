@@ -59,6 +59,10 @@ def parse():
                     help="launch/rendezvous/timing/JSON plumbing only, no GPU work (CPU test of the --gpus path, backend gloo)")
     ap.add_argument("--include-h2d", action="store_true", help="also time the loop with the COLLATED frames uploaded from pinned host memory each step (no merge)")
     ap.add_argument("--no-extras", action="store_true", help="skip value_uniform / sections / NMS / CPU legs (profiling runs)")
+    ap.add_argument("--no-back-to-back", action="store_true", help="skip the 15 back-to-back reader calls behind the timed loop (PMC passes: every reader call is then an in-loop call)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="ranks beyond the visible GPUs share devices (rank r -> cuda:(r mod device_count)): runs the N-rank path with real kernels on a 1-GPU box (use --backend gloo)")
+    ap.add_argument("--all-legs", action="store_true", help="with --gpus > 1: also run the uniform / H2D-merge / Waymo legs (default: value, roofline, value_train only, so that an 8-rank run stays short)")
     return ap.parse_args()
 
 
@@ -242,7 +246,8 @@ def sections(model, examples, batch):
 
 
 
-def train_leg(dev, rank, world, frames=4, steps=5, warmup=3):
+def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAMES", "4")), steps=int(os.environ.get("PNX_BENCH_TRAIN_STEPS", "5")),
+              warmup=int(os.environ.get("PNX_BENCH_TRAIN_WARMUP", "3"))):
     """One data-parallel TRAINING step of PillarNeXt-B (reference: trainer/trainer/trainer.py:94-108 -- forward, loss, backward, clip 35,
     AdamW, OneCycle) on synthetic C2 frames + labels, `frames` per GPU, under bf16 autocast in channels_last (the reference trains in
     fp32; the bf16 step is what this repository optimises and is labelled as such).  DDP over the job's process group when world > 1
@@ -317,7 +322,7 @@ def train_leg(dev, rank, world, frames=4, steps=5, warmup=3):
                      "step": "forward + CenterHead losses + backward + clip 35 + AdamW + OneCycle, DDP + SyncBN when n_gpus > 1",
                      "loss_finite": finite, "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                      "miopen": "find (cudnn.benchmark)" if find else "immediate mode", "leg_seconds": round(time.perf_counter() - t_leg, 1)},
-           "roofline_train": {"bound": "mfma", "kernel": "whole training step (backbone 3x3 layers: forward + dgrad on the masked HIP kernels, wgrad and the dense layers on MIOpen)",
+           "roofline_train": {"bound": "mfma", "kernel": "whole training step (backbone 3x3 layers: forward, stride-1 dgrad and every weight gradient on the masked HIP kernels; stride-2 dgrad and the dense neck / head layers on MIOpen)",
                               "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s (dense-equivalent bf16 FLOPs, 3 x forward)",
                               "frac": round(tf / 2500.0, 4), "algorithmic_flops_per_step": flops}}
     torch.backends.cudnn.benchmark = bench_mode
@@ -375,6 +380,8 @@ def main():
 
     import ctypes
 
+    if a.share_gpu:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     # The dense 256-channel layers at 180 x 180 (neck pre_conv, ASPP) are MIOpen's.  Its find step times CK's grouped convolution (287 us) and the
     # asm implicit-GEMM solver (477 us) and picked the slower one in about one run of four (and in every run under rocprofv3): +0.95 ms per
@@ -415,10 +422,13 @@ def main():
         out = serving_loop(model, exs, steps, upload)
         barrier()
         dt = time.perf_counter() - t0
+        timed.rank_ms = [round(dt / steps * 1e3, 3)]
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            t = torch.zeros(world, dtype=torch.float64, device=dev)
+            t[rank] = dt
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)          # every rank's own time: the line reports min / max over ranks, value uses the max
+            timed.rank_ms = [round(float(v) / steps * 1e3, 3) for v in t.tolist()]
+            dt = float(t.max().item())
         return dt, out
 
     L = _lib.lib()
@@ -427,6 +437,7 @@ def main():
             model(examples[i % ROTATE])
         _lib.check(L.pnx_profile_begin(max(a.steps, 1)), "pnx_profile_begin")
         dt, out = timed(examples, a.steps)
+        rank_ms = list(timed.rank_ms)
         host_ms = serving_loop.host_enqueue_ms
         r_us, c_us, ns = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
         _lib.check(L.pnx_profile_end(ctypes.byref(r_us), ctypes.byref(c_us), ctypes.byref(ns)), "pnx_profile_end")
@@ -434,27 +445,42 @@ def main():
         # the same reader calls back to back, nothing else on the GPU between them: the convolutions of the detector leave the chip in a
         # power / cache state in which the reader's kernels run 12-20 % slower (profiles/r04_reader_between.txt); `roofline` is the in-loop figure
         ny_, nx_ = (int(v) for v in model.reader.grid_size)
-        cv = torch.empty((a.batch, 64, ny_, nx_), dtype=model.dtype, device=dev, memory_format=torch.channels_last)
-        oc = torch.empty((a.batch, ny_, nx_), dtype=torch.uint8, device=dev)
-        for i in range(3):
-            model.reader.forward_dense(examples[i % ROTATE]["points"], a.batch, dtype=model.dtype, out=cv, occupancy=oc)
-        torch.cuda.synchronize()
-        _lib.check(L.pnx_profile_begin(12), "pnx_profile_begin")
-        for i in range(12):
-            model.reader.forward_dense(examples[i % ROTATE]["points"], a.batch, dtype=model.dtype, out=cv, occupancy=oc)
-        torch.cuda.synchronize()
         rb_us, cb_us, nb_ = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
-        _lib.check(L.pnx_profile_end(ctypes.byref(rb_us), ctypes.byref(cb_us), ctypes.byref(nb_)), "pnx_profile_end")
-        del cv, oc
+        if not a.no_back_to_back:
+            cv = torch.empty((a.batch, 64, ny_, nx_), dtype=model.dtype, device=dev, memory_format=torch.channels_last)
+            oc = torch.empty((a.batch, ny_, nx_), dtype=torch.uint8, device=dev)
+            for i in range(3):
+                model.reader.forward_dense(examples[i % ROTATE]["points"], a.batch, dtype=model.dtype, out=cv, occupancy=oc)
+            torch.cuda.synchronize()
+            _lib.check(L.pnx_profile_begin(12), "pnx_profile_begin")
+            for i in range(12):
+                model.reader.forward_dense(examples[i % ROTATE]["points"], a.batch, dtype=model.dtype, out=cv, occupancy=oc)
+            torch.cuda.synchronize()
+            _lib.check(L.pnx_profile_end(ctypes.byref(rb_us), ctypes.byref(cb_us), ctypes.byref(nb_)), "pnx_profile_end")
+            del cv, oc
 
         extras = {}
-        if not a.no_extras:
+        short = world > 1 and not a.all_legs   # an N-rank run: value, roofline and value_train only (DESIGN.md section 7 gives its expected wall time)
+        if not a.no_extras and not short:
             other = "uniform" if a.dist == "sweep" else "sweep"
             ex2 = make_examples(other)
             for i in range(ROTATE):
                 model(ex2[i])
-            dt2, _ = timed(ex2, max(a.steps // 2, 4))
-            extras[f"value_{other}"] = round(a.batch * world * max(a.steps // 2, 4) / dt2, 2)
+            st2 = max(a.steps // 2, 4)
+            _lib.check(L.pnx_profile_begin(st2), "pnx_profile_begin")
+            dt2, _ = timed(ex2, st2)
+            r2_us, c2_us, n2 = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
+            _lib.check(L.pnx_profile_end(ctypes.byref(r2_us), ctypes.byref(c2_us), ctypes.byref(n2)), "pnx_profile_end")
+            extras[f"value_{other}"] = round(a.batch * world * st2 / dt2, 2)
+            cnt2 = torch.zeros(2, dtype=torch.int32, device=dev)
+            model.reader.forward_dense(ex2[0]["points"], a.batch, counts=cnt2)
+            b2 = 24 * ex2[0]["points"].shape[0] + a.batch * nx_ * ny_ * 64 * 2
+            # SURVEY 8(d) asks for the reader's roofline on BOTH distributions: same byte formula, same in-loop HIP-event interval
+            extras[f"roofline_{other}"] = {"bound": "hbm", "kernel": f"reader, all of its kernels, cloud={other}, in the detector's loop",
+                                           "achieved": round(b2 / r2_us.value / 1e3, 1) if r2_us.value > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(b2 / r2_us.value / 1e3 / HBM_PEAK_GBS, 4) if r2_us.value > 0 else None,
+                                           "algorithmic_bytes_per_launch": b2, "kernel_us": round(r2_us.value, 2), "samples": n2.value,
+                                           "pillars_per_launch": int(cnt2[0]), "kept_points_per_launch": int(cnt2[1])}
             # the loader's side of the contract in the loop: raw sweeps -> pinned memory -> H2D on a side stream -> device merge
             from pillarnext_amd.io import PointUploader, SweepMerger
 
@@ -520,9 +546,10 @@ def main():
                     del wm, wex
                     torch.cuda.empty_cache()
             # the training step (BASELINE configs[2]: 4 frames per GPU), timed by this run: value_train / roofline_train
+        if not a.no_extras:
             if a.config == "C2" and not os.environ.get("PNX_BENCH_NO_TRAIN"):
                 extras.update(train_leg(dev, rank, world))
-            if rank == 0:
+            if rank == 0 and not short:
                 extras["sections_us"] = sections(model, examples, a.batch)
                 extras["nms_us"] = nms_bench(dev)
             for i in range(ROTATE):  # leave the persistent workspaces in the main distribution's state
@@ -544,12 +571,13 @@ def main():
     fill_gbs = launch_bytes / (c_us.value * 1e-6) / 1e9 if c_us.value > 0 else None
     pfn_flops = 2.0 * n_kept * (10 * 32 + 64 * 64)               # 8 832 FLOP per kept point
     pfn_tf = pfn_flops / (pfn_us * 1e-6) / 1e12 if pfn_us > 0 else None
-    traffic, tsrc = None, None
+    traffic, tsrc, tcond = None, None, None
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tj):
         try:
             ent = json.load(open(tj)).get(f"{a.config}_b{a.batch}_{a.dist}", {})
             traffic = ent.get("hbm_bytes_per_launch") if ent.get("pipeline") == "spans" else None   # entries of older pipelines do not describe this one
+            tcond = ent.get("condition", "reader calls back to back (tools/reader_ab.py)") if traffic is not None else None
             tsrc = ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/profile_round.sh at this batch size, not measured in this run)" if traffic is not None
                     else f"no PMC entry for {a.config} / {a.batch} frames / {a.dist} of the current pipeline: run tools/profile_round.sh with PNX_BENCH_BATCH={a.batch}")
         except Exception:
@@ -559,6 +587,8 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "host_enqueue_ms_per_step": round(host_ms, 3),   # launch-thread time inside forward_async per step (launch plans: pnx_enqueue)
+        "ranks": {"world_size_seen_by_backend": dist.get_world_size() if world > 1 else 1, "backend": a.backend if world > 1 else None,
+                  "ms_per_step_min": min(rank_ms), "ms_per_step_max": max(rank_ms)},
         "config": {"workload": f"{a.config}: PillarNeXt-B nuScenes inference, {cfg['n']} pts/frame, voxel {cfg['voxel_size'][0]} m, BEV {nx}x{ny}, "
                                f"6 tasks/10 classes, cloud={a.dist} (1.5 % of the rows outside the range), random-init weights, {ROTATE} distinct frame batches rotating, "
                                f"inputs resident in HBM (value_with_h2d_merge: raw sweeps uploaded from pinned memory + merged on the device every step)",
@@ -567,10 +597,10 @@ def main():
                    "kept_points_per_launch": n_kept},
         "roofline": {"bound": "hbm", "kernel": "reader, ALL of its kernels (clear, chunk sort, then slab totals + span carve + span grouping/PFN + tail with the canvas zero-fill kernel beside them on a second stream)",
                      "achieved": round(reader_gbs, 1) if reader_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(reader_gbs / HBM_PEAK_GBS, 4) if reader_gbs else None, "traffic": traffic, "traffic_source": tsrc,
+                     "frac": round(reader_gbs / HBM_PEAK_GBS, 4) if reader_gbs else None, "traffic": traffic, "traffic_source": tsrc, "traffic_condition": tcond,
                      "algorithmic_bytes_per_launch": reader_bytes, "kernel_us": round(r_us.value, 2), "samples": ns.value,
                      "voxelize_us": round(vox_us, 2),
-                     "back_to_back": {"kernel_us": round(rb_us.value, 2), "frac": round(reader_bytes / rb_us.value / 1e3 / HBM_PEAK_GBS, 4) if rb_us.value > 0 else None,
+                     "back_to_back": None if a.no_back_to_back else {"kernel_us": round(rb_us.value, 2), "frac": round(reader_bytes / rb_us.value / 1e3 / HBM_PEAK_GBS, 4) if rb_us.value > 0 else None,
                                       "note": "the same reader calls with nothing else on the GPU between them (12 calls); frac above is measured inside the detector's loop"}},
         "roofline_fill": {"bound": "hbm", "kernel": "k_span_pfn (span grouping + PFN: the pillar cells) and k_canvas_fill_bytes (every pillar-free tile) running concurrently, fork to join",
                           "achieved": round(fill_gbs, 1) if fill_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

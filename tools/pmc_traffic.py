@@ -6,7 +6,8 @@ coalesced reads on gfx950; WRITE_SIZE is taken as reported.  Two kinds of entrie
   <key>            the WHOLE reader: every dispatch of every reader kernel (and the workspace memset) summed, divided by the number of
                    reader calls (= dispatches of k_chunk_sort) -- what bench.py's `roofline.traffic` quotes
   <key>:<kernel>   one kernel, average per dispatch
-usage: pmc_traffic.py fetch.csv write.csv <key> <out.json>"""
+usage: pmc_traffic.py fetch.csv write.csv <key> <out.json> [condition]     condition = how the profiled reader calls ran (recorded in the entry and
+quoted by bench.py as roofline.traffic_condition)"""
 import csv
 import json
 import sys
@@ -21,6 +22,7 @@ def rows(path, counter):
 
 def main():
     fetch_csv, write_csv, key, out = sys.argv[1:5]
+    cond = sys.argv[5] if len(sys.argv) > 5 else "reader calls back to back (tools/reader_ab.py)"
     f, w = rows(fetch_csv, "FETCH_SIZE"), rows(write_csv, "WRITE_SIZE")
     try:
         d = json.load(open(out))
@@ -29,11 +31,14 @@ def main():
     for k in [k for k in d if k.startswith(key + ":")]:   # per-kernel entries of an earlier pipeline
         del d[k]
     calls = max(sum(1 for n, _ in f if "k_chunk_sort" in n) or sum(1 for n, _ in f if "k_keys" in n), 1)
-    tot_f = sum(v for n, v in f if any(k in n for k in READER))
-    tot_w = sum(v for n, v in w if any(k in n for k in READER))
-    d[key] = {"kernel": "all reader kernels", "pipeline": "spans" if any("k_chunk_sort" in n for n, _ in f) else "bins", "reader_calls": calls, "fetch_size_kib_raw_per_call": tot_f / calls, "write_size_kib_per_call": tot_w / calls,
+    names = READER
+    if any("k_chunk_sort" in n for n, _ in f):   # the span pipeline clears with its own kernel: generic names (memset, k_fill, scans) belong to other ops of the process
+        names = ["k_clear2", "k_chunk_sort", "k_slab_totals", "k_span_carve", "k_span_pfn", "k_pfn3", "k_canvas_fill"]
+    tot_f = sum(v for n, v in f if any(k in n for k in names))
+    tot_w = sum(v for n, v in w if any(k in n for k in names))
+    d[key] = {"kernel": "all reader kernels", "pipeline": "spans" if any("k_chunk_sort" in n for n, _ in f) else "bins", "reader_calls": calls, "condition": cond, "fetch_size_kib_raw_per_call": tot_f / calls, "write_size_kib_per_call": tot_w / calls,
               "hbm_bytes_per_launch": int((2 * tot_f + tot_w) / calls * 1024), "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as reported"}
-    for k in READER:
+    for k in names:
         fv = [v for n, v in f if k in n]
         wv = [v for n, v in w if k in n]
         if fv or wv:
