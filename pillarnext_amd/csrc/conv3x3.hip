@@ -65,7 +65,9 @@ __device__ __forceinline__ float round_el(float x) { return __uint_as_float(el_l
 //      store d of lane L is chunk L&7 of pixel 8d + (L>>3): every store instruction writes 8 complete 128-byte lines.
 // Both must be called by all 64 lanes.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void pack_tile(const v16f& a, bool act, int relu, uint4 (&out)[2]) {
+// `res` (optional): the residual lines of this lane's pixel for the tile, res[t] = channels 16 t + 8 kb + 0..7 -- exactly the 8 consecutive channels the
+// lane holds after the swap, added in fp32 before the ReLU.
+__device__ __forceinline__ void pack_tile(const v16f& a, bool act, int relu, uint4 (&out)[2], const uint4* res = nullptr) {
 #pragma unroll
   for (int t = 0; t < 2; t++) {
     float v[8];
@@ -74,6 +76,11 @@ __device__ __forceinline__ void pack_tile(const v16f& a, bool act, int relu, uin
       const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[8 * t + i]), __float_as_uint(a[8 * t + 4 + i]), false, false);
       v[i] = __uint_as_float(r.x);
       v[4 + i] = __uint_as_float(r.y);
+    }
+    if (res != nullptr) {
+      const uint4 q = res[t];
+      v[0] += __uint_as_float(el_lo_bits(q.x)), v[1] += __uint_as_float(el_hi_bits(q.x)), v[2] += __uint_as_float(el_lo_bits(q.y)), v[3] += __uint_as_float(el_hi_bits(q.y));
+      v[4] += __uint_as_float(el_lo_bits(q.z)), v[5] += __uint_as_float(el_hi_bits(q.z)), v[6] += __uint_as_float(el_lo_bits(q.w)), v[7] += __uint_as_float(el_hi_bits(q.w));
     }
     if (relu) {
 #pragma unroll
@@ -156,6 +163,17 @@ __device__ __forceinline__ void load_residual(uint4 (&rq)[2][2], const uint16_t*
     for (int t = 0; t < 2; t++) {
       rq[m][t] = make_uint4(0, 0, 0, 0);
       if (act) rq[m][t] = *reinterpret_cast<const uint4*>(res_px + m * 32 + 16 * t + 8 * kb);
+    }
+}
+// the same lines from a WAVE-UNIFORM row pointer (pixel 0 of the row segment, channel base of the 64-channel group) + one per-lane byte offset
+// ((px * CSTRIDE + 8 kb) * 2, the same for every row): scalar base + 32-bit lane offset + immediate, no 64-bit pointer per row in vector registers
+__device__ __forceinline__ void load_residual_u(uint4 (&rq)[2][2], const uint16_t* __restrict__ row, uint32_t lane_off, bool act) {
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      rq[m][t] = make_uint4(0, 0, 0, 0);
+      if (act) rq[m][t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(row) + lane_off + (uint32_t)((m * 32 + 16 * t) * 2));
     }
 }
 __device__ __forceinline__ void add_residual(v16f (&acc2)[2], const uint4 (&rq)[2][2]) {
@@ -491,8 +509,8 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __res
 // the taps, and the epilogue.  No barrier inside.
 template <int NR, int COUT, bool HAS_RES>
 __device__ __forceinline__ void conv_rows(const uint4* __restrict__ s_in, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
-                                          const uint4 (&rq)[4][2][2], const int (&rbase)[4], const uint32_t (&rmask)[4], uint16_t* const (&yrow)[4],
-                                          int n_valid, int relu, int px, int kb, int lane) {
+                                          const uint16_t* const (&rrow_res)[4], uint32_t res_off, const int (&rbase)[4], const uint32_t (&rmask)[4],
+                                          uint16_t* const (&yrow)[4], int n_valid, int relu, int px, int kb, int lane) {
   constexpr int MTALL = COUT / 32;
 #pragma unroll 1
   for (int mg = 0; mg < MTALL; mg += 2) {  // 64 output channels per pass over the staged tile
@@ -503,19 +521,46 @@ __device__ __forceinline__ void conv_rows(const uint4* __restrict__ s_in, const 
 #pragma unroll
       for (int j = 0; j < NR; j++) acc[j][m] = bq;
     }
-    if (HAS_RES) {  // single pass (COUT == 64) by construction
+#ifdef PNX_CONV_RES_EARLY  // round 2-4 form: the residual starts the accumulators (64 registers held across the staging: 212 B/lane of scratch)
+    if (HAS_RES) {
 #pragma unroll
-      for (int j = 0; j < NR; j++) add_residual(acc[j], rq[j]);
+      for (int j = 0; j < NR; j++) {
+        uint4 rq[2][2];
+        load_residual_u(rq, rrow_res[j], res_off, (rmask[j] >> px) & 1u);
+        add_residual(acc[j], rq);
+      }
     }
+#endif
+    // The residual (HAS_RES: one 64-channel pass by construction) joins in the epilogue: the lines of row 0 are requested here and arrive under the
+    // tap loop (16 registers), the lines of row j + 1 are requested before row j is packed and stored -- a load is never issued BEHIND a store it
+    // then has to wait for (gfx9 vmcnt is in-order), and nothing is held across the staging of the tile.
+    uint4 rq[2][2];
+#ifndef PNX_CONV_RES_EARLY
+    if (HAS_RES) load_residual_u(rq, rrow_res[0], res_off, rmask[0] >> px & 1u);
+#endif
     conv_taps<NR, MTALL>(acc, s_in, wfrag, rbase, mg, px, kb, lane);
 #pragma unroll
     for (int j = 0; j < NR; j++) {
       const bool act = (rmask[j] >> px) & 1u;
+      uint4 rc[2][2];
+#ifndef PNX_CONV_RES_EARLY
+      if (HAS_RES) {
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+          for (int t = 0; t < 2; t++) rc[m][t] = rq[m][t];
+        if (j + 1 < NR) load_residual_u(rq, rrow_res[j + 1], res_off, rmask[j + 1] >> px & 1u);
+      }
+#endif
       uint4 D[4];
 #pragma unroll
       for (int m = 0; m < 2; m++) {
         uint4 pk[2];
+#ifndef PNX_CONV_RES_EARLY
+        pack_tile(acc[j][m], act, relu, pk, HAS_RES ? rc[m] : nullptr);
+#else
         pack_tile(acc[j][m], act, relu, pk);
+#endif
         D[2 * m] = pk[0], D[2 * m + 1] = pk[1];
       }
       transpose_row64(D, lane);
@@ -566,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
   CT_DECL
   int it = 0;
   for (; tileA >= 0; tileA = tileB, tileB = tileC, idxB = idxC, it++) {
-    const int64_t tile = tileA;
+    const int64_t tile = (int64_t)__builtin_amdgcn_readfirstlane((int)tileA);  // uniform by construction: everything derived from it (origins, row pointers) lives in scalar registers
     sched_draw(s_next, it, slot);
     uint32_t* const s_rowmask = s_rowmask2 + (it & 1) * TH;
     const int tx = (int)(tile % tiles_x);
@@ -630,23 +675,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
     }
     const uint32_t need = am | (am << 1) | (am << 2);  // halo rows some active row reads
     CT_TOCK(1)
-    // ---- residual lines: requested before the tile is staged, consumed after
-    uint4 rq[4][2][2];
-    if (HAS_RES) {
+    // ---- residual lines of this lane's pixel in the wave's rows (requested inside conv_rows)
+    const uint16_t* rres[4];  // wave-uniform: pixel 0 of the row segment
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        load_residual(rq[j], res + (((int64_t)b * H + (y0 + rrow[j])) * W + (ox < W ? ox : 0)) * COUT, (rmask[j] >> px) & 1u, kb);
-    }
+    for (int j = 0; j < 4; j++) rres[j] = HAS_RES ? res + (((int64_t)b * H + (y0 + rrow[j])) * W + x0) * COUT : nullptr;
+    const uint32_t res_off = (uint32_t)(px * COUT + 8 * kb) * 2u;
     stage_tile64<CIN>(s_in, x, b, H, W, 0, y0, x0, need);
     CT_TOCK(2)
     __syncthreads();
     CT_TOCK(3)
     const int n_valid = W - x0;
     switch (nr) {  // wave-uniform
-      case 1: conv_rows<1, COUT, HAS_RES>(s_in, wfrag, bias, rq, rbase, rmask, yrow, n_valid, relu, px, kb, lane); break;
-      case 2: conv_rows<2, COUT, HAS_RES>(s_in, wfrag, bias, rq, rbase, rmask, yrow, n_valid, relu, px, kb, lane); break;
-      case 3: conv_rows<3, COUT, HAS_RES>(s_in, wfrag, bias, rq, rbase, rmask, yrow, n_valid, relu, px, kb, lane); break;
-      case 4: conv_rows<4, COUT, HAS_RES>(s_in, wfrag, bias, rq, rbase, rmask, yrow, n_valid, relu, px, kb, lane); break;
+      case 1: conv_rows<1, COUT, HAS_RES>(s_in, wfrag, bias, rres, res_off, rbase, rmask, yrow, n_valid, relu, px, kb, lane); break;
+      case 2: conv_rows<2, COUT, HAS_RES>(s_in, wfrag, bias, rres, res_off, rbase, rmask, yrow, n_valid, relu, px, kb, lane); break;
+      case 3: conv_rows<3, COUT, HAS_RES>(s_in, wfrag, bias, rres, res_off, rbase, rmask, yrow, n_valid, relu, px, kb, lane); break;
+      case 4: conv_rows<4, COUT, HAS_RES>(s_in, wfrag, bias, rres, res_off, rbase, rmask, yrow, n_valid, relu, px, kb, lane); break;
       default: break;
     }
     CT_TOCK(4)
@@ -659,6 +702,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
 constexpr int L128_TH = 8;
 constexpr int L128_NSTAGE = (L128_TH + 2) * LDS_HW * 8;
 
+// PNX_CONV64_SMALL=1: the 64 -> 64 layers on 8 x 32 tiles with three workgroups per CU (<= 168 registers) instead of 16 x 32 tiles with two
+// (measured in round 5, profiles/r05_conv_ab.txt)
+bool conv64_small_tiles() {
+  static const int v = getenv("PNX_CONV64_SMALL") != nullptr && atoi(getenv("PNX_CONV64_SMALL")) != 0;
+  return v != 0;
+}
 int next_sched_slot() {
   static unsigned int n = 0;  // one host thread per process drives the launches (pnx.h: not thread-safe)
   return (int)(n++ & 63u);
@@ -689,14 +738,25 @@ __device__ __forceinline__ void conv_rows_x(uint4* __restrict__ s_in, const uint
 #pragma unroll
         for (int j = 0; j < NR; j++) acc[j][m] = bq;
       }
+#ifdef PNX_CONV_RES_EARLY
       if (HAS_RES) {
 #pragma unroll
         for (int j = 0; j < NR; j++) {
           uint4 rq[2][2];
-          load_residual(rq, res + (((int64_t)b * H + (y0 + rrow[j])) * W + (ox < W ? ox : 0)) * COUT + mg * 32, (rmask[j] >> px) & 1u, kb);
+          load_residual_u(rq, res + (((int64_t)b * H + (y0 + rrow[j])) * W + x0) * COUT + mg * 32, (uint32_t)(px * COUT + 8 * kb) * 2u, (rmask[j] >> px) & 1u);
           add_residual(acc[j], rq);
         }
       }
+#endif
+    }
+    // residual of this pass: row 0's lines are requested before the LAST input slab's taps and arrive under them, row j + 1's before row j is packed
+    // (see conv_rows); nothing is held across a barrier-bracketed slab change
+    const uint16_t* rres[NRA];  // wave-uniform: pixel 0 of the row segment, first channel of this wave's 64-channel group
+    const uint32_t res_off = (uint32_t)(px * COUT + 8 * kb) * 2u;
+    uint4 rq[2][2];
+    if (NR > 0 && HAS_RES) {
+#pragma unroll
+      for (int j = 0; j < NR; j++) rres[j] = res + (((int64_t)b * H + (y0 + rrow[j])) * W + x0) * COUT + mg * 32;
     }
 #pragma unroll 1
     for (int sl = 0; sl < NS; sl++) {
@@ -705,6 +765,9 @@ __device__ __forceinline__ void conv_rows_x(uint4* __restrict__ s_in, const uint
         stage_tile64<CIN, L128_TH>(s_in, x, b, H, W, 64 * sl, y0, x0, need);
         __syncthreads();
       }
+#ifndef PNX_CONV_RES_EARLY
+      if (NR > 0 && HAS_RES && sl == NS - 1) load_residual_u(rq, rres[0], res_off, rmask[0] >> px & 1u);
+#endif
       if (NR > 0) conv_taps<NRA, COUT / 32, CIN / 16>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 4 * sl);
     }
     if (NR > 0) {
@@ -712,11 +775,25 @@ __device__ __forceinline__ void conv_rows_x(uint4* __restrict__ s_in, const uint
 #pragma unroll
       for (int j = 0; j < NR; j++) {
         const bool act = (rmask[j] >> px) & 1u;
+        uint4 rc[2][2];
+#ifndef PNX_CONV_RES_EARLY
+        if (HAS_RES) {
+#pragma unroll
+          for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) rc[m][t] = rq[m][t];
+          if (j + 1 < NR) load_residual_u(rq, rres[j + 1], res_off, rmask[j + 1] >> px & 1u);
+        }
+#endif
         uint4 D[4];
 #pragma unroll
         for (int m = 0; m < 2; m++) {
           uint4 pk[2];
+#ifndef PNX_CONV_RES_EARLY
+          pack_tile(acc[j][m], act, relu, pk, HAS_RES ? rc[m] : nullptr);
+#else
           pack_tile(acc[j][m], act, relu, pk);
+#endif
           D[2 * m] = pk[0], D[2 * m + 1] = pk[1];
         }
         transpose_row64(D, lane);
@@ -726,8 +803,8 @@ __device__ __forceinline__ void conv_rows_x(uint4* __restrict__ s_in, const uint
   }
 }
 
-template <int CIN, int COUT, bool HAS_RES>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
+template <int CIN, int COUT, bool HAS_RES, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void k_conv3x3_ldsx(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                       const float* __restrict__ bias, const uint16_t* __restrict__ res,
                                                       const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
                                                       int relu, uint8_t* __restrict__ row_dirty, int slot, const int32_t* __restrict__ tlist,
@@ -768,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
   for (int j = 0; j < 2; j++) aN[j] = false, wasN[j] = 1;
   int it = 0;
   for (; tileA >= 0; tileA = tileB, tileB = tileC, idxB = idxC, it++) {
-    const int64_t tile = tileA;
+    const int64_t tile = (int64_t)__builtin_amdgcn_readfirstlane((int)tileA);  // uniform by construction: everything derived from it (origins, row pointers) lives in scalar registers
     sched_draw(s_next, it, slot);
     uint32_t* const s_rowmask = s_rowmask2 + (it & 1) * TH;
     const int tx = (int)(tile % tiles_x);
@@ -842,17 +919,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
   sched_done(slot);
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int OCC = 2>
 int launch_ldsx(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
                 uint8_t* row_dirty, const int32_t* tlist, const int32_t* tcount, hipStream_t st) {
   const int slot = mask != nullptr ? next_sched_slot() : -1;
   int64_t nb = (int64_t)B * ((H + L128_TH - 1) / L128_TH) * ((W + 31) / 32);
-  if (nb > 512) nb = 512;  // resident workgroups: 2 per CU (registers)
+  if (nb > 256 * OCC) nb = 256 * OCC;  // resident workgroups: OCC per CU (registers)
   if (res != nullptr)
-    k_conv3x3_ldsx<CIN, COUT, true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y,
+    k_conv3x3_ldsx<CIN, COUT, true, OCC><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y,
                                                                  B, H, W, relu, row_dirty, slot, tlist, tcount);
   else
-    k_conv3x3_ldsx<CIN, COUT, false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W,
+    k_conv3x3_ldsx<CIN, COUT, false, OCC><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W,
                                                                   relu, row_dirty, slot, tlist, tcount);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
@@ -1347,6 +1424,7 @@ int PNX_CONV_FN(pnx_deconv2x2)(const void* x, const void* wfrag, const float* bi
 #ifndef PNX_CONV_F16  // type-independent helpers: in the bf16 object only
 int pnx_conv3x3_tile_rows(int32_t cin, int32_t cout, int32_t stride) {
   if (stride != 1) return 0;
+  if (cin == 64 && cout == 64 && conv64_small_tiles()) return L128_TH;
   if (cin == 64 && (cout == 64 || cout == 320 || cout == 384 || cout == 448)) return LDS_TH;
   if ((cin == 128 && cout == 128) || (cin == 256 && (cout == 256 || cout == 64))) return L128_TH;
   return 0;
@@ -1382,6 +1460,8 @@ int PNX_CONV_FN(pnx_conv3x3)(const void* x, const void* wfrag, const float* bias
   const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1 && getenv("PNX_CONV_DIRECT") == nullptr) {
+    if (cin == 64 && cout == 64 && conv64_small_tiles())
+      return launch_ldsx<64, 64, 3>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
     if (cin == 64 && cout == 64) return launch_lds<64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
     if (cin == 128 && cout == 128) return launch_ldsx<128, 128>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
     if (cin == 256 && cout == 64) return launch_ldsx<256, 64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);

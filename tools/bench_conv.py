@@ -10,6 +10,7 @@ ap.add_argument("--cin", type=int, default=64); ap.add_argument("--cout", type=i
 ap.add_argument("--hw", type=int, default=1440); ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--density", type=float, default=1.0); ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--stride", type=int, default=1); ap.add_argument("--tiles", action="store_true"); ap.add_argument("--miopen", action="store_true"); ap.add_argument("--res", action="store_true")
+ap.add_argument("--dilate", action="store_true", help="with --lidar: the stage's active set after its entry SparseConv2d (3x3 dilation of the pooled occupancy) -- what the stage's blocks run on")
 ap.add_argument("--lidar", type=int, default=-1, help="backbone stage (0..3): active sites = the C2 sweep occupancy pooled to that stage (sets --hw)")
 a = ap.parse_args()
 lidar_mask = None
@@ -27,6 +28,8 @@ if a.lidar >= 0:
     occ_in = occ
     for _ in range(a.lidar):
         occ_in, occ = occ, ops.mask_pool3(occ, 2)
+    if a.dilate:
+        occ = ops.mask_pool3(occ, 1)
     lidar_mask, a.hw = occ, occ.shape[-1]
     if a.stride == 1:
         occ_in = occ
