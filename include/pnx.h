@@ -331,6 +331,11 @@ int pnx_boxes_aligned_overlap_bev(const float* boxes_a, const float* boxes_b, in
 /* boxes_aligned_iou3d_gpu (iou3d_nms_utils.py:49-89): out (n) 3-D IoU of pair i, fused */
 int pnx_boxes_aligned_iou3d(const float* boxes_a, const float* boxes_b, int64_t n, float* out, pnx_stream_t stream);
 
+/* Host twins of pnx_boxes_iou_bev / the aligned pair form: det3d/core/iou3d_nms/src/iou3d_cpu.cpp:232-273 (boxes_iou_bev_cpu (N,M),
+ * boxes_aligned_iou_bev_cpu (N,1)) -- HOST pointers, no GPU needed, synchronous.  Compiled from the same source as the device kernels
+ * (csrc/iou3d_geom.h) with the same flags: results equal pnx_boxes_iou_bev's bit for bit (and the reference's libm-based values to 1e-5). */
+int pnx_boxes_iou_bev_cpu(const float* boxes_a_host, int64_t n, const float* boxes_b_host, int64_t m, float* out_host);
+int pnx_boxes_aligned_iou_bev_cpu(const float* boxes_a_host, const float* boxes_b_host, int64_t n, float* out_host);
 /* nms_gpu / nms_normal_gpu (iou3d_nms.cpp:113-159 / :162-211) for `num_segments` independent,
  * already score-sorted box lists laid end to end:  segment s = boxes[seg_offsets[s] .. seg_offsets[s+1]).
  * The bitmask AND the greedy scan run on the device (the reference copies the mask to the host).

@@ -702,12 +702,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_lds(const uint16_t* __restri
 constexpr int L128_TH = 8;
 constexpr int L128_NSTAGE = (L128_TH + 2) * LDS_HW * 8;
 
-// PNX_CONV64_SMALL=1: the 64 -> 64 layers on 8 x 32 tiles with three workgroups per CU (<= 168 registers) instead of 16 x 32 tiles with two
-// (measured in round 5, profiles/r05_conv_ab.txt)
-bool conv64_small_tiles() {
-  static const int v = getenv("PNX_CONV64_SMALL") != nullptr && atoi(getenv("PNX_CONV64_SMALL")) != 0;
-  return v != 0;
-}
 int next_sched_slot() {
   static unsigned int n = 0;  // one host thread per process drives the launches (pnx.h: not thread-safe)
   return (int)(n++ & 63u);
@@ -803,8 +797,8 @@ __device__ __forceinline__ void conv_rows_x(uint4* __restrict__ s_in, const uint
   }
 }
 
-template <int CIN, int COUT, bool HAS_RES, int OCC = 2>
-__global__ __launch_bounds__(256, OCC) void k_conv3x3_ldsx(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
+template <int CIN, int COUT, bool HAS_RES>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                       const float* __restrict__ bias, const uint16_t* __restrict__ res,
                                                       const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W,
                                                       int relu, uint8_t* __restrict__ row_dirty, int slot, const int32_t* __restrict__ tlist,
@@ -919,17 +913,17 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_ldsx(const uint16_t* __res
   sched_done(slot);
 }
 
-template <int CIN, int COUT, int OCC = 2>
+template <int CIN, int COUT>
 int launch_ldsx(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
                 uint8_t* row_dirty, const int32_t* tlist, const int32_t* tcount, hipStream_t st) {
   const int slot = mask != nullptr ? next_sched_slot() : -1;
   int64_t nb = (int64_t)B * ((H + L128_TH - 1) / L128_TH) * ((W + 31) / 32);
-  if (nb > 256 * OCC) nb = 256 * OCC;  // resident workgroups: OCC per CU (registers)
+  if (nb > 512) nb = 512;  // resident workgroups: 2 per CU (registers)
   if (res != nullptr)
-    k_conv3x3_ldsx<CIN, COUT, true, OCC><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y,
+    k_conv3x3_ldsx<CIN, COUT, true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y,
                                                                  B, H, W, relu, row_dirty, slot, tlist, tcount);
   else
-    k_conv3x3_ldsx<CIN, COUT, false, OCC><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W,
+    k_conv3x3_ldsx<CIN, COUT, false><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W,
                                                                   relu, row_dirty, slot, tlist, tcount);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
@@ -1424,7 +1418,6 @@ int PNX_CONV_FN(pnx_deconv2x2)(const void* x, const void* wfrag, const float* bi
 #ifndef PNX_CONV_F16  // type-independent helpers: in the bf16 object only
 int pnx_conv3x3_tile_rows(int32_t cin, int32_t cout, int32_t stride) {
   if (stride != 1) return 0;
-  if (cin == 64 && cout == 64 && conv64_small_tiles()) return L128_TH;
   if (cin == 64 && (cout == 64 || cout == 320 || cout == 384 || cout == 448)) return LDS_TH;
   if ((cin == 128 && cout == 128) || (cin == 256 && (cout == 256 || cout == 64))) return L128_TH;
   return 0;
@@ -1460,8 +1453,6 @@ int PNX_CONV_FN(pnx_conv3x3)(const void* x, const void* wfrag, const float* bias
   const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1 && getenv("PNX_CONV_DIRECT") == nullptr) {
-    if (cin == 64 && cout == 64 && conv64_small_tiles())
-      return launch_ldsx<64, 64, 3>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
     if (cin == 64 && cout == 64) return launch_lds<64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
     if (cin == 128 && cout == 128) return launch_ldsx<128, 128>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
     if (cin == 256 && cout == 64) return launch_ldsx<256, 64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);

@@ -17,180 +17,10 @@
 #include "pnx_common.h"
 
 #define PNX_HD __device__ __forceinline__
-#include "pnx_detmath.h"
+#define PNX_GEOM __device__ __forceinline__
+#include "iou3d_geom.h"
 
 namespace {
-
-constexpr float kEps = 1e-8f;
-constexpr int kMaxPts = 16;  // 2 convex quadrilaterals: <= 8 edge crossings + <= 8 contained corners
-
-struct Pt {
-  float x, y;
-};
-
-// Everything box_overlap needs from one box.
-struct BoxPre {
-  float cx, cy;    // centre
-  float hxm, hym;  // dx/2 + MARGIN, dy/2 + MARGIN            (cu:52,60)
-  float cn, sn;    // cos(-heading), sin(-heading)            (cu:56)
-  Pt c[4];         // rotated corners                         (cu:124-149)
-  float area;      // dx*dy                                   (cu:230-231)
-  float rad;       // conservative bounding radius (half diagonal + margin + slack) for the exact-zero early out
-};
-
-__device__ __forceinline__ BoxPre make_box(const float* __restrict__ b) {
-  BoxPre o;
-  const float MARGIN = 1e-2f;
-  const float x = b[0], y = b[1], dx = b[3], dy = b[4], ang = b[6];
-  o.cx = x;
-  o.cy = y;
-  o.hxm = dx / 2 + MARGIN;
-  o.hym = dy / 2 + MARGIN;
-  pnx_sincosf(-ang, &o.sn, &o.cn);
-  float s, c;
-  pnx_sincosf(ang, &s, &c);
-  const float dxh = dx / 2, dyh = dy / 2;
-  const float x1 = x - dxh, y1 = y - dyh, x2 = x + dxh, y2 = y + dyh;
-  const float px[4] = {x1, x2, x2, x1}, py[4] = {y1, y1, y2, y2};
-#pragma unroll
-  for (int k = 0; k < 4; k++) {  // rotate_around_center (cu:94-98)
-    o.c[k].x = (px[k] - x) * c + (py[k] - y) * (-s) + x;
-    o.c[k].y = (px[k] - x) * s + (py[k] - y) * c + y;
-  }
-  o.area = dx * dy;
-  o.rad = sqrtf(dxh * dxh + dyh * dyh) * 1.001f + 0.05f;
-  return o;
-}
-
-__device__ __forceinline__ float cross3(Pt p1, Pt p2, Pt p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
-
-__device__ __forceinline__ bool rect_cross(Pt p1, Pt p2, Pt q1, Pt q2) {  // cu:43-49
-  return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) && fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) &&
-         fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
-}
-
-__device__ __forceinline__ bool seg_isect(Pt p1, Pt p0, Pt q1, Pt q0, Pt* ans) {  // cu:63-92
-  if (!rect_cross(p0, p1, q0, q1)) return false;
-  const float s1 = cross3(q0, p1, p0);
-  const float s2 = cross3(p1, q1, p0);
-  const float s3 = cross3(p0, q1, q0);
-  const float s4 = cross3(q1, p1, q0);
-  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
-  const float s5 = cross3(q1, p1, p0);
-  if (fabsf(s5 - s1) > kEps) {
-    ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
-    ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
-  } else {
-    const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
-    const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
-    const float D = a0 * b1 - a1 * b0;
-    ans->x = (b0 * c1 - b1 * c0) / D;
-    ans->y = (a1 * c0 - a0 * c1) / D;
-  }
-  return true;
-}
-
-__device__ __forceinline__ bool in_box(const BoxPre& b, Pt p) {  // cu:51-61
-  const float rot_x = (p.x - b.cx) * b.cn + (p.y - b.cy) * (-b.sn);
-  const float rot_y = (p.x - b.cx) * b.sn + (p.y - b.cy) * b.cn;
-  return fabsf(rot_x) < b.hxm && fabsf(rot_y) < b.hym;
-}
-
-// Overlap area of two rotated rectangles (cu:104-225).  spx/spy/sang: lane-major LDS scratch,
-// element k of this thread at [k * STRIDE + tid].
-// Boxes whose bounding circles (inflated well beyond the 1e-2 in-box margin and any rounding) do not touch
-// have no edge crossing and no contained corner: the reference computes cnt = 0 -> area exactly 0.
-__device__ __forceinline__ bool far_apart(const BoxPre& A, const BoxPre& B) {
-  const float ddx = A.cx - B.cx, ddy = A.cy - B.cy, rr = A.rad + B.rad;
-  return ddx * ddx + ddy * ddy > rr * rr;  // false for NaN -> full path
-}
-
-template <int STRIDE>
-__device__ __forceinline__ float box_overlap(const BoxPre& A, const BoxPre& B, float* spx, float* spy, float* sang, int tid) {
-  if (far_apart(A, B)) return 0.f;
-  int cnt = 0;
-  float sumx = 0.f, sumy = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      Pt ans;
-      if (seg_isect(A.c[(i + 1) & 3], A.c[i], B.c[(j + 1) & 3], B.c[j], &ans)) {
-        sumx = sumx + ans.x;
-        sumy = sumy + ans.y;
-        if (cnt < kMaxPts) {
-          spx[cnt * STRIDE + tid] = ans.x;
-          spy[cnt * STRIDE + tid] = ans.y;
-        }
-        cnt++;
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 4; k++) {  // B[k] in A, then A[k] in B (cu:177-194)
-    if (in_box(A, B.c[k])) {
-      sumx = sumx + B.c[k].x;
-      sumy = sumy + B.c[k].y;
-      if (cnt < kMaxPts) {
-        spx[cnt * STRIDE + tid] = B.c[k].x;
-        spy[cnt * STRIDE + tid] = B.c[k].y;
-      }
-      cnt++;
-    }
-    if (in_box(B, A.c[k])) {
-      sumx = sumx + A.c[k].x;
-      sumy = sumy + A.c[k].y;
-      if (cnt < kMaxPts) {
-        spx[cnt * STRIDE + tid] = A.c[k].x;
-        spy[cnt * STRIDE + tid] = A.c[k].y;
-      }
-      cnt++;
-    }
-  }
-  if (cnt > kMaxPts) cnt = kMaxPts;
-  if (cnt < 3) return 0.f;  // fewer than 3 vertices: the fan below sums to exactly 0 (cnt==0: loops do not run)
-  const float ccx = sumx / cnt, ccy = sumy / cnt;
-  for (int k = 0; k < cnt; k++) sang[k * STRIDE + tid] = pnx_atan2f(spy[k * STRIDE + tid] - ccy, spx[k * STRIDE + tid] - ccx);
-  // bubble sort ascending, swap iff a > b (cu:200-209)
-  for (int j = 0; j < cnt - 1; j++) {
-    for (int i = 0; i < cnt - j - 1; i++) {
-      const float a0 = sang[i * STRIDE + tid], a1 = sang[(i + 1) * STRIDE + tid];
-      if (a0 > a1) {
-        sang[i * STRIDE + tid] = a1;
-        sang[(i + 1) * STRIDE + tid] = a0;
-        const float tx = spx[i * STRIDE + tid], ty = spy[i * STRIDE + tid];
-        spx[i * STRIDE + tid] = spx[(i + 1) * STRIDE + tid];
-        spy[i * STRIDE + tid] = spy[(i + 1) * STRIDE + tid];
-        spx[(i + 1) * STRIDE + tid] = tx;
-        spy[(i + 1) * STRIDE + tid] = ty;
-      }
-    }
-  }
-  const float x0 = spx[tid], y0 = spy[tid];
-  float area = 0.f;
-  for (int k = 0; k < cnt - 1; k++) {  // fan shoelace about vertex 0 (cu:219-224)
-    const float ux = spx[k * STRIDE + tid] - x0, uy = spy[k * STRIDE + tid] - y0;
-    const float vx = spx[(k + 1) * STRIDE + tid] - x0, vy = spy[(k + 1) * STRIDE + tid] - y0;
-    area += ux * vy - uy * vx;
-  }
-  return fabsf(area) / 2.0f;
-}
-
-template <int STRIDE>
-__device__ __forceinline__ float iou_bev(const BoxPre& A, const BoxPre& B, float* spx, float* spy, float* sang, int tid) {  // cu:227-234
-  const float s = box_overlap<STRIDE>(A, B, spx, spy, sang, tid);
-  return s / fmaxf(A.area + B.area - s, kEps);
-}
-
-__device__ __forceinline__ float iou_normal(const float* a, const float* b) {  // cu:327-338
-  const float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
-  const float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
-  const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
-  const float interS = width * height;
-  const float Sa = a[3] * a[4];
-  const float Sb = b[3] * b[4];
-  return interS / fmaxf(Sa + Sb - interS, kEps);
-}
 
 // ---- N x M pairs (boxes_overlap_kernel cu:236-249, boxes_iou_bev_kernel cu:264-278) and aligned pairs
 enum { MODE_OVERLAP = 0, MODE_IOU = 1, MODE_IOU3D = 2 };
@@ -243,7 +73,16 @@ __device__ __forceinline__ int seg_size(const int32_t* __restrict__ seg_off, con
 //   2. the surviving (row, col) pairs of the whole tile are packed into one LDS list and dealt out evenly to the 64 lanes,
 //      so the expensive clipping runs with all lanes busy; results are OR-ed into the row masks with LDS atomics.
 // Pairs rejected in phase 1 have overlap exactly 0 in the reference too (cnt = 0), so the mask is bit-identical.
-__global__ __launch_bounds__(64) void k_nms_mask_rot(const float* __restrict__ boxes, const int32_t* __restrict__ seg_off,
+// Per-box work once per BOX, not once per tile a box takes part in (a 1000-box list has 136 tiles: every box was set up 17 times, two fp64 sincos
+// each): one thread per box writes its BoxPre (64 bytes) into the workspace, the mask kernel reads them back with coalesced 16-byte loads.
+// pre[seg * cbmax * 64 + i] = box i of segment seg (the slots a tile of the mask kernel reads are exactly the ones written here).
+__global__ __launch_bounds__(256) void k_box_pre(const float* __restrict__ boxes, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_len,
+                                                 int cbmax, BoxPre* __restrict__ pre) {
+  const int seg = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i < seg_size(seg_off, seg_len, seg)) pre[(int64_t)seg * cbmax * 64 + i] = make_box(boxes + (int64_t)(seg_off[seg] + i) * 7);
+}
+
+__global__ __launch_bounds__(64) void k_nms_mask_rot(const BoxPre* __restrict__ pre, const int32_t* __restrict__ seg_off,
                                                      const int32_t* __restrict__ seg_len, const float* __restrict__ thresh,
                                                      uint64_t* __restrict__ mask, int cbmax) {
   const int seg = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
@@ -253,22 +92,33 @@ __global__ __launch_bounds__(64) void k_nms_mask_rot(const float* __restrict__ b
   const float thr = thresh[seg];
   const int row_size = min(n - rb * 64, 64), col_size = min(n - cb * 64, 64);
   const int t = threadIdx.x;
-  __shared__ BoxPre s_col[64], s_row[64];
+  __shared__ float4 s_ccr[64];  // centre and bounding radius of the column boxes: all phase 1 needs (one broadcast 16-byte read per column)
   __shared__ unsigned short s_pairs[4096];
   __shared__ unsigned int s_bits[64 * 2];
   __shared__ float spx[kMaxPts * 64], spy[kMaxPts * 64], sang[kMaxPts * 64];
-  if (t < col_size) s_col[t] = make_box(boxes + (int64_t)(off + cb * 64 + t) * 7);
-  if (t < row_size) s_row[t] = make_box(boxes + (int64_t)(off + rb * 64 + t) * 7);
+  const BoxPre* prow = pre + (int64_t)seg * cbmax * 64 + rb * 64;
+  const BoxPre* pcol = pre + (int64_t)seg * cbmax * 64 + cb * 64;
+  float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t < col_size) s_ccr[t] = make_float4(pcol[t].cx, pcol[t].cy, pcol[t].rad, 0.f);
+  if (t < row_size) me = make_float4(prow[t].cx, prow[t].cy, prow[t].rad, 0.f);
   s_bits[t] = 0;
   s_bits[64 + t] = 0;
   __syncthreads();
-  // phase 1: candidate columns of my row
+  // phase 1: candidate columns of my row (far_apart on the three numbers; same expression, same result)
   uint64_t cand = 0;
   if (t < row_size) {
-    const BoxPre A = s_row[t];
     const int start = (rb == cb) ? t + 1 : 0;
-    for (int k = start; k < col_size; k++)
-      if (thr < 0.f || !far_apart(A, s_col[k])) cand |= 1ULL << k;  // iou 0 > thr only for a negative threshold
+    if (thr < 0.f) {  // iou 0 > thr only for a negative threshold: then every pair is a candidate
+      for (int k = start; k < col_size; k++) cand |= 1ULL << k;
+    } else {
+#pragma unroll 8
+      for (int k = 0; k < 64; k++) {
+        const float4 c = s_ccr[k < col_size ? k : 0];
+        const float ddx = me.x - c.x, ddy = me.y - c.y, rr = me.z + c.z;
+        const bool far = ddx * ddx + ddy * ddy > rr * rr;  // false for NaN -> full path
+        if (k >= start && k < col_size && !far) cand |= 1ULL << k;
+      }
+    }
   }
   // pack the pairs: exclusive prefix of the per-row counts across the wave
   const int cnt = __popcll(cand);
@@ -287,11 +137,12 @@ __global__ __launch_bounds__(64) void k_nms_mask_rot(const float* __restrict__ b
     s_pairs[o++] = (unsigned short)((t << 6) | k);
   }
   __syncthreads();
-  // phase 2: the real work, evenly spread
+  // phase 2: the real work, evenly spread; the two boxes of a pair come from the precomputed array (L1 / L2: 128 boxes per tile)
   for (int e = t; e < total; e += 64) {
     const int pr = s_pairs[e];
     const int i = pr >> 6, k = pr & 63;
-    const float v = iou_bev<64>(s_row[i], s_col[k], spx, spy, sang, t);  // row box first, as cu:317
+    const BoxPre A = prow[i], B = pcol[k];
+    const float v = iou_bev<64>(A, B, spx, spy, sang, t);  // row box first, as cu:317
     if (v > thr) atomicOr(&s_bits[2 * i + (k >> 5)], 1u << (k & 31));
   }
   __syncthreads();
@@ -390,6 +241,8 @@ int launch_pairs(int mode, const float* a, int64_t n, const float* b, int64_t m,
   return PNX_OK;
 }
 
+size_t nms_pre_bytes(int num_segments, int max_seg_len) { return (size_t)num_segments * (size_t)((max_seg_len + 63) / 64) * 64 * sizeof(BoxPre); }
+
 template <bool ROTATED>
 int nms_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* seg_len, int32_t num_segments, int32_t max_seg_len, const float* thresh,
                 int32_t post_max, int32_t* keep, int32_t* keep_count, void* workspace, size_t workspace_bytes, hipStream_t st) {
@@ -409,8 +262,17 @@ int nms_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* s
   PNX_REQUIRE(((uintptr_t)workspace & 7) == 0 && workspace_bytes >= 8, PNX_ERR_WORKSPACE, "bad workspace");
   uint64_t* mask = (uint64_t*)workspace;
   dim3 grid(cbmax, cbmax, num_segments);
-  if (ROTATED) k_nms_mask_rot<<<grid, 64, 0, st>>>(boxes, seg_offsets, seg_len, thresh, mask, cbmax);
-  else k_nms_mask<false><<<grid, 64, 0, st>>>(boxes, seg_offsets, seg_len, thresh, mask, cbmax);
+  if (ROTATED) {
+    // workspace = [num_segments * cbmax * 64 BoxPre | mask words]: the per-box precompute in front (its size is known on the host), the mask behind
+    const size_t pre_bytes = nms_pre_bytes(num_segments, max_seg_len);
+    PNX_REQUIRE(workspace_bytes > pre_bytes + 8, PNX_ERR_WORKSPACE, "workspace smaller than pnx_nms_workspace_bytes");
+    BoxPre* pre = reinterpret_cast<BoxPre*>(workspace);
+    mask = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + pre_bytes);
+    k_box_pre<<<dim3((unsigned)((max_seg_len + 255) / 256), (unsigned)num_segments), 256, 0, st>>>(boxes, seg_offsets, seg_len, cbmax, pre);
+    k_nms_mask_rot<<<grid, 64, 0, st>>>(pre, seg_offsets, seg_len, thresh, mask, cbmax);
+  } else {
+    k_nms_mask<false><<<grid, 64, 0, st>>>(boxes, seg_offsets, seg_len, thresh, mask, cbmax);
+  }
   k_nms_greedy<<<num_segments, 64, cbmax * sizeof(uint64_t), st>>>(mask, seg_offsets, seg_len, cbmax, post_max, keep, keep_count);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
@@ -434,9 +296,9 @@ int pnx_boxes_aligned_iou3d(const float* a, const float* b, int64_t n, float* ou
 }
 
 size_t pnx_nms_workspace_bytes(int64_t total_boxes, int32_t num_segments, int32_t max_seg_len) {
-  (void)num_segments;
   if (total_boxes <= 0 || max_seg_len <= 0) return 8;
-  return (size_t)total_boxes * (size_t)((max_seg_len + 63) / 64) * sizeof(uint64_t) + 8;
+  // (rotated NMS) the per-box precompute of every segment slot, then the mask words
+  return nms_pre_bytes(num_segments > 0 ? num_segments : 0, max_seg_len) + (size_t)total_boxes * (size_t)((max_seg_len + 63) / 64) * sizeof(uint64_t) + 8;
 }
 
 int pnx_nms_rotated_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* seg_len, int32_t num_segments, int32_t max_seg_len,

@@ -48,21 +48,33 @@ def nms_normal_gpu(boxes, keep, nms_overlap_thresh):
     return _nms(boxes, keep, nms_overlap_thresh, False)
 
 
+def _host(t, name):
+    if t.is_cuda or t.dtype != torch.float32:
+        raise ops.PnxError(f"{name} must be a CPU fp32 tensor (iou3d_cpu.cpp:236-238)")
+    return t.contiguous()
+
+
 def boxes_iou_bev_cpu(boxes_a, boxes_b, ans_iou):
-    """iou3d_cpu.cpp:232-252 -- CPU tensors in/out; evaluated by the same HIP kernel (staged through the GPU),
-    so CPU and GPU entry points agree bit for bit."""
-    out = torch.empty(ans_iou.shape, dtype=torch.float32, device="cuda")
-    ops.boxes_iou_bev(boxes_a.contiguous().cuda(), boxes_b.contiguous().cuda(), out)
-    ans_iou.copy_(out.cpu())
+    """iou3d_cpu.cpp:232-252 -- CPU tensors in/out, no GPU involved: pnx_boxes_iou_bev_cpu, the device kernel's arithmetic compiled for the host
+    (csrc/iou3d_geom.h), so the CPU and GPU entry points agree bit for bit."""
+    from ._lib import check, lib, ptr
+
+    a, b = _host(boxes_a, "boxes_a"), _host(boxes_b, "boxes_b")
+    out = ans_iou if ans_iou.is_contiguous() and ans_iou.dtype == torch.float32 and not ans_iou.is_cuda else torch.empty(ans_iou.shape, dtype=torch.float32)
+    check(lib().pnx_boxes_iou_bev_cpu(ptr(a), a.shape[0], ptr(b), b.shape[0], ptr(out)), "pnx_boxes_iou_bev_cpu")
+    if out is not ans_iou:
+        ans_iou.copy_(out)
     return 1
 
 
 def boxes_aligned_iou_bev_cpu(boxes_a, boxes_b, ans_iou):
     """iou3d_cpu.cpp:254-273 -- pairwise IoU-BEV, CPU tensors in/out (see boxes_iou_bev_cpu)."""
-    a, b = boxes_a.contiguous().cuda(), boxes_b.contiguous().cuda()
-    ov = torch.empty((a.shape[0], 1), dtype=torch.float32, device="cuda")
-    ops.boxes_aligned_overlap_bev(a, b, ov)
-    s = ov[:, 0]
-    iou = s / torch.clamp(a[:, 3] * a[:, 4] + b[:, 3] * b[:, 4] - s, min=1e-8)
-    ans_iou.copy_(iou.view(ans_iou.shape).cpu())
+    from ._lib import check, lib, ptr
+
+    a, b = _host(boxes_a, "boxes_a"), _host(boxes_b, "boxes_b")
+    if a.shape[0] != b.shape[0]:
+        raise ops.PnxError("aligned IoU needs equally many boxes")
+    out = torch.empty((a.shape[0],), dtype=torch.float32)
+    check(lib().pnx_boxes_aligned_iou_bev_cpu(ptr(a), ptr(b), a.shape[0], ptr(out)), "pnx_boxes_aligned_iou_bev_cpu")
+    ans_iou.copy_(out.view(ans_iou.shape))
     return 1
