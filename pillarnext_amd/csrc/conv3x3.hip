@@ -133,6 +133,12 @@ __device__ __forceinline__ void transpose_row64(uint4 (&R)[4], int lane) {
 template <int CSTRIDE>
 __device__ __forceinline__ void store_row64(const uint4 (&D)[4], uint16_t* __restrict__ row, int n_valid, int lane) {
   const uint32_t voff = (uint32_t)((lane >> 3) * CSTRIDE + (lane & 7) * 8) * 2u;
+#ifdef PNX_CONV_DBG_NOSTORE  // timing experiment: the output lines are computed but not stored (one lane keeps the values alive)
+  if (n_valid != -12345) {
+    if ((D[0].x ^ D[1].y ^ D[2].z ^ D[3].w) == 0x12345678u && lane == 77) row[0] = 1;
+    return;
+  }
+#endif
 #pragma unroll
   for (int d = 0; d < 4; d++) {
     const int P = 8 * d + (lane >> 3);
@@ -406,6 +412,9 @@ __device__ __forceinline__ void stage_tile64(uint4* __restrict__ s_in, const uin
                                              uint32_t need) {
   constexpr int NROW = TH + 2, NEXTRA = NROW * 16;
   static_assert(NEXTRA <= 512, "two slots of the extra columns per thread");
+#ifdef PNX_CONV_DBG_NOSTAGE  // timing experiment: the tile is not staged (the taps run on whatever LDS holds)
+  return;
+#endif
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const uint16_t* xt = x + (((int64_t)b * H + (y0 - 1)) * W + (x0 - 1)) * CSTRIDE + ch0;  // element (0, 0) of the halo tile
@@ -461,6 +470,11 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __res
   for (int cbl = 0; cbl < 4; cbl++)
 #pragma unroll
     for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[((kstep0 + cbl) * MTALL + mg + m) * 64 + lane];
+#ifdef PNX_CONV_DBG_SAMEW  // timing experiment (tools/conv_ab.sh): every tap re-reads the fragments of tap 0 (L1-resident) -- results are wrong
+#define PNX_W_TAP(tn) 0
+#else
+#define PNX_W_TAP(tn) (tn)
+#endif
   uint4 qn[NR];
   {
     const int c0 = tap_slot<STRIDE>(px, 0), sw = lds_swz(c0);
@@ -498,7 +512,7 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __res
       }
       if (tap < 8) {
 #pragma unroll
-        for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[((tn * CB + kstep0 + cbl) * MTALL + mg + m) * 64 + lane];
+        for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[((PNX_W_TAP(tn) * CB + kstep0 + cbl) * MTALL + mg + m) * 64 + lane];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
