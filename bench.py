@@ -247,7 +247,7 @@ def sections(model, examples, batch):
 
 
 def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAMES", "4")), steps=int(os.environ.get("PNX_BENCH_TRAIN_STEPS", "5")),
-              warmup=int(os.environ.get("PNX_BENCH_TRAIN_WARMUP", "3"))):
+              warmup=int(os.environ.get("PNX_BENCH_TRAIN_WARMUP", "3")), amp=True):
     """One data-parallel TRAINING step of PillarNeXt-B (reference: trainer/trainer/trainer.py:94-108 -- forward, loss, backward, clip 35,
     AdamW, OneCycle) on synthetic C2 frames + labels, `frames` per GPU, under bf16 autocast in channels_last (the reference trains in
     fp32; the bf16 step is what this repository optimises and is labelled as such).  DDP over the job's process group when world > 1
@@ -279,7 +279,7 @@ def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAME
     ex.update(points=pts, batch_size=frames)
 
     def step():
-        with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16):   # the inference legs around this run under no_grad
+        with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):   # the inference legs around this run under no_grad
             loss, _ = model(ex)
         opt.zero_grad()
         loss.backward()
@@ -293,7 +293,7 @@ def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAME
     # single-GPU run (what BENCH_rNN.json records) pays for it; the multi-GPU scaling runs take the immediate mode unless
     # PNX_BENCH_TRAIN_FIND=1 -- `train.miopen` says which one a line was measured with.
     bench_mode = torch.backends.cudnn.benchmark
-    find = os.environ.get("PNX_BENCH_TRAIN_FIND", "1" if world == 1 else "0") == "1"
+    find = os.environ.get("PNX_BENCH_TRAIN_FIND", "1" if world == 1 else "0") == "1" and amp   # the fp32 leg: immediate mode (its find pass over fp32 wrw problems takes minutes)
     torch.backends.cudnn.benchmark = find
     t_leg = time.perf_counter()
     for _ in range(warmup):
@@ -316,9 +316,19 @@ def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAME
     finite = bool(torch.isfinite(loss))
     flops = 3 * 2.96e12 * frames                      # 2.96 TFLOP per frame forward (dense-equivalent, 1440^2, 6 tasks); x 3 for dgrad + wgrad
     tf = flops * steps / dt / 1e12
+    if not amp:   # the reference's precision (trainer/trainer/trainer.py:94-108: fp32 throughout, no autocast in its tree), channels_last, torch / MIOpen convolutions
+        torch.backends.cudnn.benchmark = bench_mode
+        res = {"value_train_fp32": round(frames * world * steps / dt, 2),
+               "train_fp32": {"frames_per_gpu_per_step": frames, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
+                              "dtype": "fp32, channels_last -- the reference's training precision; convolutions on MIOpen (the masked HIP convolution kernels are bf16 / fp16)",
+                              "loss_finite": finite, "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                              "miopen": "immediate mode", "leg_seconds": round(time.perf_counter() - t_leg, 1)}}
+        del model, opt, ex
+        torch.cuda.empty_cache()
+        return res
     res = {"value_train": round(frames * world * steps / dt, 2),
            "train": {"frames_per_gpu_per_step": frames, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
-                     "dtype": "bf16 autocast, channels_last (the reference trains fp32: tools/train_step.py --nhwc times that)",
+                     "dtype": "bf16 autocast, channels_last (the reference trains fp32: value_train_fp32 / train_fp32 beside this line time that)",
                      "step": "forward + CenterHead losses + backward + clip 35 + AdamW + OneCycle, DDP + SyncBN when n_gpus > 1",
                      "loss_finite": finite, "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                      "miopen": "find (cudnn.benchmark)" if find else "immediate mode", "leg_seconds": round(time.perf_counter() - t_leg, 1)},
@@ -549,6 +559,8 @@ def main():
         if not a.no_extras:
             if a.config == "C2" and not os.environ.get("PNX_BENCH_NO_TRAIN"):
                 extras.update(train_leg(dev, rank, world))
+                if not short and not os.environ.get("PNX_BENCH_NO_TRAIN_FP32"):
+                    extras.update(train_leg(dev, rank, world, steps=3, warmup=2, amp=False))
             if rank == 0 and not short:
                 extras["sections_us"] = sections(model, examples, a.batch)
                 extras["nms_us"] = nms_bench(dev)

@@ -18,6 +18,7 @@ timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --out
 cd $R
 python tools/steady_trace.py $O/bench_trace 3 45 > $O/bench_steady_trace.md 2>&1
 python tools/prof_summary.py $(find $O/reader_trace -name "*.db" | head -1) 30 > $O/reader_kernels.md 2>&1
+python tools/span_spread.py $O/reader_trace 4 > $O/span_spread.md 2>&1
 F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1)
 echo "pmc files: $F $W"
 cp profiles/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null
