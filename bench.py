@@ -20,7 +20,10 @@ under a launcher (RANK/LOCAL_RANK/WORLD_SIZE set) it is one rank.  Frames are sh
   value_with_h2d_merge   the same loop fed the way the reference's loader feeds it (collate.py:15-22, trainer.py:111, nusc.py:101-121):
                   every step the frames' RAW sweeps are copied into pinned memory, uploaded on a side stream (double-buffered) and merged
                   on the device (pnx_merge_sweeps: per-sweep transform, time lag, batch index) before the reader sees them
-  value_uniform   frames/s on the worst-case uniform cloud (~1.2 points per pillar)
+  value_train_fp32 / train_fp32   the same step at the reference's precision (fp32 channels_last, torch / MIOpen convolutions, immediate mode); N = 1 only;
+                  PNX_BENCH_NO_TRAIN_FP32=1 skips it (MIOpen compiles its fp32 kernels for ~3.5 minutes on a fresh box)
+  value_uniform / roofline_uniform   frames/s on the worst-case uniform cloud (~1.2 points per pillar) and the reader's in-loop roofline on it
+  ranks           per-rank ms/step (min / max) and the world size the backend reports; N > 1 runs the short form (value, roofline, value_train)
   value_c4/_c5    frames/s of the Waymo detector (configs/pillarnext_b_waymo.yaml) at BASELINE configs[3] / [4]: 180 k points bf16, 540 k fp16
   sections_us     reader / backbone / neck / head / decode+NMS per step (torch.cuda events, separate short pass)
   nms_us          stand-alone batched rotated NMS on SURVEY 8d's box sets
