@@ -42,7 +42,7 @@ def build(force=False, verbose=False):
         elif src == "chunk_sort.hip":
             extra = ["-DPNX_BINS_TIMERS"] if os.environ.get("PNX_BINS_TIMERS") else []
         elif src == "conv3x3.hip":
-            extra = ["-fno-honor-nans"] + (["-DPNX_CONV_TIMERS"] if os.environ.get("PNX_CONV_TIMERS") else []) + (["-DPNX_CONV_F16"] if variant else []) + (os.environ.get("PNX_CONV_DEFS") or "").split()
+            extra = ["-fno-honor-nans"] + (os.environ.get("PNX_CONV_FLAGS") or "").split() + (["-DPNX_CONV_TIMERS"] if os.environ.get("PNX_CONV_TIMERS") else []) + (["-DPNX_CONV_F16"] if variant else []) + (os.environ.get("PNX_CONV_DEFS") or "").split()
         cmd = [_hipcc()] + FLAGS + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -503,6 +503,9 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __res
 #pragma unroll
         for (int j = 0; j < NR; j++) qn[j] = s_in[rbase[j] + cbasen + chunk];
       }
+#ifdef PNX_TAPS_PRIO  // scheduling experiment (tools/conv_sched.sh): the MFMA cluster at raised wave priority
+      __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll
       for (int j = 0; j < NR; j++) {
         const el8 bfr = __builtin_bit_cast(el8, qc[j]);
@@ -510,11 +513,16 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __res
         for (int m = 0; m < 2; m++)
           acc[j][m] = PNX_MFMA32(__builtin_bit_cast(el8, w[cbl][m]), bfr, acc[j][m]);
       }
+#ifdef PNX_TAPS_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if (tap < 8) {
 #pragma unroll
         for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[((PNX_W_TAP(tn) * CB + kstep0 + cbl) * MTALL + mg + m) * 64 + lane];
       }
+#ifndef PNX_TAPS_NOSB  // scheduling experiment: without the fence the compiler may interleave neighbouring k-steps
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   }
 }

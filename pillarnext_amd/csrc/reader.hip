@@ -949,17 +949,24 @@ int reader_forward_spans(const float* points, int64_t n, int32_t stride, const G
     rc = launch_fill_kernel(fj, n_fill, st);
     if (rc != PNX_OK) return rc;
   }
+  // From here on the fill may be writing the caller's canvas on the side stream: EVERY return path joins it back into `st` first, so that whatever
+  // the caller does with the canvas next (reuse, free after an error) is ordered behind the fill.
   rc = pnx_launch_span_pfn(F, T, w.sg, w.counters, w.tick, w.rec64, w.pfirst, w.pcnt, w.cell, w.row_of, w.biglist, w.bigcap, w.pcap,
                            ranked ? w.wcomb : nullptr, w.wblk, coords, pillar_capacity, pfn_folded, g1, g1_rows, direct ? canvas : nullptr, canvas_dtype,
                            fill_nt ? 1 : 0, n, gd, st);
-  if (rc != PNX_OK) return rc;
-  if (n > 0) {
+  if (rc == PNX_OK && n > 0) {
     const int tb = 128;
     rc = pnx_launch_pfn3_tail(F, w.rec64, w.pfirst, w.pcnt, w.cell, w.counters, w.biglist, w.bigcap, pfn_folded, g1, g1_rows, direct ? canvas : nullptr,
                               canvas_dtype, tb, st, ranked ? w.row_of : nullptr);
-    if (rc != PNX_OK) return rc;
   }
-  if (side) PNX_CHECK_HIP(hipStreamWaitEvent(st, fs->join, 0));
+  if (side) {
+    const hipError_t je = hipStreamWaitEvent(st, fs->join, 0);
+    if (rc == PNX_OK && je != hipSuccess) {
+      pnx_set_error("hipStreamWaitEvent(join) failed: %s", hipGetErrorString(je));
+      return PNX_ERR_HIP;
+    }
+  }
+  if (rc != PNX_OK) return rc;
   prof_mark(5, st);
   prof_mark(2, st);
   if (feat_max && g1 != feat_max) {  // caller's buffer is smaller than the worst case: copy what fits (P is unknown on the host)
