@@ -133,12 +133,6 @@ __device__ __forceinline__ void transpose_row64(uint4 (&R)[4], int lane) {
 template <int CSTRIDE>
 __device__ __forceinline__ void store_row64(const uint4 (&D)[4], uint16_t* __restrict__ row, int n_valid, int lane) {
   const uint32_t voff = (uint32_t)((lane >> 3) * CSTRIDE + (lane & 7) * 8) * 2u;
-#ifdef PNX_CONV_DBG_NOSTORE  // timing experiment: the output lines are computed but not stored (one lane keeps the values alive)
-  if (n_valid != -12345) {
-    if ((D[0].x ^ D[1].y ^ D[2].z ^ D[3].w) == 0x12345678u && lane == 77) row[0] = 1;
-    return;
-  }
-#endif
 #pragma unroll
   for (int d = 0; d < 4; d++) {
     const int P = 8 * d + (lane >> 3);
@@ -503,9 +497,6 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __res
 #pragma unroll
         for (int j = 0; j < NR; j++) qn[j] = s_in[rbase[j] + cbasen + chunk];
       }
-#ifdef PNX_TAPS_PRIO  // scheduling experiment (tools/conv_sched.sh): the MFMA cluster at raised wave priority
-      __builtin_amdgcn_s_setprio(2);
-#endif
 #pragma unroll
       for (int j = 0; j < NR; j++) {
         const el8 bfr = __builtin_bit_cast(el8, qc[j]);
@@ -513,16 +504,11 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __res
         for (int m = 0; m < 2; m++)
           acc[j][m] = PNX_MFMA32(__builtin_bit_cast(el8, w[cbl][m]), bfr, acc[j][m]);
       }
-#ifdef PNX_TAPS_PRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
       if (tap < 8) {
 #pragma unroll
         for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[((PNX_W_TAP(tn) * CB + kstep0 + cbl) * MTALL + mg + m) * 64 + lane];
       }
-#ifndef PNX_TAPS_NOSB  // scheduling experiment: without the fence the compiler may interleave neighbouring k-steps
-      __builtin_amdgcn_sched_barrier(0);
-#endif
+      __builtin_amdgcn_sched_barrier(0);  // (round 5, profiles/r05_conv_sched.txt: without this fence 128 / 256 channels run 3-4 % slower; s_setprio around the MFMAs: no gain)
     }
   }
 }

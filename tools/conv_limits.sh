@@ -3,11 +3,10 @@
 # (instrumented builds, results of the altered kernels are WRONG by construction; timing only):
 #   SAMEW    every tap re-reads tap 0's weight fragments (L1-resident): the cost of streaming the weights from L2
 #   NOSTAGE  the input tile is not staged: the cost of the HBM -> LDS staging (and its barriers' waits)
-#   NOSTORE  the output lines are not stored
-#   ALL      all three: the MFMA + LDS-read loop alone
+# (round 5 also built a no-store variant: the compiler deleted the arithmetic with the stores, its numbers were void; removed)
 # usage (GPU box): bash tools/conv_limits.sh > gpurun_out/<tag>/conv_limits.txt
 P="python tools/bench_conv.py --batch 12 --tiles --dilate"
-for v in default SAMEW NOSTAGE NOSTORE ALL; do
+for v in default SAMEW NOSTAGE; do
   echo "## $v"
   if [ $v = default ]; then unset PNX_LIB; else export PNX_LIB=$PWD/tools/instrumented/libpnx_dbg_$v.so; fi
   $P --cin 64 --cout 64 --lidar 0 2>/dev/null | tail -1
