@@ -187,7 +187,7 @@ int pnx_group_points(const float* points, int64_t n_points, int32_t row_stride, 
  *   (cells without a point hold 0).  ca + cb <= 128, cout <= 256.  The maximum is order-free: deterministic. */
 int pnx_pfn_layer_eval(const float* xa, int32_t lda, int32_t ca, const float* gb, int32_t cb, const int64_t* inv, const float* wt, const float* shift,
                        int32_t cout, int64_t n, int64_t num_groups, float* y, int32_t ldy, float* gmax, pnx_stream_t stream);
-/* SingleView.bilinear_interpolate (mvf_encoder.py:208-246) on a channels-last map: image (batch, h, w, channels) fp32 / bf16;
+/* SingleView.bilinear_interpolate (mvf_encoder.py:208-246) on a channels-last map: image (batch, h, w, channels) fp32 / bf16 / fp16;
  *   sample position of point p = ((pos[p, 0:2] - pos_min) / pos_voxel) / ds_rate in (w, h) order (:184,:204), sample image = cell_coords[unq_inv[p]][0]
  *   (:203); corners clamped to the map, weights from the CLAMPED corners (:227-240); out (n, out_ld) fp32.  ds_rate must be a power of two. */
 int pnx_bilinear_gather(const void* image, int32_t dtype, int32_t batch, int32_t h, int32_t w, int32_t channels, const float* pos, int32_t pos_ld,

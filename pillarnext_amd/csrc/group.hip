@@ -275,6 +275,8 @@ template <>
 __device__ __forceinline__ float ld_f<float>(const float* p) { return *p; }
 template <>
 __device__ __forceinline__ float ld_f<uint16_t>(const uint16_t* p) { return __uint_as_float((uint32_t)*p << 16); }  // bf16
+template <>
+__device__ __forceinline__ float ld_f<_Float16>(const _Float16* p) { return (float)*p; }
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_bilinear(const T* __restrict__ img, int B, int H, int W, int C, const float* __restrict__ pos, int ldp,
                                                      float mn0, float mn1, float vs0, float vs1, const int32_t* __restrict__ cell_coords,
@@ -387,7 +389,7 @@ int pnx_bilinear_gather(const void* image, int32_t dtype, int32_t batch, int32_t
                         int64_t n, float* out, int32_t out_ld, pnx_stream_t stream) {
   PNX_REQUIRE(image && pos && pos_min2_host && pos_voxel2_host && cell_coords && unq_inv && out && batch > 0 && h > 0 && w > 0 && channels > 0 && pos_ld >= 2 && out_ld >= channels && n >= 0,
               PNX_ERR_INVALID, "pnx_bilinear_gather: bad arguments");
-  PNX_REQUIRE(dtype == PNX_F32 || dtype == PNX_BF16, PNX_ERR_UNSUPPORTED, "pnx_bilinear_gather: fp32 or bf16 maps");
+  PNX_REQUIRE(dtype == PNX_F32 || dtype == PNX_BF16 || dtype == PNX_F16, PNX_ERR_UNSUPPORTED, "pnx_bilinear_gather: fp32, bf16 or fp16 maps");
   PNX_REQUIRE(ds_rate >= 1 && (ds_rate & (ds_rate - 1)) == 0, PNX_ERR_UNSUPPORTED, "pnx_bilinear_gather: ds_rate %d is not a power of two", ds_rate);
   if (n == 0) return PNX_OK;
   int64_t nb = (n + 3) / 4;
@@ -397,8 +399,11 @@ int pnx_bilinear_gather(const void* image, int32_t dtype, int32_t batch, int32_t
   if (dtype == PNX_F32)
     k_bilinear<float><<<(unsigned)nb, kBlock, 0, st>>>((const float*)image, batch, h, w, channels, pos, pos_ld, pos_min2_host[0], pos_min2_host[1], pos_voxel2_host[0],
                                                        pos_voxel2_host[1], cell_coords, unq_inv, inv_ds, n, out, out_ld);
-  else
+  else if (dtype == PNX_BF16)
     k_bilinear<uint16_t><<<(unsigned)nb, kBlock, 0, st>>>((const uint16_t*)image, batch, h, w, channels, pos, pos_ld, pos_min2_host[0], pos_min2_host[1],
+                                                          pos_voxel2_host[0], pos_voxel2_host[1], cell_coords, unq_inv, inv_ds, n, out, out_ld);
+  else
+    k_bilinear<_Float16><<<(unsigned)nb, kBlock, 0, st>>>((const _Float16*)image, batch, h, w, channels, pos, pos_ld, pos_min2_host[0], pos_min2_host[1],
                                                           pos_voxel2_host[0], pos_voxel2_host[1], cell_coords, unq_inv, inv_ds, n, out, out_ld);
   PNX_LAUNCH_CHECK();
   return PNX_OK;

@@ -11,8 +11,9 @@ Same class names, constructor arguments and state-dict keys as the reference.  W
   * the PFN layers of a view in eval mode: pnx_pfn_layer_eval (Linear + folded BatchNorm + ReLU + per-cell max; the concat [x, max[inv]] of a
     non-last layer is read in place by the next one); in training they are reader.PFNLayer on the HIP scatter-max (autograd);
   * sampling the view's map back at the points: pnx_bilinear_gather (eval) / its torch statement over flat indices (training: needs autograd);
-  * the per-view sparse ResNets: the masked-dense blocks of models.py (spconv is absent from the image; like the backbone that part is
-    unpinned), the two PointNets: torch Linear (rocBLAS) + BatchNorm + ReLU.
+  * the per-view sparse ResNets: in eval mode the masked HIP convolution kernels of the PillarNeXt backbone (csrc/conv3x3.hip; BatchNorm folded,
+    bf16, the 48 / 96 / 192 channels zero-padded to the kernels' 64 / 128 / 256: _HipViewNet), in training the masked-dense blocks of models.py
+    (spconv is absent from the image; like the backbone that part is unpinned); the two PointNets: torch Linear (rocBLAS) + BatchNorm + ReLU.
 CUDA tensors only: there is no CPU path."""
 import numpy as np
 import torch
@@ -100,6 +101,102 @@ def _fold_pfn(pfn):
     return wt, (pfn.norm.bias.detach().float() - pfn.norm.running_mean.float() * a).contiguous()
 
 
+def _pad_to(c):
+    """Channel count of the masked HIP convolution kernel that serves c channels (csrc/conv3x3.hip: 64, 128, 256)."""
+    for k in (64, 128, 256):
+        if c <= k:
+            return k
+    return 0
+
+
+class _HipViewNet:
+    """The sparse ResNet of one view (mvf:165-185: per stage a SparseConv2d block + n SubM basic blocks, 48 / 96 / 192 / 192 channels in the YAML) in eval
+    mode on the masked HIP convolution kernels of the PillarNeXt backbone: BatchNorm folded into the weights, channels zero-padded to the kernels'
+    64 / 128 / 256 (padded output channels have zero weights and zero bias, so they stay exactly 0 and cost MFMA lanes, not correctness), bf16
+    channels_last, active-site masks as uint8 maps (SparseConv2d: mask_out = the 3x3 / stride pooled mask, SubM: unchanged).  Built from a
+    SingleView's `blocks`; rebuilt when its parameters change.  Inference only."""
+
+    def __init__(self, blocks, dtype=torch.bfloat16):
+        from .models import SparseBasicBlock, SparseConvBlock, _fold_bn, _HipConv3x3
+
+        self.dtype, self.stages = dtype, []
+        self.version = _params_version(blocks)
+        for seq in blocks:
+            mods = []
+            for m in seq:
+                if isinstance(m, SparseConvBlock):
+                    mods.append(("conv", self._conv(m.conv, m.norm, _fold_bn, _HipConv3x3), m.stride, m.subm))
+                elif isinstance(m, SparseBasicBlock):
+                    mods.append(("block", self._conv(m.block1.conv, m.block1.norm, _fold_bn, _HipConv3x3), self._conv(m.conv2, m.norm2, _fold_bn, _HipConv3x3)))
+                else:
+                    raise ops.PnxError(f"_HipViewNet: unexpected module {type(m).__name__}")
+            self.stages.append(mods)
+        self.cin = self.stages[0][0][1].cin
+        self.cout_true = blocks[-1][-1].norm2.num_features if hasattr(blocks[-1][-1], "norm2") else blocks[-1][-1].norm.num_features
+
+    def _conv(self, conv, norm, fold, HipConv):
+        if tuple(conv.kernel_size) != (3, 3) or tuple(conv.padding) != (1, 1) or conv.bias is not None:
+            raise ops.PnxError("_HipViewNet: 3x3 / pad 1 / bias-free convolutions only")
+        w, b = fold(conv.weight, norm)
+        co, ci = w.shape[:2]
+        cop, cip = _pad_to(co), _pad_to(ci)
+        stride = int(conv.stride[0])
+        shapes = ops.CONV3X3_SHAPES_S1 if stride == 1 else ops.CONV3X3_SHAPES_S2
+        if not cop or not cip or (cip, cop) not in shapes:
+            raise ops.PnxError(f"_HipViewNet: no kernel for {ci} -> {co} channels at stride {stride}")
+        wp = torch.zeros((cop, cip, 3, 3), dtype=torch.float32, device=w.device)
+        wp[:co, :ci] = w
+        bp = torch.zeros((cop,), dtype=torch.float32, device=w.device)
+        bp[:co] = b
+        return HipConv(wp, bp, stride, dtype=self.dtype).to(w.device)
+
+    @staticmethod
+    def supported(blocks):
+        try:
+            from .models import SparseBasicBlock, SparseConvBlock
+
+            for seq in blocks:
+                for m in seq:
+                    if isinstance(m, SparseConvBlock):
+                        cs = [(m.conv, m.stride)]
+                    elif isinstance(m, SparseBasicBlock):
+                        cs = [(m.block1.conv, 1), (m.conv2, 1)]
+                    else:
+                        return False
+                    for c, st in cs:
+                        shapes = ops.CONV3X3_SHAPES_S1 if st == 1 else ops.CONV3X3_SHAPES_S2
+                        if tuple(c.kernel_size) != (3, 3) or c.bias is not None or (_pad_to(c.in_channels), _pad_to(c.out_channels)) not in shapes:
+                            return False
+            return True
+        except Exception:
+            return False
+
+    def __call__(self, cell_features, coords, batch_size, H, W):
+        """cell_features (P, C) fp32 at coords (P, 3) int32 [b, h, w] -> (map (B, Cpad, H', W') channels_last in self.dtype, true channel count)."""
+        dev = cell_features.device
+        canvas = torch.zeros((batch_size, H, W, self.cin), dtype=self.dtype, device=dev)
+        occ = torch.zeros((batch_size, H, W), dtype=torch.uint8, device=dev)
+        u = coords.long()
+        canvas[u[:, 0], u[:, 1], u[:, 2], : cell_features.shape[1]] = cell_features.to(self.dtype)
+        occ[u[:, 0], u[:, 1], u[:, 2]] = 1
+        x, mask = canvas.permute(0, 3, 1, 2), occ                     # channels_last view of the NHWC canvas
+        for mods in self.stages:
+            for m in mods:
+                if m[0] == "conv":
+                    _, conv, stride, subm = m
+                    if not subm:
+                        mask = ops.mask_pool3(mask, stride)             # active set of a SparseConv2d's output (SURVEY H2)
+                    x = conv(x, mask)
+                else:
+                    _, c1, c2 = m
+                    x = c2(c1(x, mask), mask, residual=x)
+        return x
+
+
+def _params_version(module):
+    return tuple((p.data_ptr(), p._version) for p in list(module.parameters()) + list(module.buffers()))
+
+
 class SingleView(nn.Module):
     """PFN layers + a sparse ResNet over one view's cells, sampled back at the points (mvf:143-206).  The sparse blocks are the
     masked-dense stand-ins of models.py (same keys: blocks.{i}.{j}.conv.weight ...)."""
@@ -118,6 +215,15 @@ class SingleView(nn.Module):
         self.blocks = nn.ModuleList([_Seq([SparseConvBlock(in_filters[i], ds_num_filters[i], kernel_size[i], ds_layer_strides[i], use_subm=False)]
                                           + [SparseBasicBlock(ds_num_filters[i], kernel_size[i]) for _ in range(n)]) for i, n in enumerate(layer_nums)])
         self.ds_rate = np.prod(np.array(ds_layer_strides))
+        self.conv_dtype = None      # None: the blocks run as fp32 torch modules; torch.bfloat16 / float16: eval runs them on the HIP kernels (use_hip_convs)
+
+    def use_hip_convs(self, dtype=torch.bfloat16):
+        """Inference in 16-bit activations for the view's sparse ResNet (what FusedPillarNeXt is to the PillarNeXt backbone): eval-mode forwards under
+        no_grad run `blocks` on the masked HIP convolution kernels (_HipViewNet).  dtype=None switches back to the fp32 modules."""
+        if dtype is not None and dtype not in ops._HALF:
+            raise ops.PnxError("use_hip_convs: torch.bfloat16, torch.float16 or None")
+        self.conv_dtype = dtype
+        return self
 
     def _pos_columns(self, features):
         return features[:, 0:2] if self.mode == "pillar" else features[:, 10:12]
@@ -144,6 +250,18 @@ class SingleView(nn.Module):
         if batch_size is None:
             batch_size = len(torch.unique(unq[:, 0]))                          # the reference's rule (mvf:190)
         H, W = int(grid_size[0]), int(grid_size[1])
+        if self.conv_dtype is not None and not (self.training or torch.is_grad_enabled()):
+            # eval, 16-bit inference requested (use_hip_convs): the view's sparse ResNet on the masked HIP convolution kernels
+            net = self.__dict__.get("_hip_net")
+            if net is None or net.version != _params_version(self.blocks) or net.dtype != self.conv_dtype:
+                net = _HipViewNet(self.blocks, self.conv_dtype) if _HipViewNet.supported(self.blocks) else False
+                self.__dict__["_hip_net"] = net
+            if net is False:
+                raise ops.PnxError("SingleView.use_hip_convs: this view's layer shapes have no masked HIP convolution kernel")
+            if net:
+                x = net(fv, unq, batch_size, H, W)
+                out = ops.bilinear_gather(x, pos, self.bias, self.voxel_size, unq, unq_inv, int(self.ds_rate))
+                return out[:, : net.cout_true].contiguous()
         canvas = torch.zeros((batch_size, H, W, fv.shape[1]), dtype=fv.dtype, device=fv.device)
         mask = torch.zeros((batch_size, 1, H, W), dtype=fv.dtype, device=fv.device)
         u = unq.long()
@@ -152,7 +270,7 @@ class SingleView(nn.Module):
         x = canvas.permute(0, 3, 1, 2)                                         # channels_last view of the NHWC canvas
         for blk in self.blocks:
             x, mask = blk(x, mask)
-        if not (self.training or torch.is_grad_enabled() and x.requires_grad) and x.dtype in (torch.float32, torch.bfloat16):
+        if not (self.training or torch.is_grad_enabled() and x.requires_grad) and x.dtype in ops._DT:
             return ops.bilinear_gather(x.contiguous(memory_format=torch.channels_last), pos, self.bias, self.voxel_size, unq, unq_inv, int(self.ds_rate))
         vs = torch.from_numpy(self.voxel_size).type_as(pos).to(pos.device)
         bias = torch.from_numpy(self.bias).type_as(pos).to(pos.device)
@@ -181,6 +299,11 @@ class MVFFeatureNet(nn.Module):
         self.ds_rate = np.prod(np.array(ds_layer_strides))
         self.pointnet1 = PointNet(c, ds_num_filters[-1])
         self.pointnet2 = PointNet(ds_num_filters[-1] * 3, out_channels)
+
+    def use_hip_convs(self, dtype=torch.bfloat16):
+        """Both views' sparse ResNets on the masked HIP convolution kernels in eval mode (SingleView.use_hip_convs)."""
+        self.pillarview.use_hip_convs(dtype), self.cylinderview.use_hip_convs(dtype)
+        return self
 
     def group_views(self, points, batch_size=None):
         """Both groupings of the range-masked points (mvf:290-304): (feat (N', 2 (F + 5)), pillar result, cylinder result)."""

@@ -198,9 +198,9 @@ def pfn_layer_eval(xa, gb, inv, wt, shift, num_groups, store=True, want_max=True
 
 
 def bilinear_gather(image, pos, pos_min, pos_voxel, cell_coords, unq_inv, ds_rate):
-    """pnx_bilinear_gather: image (B, C, H, W) channels_last fp32 / bf16; pos (N, >= 2) fp32 columns (may be a slice of a wider buffer); -> (N, C) fp32."""
-    if not (image.is_cuda and image.dim() == 4 and image.is_contiguous(memory_format=torch.channels_last) and image.dtype in (torch.float32, torch.bfloat16)):
-        raise PnxError("bilinear_gather needs a channels_last fp32 / bf16 CUDA map")
+    """pnx_bilinear_gather: image (B, C, H, W) channels_last fp32 / bf16 / fp16; pos (N, >= 2) fp32 columns (may be a slice of a wider buffer); -> (N, C) fp32."""
+    if not (image.is_cuda and image.dim() == 4 and image.is_contiguous(memory_format=torch.channels_last) and image.dtype in _DT):
+        raise PnxError("bilinear_gather needs a channels_last fp32 / bf16 / fp16 CUDA map")
     if not (pos.is_cuda and pos.dtype == torch.float32 and pos.stride(1) == 1 and cell_coords.dtype == torch.int32 and unq_inv.dtype == torch.int64):
         raise PnxError("bilinear_gather: pos fp32 rows, int32 coords, int64 unq_inv")
     B, C, H, W = image.shape
