@@ -67,60 +67,68 @@ __device__ __forceinline__ int seg_size(const int32_t* __restrict__ seg_off, con
   return n;
 }
 
-// Rotated variant.  The reference lets every lane walk its 64 columns serially through the full polygon clipping
-// (cu:311-321), although almost all pairs are far apart.  Here a tile works in two phases:
-//   1. every lane (= row) builds the 64-bit set of columns whose bounding circles touch its own (a dozen flops per pair);
-//   2. the surviving (row, col) pairs of the whole tile are packed into one LDS list and dealt out evenly to the 64 lanes,
-//      so the expensive clipping runs with all lanes busy; results are OR-ed into the row masks with LDS atomics.
-// Pairs rejected in phase 1 have overlap exactly 0 in the reference too (cnt = 0), so the mask is bit-identical.
-// Per-box work once per BOX, not once per tile a box takes part in (a 1000-box list has 136 tiles: every box was set up 17 times, two fp64 sincos
-// each): one thread per box writes its BoxPre (64 bytes) into the workspace, the mask kernel reads them back with coalesced 16-byte loads.
-// pre[seg * cbmax * 64 + i] = box i of segment seg (the slots a tile of the mask kernel reads are exactly the ones written here).
+// Rotated variant.  The reference lets every lane walk its 64 columns serially through the full polygon clipping (cu:311-321), although almost
+// all pairs are far apart.  Round 5 splits the work by what it costs:
+//   k_box_pre    once per BOX: sin / cos of +-heading, rotated corners, extents, bounding radius (64 bytes into the workspace) -- a 1000-box list has
+//                136 tiles, every box used to be set up 17 times -- and the box's row of mask words zeroed
+//   k_nms_cand   one wave per 64 x 64 tile on or above the diagonal: every lane (= row) builds the 64-bit set of columns whose bounding circles touch
+//                its own (a dozen flops per pair, the column data through one broadcast 16-byte LDS read each) and the tile APPENDS its surviving
+//                (row, col) pairs to one global list (one atomic per tile); a tile that no longer fits the list goes to an overflow list
+//   k_nms_pairs  the expensive clipping, one pair per thread over the global list: every lane busy whatever the tiles looked like (a sparse scene
+//                has 2-3 candidate pairs per tile: the per-tile form ran the clipping with 2-3 of 64 lanes); hits are OR-ed into the mask words
+//   k_nms_tiles  the overflow tiles, processed tile by tile as in rounds 1-4 (pairs packed in LDS, dealt to the 64 lanes)
+// Pairs rejected by the bounding circles have overlap exactly 0 in the reference too (cnt = 0), and OR is order-free: the mask is bit-identical.
+// pre[seg * cbmax * 64 + i] = box i of segment seg.
 __global__ __launch_bounds__(256) void k_box_pre(const float* __restrict__ boxes, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_len,
-                                                 int cbmax, BoxPre* __restrict__ pre) {
+                                                 int cbmax, BoxPre* __restrict__ pre, uint64_t* __restrict__ mask) {
   const int seg = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-  if (i < seg_size(seg_off, seg_len, seg)) pre[(int64_t)seg * cbmax * 64 + i] = make_box(boxes + (int64_t)(seg_off[seg] + i) * 7);
+  if (i >= seg_size(seg_off, seg_len, seg)) return;
+  const int64_t gi = seg_off[seg] + i;
+  pre[(int64_t)seg * cbmax * 64 + i] = make_box(boxes + gi * 7);
+  for (int c = i >> 6; c < cbmax; c++) mask[gi * cbmax + c] = 0;  // the words on or above the diagonal: the only ones anybody reads (iou3d_nms.cpp:150)
 }
 
-__global__ __launch_bounds__(64) void k_nms_mask_rot(const BoxPre* __restrict__ pre, const int32_t* __restrict__ seg_off,
-                                                     const int32_t* __restrict__ seg_len, const float* __restrict__ thresh,
-                                                     uint64_t* __restrict__ mask, int cbmax) {
-  const int seg = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
-  if (cb < rb) return;
-  const int off = seg_off[seg], n = seg_size(seg_off, seg_len, seg);
-  if (rb * 64 >= n || cb * 64 >= n) return;
-  const float thr = thresh[seg];
-  const int row_size = min(n - rb * 64, 64), col_size = min(n - cb * 64, 64);
-  const int t = threadIdx.x;
-  __shared__ float4 s_ccr[64];  // centre and bounding radius of the column boxes: all phase 1 needs (one broadcast 16-byte read per column)
-  __shared__ unsigned short s_pairs[4096];
-  __shared__ unsigned int s_bits[64 * 2];
-  __shared__ float spx[kMaxPts * 64], spy[kMaxPts * 64], sang[kMaxPts * 64];
-  const BoxPre* prow = pre + (int64_t)seg * cbmax * 64 + rb * 64;
-  const BoxPre* pcol = pre + (int64_t)seg * cbmax * 64 + cb * 64;
-  float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (t < col_size) s_ccr[t] = make_float4(pcol[t].cx, pcol[t].cy, pcol[t].rad, 0.f);
-  if (t < row_size) me = make_float4(prow[t].cx, prow[t].cy, prow[t].rad, 0.f);
-  s_bits[t] = 0;
-  s_bits[64 + t] = 0;
-  __syncthreads();
-  // phase 1: candidate columns of my row (far_apart on the three numbers; same expression, same result)
+struct NmsLists {
+  unsigned long long* pairs;  // seg << 40 | row << 20 | col (row, col: box index inside the segment)
+  unsigned long long* tiles;  // overflow: seg << 40 | rb << 20 | cb
+  unsigned int* counts;       // {pairs appended, overflow tiles}
+  unsigned int pair_cap, tile_cap;
+};
+
+__device__ __forceinline__ uint64_t tile_candidates(const BoxPre* __restrict__ prow, const float4* s_ccr, int t, int row_size, int col_size, bool diag, float thr) {
   uint64_t cand = 0;
   if (t < row_size) {
-    const int start = (rb == cb) ? t + 1 : 0;
+    const int start = diag ? t + 1 : 0;
     if (thr < 0.f) {  // iou 0 > thr only for a negative threshold: then every pair is a candidate
       for (int k = start; k < col_size; k++) cand |= 1ULL << k;
     } else {
+      const float mx = prow[t].cx, my = prow[t].cy, mr = prow[t].rad;
 #pragma unroll 8
       for (int k = 0; k < 64; k++) {
         const float4 c = s_ccr[k < col_size ? k : 0];
-        const float ddx = me.x - c.x, ddy = me.y - c.y, rr = me.z + c.z;
-        const bool far = ddx * ddx + ddy * ddy > rr * rr;  // false for NaN -> full path
+        const float ddx = mx - c.x, ddy = my - c.y, rr = mr + c.z;
+        const bool far = ddx * ddx + ddy * ddy > rr * rr;  // far_apart's expression; false for NaN -> full path
         if (k >= start && k < col_size && !far) cand |= 1ULL << k;
       }
     }
   }
-  // pack the pairs: exclusive prefix of the per-row counts across the wave
+  return cand;
+}
+
+__global__ __launch_bounds__(64) void k_nms_cand(const BoxPre* __restrict__ pre, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_len,
+                                                 const float* __restrict__ thresh, int cbmax, NmsLists L) {
+  const int seg = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;
+  const int n = seg_size(seg_off, seg_len, seg);
+  if (rb * 64 >= n || cb * 64 >= n) return;
+  const int row_size = min(n - rb * 64, 64), col_size = min(n - cb * 64, 64);
+  const int t = threadIdx.x;
+  __shared__ float4 s_ccr[64];
+  const BoxPre* prow = pre + (int64_t)seg * cbmax * 64 + rb * 64;
+  const BoxPre* pcol = pre + (int64_t)seg * cbmax * 64 + cb * 64;
+  if (t < col_size) s_ccr[t] = make_float4(pcol[t].cx, pcol[t].cy, pcol[t].rad, 0.f);
+  __syncthreads();
+  const uint64_t cand = tile_candidates(prow, s_ccr, t, row_size, col_size, rb == cb, thresh[seg]);
   const int cnt = __popcll(cand);
   int inc = cnt;
 #pragma unroll
@@ -129,24 +137,96 @@ __global__ __launch_bounds__(64) void k_nms_mask_rot(const BoxPre* __restrict__ 
     if (t >= d) inc += y;
   }
   const int total = __shfl(inc, 63);
-  int o = inc - cnt;
+  if (total == 0) return;
+  unsigned int base = 0;
+  if (t == 0) base = atomicAdd(&L.counts[0], (unsigned int)total);
+  base = __shfl(base, 0);
+  if ((unsigned long long)base + (unsigned int)total > L.pair_cap) {  // the list is full: this tile is done the old way (k_nms_tiles)
+    for (unsigned long long q = (unsigned long long)base + t; q < L.pair_cap; q += 64) L.pairs[q] = ~0ull;  // the one tile that straddles the end: its slots stay empty
+    if (t == 0) {
+      const unsigned int k = atomicAdd(&L.counts[1], 1u);
+      if (k < L.tile_cap) L.tiles[k] = ((unsigned long long)seg << 40) | ((unsigned long long)rb << 20) | (unsigned long long)cb;
+    }
+    return;
+  }
+  unsigned int o = base + (unsigned int)(inc - cnt);
+  const unsigned long long hi = ((unsigned long long)seg << 40) | ((unsigned long long)(rb * 64 + t) << 20) | (unsigned long long)(cb * 64);
   uint64_t c = cand;
   while (c) {
     const int k = __ffsll((long long)c) - 1;
     c &= c - 1;
-    s_pairs[o++] = (unsigned short)((t << 6) | k);
+    L.pairs[o++] = hi | (unsigned long long)k;
   }
-  __syncthreads();
-  // phase 2: the real work, evenly spread; the two boxes of a pair come from the precomputed array (L1 / L2: 128 boxes per tile)
-  for (int e = t; e < total; e += 64) {
-    const int pr = s_pairs[e];
-    const int i = pr >> 6, k = pr & 63;
-    const BoxPre A = prow[i], B = pcol[k];
-    const float v = iou_bev<64>(A, B, spx, spy, sang, t);  // row box first, as cu:317
-    if (v > thr) atomicOr(&s_bits[2 * i + (k >> 5)], 1u << (k & 31));
+}
+
+__global__ __launch_bounds__(256) void k_nms_pairs(const BoxPre* __restrict__ pre, const int32_t* __restrict__ seg_off, const float* __restrict__ thresh,
+                                                   uint64_t* __restrict__ mask, int cbmax, NmsLists L) {
+  __shared__ float spx[kMaxPts * 256], spy[kMaxPts * 256], sang[kMaxPts * 256];
+  const unsigned int n = min(L.counts[0], L.pair_cap);  // entries behind the capacity belong to tiles that went to the overflow list
+  for (unsigned int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const unsigned long long p = L.pairs[e];
+    if (p == ~0ull) continue;  // slot of the tile that straddled the end of the list
+    const int seg = (int)(p >> 40), i = (int)((p >> 20) & 0xfffff), k = (int)(p & 0xfffff);
+    const BoxPre* ps = pre + (int64_t)seg * cbmax * 64;
+    const BoxPre A = ps[i], B = ps[k];
+    const float v = iou_bev<256>(A, B, spx, spy, sang, threadIdx.x);  // row box first, as cu:317
+    if (v > thresh[seg]) {
+      unsigned int* w = reinterpret_cast<unsigned int*>(mask + (int64_t)(seg_off[seg] + i) * cbmax + (k >> 6));
+      atomicOr(w + ((k >> 5) & 1), 1u << (k & 31));
+    }
   }
-  __syncthreads();
-  if (t < row_size) mask[(int64_t)(off + rb * 64 + t) * cbmax + cb] = (uint64_t)s_bits[2 * t] | ((uint64_t)s_bits[2 * t + 1] << 32);
+}
+
+// The per-tile form of rounds 1-4, for the tiles the pair list had no room for (dense clusters of thousands of boxes): candidates packed in LDS and
+// dealt out to the 64 lanes; the tile owns its mask words.
+__global__ __launch_bounds__(64) void k_nms_tiles(const BoxPre* __restrict__ pre, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_len,
+                                                  const float* __restrict__ thresh, uint64_t* __restrict__ mask, int cbmax, NmsLists L) {
+  __shared__ float4 s_ccr[64];
+  __shared__ unsigned short s_pairs[4096];
+  __shared__ unsigned int s_bits[64 * 2];
+  __shared__ float spx[kMaxPts * 64], spy[kMaxPts * 64], sang[kMaxPts * 64];
+  const int t = threadIdx.x;
+  const unsigned int n_tiles = min(L.counts[1], L.tile_cap);
+  for (unsigned int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+    const unsigned long long code = L.tiles[ti];
+    const int seg = (int)(code >> 40), rb = (int)((code >> 20) & 0xfffff), cb = (int)(code & 0xfffff);
+    const int off = seg_off[seg], n = seg_size(seg_off, seg_len, seg);
+    const float thr = thresh[seg];
+    const int row_size = min(n - rb * 64, 64), col_size = min(n - cb * 64, 64);
+    const BoxPre* prow = pre + (int64_t)seg * cbmax * 64 + rb * 64;
+    const BoxPre* pcol = pre + (int64_t)seg * cbmax * 64 + cb * 64;
+    __syncthreads();  // the previous tile's readers are done
+    if (t < col_size) s_ccr[t] = make_float4(pcol[t].cx, pcol[t].cy, pcol[t].rad, 0.f);
+    s_bits[t] = 0;
+    s_bits[64 + t] = 0;
+    __syncthreads();
+    const uint64_t cand = tile_candidates(prow, s_ccr, t, row_size, col_size, rb == cb, thr);
+    const int cnt = __popcll(cand);
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(inc, d);
+      if (t >= d) inc += y;
+    }
+    const int total = __shfl(inc, 63);
+    int o = inc - cnt;
+    uint64_t c = cand;
+    while (c) {
+      const int k = __ffsll((long long)c) - 1;
+      c &= c - 1;
+      s_pairs[o++] = (unsigned short)((t << 6) | k);
+    }
+    __syncthreads();
+    for (int e = t; e < total; e += 64) {
+      const int pr = s_pairs[e];
+      const int i = pr >> 6, k = pr & 63;
+      const BoxPre A = prow[i], B = pcol[k];
+      const float v = iou_bev<64>(A, B, spx, spy, sang, t);
+      if (v > thr) atomicOr(&s_bits[2 * i + (k >> 5)], 1u << (k & 31));
+    }
+    __syncthreads();
+    if (t < row_size) mask[(int64_t)(off + rb * 64 + t) * cbmax + cb] = (uint64_t)s_bits[2 * t] | ((uint64_t)s_bits[2 * t + 1] << 32);
+  }
 }
 
 template <bool ROTATED>
@@ -192,10 +272,13 @@ __global__ __launch_bounds__(64) void k_nms_greedy(const uint64_t* __restrict__ 
   for (int j = t; j < cb; j += 64) s_remv[j] = 0;
   __syncthreads();
   int nkept = 0;
+  // diagonal words: lane t holds the in-block suppression set of box nb*64+t; the NEXT block's words are requested before this block is resolved
+  // (one dependent L2 round trip per block otherwise: 64 of them for a 4096-box list)
+  uint64_t diag_next = (t < min(64, n)) ? mask[(int64_t)(off + t) * cbmax] : 0ULL;
   for (int nb = 0; nb < cb; nb++) {
     const int bsz = min(64, n - nb * 64);
-    // diagonal words of this block: lane t holds the in-block suppression set of box nb*64+t
-    const uint64_t diag = (t < bsz) ? mask[(int64_t)(off + nb * 64 + t) * cbmax + nb] : 0ULL;
+    const uint64_t diag = diag_next;
+    if (nb + 1 < cb) diag_next = (t < min(64, n - (nb + 1) * 64)) ? mask[(int64_t)(off + (nb + 1) * 64 + t) * cbmax + nb + 1] : 0ULL;
     uint64_t cur = s_remv[nb];
     uint64_t kept = 0;
     for (int k = 0; k < bsz; k++) {  // wave-uniform serial resolve
@@ -212,14 +295,20 @@ __global__ __launch_bounds__(64) void k_nms_greedy(const uint64_t* __restrict__ 
     }
     nkept += __popcll(kept);
     if (post_max > 0 && nkept >= post_max) break;
-    // fold the kept rows into the words still to come
+    // fold the kept rows into the words still to come: four rows' words in flight per step (a load per step waited for its own round trip)
     for (int j = nb + 1 + t; j < cb; j += 64) {
       uint64_t acc = s_remv[j];
       uint64_t kk = kept;
+      const uint64_t* col = mask + (int64_t)(off + nb * 64) * cbmax + j;
       while (kk) {
-        const int k = __ffsll((long long)kk) - 1;
-        kk &= kk - 1;
-        acc |= mask[(int64_t)(off + nb * 64 + k) * cbmax + j];
+        int r[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          r[q] = kk ? __ffsll((long long)kk) - 1 : r[0];  // fewer than four left: repeat the first (OR is idempotent)
+          kk &= kk - 1;
+        }
+        const uint64_t w0 = col[(int64_t)r[0] * cbmax], w1 = col[(int64_t)r[1] * cbmax], w2 = col[(int64_t)r[2] * cbmax], w3 = col[(int64_t)r[3] * cbmax];
+        acc |= (w0 | w1) | (w2 | w3);
       }
       s_remv[j] = acc;
     }
@@ -241,7 +330,27 @@ int launch_pairs(int mode, const float* a, int64_t n, const float* b, int64_t m,
   return PNX_OK;
 }
 
-size_t nms_pre_bytes(int num_segments, int max_seg_len) { return (size_t)num_segments * (size_t)((max_seg_len + 63) / 64) * 64 * sizeof(BoxPre); }
+// Host-side layout of the rotated NMS workspace in front of the mask words (all sizes follow from num_segments and max_seg_len).
+struct NmsLayout {
+  size_t pairs_off, tiles_off, counts_off, mask_off;
+  unsigned int pair_cap, tile_cap;
+};
+NmsLayout nms_layout(int num_segments, int max_seg_len) {
+  NmsLayout l;
+  const size_t cb = (size_t)((max_seg_len + 63) / 64), slots = (size_t)num_segments * cb * 64;
+  size_t pc = slots * 32;  // room for 32 candidate pairs per box on average; what does not fit is done tile by tile
+  if (pc > ((size_t)1 << 24)) pc = (size_t)1 << 24;
+  if (pc < 4096) pc = 4096;
+  if (const char* e = getenv("PNX_NMS_PAIR_CAP")) pc = (size_t)(atoi(e) > 64 ? atoi(e) : 64);  // tests: a tiny list sends (almost) every tile down the overflow path
+  size_t tc = (size_t)num_segments * cb * (cb + 1) / 2;  // every tile on or above the diagonal
+  if (tc > ((size_t)1 << 24)) tc = (size_t)1 << 24;
+  l.pair_cap = (unsigned int)pc, l.tile_cap = (unsigned int)(tc < 1 ? 1 : tc);
+  l.pairs_off = pnx_align_up(slots * sizeof(BoxPre), 256);
+  l.tiles_off = pnx_align_up(l.pairs_off + pc * sizeof(unsigned long long), 256);
+  l.counts_off = pnx_align_up(l.tiles_off + (size_t)l.tile_cap * sizeof(unsigned long long), 256);
+  l.mask_off = l.counts_off + 256;
+  return l;
+}
 
 template <bool ROTATED>
 int nms_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* seg_len, int32_t num_segments, int32_t max_seg_len, const float* thresh,
@@ -263,13 +372,24 @@ int nms_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* s
   uint64_t* mask = (uint64_t*)workspace;
   dim3 grid(cbmax, cbmax, num_segments);
   if (ROTATED) {
-    // workspace = [num_segments * cbmax * 64 BoxPre | mask words]: the per-box precompute in front (its size is known on the host), the mask behind
-    const size_t pre_bytes = nms_pre_bytes(num_segments, max_seg_len);
-    PNX_REQUIRE(workspace_bytes > pre_bytes + 8, PNX_ERR_WORKSPACE, "workspace smaller than pnx_nms_workspace_bytes");
-    BoxPre* pre = reinterpret_cast<BoxPre*>(workspace);
-    mask = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + pre_bytes);
-    k_box_pre<<<dim3((unsigned)((max_seg_len + 255) / 256), (unsigned)num_segments), 256, 0, st>>>(boxes, seg_offsets, seg_len, cbmax, pre);
-    k_nms_mask_rot<<<grid, 64, 0, st>>>(pre, seg_offsets, seg_len, thresh, mask, cbmax);
+    // workspace = [segment slots of BoxPre | pair list | overflow tile list | counters | mask words]; every size is known on the host
+    const NmsLayout lay = nms_layout(num_segments, max_seg_len);
+    PNX_REQUIRE(workspace_bytes > lay.mask_off + 8, PNX_ERR_WORKSPACE, "workspace smaller than pnx_nms_workspace_bytes");
+    PNX_REQUIRE(max_seg_len < (1 << 20) && (size_t)num_segments * cbmax * (cbmax + 1) / 2 <= ((size_t)1 << 24), PNX_ERR_UNSUPPORTED,
+                "rotated NMS: segments of at most 2^20 boxes, at most 2^24 mask tiles in all");
+    char* wsb = reinterpret_cast<char*>(workspace);
+    BoxPre* pre = reinterpret_cast<BoxPre*>(wsb);
+    NmsLists L;
+    L.pairs = reinterpret_cast<unsigned long long*>(wsb + lay.pairs_off);
+    L.tiles = reinterpret_cast<unsigned long long*>(wsb + lay.tiles_off);
+    L.counts = reinterpret_cast<unsigned int*>(wsb + lay.counts_off);
+    L.pair_cap = lay.pair_cap, L.tile_cap = lay.tile_cap;
+    mask = reinterpret_cast<uint64_t*>(wsb + lay.mask_off);
+    PNX_CHECK_HIP(hipMemsetAsync(L.counts, 0, 2 * sizeof(unsigned int), st));
+    k_box_pre<<<dim3((unsigned)((max_seg_len + 255) / 256), (unsigned)num_segments), 256, 0, st>>>(boxes, seg_offsets, seg_len, cbmax, pre, mask);
+    k_nms_cand<<<grid, 64, 0, st>>>(pre, seg_offsets, seg_len, thresh, cbmax, L);
+    k_nms_pairs<<<1024, 256, 0, st>>>(pre, seg_offsets, thresh, mask, cbmax, L);
+    k_nms_tiles<<<2048, 64, 0, st>>>(pre, seg_offsets, seg_len, thresh, mask, cbmax, L);
   } else {
     k_nms_mask<false><<<grid, 64, 0, st>>>(boxes, seg_offsets, seg_len, thresh, mask, cbmax);
   }
@@ -297,8 +417,8 @@ int pnx_boxes_aligned_iou3d(const float* a, const float* b, int64_t n, float* ou
 
 size_t pnx_nms_workspace_bytes(int64_t total_boxes, int32_t num_segments, int32_t max_seg_len) {
   if (total_boxes <= 0 || max_seg_len <= 0) return 8;
-  // (rotated NMS) the per-box precompute of every segment slot, then the mask words
-  return nms_pre_bytes(num_segments > 0 ? num_segments : 0, max_seg_len) + (size_t)total_boxes * (size_t)((max_seg_len + 63) / 64) * sizeof(uint64_t) + 8;
+  // (rotated NMS) per-box precompute, candidate-pair list, overflow tile list, counters -- then the mask words
+  return nms_layout(num_segments > 0 ? num_segments : 0, max_seg_len).mask_off + (size_t)total_boxes * (size_t)((max_seg_len + 63) / 64) * sizeof(uint64_t) + 8;
 }
 
 int pnx_nms_rotated_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* seg_len, int32_t num_segments, int32_t max_seg_len,

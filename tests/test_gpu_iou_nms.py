@@ -147,3 +147,23 @@ def test_iou3d_utils_mirror(oracle):
     o3 = ov * oh
     ref = o3 / np.clip((a[:, 3] * a[:, 4] * a[:, 5])[:, None] + (b[:, 3] * b[:, 4] * b[:, 5])[None] - o3, 1e-6, None)
     np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7)
+
+
+def test_nms_pair_list_overflow_path_is_bit_identical(oracle, monkeypatch):
+    """Round 5's rotated NMS appends the bounding-circle candidates of all tiles to ONE global pair list and clips them one pair per thread; tiles
+    that no longer fit the list are processed tile by tile (the rounds 1-4 form).  With a 64-entry list almost every tile takes that path, one
+    tile straddles the end of the list: the keep indices must equal the default path's and the oracle's."""
+    from pillarnext_amd import ops, synth
+
+    for n, seed, thr in ((1000, 11, 0.2), (3000, 12, 0.7)):
+        boxes, _ = synth.clustered_boxes(n, seed)
+        b = torch.from_numpy(boxes).cuda()
+        k0, c0 = ops.nms_single(b, thr)
+        monkeypatch.setenv("PNX_NMS_PAIR_CAP", "64")
+        k1, c1 = ops.nms_single(b, thr)
+        monkeypatch.setenv("PNX_NMS_PAIR_CAP", "5000")
+        k2, c2 = ops.nms_single(b, thr)
+        monkeypatch.delenv("PNX_NMS_PAIR_CAP")
+        ref = oracle.nms_rotated(boxes, thr, "det")
+        assert c0 == c1 == c2 == len(ref)
+        assert np.array_equal(k0.cpu().numpy(), ref) and torch.equal(k0, k1) and torch.equal(k0, k2)
