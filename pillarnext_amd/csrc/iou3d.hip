@@ -115,47 +115,83 @@ __device__ __forceinline__ uint64_t tile_candidates(const BoxPre* __restrict__ p
   return cand;
 }
 
-__global__ __launch_bounds__(64) void k_nms_cand(const BoxPre* __restrict__ pre, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_len,
-                                                 const float* __restrict__ thresh, int cbmax, NmsLists L) {
-  const int seg = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
-  if (cb < rb) return;
+constexpr int kStrip = 16;  // column tiles per workgroup of k_nms_cand: ONE atomic on the list counter per strip (same-address atomics run at ~90 per us:
+                            // one per tile was 69 us for the 6 240 tiles of three 4 096-box lists)
+__global__ __launch_bounds__(256) void k_nms_cand(const BoxPre* __restrict__ pre, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_len,
+                                                  const float* __restrict__ thresh, int cbmax, NmsLists L) {
+  const int seg = blockIdx.z, rb = blockIdx.y, cb0 = blockIdx.x * kStrip;
+  if (cb0 + kStrip <= rb) return;  // the whole strip lies below the diagonal
   const int n = seg_size(seg_off, seg_len, seg);
-  if (rb * 64 >= n || cb * 64 >= n) return;
-  const int row_size = min(n - rb * 64, 64), col_size = min(n - cb * 64, 64);
-  const int t = threadIdx.x;
-  __shared__ float4 s_ccr[64];
-  const BoxPre* prow = pre + (int64_t)seg * cbmax * 64 + rb * 64;
-  const BoxPre* pcol = pre + (int64_t)seg * cbmax * 64 + cb * 64;
-  if (t < col_size) s_ccr[t] = make_float4(pcol[t].cx, pcol[t].cy, pcol[t].rad, 0.f);
-  __syncthreads();
-  const uint64_t cand = tile_candidates(prow, s_ccr, t, row_size, col_size, rb == cb, thresh[seg]);
-  const int cnt = __popcll(cand);
-  int inc = cnt;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int y = __shfl_up(inc, d);
-    if (t >= d) inc += y;
-  }
-  const int total = __shfl(inc, 63);
-  if (total == 0) return;
-  unsigned int base = 0;
-  if (t == 0) base = atomicAdd(&L.counts[0], (unsigned int)total);
-  base = __shfl(base, 0);
-  if ((unsigned long long)base + (unsigned int)total > L.pair_cap) {  // the list is full: this tile is done the old way (k_nms_tiles)
-    for (unsigned long long q = (unsigned long long)base + t; q < L.pair_cap; q += 64) L.pairs[q] = ~0ull;  // the one tile that straddles the end: its slots stay empty
-    if (t == 0) {
-      const unsigned int k = atomicAdd(&L.counts[1], 1u);
-      if (k < L.tile_cap) L.tiles[k] = ((unsigned long long)seg << 40) | ((unsigned long long)rb << 20) | (unsigned long long)cb;
+  if (rb * 64 >= n || cb0 * 64 >= n) return;
+  const int row_size = min(n - rb * 64, 64);
+  const int t = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ float4 s_ccr[4][64];
+  __shared__ unsigned long long s_cand[kStrip][64];
+  __shared__ unsigned int s_tot[kStrip], s_pre[kStrip];
+  __shared__ unsigned int s_base, s_fill;
+  const BoxPre* pseg = pre + (int64_t)seg * cbmax * 64;
+  const BoxPre* prow = pseg + rb * 64;
+  const float thr = thresh[seg];
+  for (int q = 0; q < kStrip / 4; q++) {  // wave wv takes tiles wv, wv + 4, ... of the strip
+    const int ti = q * 4 + wv, cb = cb0 + ti;
+    uint64_t cand = 0;
+    const bool live = cb >= rb && cb * 64 < n;  // wave-uniform
+    if (live) {
+      const int col_size = min(n - cb * 64, 64);
+      if (t < col_size) s_ccr[wv][t] = make_float4(pseg[cb * 64 + t].cx, pseg[cb * 64 + t].cy, pseg[cb * 64 + t].rad, 0.f);
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes are visible to its reads (one wave per s_ccr slice)
+      cand = tile_candidates(prow, s_ccr[wv], t, row_size, col_size, rb == cb, thr);
     }
+    s_cand[ti][t] = cand;
+    int tot = __popcll(cand);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+    if (t == 0) s_tot[ti] = (unsigned int)tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int run = 0;
+    for (int i = 0; i < kStrip; i++) {
+      s_pre[i] = run;
+      run += s_tot[i];
+    }
+    unsigned int base = run ? atomicAdd(&L.counts[0], run) : 0u;
+    if (run && (unsigned long long)base + run > L.pair_cap) {  // the list is full: the strip's tiles are done the old way (k_nms_tiles)
+      s_fill = base;  // the one strip that straddles the end of the list marks its slots empty (below, all threads)
+      unsigned int live_tiles = 0;
+      for (int i = 0; i < kStrip; i++) live_tiles += s_tot[i] ? 1u : 0u;
+      unsigned int k = atomicAdd(&L.counts[1], live_tiles);
+      for (int i = 0; i < kStrip; i++)
+        if (s_tot[i] && k < L.tile_cap) L.tiles[k++] = ((unsigned long long)seg << 40) | ((unsigned long long)rb << 20) | (unsigned long long)(cb0 + i);
+      base = 0xffffffffu;
+    }
+    s_base = base;
+  }
+  __syncthreads();
+  const unsigned int base = s_base;
+  if (base == 0xffffffffu) {
+    for (unsigned long long q = (unsigned long long)s_fill + threadIdx.x; q < L.pair_cap; q += 256) L.pairs[q] = ~0ull;
     return;
   }
-  unsigned int o = base + (unsigned int)(inc - cnt);
-  const unsigned long long hi = ((unsigned long long)seg << 40) | ((unsigned long long)(rb * 64 + t) << 20) | (unsigned long long)(cb * 64);
-  uint64_t c = cand;
-  while (c) {
-    const int k = __ffsll((long long)c) - 1;
-    c &= c - 1;
-    L.pairs[o++] = hi | (unsigned long long)k;
+  for (int q = 0; q < kStrip / 4; q++) {
+    const int ti = q * 4 + wv;
+    if (s_tot[ti] == 0) continue;
+    uint64_t c = s_cand[ti][t];
+    const int cnt = __popcll(c);
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(inc, d);
+      if (t >= d) inc += y;
+    }
+    unsigned int o = base + s_pre[ti] + (unsigned int)(inc - cnt);
+    const unsigned long long hi = ((unsigned long long)seg << 40) | ((unsigned long long)(rb * 64 + t) << 20) | (unsigned long long)((cb0 + ti) * 64);
+    while (c) {
+      const int k = __ffsll((long long)c) - 1;
+      c &= c - 1;
+      L.pairs[o++] = hi | (unsigned long long)k;
+    }
   }
 }
 
@@ -295,20 +331,23 @@ __global__ __launch_bounds__(64) void k_nms_greedy(const uint64_t* __restrict__ 
     }
     nkept += __popcll(kept);
     if (post_max > 0 && nkept >= post_max) break;
-    // fold the kept rows into the words still to come: four rows' words in flight per step (a load per step waited for its own round trip)
+    // fold the kept rows into the words still to come: sixteen rows' words in flight per step (one load per step waited for its own L2 round trip: 173 us for three 4 096-box lists)
     for (int j = nb + 1 + t; j < cb; j += 64) {
       uint64_t acc = s_remv[j];
       uint64_t kk = kept;
       const uint64_t* col = mask + (int64_t)(off + nb * 64) * cbmax + j;
       while (kk) {
-        int r[4];
+        int r[16];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          r[q] = kk ? __ffsll((long long)kk) - 1 : r[0];  // fewer than four left: repeat the first (OR is idempotent)
+        for (int q = 0; q < 16; q++) {
+          r[q] = kk ? __ffsll((long long)kk) - 1 : r[0];  // fewer than sixteen left: repeat the first (OR is idempotent)
           kk &= kk - 1;
         }
-        const uint64_t w0 = col[(int64_t)r[0] * cbmax], w1 = col[(int64_t)r[1] * cbmax], w2 = col[(int64_t)r[2] * cbmax], w3 = col[(int64_t)r[3] * cbmax];
-        acc |= (w0 | w1) | (w2 | w3);
+        uint64_t w[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) w[q] = col[(int64_t)r[q] * cbmax];
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc |= w[q];
       }
       s_remv[j] = acc;
     }
@@ -387,7 +426,7 @@ int nms_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* s
     mask = reinterpret_cast<uint64_t*>(wsb + lay.mask_off);
     PNX_CHECK_HIP(hipMemsetAsync(L.counts, 0, 2 * sizeof(unsigned int), st));
     k_box_pre<<<dim3((unsigned)((max_seg_len + 255) / 256), (unsigned)num_segments), 256, 0, st>>>(boxes, seg_offsets, seg_len, cbmax, pre, mask);
-    k_nms_cand<<<grid, 64, 0, st>>>(pre, seg_offsets, seg_len, thresh, cbmax, L);
+    k_nms_cand<<<dim3((unsigned)((cbmax + kStrip - 1) / kStrip), (unsigned)cbmax, (unsigned)num_segments), 256, 0, st>>>(pre, seg_offsets, seg_len, thresh, cbmax, L);
     k_nms_pairs<<<1024, 256, 0, st>>>(pre, seg_offsets, thresh, mask, cbmax, L);
     k_nms_tiles<<<2048, 64, 0, st>>>(pre, seg_offsets, seg_len, thresh, mask, cbmax, L);
   } else {
