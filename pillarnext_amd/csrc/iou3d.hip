@@ -80,8 +80,9 @@ __device__ __forceinline__ int seg_size(const int32_t* __restrict__ seg_off, con
 // Pairs rejected by the bounding circles have overlap exactly 0 in the reference too (cnt = 0), and OR is order-free: the mask is bit-identical.
 // pre[seg * cbmax * 64 + i] = box i of segment seg.
 __global__ __launch_bounds__(256) void k_box_pre(const float* __restrict__ boxes, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_len,
-                                                 int cbmax, BoxPre* __restrict__ pre, uint64_t* __restrict__ mask) {
+                                                 int cbmax, BoxPre* __restrict__ pre, uint64_t* __restrict__ mask, unsigned int* __restrict__ counts) {
   const int seg = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (seg == 0 && i < 2) counts[i] = 0;  // the two list counters of this call (k_nms_cand starts behind this kernel)
   if (i >= seg_size(seg_off, seg_len, seg)) return;
   const int64_t gi = seg_off[seg] + i;
   pre[(int64_t)seg * cbmax * 64 + i] = make_box(boxes + gi * 7);
@@ -115,12 +116,13 @@ __device__ __forceinline__ uint64_t tile_candidates(const BoxPre* __restrict__ p
   return cand;
 }
 
-constexpr int kStrip = 16;  // column tiles per workgroup of k_nms_cand: ONE atomic on the list counter per strip (same-address atomics run at ~90 per us:
-                            // one per tile was 69 us for the 6 240 tiles of three 4 096-box lists)
+constexpr int kStrip = 16;  // at most this many column tiles per workgroup of k_nms_cand (`strip` = 4, 8 or 16, chosen by the host from the number of
+                            // tiles): ONE atomic on the list counter per strip -- same-address atomics run at ~90 per us, one per tile was 69 us for
+                            // the 6 240 tiles of three 4 096-box lists; few tiles (ten 1000-box lists: 1 360) want small strips and many workgroups
 __global__ __launch_bounds__(256) void k_nms_cand(const BoxPre* __restrict__ pre, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_len,
-                                                  const float* __restrict__ thresh, int cbmax, NmsLists L) {
-  const int seg = blockIdx.z, rb = blockIdx.y, cb0 = blockIdx.x * kStrip;
-  if (cb0 + kStrip <= rb) return;  // the whole strip lies below the diagonal
+                                                  const float* __restrict__ thresh, int cbmax, int strip, NmsLists L) {
+  const int seg = blockIdx.z, rb = blockIdx.y, cb0 = blockIdx.x * strip;
+  if (cb0 + strip <= rb) return;  // the whole strip lies below the diagonal
   const int n = seg_size(seg_off, seg_len, seg);
   if (rb * 64 >= n || cb0 * 64 >= n) return;
   const int row_size = min(n - rb * 64, 64);
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void k_nms_cand(const BoxPre* __restrict__ pre
   const BoxPre* pseg = pre + (int64_t)seg * cbmax * 64;
   const BoxPre* prow = pseg + rb * 64;
   const float thr = thresh[seg];
-  for (int q = 0; q < kStrip / 4; q++) {  // wave wv takes tiles wv, wv + 4, ... of the strip
+  for (int q = 0; q < strip / 4; q++) {  // wave wv takes tiles wv, wv + 4, ... of the strip
     const int ti = q * 4 + wv, cb = cb0 + ti;
     uint64_t cand = 0;
     const bool live = cb >= rb && cb * 64 < n;  // wave-uniform
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void k_nms_cand(const BoxPre* __restrict__ pre
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned int run = 0;
-    for (int i = 0; i < kStrip; i++) {
+    for (int i = 0; i < strip; i++) {
       s_pre[i] = run;
       run += s_tot[i];
     }
@@ -160,9 +162,9 @@ __global__ __launch_bounds__(256) void k_nms_cand(const BoxPre* __restrict__ pre
     if (run && (unsigned long long)base + run > L.pair_cap) {  // the list is full: the strip's tiles are done the old way (k_nms_tiles)
       s_fill = base;  // the one strip that straddles the end of the list marks its slots empty (below, all threads)
       unsigned int live_tiles = 0;
-      for (int i = 0; i < kStrip; i++) live_tiles += s_tot[i] ? 1u : 0u;
+      for (int i = 0; i < strip; i++) live_tiles += s_tot[i] ? 1u : 0u;
       unsigned int k = atomicAdd(&L.counts[1], live_tiles);
-      for (int i = 0; i < kStrip; i++)
+      for (int i = 0; i < strip; i++)
         if (s_tot[i] && k < L.tile_cap) L.tiles[k++] = ((unsigned long long)seg << 40) | ((unsigned long long)rb << 20) | (unsigned long long)(cb0 + i);
       base = 0xffffffffu;
     }
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void k_nms_cand(const BoxPre* __restrict__ pre
     for (unsigned long long q = (unsigned long long)s_fill + threadIdx.x; q < L.pair_cap; q += 256) L.pairs[q] = ~0ull;
     return;
   }
-  for (int q = 0; q < kStrip / 4; q++) {
+  for (int q = 0; q < strip / 4; q++) {
     const int ti = q * 4 + wv;
     if (s_tot[ti] == 0) continue;
     uint64_t c = s_cand[ti][t];
@@ -424,9 +426,11 @@ int nms_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* s
     L.counts = reinterpret_cast<unsigned int*>(wsb + lay.counts_off);
     L.pair_cap = lay.pair_cap, L.tile_cap = lay.tile_cap;
     mask = reinterpret_cast<uint64_t*>(wsb + lay.mask_off);
-    PNX_CHECK_HIP(hipMemsetAsync(L.counts, 0, 2 * sizeof(unsigned int), st));
-    k_box_pre<<<dim3((unsigned)((max_seg_len + 255) / 256), (unsigned)num_segments), 256, 0, st>>>(boxes, seg_offsets, seg_len, cbmax, pre, mask);
-    k_nms_cand<<<dim3((unsigned)((cbmax + kStrip - 1) / kStrip), (unsigned)cbmax, (unsigned)num_segments), 256, 0, st>>>(pre, seg_offsets, seg_len, thresh, cbmax, L);
+    const size_t n_tiles = (size_t)num_segments * cbmax * (cbmax + 1) / 2;
+    const int strip = n_tiles <= 2048 ? 4 : (n_tiles <= 8192 ? 8 : kStrip);
+    k_box_pre<<<dim3((unsigned)((max_seg_len + 255) / 256), (unsigned)num_segments), 256, 0, st>>>(boxes, seg_offsets, seg_len, cbmax, pre, mask, L.counts);
+    k_nms_cand<<<dim3((unsigned)((cbmax + strip - 1) / strip), (unsigned)cbmax, (unsigned)num_segments), 256, 0, st>>>(pre, seg_offsets, seg_len, thresh, cbmax,
+                                                                                                                      strip, L);
     k_nms_pairs<<<1024, 256, 0, st>>>(pre, seg_offsets, thresh, mask, cbmax, L);
     k_nms_tiles<<<2048, 64, 0, st>>>(pre, seg_offsets, seg_len, thresh, mask, cbmax, L);
   } else {

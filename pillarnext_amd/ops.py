@@ -256,7 +256,7 @@ def nms_batched(boxes, seg_offsets, thresh, max_seg_len, post_max=0, rotated=Tru
     S = seg_offsets.numel() - 1
     T = boxes.shape[0]
     keep = torch.empty((max(T, 1),), dtype=torch.int32, device=boxes.device)
-    cnt = torch.zeros((max(S, 1),), dtype=torch.int32, device=boxes.device)
+    cnt = (torch.empty if S > 0 and max_seg_len > 0 else torch.zeros)((max(S, 1),), dtype=torch.int32, device=boxes.device)   # the greedy scan writes every segment's count
     nbytes = lib().pnx_nms_workspace_bytes(T, S, max_seg_len)
     buf = _NMS_WS.get(nbytes, boxes.device)
     fn = lib().pnx_nms_rotated_batched if rotated else lib().pnx_nms_normal_batched
