@@ -929,6 +929,7 @@ class FusedPillarNeXt(nn.Module):
         self.use_plan = os.environ.get("PNX_PLAN", "1") != "0"
         self.sparse_ws = os.environ.get("PNX_SPARSE_WS", "1") != "0"
         self.tile_lists = os.environ.get("PNX_TILE_LISTS", "1") != "0"
+        self.decode_on_side_stream = os.environ.get("PNX_DECODE_STREAM", "0") == "1"   # measured in round 5: see DESIGN.md section 6
         self.reader = det.reader
         self.post_processing = det.post_processing
         self.head_ref = det.head  # predict() / rectifier / class bookkeeping
@@ -1320,7 +1321,23 @@ class FusedPillarNeXt(nn.Module):
         """Enqueue the whole frame batch (reader -> ... -> NMS -> D2H copy) and return a decode.PendingDetections."""
         packed = []
         self.forward_preds(example["points"], example["batch_size"], packed_out=packed)
-        return self.launch_decode(packed, example.get("token"))
+        if not (self.decode_on_side_stream and packed and isinstance(packed[0], LazyTask)):
+            return self.launch_decode(packed, example.get("token"))
+        # The decoder (keys, radix select, candidate evaluation, boxes, NMS, gather, D2H) is a chain of small latency-bound launches: on its own stream
+        # it runs beside the NEXT batch's reader and convolutions instead of in front of them.  It reads only this step's fresh tensors (the dense
+        # [iou] hm maps and the deblocked maps) and constants; its scratch is per stream (decode.PackedDecoder).
+        main = torch.cuda.current_stream()
+        side = self.__dict__.get("_decode_stream")
+        if side is None or side.device != main.device:
+            side = self.__dict__["_decode_stream"] = torch.cuda.Stream(device=main.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            pend = self.launch_decode(packed, example.get("token"))
+        for p in packed:   # allocated on the main stream, consumed on the side stream: the caching allocator must not hand them out before that work ran
+            p.dense.record_stream(side), p.up.record_stream(side)
+        return pend
 
     def launch_decode(self, packed, tokens=None):
         if not (packed and isinstance(packed[0], LazyTask)):
