@@ -912,6 +912,49 @@ class LazyTask:
         self.dense, self.up = dense, up
 
 
+class _DeferredDecode:
+    """The decoder launch of one frame batch, held back until the next batch's reader has been enqueued (FusedPillarNeXt.forward_async with
+    decode_on_side_stream) or until somebody asks for the result.  Behaves like the decode.PendingDetections it turns into."""
+
+    def __init__(self, model, packed, tokens):
+        self.model, self.packed, self.tokens = model, packed, tokens
+        self.head_done = torch.cuda.Event()
+        self.head_done.record()                       # the head of this batch, on the caller's stream
+        self.launched, self.pend = False, None
+
+    def launch(self, behind_reader=False):
+        if self.launched:
+            return
+        self.launched = True
+        m = self.model
+        main = torch.cuda.current_stream()
+        side = m.__dict__.get("_decode_stream")
+        if side is None or side.device != main.device:
+            side = m.__dict__["_decode_stream"] = torch.cuda.Stream(device=main.device)
+        side.wait_event(self.head_done)
+        if behind_reader:                             # called right after the next batch's reader was enqueued on `main`
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+        with torch.cuda.stream(side):
+            self.pend = m.launch_decode(self.packed, self.tokens)
+        for p in self.packed:   # allocated on the main stream, consumed on the side stream: the caching allocator must not hand them out before that work ran
+            p.dense.record_stream(side), p.up.record_stream(side)
+        self.packed = None
+        if m.__dict__.get("_deferred") is self:
+            m.__dict__["_deferred"] = None
+
+    def result(self):
+        self.launch()
+        return self.pend.result()
+
+    def __getattr__(self, name):                      # flag_h, event, done, ... of the PendingDetections
+        if name in ("pend", "launched", "packed", "model", "tokens", "head_done"):
+            raise AttributeError(name)
+        self.launch()
+        return getattr(self.pend, name)
+
+
 class FusedPillarNeXt(nn.Module):
     """Inference-only re-expression of SingleStageDetector (eval BN folded, epilogues fused, the 6-7 SepHead branches of a
     task merged into two convolutions).  Mathematically the same network; weights come from the trained modules.
@@ -1060,7 +1103,7 @@ class FusedPillarNeXt(nn.Module):
         self.lazy_head = self.lazy_head and all(self._lazy_ok)
 
     @torch.no_grad()
-    def forward_preds(self, points, batch_size, marks=None, packed_out=None, taps=None, lazy=None):
+    def forward_preds(self, points, batch_size, marks=None, packed_out=None, taps=None, lazy=None, after_reader=None):
         """packed_out: a list that receives, per task, the packed NHWC head output -- or, with the lazy head (lazy=None: the model's
         setting), a LazyTask (dense [iou] hm map + deblocked features) for launch_decode()."""
         def mark(name):
@@ -1075,12 +1118,16 @@ class FusedPillarNeXt(nn.Module):
         if planned:
             bb = self._backbone_plan(batch_size, points.device)
             self.reader.forward_dense(points, batch_size, dtype=self.dtype, out=bb["canvas"], occupancy=bb["occ"])
+            if after_reader is not None:
+                after_reader()
             bb["plan"].run()
             x, mask = bb["out"], bb["mask"]
         else:
             occ = torch.empty((batch_size, ny, nx), dtype=torch.uint8, device=points.device)
             x = self.reader.forward_dense(points, batch_size, dtype=self.dtype, occupancy=occ)
             mask = occ
+            if after_reader is not None:
+                after_reader()
         mark("reader")
         for si, (mods, (stride, subm)) in enumerate(zip(self.stages, self.stage_meta) if not planned else ()):
             if not subm:
@@ -1319,25 +1366,18 @@ class FusedPillarNeXt(nn.Module):
     @torch.no_grad()
     def forward_async(self, example):
         """Enqueue the whole frame batch (reader -> ... -> NMS -> D2H copy) and return a decode.PendingDetections."""
+        prev = self.__dict__.get("_deferred")   # the previous batch's decoder, if nobody asked for its result yet
         packed = []
-        self.forward_preds(example["points"], example["batch_size"], packed_out=packed)
+        self.forward_preds(example["points"], example["batch_size"], packed_out=packed,
+                           after_reader=(lambda: prev.launch(behind_reader=True)) if prev is not None and not prev.launched else None)
         if not (self.decode_on_side_stream and packed and isinstance(packed[0], LazyTask)):
             return self.launch_decode(packed, example.get("token"))
-        # The decoder (keys, radix select, candidate evaluation, boxes, NMS, gather, D2H) is a chain of small latency-bound launches: on its own stream
-        # it runs beside the NEXT batch's reader and convolutions instead of in front of them.  It reads only this step's fresh tensors (the dense
-        # [iou] hm maps and the deblocked maps) and constants; its scratch is per stream (decode.PackedDecoder).
-        main = torch.cuda.current_stream()
-        side = self.__dict__.get("_decode_stream")
-        if side is None or side.device != main.device:
-            side = self.__dict__["_decode_stream"] = torch.cuda.Stream(device=main.device)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            pend = self.launch_decode(packed, example.get("token"))
-        for p in packed:   # allocated on the main stream, consumed on the side stream: the caching allocator must not hand them out before that work ran
-            p.dense.record_stream(side), p.up.record_stream(side)
-        return pend
+        # The decoder (keys, radix select, candidate evaluation, boxes, NMS, gather, D2H) is a chain of small latency-bound launches.  On its own
+        # stream, and started only once the NEXT batch's reader is through (so that the HBM-bound reader keeps the GPU to itself), it runs beside
+        # that batch's convolutions instead of in front of them.  It reads only this step's fresh tensors (dense [iou] hm maps, deblocked maps) and
+        # constants; its scratch is per stream (decode.PackedDecoder).  Nobody enqueues a next batch: result() launches it at once.
+        d = self.__dict__["_deferred"] = _DeferredDecode(self, packed, example.get("token"))
+        return d
 
     def launch_decode(self, packed, tokens=None):
         if not (packed and isinstance(packed[0], LazyTask)):
