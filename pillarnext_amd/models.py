@@ -959,7 +959,8 @@ class FusedPillarNeXt(nn.Module):
     """Inference-only re-expression of SingleStageDetector (eval BN folded, epilogues fused, the 6-7 SepHead branches of a
     task merged into two convolutions).  Mathematically the same network; weights come from the trained modules.
     One instance drives ONE stream: the stage workspaces, the launch plans' canvas and the decoder's scratch are persistent and reused
-    from call to call in stream order (a second stream needs a second instance)."""
+    from call to call in stream order (a second stream needs a second instance).  forward_async additionally owns one internal side stream
+    for the decoder (decode_on_side_stream); everything it returns is ordered for the caller by PendingDetections.result()."""
 
     def __init__(self, det, dtype=torch.bfloat16, hip_conv=None):
         super().__init__()
@@ -972,7 +973,9 @@ class FusedPillarNeXt(nn.Module):
         self.use_plan = os.environ.get("PNX_PLAN", "1") != "0"
         self.sparse_ws = os.environ.get("PNX_SPARSE_WS", "1") != "0"
         self.tile_lists = os.environ.get("PNX_TILE_LISTS", "1") != "0"
-        self.decode_on_side_stream = os.environ.get("PNX_DECODE_STREAM", "0") == "1"   # measured in round 5: see DESIGN.md section 6
+        # the decoder on its own stream, launched behind the NEXT batch's reader (forward_async / _DeferredDecode): +4.8 % frames/s in bench.py's
+        # serving loop with the reader's in-loop time unchanged (round 5); PNX_DECODE_STREAM=0: everything on one stream
+        self.decode_on_side_stream = os.environ.get("PNX_DECODE_STREAM", "1") != "0"
         self.reader = det.reader
         self.post_processing = det.post_processing
         self.head_ref = det.head  # predict() / rectifier / class bookkeeping
