@@ -227,11 +227,11 @@ def nms_bench(dev):
 
 
 def sections(model, examples, batch):
-    """Per-section GPU time of one step (torch.cuda events between the sections; separate pass, 5 steps averaged)."""
+    """Per-section GPU time of one step (torch.cuda events between the sections; separate pass on ONE stream, median of 5 steps)."""
     import torch
 
     acc = {}
-    for i in range(6):
+    for i in range(7):
         marks = []
         packed = []
         model.forward_preds(examples[i % len(examples)]["points"], batch, marks=marks, packed_out=packed)
@@ -241,11 +241,12 @@ def sections(model, examples, batch):
         marks.append(("decode+nms", e))
         pend.result()
         torch.cuda.synchronize()
-        if i == 0:
+        if i < 2:
             continue
         for (_, a), (n1, b) in zip(marks[:-1], marks[1:]):
-            acc[n1] = acc.get(n1, 0.0) + a.elapsed_time(b) * 1e3 / 5
-    return {k: round(v, 1) for k, v in acc.items()}
+            acc.setdefault(n1, []).append(a.elapsed_time(b) * 1e3)
+    # median of five passes: this pass allocates a fresh canvas per call (the timed loop writes a persistent one), and an allocator stall lands in one section
+    return {k: round(sorted(v)[len(v) // 2], 1) for k, v in acc.items()}
 
 
 
@@ -460,8 +461,11 @@ def main():
         ny_, nx_ = (int(v) for v in model.reader.grid_size)
         rb_us, cb_us, nb_ = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
         if not a.no_back_to_back:
-            cv = torch.empty((a.batch, 64, ny_, nx_), dtype=model.dtype, device=dev, memory_format=torch.channels_last)
-            oc = torch.empty((a.batch, ny_, nx_), dtype=torch.uint8, device=dev)
+            # into the SAME canvas / occupancy buffers the timed loop writes (the launch plan's persistent ones): a freshly allocated 3.2 GB canvas
+            # made this figure bimodal from run to run (617 or ~700 us, with or without the decoder stream; where the allocator places it)
+            bbp = model._backbone_plan(a.batch, dev) if model._plan_ok() else None
+            cv = bbp["canvas"] if bbp is not None else torch.empty((a.batch, 64, ny_, nx_), dtype=model.dtype, device=dev, memory_format=torch.channels_last)
+            oc = bbp["occ"] if bbp is not None else torch.empty((a.batch, ny_, nx_), dtype=torch.uint8, device=dev)
             for i in range(3):
                 model.reader.forward_dense(examples[i % ROTATE]["points"], a.batch, dtype=model.dtype, out=cv, occupancy=oc)
             torch.cuda.synchronize()
@@ -470,7 +474,7 @@ def main():
                 model.reader.forward_dense(examples[i % ROTATE]["points"], a.batch, dtype=model.dtype, out=cv, occupancy=oc)
             torch.cuda.synchronize()
             _lib.check(L.pnx_profile_end(ctypes.byref(rb_us), ctypes.byref(cb_us), ctypes.byref(nb_)), "pnx_profile_end")
-            del cv, oc
+            del cv, oc, bbp
 
         extras = {}
         short = world > 1 and not a.all_legs   # an N-rank run: value, roofline and value_train only (DESIGN.md section 7 gives its expected wall time)
