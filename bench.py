@@ -378,12 +378,17 @@ def main():
             time.sleep(0.001)
         barrier()
         dt = time.perf_counter() - t0
+        rank_ms = [round(dt / max(a.steps, 1) * 1e3, 3)]
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            t = torch.zeros(world, dtype=torch.float64)
+            t[rank] = dt
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)   # every rank's own time, as the real run reports it
+            rank_ms = [round(float(v) / max(a.steps, 1) * 1e3, 3) for v in t.tolist()]
+            dt = float(t.max().item())
         if rank == 0:
-            print(json.dumps({"metric": "dry run (no GPU work)", "value": round(a.batch * world * a.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
+            print(json.dumps({"metric": "dry run (no GPU work)", "ranks": {"world_size_seen_by_backend": dist.get_world_size() if world > 1 else 1,
+                                                                            "backend": "gloo" if world > 1 else None, "ms_per_step_min": min(rank_ms),
+                                                                            "ms_per_step_max": max(rank_ms)}, "value": round(a.batch * world * a.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
                               "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none", "dry_run": True,
                               "config": {"workload": "launcher plumbing only", "global_batch": a.batch * world,

@@ -26,6 +26,8 @@ def test_gpus_2_spawns_two_ranks():
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1
     assert r["config"]["global_batch"] == 8 and r["scaling"] == "weak"
     assert r["value"] > 0 and r["ms_per_step"] > 0
+    assert r["ranks"]["world_size_seen_by_backend"] == 2 and r["ranks"]["ms_per_step_min"] <= r["ranks"]["ms_per_step_max"]
+    assert abs(r["ranks"]["ms_per_step_max"] - r["ms_per_step"]) < 1e-2          # the line's time is the slowest rank's
 
 
 def test_single_rank_default():
