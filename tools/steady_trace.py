@@ -23,6 +23,10 @@ def main():
         if len(starts) > nsteps:
             delim = name
             break
+    # the LAST delimiter belongs to the final batch, whose decoder is flushed at once instead of waiting behind a next reader (models._DeferredDecode):
+    # that interval is short, so the window ends one delimiter earlier
+    if len(starts) > nsteps + 2:
+        starts = starts[:-1]
     t0, t1 = starts[-nsteps - 1], starts[-1]
     rows = list(cur.execute("select name, count(*), avg(end-start)/1000.0, sum(end-start)/1000.0 from kernels where start >= ? and start < ? "
                             "group by name order by 4 desc", (t0, t1)))
