@@ -5,7 +5,8 @@
 
 A step = one batch of `--batch` frames through the whole path with inputs already resident in HBM:
   HIP reader (voxelize + PFN + dense bf16 canvas)  ->  dense masked ResNet-18 + ASPP + CenterHead (PyTorch-ROCm + HIP conv kernels,
-  bf16, channels_last)  ->  decode + batched rotated NMS (HIP).  FOUR different frame batches rotate through the loop.
+  bf16, channels_last)  ->  decode + batched rotated NMS (HIP; on the model's own side stream, launched behind the NEXT batch's reader, so it runs
+  beside that batch's convolutions: PNX_DECODE_STREAM=0 keeps one stream).  FOUR different frame batches rotate through the loop.
 `--gpus N` without WORLD_SIZE in the environment re-launches itself under torch.distributed.run with N ranks (one per GPU, RCCL);
 under a launcher (RANK/LOCAL_RANK/WORLD_SIZE set) it is one rank.  Frames are sharded by rank, there is no collective on the path
 ("replicas only"); time = max over ranks between barriers.  Rank 0 prints ONE JSON line.  Extra objects:
