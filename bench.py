@@ -150,6 +150,21 @@ def cpu_baselines(cfg, config, dist_name, frames_1t):
         tallc = time.perf_counter() - t0
     res["c1"] = {"value": round(nthr * 8 / tallc, 2), "cores": nthr, "value_1thread": round(48 / t1c, 2),
                  "sample": f"C1/{dist_name}: 48 frames on 1 thread, {nthr * 8} frames over {nthr} threads, same C port"}
+    # the reference's OWN rotated IoU / NMS on the host (det3d/core/iou3d_nms/src/iou3d_cpu.cpp compiled in place by oracle/Makefile into oracle/_ref,
+    # which travels with the snapshot): the "reference" kind of baseline for the post-processing half of the path
+    if O.have_ref():
+        import numpy as np
+
+        bx, _ = synth.clustered_boxes(1000, 7, spread=12.0)
+        t0 = time.perf_counter()
+        iou = O.ref_boxes_iou_bev(bx, bx)
+        t_iou = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        keep = O.ref_nms_rotated(bx, 0.2)
+        t_nms = time.perf_counter() - t0
+        res["nms_reference"] = {"kind": "reference", "cores": 1, "iou_1000x1000_ms": round(t_iou * 1e3, 1), "nms_1000_thr0.2_ms": round(t_nms * 1e3, 1),
+                                "kept": int(len(keep)), "pairs_over_thr": int((np.asarray(iou) > 0.2).sum()),
+                                "sample": "1000 clustered boxes (synth.clustered_boxes seed 7): IoU-BEV matrix, then mask + greedy NMS (iou3d_nms.cpp:113-159 host loop) -- nms_us.n1000x10 is ten such lists on the GPU"}
     return res
 
 
@@ -251,6 +266,36 @@ def sections(model, examples, batch):
 
 
 
+def backbone_roofline(sec, frames, dev):
+    """MFMA roofline of the masked-dense backbone, with the rate a tuned library GEMM reaches on THIS box next to the 2.5 PFLOP/s
+    spec peak: the chip clocks to its power budget (MI355X guide, DVFS give-back), and on random bf16 operands hipBLASLt's 8192^3 GEMM runs at
+    1.15-1.25 PFLOP/s here (1.5-1.75 on all-zero operands: profiles/r06_power_ceiling.txt) -- that, not 2.5, is what a convolution kernel can be
+    priced against in practice."""
+    import torch
+
+    n = 8192
+    g = torch.Generator(device=dev).manual_seed(1)
+    a = torch.randn((n, n), device=dev, generator=g).bfloat16()
+    b = torch.randn((n, n), device=dev, generator=g).bfloat16()
+    for _ in range(3):
+        a @ b
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        a @ b
+    e1.record()
+    torch.cuda.synchronize()
+    gemm_tf = 2.0 * n ** 3 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    us = sum(v for k, v in sec.items() if k.startswith("backbone."))
+    flops = 2.33e12 * frames                        # SURVEY 8d: 764 + 688 + 688 + 191 GFLOP per frame, dense-equivalent at 1440^2
+    tf = flops / (us * 1e-6) / 1e12 if us > 0 else None
+    return {"bound": "mfma", "kernel": "backbone: 20 masked 3x3 convolutions (k_conv3x3_pc / _ldsx / _s2), sections_us backbone.*",
+            "achieved": round(tf, 1) if tf else None, "peak": 2500.0, "unit": "TFLOP/s (dense-equivalent bf16 FLOPs: row segments without an active site are skipped, "
+            "0.30 / 0.36 / 0.42 / 0.47 of them are computed in stages 0-3 on the sweep cloud)", "frac": round(tf / 2500.0, 4) if tf else None,
+            "kernel_us": round(us, 1), "algorithmic_flops_per_launch": flops,
+            "library_gemm_tflops": round(gemm_tf, 1), "library_gemm": "torch.matmul bf16 8192^3, random-normal operands, measured in this run: the practical MFMA ceiling under the power cap"}
+
+
 def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAMES", "4")), steps=int(os.environ.get("PNX_BENCH_TRAIN_STEPS", "5")),
               warmup=int(os.environ.get("PNX_BENCH_TRAIN_WARMUP", "3")), amp=True):
     """One data-parallel TRAINING step of PillarNeXt-B (reference: trainer/trainer/trainer.py:94-108 -- forward, loss, backward, clip 35,
@@ -294,11 +339,12 @@ def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAME
         return loss
 
     # MIOpen's find pass over the forward / dgrad / wgrad shapes of a 1440^2 training graph (~50 problems: the dense neck / head layers and
-    # every weight gradient) takes ~3.5 minutes and buys a 2.2 x faster step (102 vs 227 ms) over MIOpen's immediate-mode choices.  A
-    # single-GPU run (what BENCH_rNN.json records) pays for it; the multi-GPU scaling runs take the immediate mode unless
-    # PNX_BENCH_TRAIN_FIND=1 -- `train.miopen` says which one a line was measured with.
+    # every weight gradient) takes ~2 minutes and buys a 2.2 x faster step (102 vs 227 ms) over MIOpen's immediate-mode choices.
+    # `train.miopen` / `ranks.miopen` say which mode a line was measured with.
     bench_mode = torch.backends.cudnn.benchmark
-    find = os.environ.get("PNX_BENCH_TRAIN_FIND", "1" if world == 1 else "0") == "1" and amp   # the fp32 leg: immediate mode (its find pass over fp32 wrw problems takes minutes)
+    # Round 6: the SAME mode at every N (find, each rank with its own find-db -- main()), so that value_train(N) / (N x value_train(1)) compares like with like;
+    # PNX_BENCH_TRAIN_FIND=0 switches every N to immediate mode.
+    find = os.environ.get("PNX_BENCH_TRAIN_FIND", "1") == "1" and amp   # the fp32 leg: immediate mode (its find pass over fp32 wrw problems takes minutes)
     torch.backends.cudnn.benchmark = find
     t_leg = time.perf_counter()
     for _ in range(warmup):
@@ -577,6 +623,7 @@ def main():
             if rank == 0 and not short:
                 extras["sections_us"] = sections(model, examples, a.batch)
                 extras["nms_us"] = nms_bench(dev)
+                extras["roofline_backbone"] = backbone_roofline(extras["sections_us"], a.batch, dev)
             for i in range(ROTATE):  # leave the persistent workspaces in the main distribution's state
                 model(examples[i])
 
@@ -613,7 +660,13 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "host_enqueue_ms_per_step": round(host_ms, 3),   # launch-thread time inside forward_async per step (launch plans: pnx_enqueue)
         "ranks": {"world_size_seen_by_backend": dist.get_world_size() if world > 1 else 1, "backend": a.backend if world > 1 else None,
-                  "ms_per_step_min": min(rank_ms), "ms_per_step_max": max(rank_ms)},
+                  "ms_per_step_min": min(rank_ms), "ms_per_step_max": max(rank_ms),
+                  "miopen": {"inference": "find (cudnn.benchmark), one find-db per rank" if torch.backends.cudnn.benchmark else "immediate mode",
+                             "train": "find (cudnn.benchmark), one find-db per rank" if os.environ.get("PNX_BENCH_TRAIN_FIND", "1") == "1" else "immediate mode"}},
+        # which two numbers a scaling efficiency is computed from: the same leg, the same MIOpen mode, the same frames per GPU at N and at 1
+        "efficiency_basis": {"inference": "value(N) / (N x value(1))", "train": "value_train(N) / (N x value_train(1))",
+                             "frames_per_gpu_per_step": {"inference": a.batch, "train": int(os.environ.get("PNX_BENCH_TRAIN_FRAMES", "4"))},
+                             "n1_reference": "BENCH_rNN.json of the same round (the driver's N = 1 run of this file); every N uses MIOpen find for both legs"},
         "config": {"workload": f"{a.config}: PillarNeXt-B nuScenes inference, {cfg['n']} pts/frame, voxel {cfg['voxel_size'][0]} m, BEV {nx}x{ny}, "
                                f"6 tasks/10 classes, cloud={a.dist} (1.5 % of the rows outside the range), random-init weights, {ROTATE} distinct frame batches rotating, "
                                f"inputs resident in HBM (value_with_h2d_merge: raw sweeps uploaded from pinned memory + merged on the device every step)",

@@ -455,15 +455,17 @@ template <int STRIDE>
 __device__ __forceinline__ int tap_slot(int px, int dx) {
   return STRIDE == 1 ? px + dx : (dx == 1 ? px : 32 + px + (dx >> 1));
 }
-template <int NR, int MTALL, int CB = 4, int STRIDE = 1>
-__device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __restrict__ s_in, const uint4* __restrict__ wfrag, const int (&rbase)[4],
+// MB = 32-channel output tiles per wave (2: the row-split kernels; 1: the producer / consumer kernel, whose waves split the output channels).
+// This is the ROLLED form of rounds 2-5 (9-iteration tap loop, its `tap < 8` tests compile to branches inside the loop): -DPNX_TAPS_ROLLED selects it.
+template <int NR, int MTALL, int CB = 4, int STRIDE = 1, int MB = 2>
+__device__ __forceinline__ void conv_taps_rolled(v16f (&acc)[NR][MB], const uint4* __restrict__ s_in, const uint4* __restrict__ wfrag, const int (&rbase)[4],
                                           int mg, int px, int kb, int lane, int kstep0 = 0) {
   constexpr int RS = STRIDE == 1 ? LDS_HW : S2_RS;
-  uint4 w[4][2];
+  uint4 w[4][MB];
 #pragma unroll
   for (int cbl = 0; cbl < 4; cbl++)
 #pragma unroll
-    for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[((kstep0 + cbl) * MTALL + mg + m) * 64 + lane];
+    for (int m = 0; m < MB; m++) w[cbl][m] = wfrag[((kstep0 + cbl) * MTALL + mg + m) * 64 + lane];
 #ifdef PNX_CONV_DBG_SAMEW  // timing experiment (tools/conv_ab.sh): every tap re-reads the fragments of tap 0 (L1-resident) -- results are wrong
 #define PNX_W_TAP(tn) 0
 #else
@@ -501,16 +503,86 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][2], const uint4* __res
       for (int j = 0; j < NR; j++) {
         const el8 bfr = __builtin_bit_cast(el8, qc[j]);
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+        for (int m = 0; m < MB; m++)
           acc[j][m] = PNX_MFMA32(__builtin_bit_cast(el8, w[cbl][m]), bfr, acc[j][m]);
       }
       if (tap < 8) {
 #pragma unroll
-        for (int m = 0; m < 2; m++) w[cbl][m] = wfrag[((PNX_W_TAP(tn) * CB + kstep0 + cbl) * MTALL + mg + m) * 64 + lane];
+        for (int m = 0; m < MB; m++) w[cbl][m] = wfrag[((PNX_W_TAP(tn) * CB + kstep0 + cbl) * MTALL + mg + m) * 64 + lane];
       }
       __builtin_amdgcn_sched_barrier(0);  // (round 5, profiles/r05_conv_sched.txt: without this fence 128 / 256 channels run 3-4 % slower; s_setprio around the MFMAs: no gain)
     }
   }
+}
+
+// The tap loop, fully unrolled (round 6): 36 k-steps (9 taps x 4 chunks of 16 input channels) of one 64-channel slab, software-pipelined in the source --
+// B fragments TAPS_PD k-steps ahead (LDS), weight fragments TAPS_WD k-steps ahead (L1 / L2), both in register rings indexed by compile-time constants
+// (no copies, no branches); a sched_barrier per k-step keeps hipcc from sinking the loads back to their users.  What made the full unroll spill in
+// round 2 was hoisting: 36 x NR slot addresses and 36 weight pointers are loop-invariant over the persistent tile loop, so hipcc computed all of
+// them at kernel entry.  Now the weight address is a wave-uniform base (scalar registers) + lane * 16, and the per-lane part of a slot address goes
+// through an opaque asm at every k-step.  Measured (profiles/r06_conv_pc_ab.txt): deeper prefetch (2-3 k-steps, 6-8 fragments) is slower -- the loop was
+// never latency-bound, see DESIGN.md section 4 on the power ceiling.
+#ifndef TAPS_PD
+#define TAPS_PD 1
+#endif
+#ifndef TAPS_WD
+#define TAPS_WD 4
+#endif
+template <int NR, int MTALL, int CB = 4, int STRIDE = 1, int MB = 2>
+__device__ __forceinline__ void conv_taps(v16f (&acc)[NR][MB], const uint4* __restrict__ s_in, const uint4* __restrict__ wfrag, const int (&rbase)[4],
+                                          int mg, int px, int kb, int lane, int kstep0 = 0) {
+#ifdef PNX_TAPS_ROLLED
+  conv_taps_rolled<NR, MTALL, CB, STRIDE, MB>(acc, s_in, wfrag, rbase, mg, px, kb, lane, kstep0);
+#else
+  constexpr int RS = STRIDE == 1 ? LDS_HW : S2_RS;
+  constexpr int KS = 36, PD = TAPS_PD, WD = TAPS_WD;
+  // weight fragment (k-step ks: tap = ks / 4, chunk = ks % 4; output tile m): a wave-uniform base, advanced by scalar adds, + lane * 16
+  const uint4* wu = wfrag + (int64_t)__builtin_amdgcn_readfirstlane(kstep0 * MTALL + mg) * 64;
+  auto wload = [&](int ks, uint4 (&dst)[MB]) {
+#ifdef PNX_CONV_DBG_SAMEW
+    ks &= 3;
+#endif
+#pragma unroll
+    for (int m = 0; m < MB; m++) dst[m] = wu[(((ks >> 2) * CB + (ks & 3)) * MTALL + m) * 64 + lane];
+  };
+  // per-lane slot of tap column dx, chunk cbl (before the row terms): c * 8 + ((2 cbl + kb) ^ swz(c)), c = tap_slot(px, dx), with
+  // (2 cbl + kb) ^ sw = (2 cbl ^ (sw & 6)) + (kb ^ (sw & 1))
+  int cdx[3], s6[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; dx++) {
+    const int c = tap_slot<STRIDE>(px, dx), sw = lds_swz(c);
+    cdx[dx] = c * 8 + (kb ^ (sw & 1));
+    s6[dx] = sw & 6;
+  }
+  auto bload = [&](int ks, uint4 (&dst)[NR]) {
+    const int tap = ks >> 2, cbl = ks & 3, dy = tap / 3, dx = tap - 3 * dy;
+    int c0 = cdx[dx];
+    asm volatile("" : "+v"(c0));  // opaque: slot addresses are formed k-step by k-step, not hoisted out of the tile loop and spilled
+    const int a = c0 + ((2 * cbl) ^ s6[dx]);
+#pragma unroll
+    for (int j = 0; j < NR; j++) dst[j] = s_in[a + rbase[j] + dy * (RS * 8)];
+  };
+  uint4 w[WD][MB];
+  uint4 q[PD + 1][NR];
+#pragma unroll
+  for (int k = 0; k < WD; k++) wload(k, w[k]);
+#pragma unroll
+  for (int k = 0; k < PD; k++) bload(k, q[k]);
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) {
+    if (ks + PD < KS) bload(ks + PD, q[(ks + PD) % (PD + 1)]);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+      const el8 bfr = __builtin_bit_cast(el8, q[ks % (PD + 1)][j]);
+#pragma unroll
+      for (int m = 0; m < MB; m++) acc[j][m] = PNX_MFMA32(__builtin_bit_cast(el8, w[ks % WD][m]), bfr, acc[j][m]);
+    }
+    if (ks + WD < KS) wload(ks + WD, w[ks % WD]);
+#ifndef TAPS_NOSB  // (measured, profiles/r06_conv_pc_ab.txt: without the fence -1.5 % end to end; an explicit one-load-behind-each-MFMA sched_group_barrier pattern: no difference)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+#endif
 }
 
 // Everything a wave does for its NR active rows once the tile is staged: per 64-channel pass, accumulators = bias (+ residual),
@@ -546,7 +618,10 @@ __device__ __forceinline__ void conv_rows(const uint4* __restrict__ s_in, const 
 #ifndef PNX_CONV_RES_EARLY
     if (HAS_RES) load_residual_u(rq, rrow_res[0], res_off, rmask[0] >> px & 1u);
 #endif
-    conv_taps<NR, MTALL>(acc, s_in, wfrag, rbase, mg, px, kb, lane);
+    if constexpr (COUT == 64)  // the single-pass kernel (the cross-check of k_conv3x3_pc<64, 64>) keeps the rolled loop: unrolled, its depth-2 tile loop state spills 660 B / lane
+      conv_taps_rolled<NR, MTALL>(acc, s_in, wfrag, rbase, mg, px, kb, lane);
+    else
+      conv_taps<NR, MTALL>(acc, s_in, wfrag, rbase, mg, px, kb, lane);
 #pragma unroll
     for (int j = 0; j < NR; j++) {
       const bool act = (rmask[j] >> px) & 1u;
@@ -1353,6 +1428,8 @@ int launch_lds(const void* x, const void* wfrag, const float* bias, const void* 
   return PNX_OK;
 }
 
+#include "conv_pc.h"
+
 template <int CIN, int COUT, int STRIDE>
 int launch(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int Ho,
            int Wo, int relu, uint8_t* row_dirty, hipStream_t st) {
@@ -1461,6 +1538,19 @@ int PNX_CONV_FN(pnx_conv3x3)(const void* x, const void* wfrag, const float* bias
   const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1 && getenv("PNX_CONV_DIRECT") == nullptr) {
+    static const int pc_mode = getenv("PNX_CONV_PC") != nullptr ? atoi(getenv("PNX_CONV_PC")) : 1;  // bit 0: 64 -> 64 on the producer / consumer kernel (default), bit 1: 128 -> 128 and 256 -> 256, bit 2: 64 -> 320 / 384 / 448; 0: row-split kernels only (the cross-check)
+    if (pc_mode != 0) {
+      if (cin == 64 && cout == 64) return launch_pc<64, 64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
+      if (residual == nullptr && (pc_mode & 4)) {  // slower than the multi-pass row-split kernel (profiles/r06_conv_pc_ab.txt): each pass re-reads the B fragments for half the channels
+        if (cin == 64 && cout == 320) return launch_pc<64, 320>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
+        if (cin == 64 && cout == 384) return launch_pc<64, 384>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
+        if (cin == 64 && cout == 448) return launch_pc<64, 448>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
+      }
+      if (pc_mode & 2) {
+        if (cin == 128 && cout == 128) return launch_pc<128, 128>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
+        if (cin == 256 && cout == 256) return launch_pc<256, 256>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
+      }
+    }
     if (cin == 64 && cout == 64) return launch_lds<64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
     if (cin == 128 && cout == 128) return launch_ldsx<128, 128>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);
     if (cin == 256 && cout == 64) return launch_ldsx<256, 64>(x, wfrag, bias, residual, mask, y, batch, h, w, relu, row_dirty, tile_list, tile_count, st);

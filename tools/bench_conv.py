@@ -11,6 +11,7 @@ ap.add_argument("--hw", type=int, default=1440); ap.add_argument("--batch", type
 ap.add_argument("--density", type=float, default=1.0); ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--stride", type=int, default=1); ap.add_argument("--tiles", action="store_true"); ap.add_argument("--miopen", action="store_true"); ap.add_argument("--res", action="store_true")
 ap.add_argument("--dilate", action="store_true", help="with --lidar: the stage's active set after its entry SparseConv2d (3x3 dilation of the pooled occupancy) -- what the stage's blocks run on")
+ap.add_argument("--data", default="randn", help="randn | relu (post-ReLU: half the values zero) | zero -- operand toggling sets the power draw and with it the clock")
 ap.add_argument("--lidar", type=int, default=-1, help="backbone stage (0..3): active sites = the C2 sweep occupancy pooled to that stage (sets --hw)")
 a = ap.parse_args()
 lidar_mask = None
@@ -38,6 +39,10 @@ if a.lidar >= 0:
 g = torch.Generator(device="cuda").manual_seed(0)
 hw_in = a.hw * a.stride
 x = torch.randn((a.batch, a.cin, hw_in, hw_in), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+if a.data == "relu":
+    x = torch.relu(x)
+elif a.data == "zero":
+    x = torch.zeros_like(x)
 w = (torch.randn((a.cout, a.cin, 3, 3), device="cuda", generator=g) / 24).to(torch.bfloat16)
 bias = torch.randn((a.cout,), device="cuda", generator=g)
 mask = (torch.rand((a.batch, a.hw, a.hw), device="cuda", generator=g) < a.density).to(torch.uint8) if a.density < 1 else None
@@ -73,7 +78,13 @@ if L is not None and hasattr(L, "pnx_debug_conv_timers") and not a.miopen:
     buf = (ctypes.c_ulonglong * 8)()
     L.pnx_debug_conv_timers(buf)          # reset
     run(); L.pnx_debug_conv_timers(buf)
-    names = ["rowmask+sync", "deal rows/zero rows", "residual loads + stage issue+write", "stage barrier", "taps + epilogue", "-", "-", "tile head"]
-    tot = sum(buf)
-    print("  section share of wave time:", ", ".join(f"{n} {100.0*v/tot:.1f}%" for n, v in zip(names, buf) if v))
+    if os.environ.get("PNX_CONV_PC", "1") != "0" and a.stride == 1:   # producer / consumer kernel (csrc/conv_pc.h): 8 consumer + 4 producer waves
+        names = ["c:info+deal", "c:taps", "c:barrier", "c:epilogue", "-", "p:prepare+issue", "p:wait+barrier", "prologue"]
+        ctot, ptot = sum(buf[0:4]), sum(buf[5:7])
+        print("  consumer waves:", ", ".join(f"{n} {100.0*v/ctot:.1f}%" for n, v in zip(names[:4], buf[:4]) if v), "| producer waves:",
+              ", ".join(f"{n} {100.0*v/ptot:.1f}%" for n, v in zip(names[5:7], buf[5:7]) if v), f"| consumer ticks per launch {ctot/8:.0f} per wave-slot x 256 CUs")
+    else:
+        names = ["rowmask+sync", "deal rows/zero rows", "residual loads + stage issue+write", "stage barrier", "taps + epilogue", "-", "-", "tile head"]
+        tot = sum(buf)
+        print("  section share of wave time:", ", ".join(f"{n} {100.0*v/tot:.1f}%" for n, v in zip(names, buf) if v))
 print(f"{'miopen+epilogue' if a.miopen else 'pnx_conv3x3'} {a.cin}->{a.cout} {a.hw}^2 (stride {a.stride}) b{a.batch} density {a.density}: {ms*1e3:.1f} us  {fl/ms/1e9:.0f} TFLOP/s (dense-equivalent)")
