@@ -528,6 +528,9 @@ __device__ __forceinline__ void conv_taps_rolled(v16f (&acc)[NR][MB], const uint
 #ifndef TAPS_WD
 #define TAPS_WD 4
 #endif
+#ifndef TAPS_NOBUFW  // (-DTAPS_NOBUFW: per-lane global loads, the A/B reference: profiles/r06_conv_pc_ab.txt)
+#define TAPS_BUFW
+#endif
 template <int NR, int MTALL, int CB = 4, int STRIDE = 1, int MB = 2>
 __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][MB], const uint4* __restrict__ s_in, const uint4* __restrict__ wfrag, const int (&rbase)[4],
                                           int mg, int px, int kb, int lane, int kstep0 = 0) {
@@ -536,14 +539,29 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][MB], const uint4* __re
 #else
   constexpr int RS = STRIDE == 1 ? LDS_HW : S2_RS;
   constexpr int KS = 36, PD = TAPS_PD, WD = TAPS_WD;
-  // weight fragment (k-step ks: tap = ks / 4, chunk = ks % 4; output tile m): a wave-uniform base, advanced by scalar adds, + lane * 16
+  // weight fragment (k-step ks -> tap, chunk cbl; output tile m): a wave-uniform base + lane * 16
   const uint4* wu = wfrag + (int64_t)__builtin_amdgcn_readfirstlane(kstep0 * MTALL + mg) * 64;
+#ifdef TAPS_BUFW  // weights through a buffer resource: scalar base + scalar offset + lane * 16, one instruction per fragment and no per-lane 64-bit address
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wu), 0, 0x7fffffff, 0x00020000);
+  const int wlo = lane * 16;
+#endif
   auto wload = [&](int ks, uint4 (&dst)[MB]) {
+    const int grp = ks / 3, cbl = grp & 3;
 #ifdef PNX_CONV_DBG_SAMEW
-    ks &= 3;
+    const int tap = 0;
+#else
+    const int tap = (ks % 3) * 3 + (grp >> 2);  // dy * 3 + dx
 #endif
 #pragma unroll
-    for (int m = 0; m < MB; m++) dst[m] = wu[(((ks >> 2) * CB + (ks & 3)) * MTALL + m) * 64 + lane];
+    for (int m = 0; m < MB; m++) {
+#ifdef TAPS_BUFW
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, (((tap * CB + cbl) * MTALL + m) * 64) * 16, 0);
+      dst[m] = make_uint4(r.x, r.y, r.z, r.w);
+#else
+      dst[m] = wu[((tap * CB + cbl) * MTALL + m) * 64 + lane];
+#endif
+    }
   };
   // per-lane slot of tap column dx, chunk cbl (before the row terms): c * 8 + ((2 cbl + kb) ^ swz(c)), c = tap_slot(px, dx), with
   // (2 cbl + kb) ^ sw = (2 cbl ^ (sw & 6)) + (kb ^ (sw & 1))
@@ -554,13 +572,22 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][MB], const uint4* __re
     cdx[dx] = c * 8 + (kb ^ (sw & 1));
     s6[dx] = sw & 6;
   }
-  auto bload = [&](int ks, uint4 (&dst)[NR]) {
-    const int tap = ks >> 2, cbl = ks & 3, dy = tap / 3, dx = tap - 3 * dy;
+  // k-step order: ks = (dx * 4 + cbl) * 3 + dy.  The three dy taps of a (column dx, chunk cbl) group read the SAME per-lane slots one halo row apart, i.e.
+  // the same address registers with another immediate offset: NR address adds per three k-steps instead of per k-step.
+  int addr[NR];
+  auto group_addr = [&](int grp) {
+    const int dx = grp >> 2, cbl = grp & 3;
     int c0 = cdx[dx];
-    asm volatile("" : "+v"(c0));  // opaque: slot addresses are formed k-step by k-step, not hoisted out of the tile loop and spilled
+    asm volatile("" : "+v"(c0));  // opaque: slot addresses are formed group by group, not hoisted out of the tile loop and spilled
     const int a = c0 + ((2 * cbl) ^ s6[dx]);
 #pragma unroll
-    for (int j = 0; j < NR; j++) dst[j] = s_in[a + rbase[j] + dy * (RS * 8)];
+    for (int j = 0; j < NR; j++) addr[j] = a + rbase[j];
+  };
+  auto bload = [&](int ks, uint4 (&dst)[NR]) {
+    const int dy = ks % 3;
+    if (dy == 0) group_addr(ks / 3);
+#pragma unroll
+    for (int j = 0; j < NR; j++) dst[j] = s_in[addr[j] + dy * (RS * 8)];
   };
   uint4 w[WD][MB];
   uint4 q[PD + 1][NR];
