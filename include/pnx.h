@@ -349,6 +349,10 @@ int pnx_boxes_aligned_iou_bev_cpu(const float* boxes_a_host, const float* boxes_
  *   max_seg_len   an upper bound on any segment's length (host value; sizes the launch)
  */
 size_t pnx_nms_workspace_bytes(int64_t total_boxes, int32_t num_segments, int32_t max_seg_len);
+/* Test hook: capacity (entries) of the rotated NMS's candidate-pair list, 0 = the default (32 per box); returns the previous value.  A small list sends
+ * the tiles that do not fit down the tile-by-tile path, whose keep indices must be identical.  Changes the layout pnx_nms_workspace_bytes describes:
+ * query the workspace size again after calling it.  Not thread-safe. */
+int32_t pnx_debug_nms_pair_cap(int32_t cap);
 int pnx_nms_rotated_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* seg_len, int32_t num_segments, int32_t max_seg_len,
                             const float* thresh, int32_t post_max, int32_t* keep, int32_t* keep_count, void* workspace,
                             size_t workspace_bytes, pnx_stream_t stream);

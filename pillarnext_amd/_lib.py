@@ -107,6 +107,7 @@ PROTOTYPES = {
     "pnx_boxes_iou_bev_cpu": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp]),
     "pnx_boxes_aligned_iou_bev_cpu": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "pnx_nms_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "pnx_debug_nms_pair_cap": (_i32, [_i32]),
     "pnx_nms_rotated_batched": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     "pnx_nms_normal_batched": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
 }

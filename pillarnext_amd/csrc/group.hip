@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void k_pfn_layer(const float* __restrict__ 
       for (int k = 0; k < k1; k++) acc = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f[0]), k)), wc[k * cout], acc);
       for (int k = 64; k < cin; k++)
         acc = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f[1]), k - 64)), wc[k * cout], acc);
-      acc = fmaxf(acc, 0.f);
+      acc = acc > 0.f ? acc : 0.f;  // never -0.0: the unsigned atomicMax below orders bit patterns, and 0x80000000 would beat every positive value
       if (on) {
         if (y) y[p * ldy + c] = acc;
         if (gmax) atomicMax(&gmax[g * cout + c], __float_as_uint(acc));

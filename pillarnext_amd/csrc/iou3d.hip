@@ -376,13 +376,16 @@ struct NmsLayout {
   size_t pairs_off, tiles_off, counts_off, mask_off;
   unsigned int pair_cap, tile_cap;
 };
+int g_nms_pair_cap_dbg = 0;  // 0: the default capacity
 NmsLayout nms_layout(int num_segments, int max_seg_len) {
   NmsLayout l;
   const size_t cb = (size_t)((max_seg_len + 63) / 64), slots = (size_t)num_segments * cb * 64;
   size_t pc = slots * 32;  // room for 32 candidate pairs per box on average; what does not fit is done tile by tile
   if (pc > ((size_t)1 << 24)) pc = (size_t)1 << 24;
   if (pc < 4096) pc = 4096;
-  if (const char* e = getenv("PNX_NMS_PAIR_CAP")) pc = (size_t)(atoi(e) > 64 ? atoi(e) : 64);  // tests: a tiny list sends (almost) every tile down the overflow path
+  // tests: a tiny list sends (almost) every tile down the overflow path (pnx_debug_nms_pair_cap; the environment is NOT read at call time any more -- a
+  // workspace sized at one value could be laid out with another, ADVICE r5 -- and the launch checks the workspace against the full layout)
+  if (g_nms_pair_cap_dbg > 0) pc = (size_t)(g_nms_pair_cap_dbg > 64 ? g_nms_pair_cap_dbg : 64);
   size_t tc = (size_t)num_segments * cb * (cb + 1) / 2;  // every tile on or above the diagonal
   if (tc > ((size_t)1 << 24)) tc = (size_t)1 << 24;
   l.pair_cap = (unsigned int)pc, l.tile_cap = (unsigned int)(tc < 1 ? 1 : tc);
@@ -456,6 +459,12 @@ int pnx_boxes_aligned_overlap_bev(const float* a, const float* b, int64_t n, flo
 }
 int pnx_boxes_aligned_iou3d(const float* a, const float* b, int64_t n, float* out, pnx_stream_t s) {
   return launch_pairs(MODE_IOU3D, a, n, b, n, out, 1, (hipStream_t)s);
+}
+
+int32_t pnx_debug_nms_pair_cap(int32_t cap) {  // test hook: capacity of the rotated NMS's candidate-pair list (0 = default); returns the previous value
+  const int prev = g_nms_pair_cap_dbg;
+  g_nms_pair_cap_dbg = cap > 0 ? cap : 0;
+  return prev;
 }
 
 size_t pnx_nms_workspace_bytes(int64_t total_boxes, int32_t num_segments, int32_t max_seg_len) {

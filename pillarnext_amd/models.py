@@ -15,8 +15,10 @@ that reproduces spconv's active-site semantics exactly in eval mode (SURVEY.md H
 """
 import copy
 import os
+import weakref
 
 import numpy as np
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -941,7 +943,8 @@ class _DeferredDecode:
         for p in self.packed:   # allocated on the main stream, consumed on the side stream: the caching allocator must not hand them out before that work ran
             p.dense.record_stream(side), p.up.record_stream(side)
         self.packed = None
-        if m.__dict__.get("_deferred") is self:
+        ref = m.__dict__.get("_deferred")
+        if ref is not None and ref() is self:
             m.__dict__["_deferred"] = None
 
     def result(self):
@@ -1369,7 +1372,8 @@ class FusedPillarNeXt(nn.Module):
     @torch.no_grad()
     def forward_async(self, example):
         """Enqueue the whole frame batch (reader -> ... -> NMS -> D2H copy) and return a decode.PendingDetections."""
-        prev = self.__dict__.get("_deferred")   # the previous batch's decoder, if nobody asked for its result yet
+        ref = self.__dict__.get("_deferred")    # the previous batch's decoder, if nobody asked for its result yet -- held by WEAK reference: a handle the
+        prev = ref() if ref is not None else None  # caller dropped is not launched at all, and its ~1.2 GB of deblocked maps go back to the allocator at once
         packed = []
         self.forward_preds(example["points"], example["batch_size"], packed_out=packed,
                            after_reader=(lambda: prev.launch(behind_reader=True)) if prev is not None and not prev.launched else None)
@@ -1379,8 +1383,17 @@ class FusedPillarNeXt(nn.Module):
         # stream, and started only once the NEXT batch's reader is through (so that the HBM-bound reader keeps the GPU to itself), it runs beside
         # that batch's convolutions instead of in front of them.  It reads only this step's fresh tensors (dense [iou] hm maps, deblocked maps) and
         # constants; its scratch is per stream (decode.PackedDecoder).  Nobody enqueues a next batch: result() launches it at once.
-        d = self.__dict__["_deferred"] = _DeferredDecode(self, packed, example.get("token"))
+        d = _DeferredDecode(self, packed, example.get("token"))
+        self.__dict__["_deferred"] = weakref.ref(d)
         return d
+
+    def __getstate__(self):   # copy.deepcopy / torch.save of the module: the side stream and the pending decoder are per-process launch state, not model state
+        st = dict(self.__dict__)
+        for k in ("_decode_stream", "_deferred"):
+            st.pop(k, None)
+        st["_decoder"] = None
+        st["_ws"] = {}
+        return st
 
     def launch_decode(self, packed, tokens=None):
         if not (packed and isinstance(packed[0], LazyTask)):

@@ -29,6 +29,10 @@ def batch_of(points, batch_size=None):
 
 
 def _device_points(points, who):
+    """The readers run on the HIP kernels only.  CPU tensors raise on purpose (the reference's torch_scatter path accepted them): this package is the
+    MI355X product path, which carries no CPU fallback -- a silent one would void every parity claim; the torch statement of the
+    same readers is kept with the tests' CPU checker, outside this package.  One more difference from the reference, shared by every grouping kernel: a row
+    whose batch index lies outside [0, batch_size) is DROPPED (csrc/group.hip k_group_keys); the reference would index past the batch and grow it."""
     if not points.is_cuda:
         raise PnxError(f"{who}: points must be a CUDA (ROCm) tensor; the readers have no CPU implementation")
     return points.contiguous().float()

@@ -153,17 +153,20 @@ def test_nms_pair_list_overflow_path_is_bit_identical(oracle, monkeypatch):
     """Round 5's rotated NMS appends the bounding-circle candidates of all tiles to ONE global pair list and clips them one pair per thread; tiles
     that no longer fit the list are processed tile by tile (the rounds 1-4 form).  With a 64-entry list almost every tile takes that path, one
     tile straddles the end of the list: the keep indices must equal the default path's and the oracle's."""
-    from pillarnext_amd import ops, synth
+    from pillarnext_amd import _lib, ops, synth
 
+    L = _lib.lib()
     for n, seed, thr in ((1000, 11, 0.2), (3000, 12, 0.7)):
         boxes, _ = synth.clustered_boxes(n, seed)
         b = torch.from_numpy(boxes).cuda()
         k0, c0 = ops.nms_single(b, thr)
-        monkeypatch.setenv("PNX_NMS_PAIR_CAP", "64")
-        k1, c1 = ops.nms_single(b, thr)
-        monkeypatch.setenv("PNX_NMS_PAIR_CAP", "5000")
-        k2, c2 = ops.nms_single(b, thr)
-        monkeypatch.delenv("PNX_NMS_PAIR_CAP")
+        try:
+            L.pnx_debug_nms_pair_cap(64)
+            k1, c1 = ops.nms_single(b, thr)
+            L.pnx_debug_nms_pair_cap(5000)
+            k2, c2 = ops.nms_single(b, thr)
+        finally:
+            L.pnx_debug_nms_pair_cap(0)
         ref = oracle.nms_rotated(boxes, thr, "det")
         assert c0 == c1 == c2 == len(ref)
         assert np.array_equal(k0.cpu().numpy(), ref) and torch.equal(k0, k1) and torch.equal(k0, k2)
@@ -183,7 +186,7 @@ def test_hip_against_the_compiled_reference(oracle):
     ref = oracle.ref_boxes_iou_bev(a, b)
     assert (ref > 0).mean() > 0.01
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=1e-5)
-    boxes, scores = synth.clustered_boxes(1000, 913, spread=12.0)
+    boxes, scores = synth.clustered_boxes(1000, 920, spread=12.0)   # seed 920: no pair within 7e-5 of the threshold (libm vs det-math differ by <= 1e-5)
     order = np.argsort(-scores, kind="stable")
     sb = np.ascontiguousarray(boxes[order])
     keep_ref = oracle.ref_nms_rotated(sb, 0.2)

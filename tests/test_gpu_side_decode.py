@@ -58,9 +58,21 @@ def test_deferred_decode_is_flushed_by_result_and_survives_a_dropped_pending():
     assert isinstance(p1, _DeferredDecode) and not p1.launched
     r1 = model.detections(p1.result())                     # nobody enqueued a next batch: result() launches the decoder itself
     assert p1.launched and int(p1.flag_h[0]) in (0, 1)
-    model.forward_async(ex)                                 # dropped without result(): the next call launches it behind its reader, results unused
+    model.forward_async(ex)                                 # dropped without result(): held by weak reference only, so it is never launched and its maps are freed
+    assert model.__dict__["_deferred"]() is None
     r3 = model(ex)
     model.decode_on_side_stream = False
     r4 = model(ex)
     for r in (r3, r4):
         assert torch.equal(r["a"]["scores"], r1["a"]["scores"]) and torch.equal(r["a"]["box3d_lidar"], r1["a"]["box3d_lidar"])
+    # copy.deepcopy / torch.save of the module: the side stream and the pending decoder are launch state, not model state
+    import copy
+    import io
+
+    kept = model.forward_async(ex)                          # a live pending handle and a live side stream while the module is copied
+    twin = copy.deepcopy(model)
+    torch.save(model, io.BytesIO())
+    assert "_decode_stream" not in twin.__dict__ and "_deferred" not in twin.__dict__
+    model.decode_on_side_stream = twin.decode_on_side_stream = True
+    r5, r6 = model.detections(kept.result()), twin(ex)
+    assert torch.equal(r5["a"]["scores"], r1["a"]["scores"]) and torch.equal(r6["a"]["scores"], r1["a"]["scores"])
