@@ -1535,18 +1535,27 @@ int pnx_conv3x3_tile_rows(int32_t cin, int32_t cout, int32_t stride) {
   return 0;
 }
 
-int pnx_conv_tile_list(const uint8_t* mask, const uint8_t* const* row_dirty, int32_t n_dirty, int32_t batch, int32_t h, int32_t w, int32_t tile_rows,
-                       int32_t* tile_list, int32_t* tile_count, pnx_stream_t stream) {
+static int conv_tile_list_impl(const uint8_t* mask, const uint8_t* const* row_dirty, int32_t n_dirty, int32_t batch, int32_t h, int32_t w, int32_t tile_rows,
+                               int32_t* tile_list, int32_t* tile_count, pnx_stream_t stream, bool zero_count) {
   PNX_REQUIRE(mask && tile_list && tile_count && batch > 0 && h > 0 && w > 0 && tile_rows > 0, PNX_ERR_INVALID, "bad arguments");
   PNX_REQUIRE(n_dirty >= 0 && n_dirty <= 4 && (n_dirty == 0 || row_dirty != nullptr), PNX_ERR_INVALID, "0..4 row_dirty arrays");
   DirtySet ds;
   for (int k = 0; k < 4; k++) ds.p[k] = k < n_dirty ? row_dirty[k] : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  PNX_CHECK_HIP(hipMemsetAsync(tile_count, 0, sizeof(int32_t), st));
+  if (zero_count) PNX_CHECK_HIP(hipMemsetAsync(tile_count, 0, sizeof(int32_t), st));
   const int64_t n_tiles = (int64_t)batch * ((h + tile_rows - 1) / tile_rows) * ((w + 31) / 32);
   k_tile_list<<<(unsigned)((n_tiles + 255) / 256), 256, 0, st>>>(mask, ds, batch, h, w, tile_rows, tile_list, tile_count);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
+}
+int pnx_conv_tile_list(const uint8_t* mask, const uint8_t* const* row_dirty, int32_t n_dirty, int32_t batch, int32_t h, int32_t w, int32_t tile_rows,
+                       int32_t* tile_list, int32_t* tile_count, pnx_stream_t stream) {
+  return conv_tile_list_impl(mask, row_dirty, n_dirty, batch, h, w, tile_rows, tile_list, tile_count, stream, true);
+}
+// internal (enqueue.hip): *tile_count is already zero -- pnx_enqueue clears the counters of all tile-list entries of a table in one launch
+int pnx_conv_tile_list_prezeroed(const uint8_t* mask, const uint8_t* const* row_dirty, int32_t n_dirty, int32_t batch, int32_t h, int32_t w, int32_t tile_rows,
+                                 int32_t* tile_list, int32_t* tile_count, pnx_stream_t stream) {
+  return conv_tile_list_impl(mask, row_dirty, n_dirty, batch, h, w, tile_rows, tile_list, tile_count, stream, false);
 }
 
 #endif

@@ -413,10 +413,13 @@ struct RsState {
   int32_t* n_open;             // segments not finished
 };
 
-__global__ __launch_bounds__(256) void k_rs_init(RsState st, int S, int k) {
+// per-list state of the select + the overflow histograms (S x kRsBins words, zero) in ONE launch (round 6: the memset of `ovf` was one of nine
+// fillBufferAligned dispatches per step)
+__global__ __launch_bounds__(256) void k_rs_init(RsState st, int S, int k, uint32_t* __restrict__ ovf) {
   const int s = blockIdx.x * 256 + threadIdx.x;
   if (s < S) st.prefix[s] = 0ull, st.thr[s] = 0ull, st.rem[s] = (uint32_t)k, st.flag[s] = 0u, st.total[s] = 0u, st.cursor[s] = 0u;
   if (s == 0) *st.n_open = S;
+  for (int64_t e = s; e < (int64_t)S * kRsBins; e += (int64_t)gridDim.x * 256) ovf[e] = 0u;
 }
 
 __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const unsigned long long* __restrict__ keys, int64_t n, int p, RsState st, int32_t* __restrict__ slotseg,
@@ -647,8 +650,11 @@ int pnx_decode_topk(const uint64_t* keys, int64_t n_keys, int32_t num_segments, 
   rs.cursor = c.take<uint32_t>(S + 8);
   rs.n_open = c.take<int32_t>(S + 8);
   unsigned long long* list = c.take<unsigned long long>((size_t)S * kRsMaxK);
-  PNX_CHECK_HIP(hipMemsetAsync(ovf, 0, (size_t)S * kRsBins * 4, st));
-  k_rs_init<<<(S + 255) / 256, 256, 0, st>>>(rs, S, pre_max);
+  {
+    int nb = (int)(((int64_t)S * kRsBins + 256 * 8 - 1) / (256 * 8));
+    nb = nb < (S + 255) / 256 ? (S + 255) / 256 : (nb > 1024 ? 1024 : nb);
+    k_rs_init<<<nb, 256, 0, st>>>(rs, S, pre_max, ovf);
+  }
   for (int p = 0; p < 6; p++) {
     if (nchunks > 0) k_rs_hist<<<nchunks, kRsThreads, 0, st>>>((const unsigned long long*)keys, n_keys, p, rs, slotseg, rows, ovf);
     k_rs_select<<<S, 256, 0, st>>>(p, rs, slotseg, nchunks * kRsSlots, rows, ovf);
