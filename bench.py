@@ -266,12 +266,14 @@ def sections(model, examples, batch):
 
 
 
-def backbone_roofline(sec, frames, dev):
-    """MFMA roofline of the masked-dense backbone, with the rate a tuned library GEMM reaches on THIS box next to the 2.5 PFLOP/s
-    spec peak: the chip clocks to its power budget (MI355X guide, DVFS give-back), and on random bf16 operands hipBLASLt's 8192^3 GEMM runs at
-    1.15-1.25 PFLOP/s here (1.5-1.75 on all-zero operands: profiles/r06_power_ceiling.txt) -- that, not 2.5, is what a convolution kernel can be
-    priced against in practice."""
+def backbone_roofline(sec, frames, dev, model, example):
+    """MFMA roofline of the masked-dense backbone in REAL FLOPs -- the row segments the kernels compute, measured on this batch's masks --
+    with the rate a tuned library GEMM reaches on THIS box next to the 2.5 PFLOP/s spec peak: the chip clocks to its power budget (MI355X guide, DVFS
+    give-back), and on random bf16 operands hipBLASLt's 8192^3 GEMM runs at 1.15-1.25 PFLOP/s here (1.5-1.75 on all-zero operands:
+    profiles/r06_power_ceiling.txt) -- that, not 2.5, is what a convolution kernel can be priced against in practice."""
     import torch
+
+    from pillarnext_amd import ops
 
     n = 8192
     g = torch.Generator(device=dev).manual_seed(1)
@@ -286,14 +288,29 @@ def backbone_roofline(sec, frames, dev):
     e1.record()
     torch.cuda.synchronize()
     gemm_tf = 2.0 * n ** 3 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e12
-    us = sum(v for k, v in sec.items() if k.startswith("backbone."))
-    flops = 2.33e12 * frames                        # 764 + 688 + 688 + 191 GFLOP per frame, dense-equivalent at 1440^2
-    tf = flops / (us * 1e-6) / 1e12 if us > 0 else None
+    del a, b
+    # active 32-pixel row segments per stage: stage 0 runs on the 3x3 dilation of the occupancy (its entry layer is a SparseConv2d, sparse_resnet.py:53-54),
+    # stages 1-3 on the stride-2 pooled masks (sparse_conv.py:16-29)
+    ny, nx = (int(v) for v in model.reader.grid_size)
+    occ = torch.empty((frames, ny, nx), dtype=torch.uint8, device=dev)
+    model.reader.forward_dense(example["points"], frames, dtype=model.dtype, occupancy=occ)
+    fr, m = [], occ
+    for stage in range(4):
+        m = ops.mask_pool3(m, 1 if stage == 0 else 2)
+        fr.append(float(torch.nn.functional.max_pool1d(m.float(), 32, 32, ceil_mode=True).mean().item()))
+    dense = [764e9, 688e9, 688e9, 191e9]            # dense-equivalent FLOPs per frame and stage at 1440^2
+    us = [sec.get(f"backbone.stage{i}", 0.0) for i in range(4)]
+    real = sum(d * f for d, f in zip(dense, fr)) * frames
+    tot_us = sum(us)
+    tf = real / (tot_us * 1e-6) / 1e12 if tot_us > 0 else None
+    per_stage = [round(d * f * frames / (u * 1e-6) / 1e12, 1) if u > 0 else None for d, f, u in zip(dense, fr, us)]
     return {"bound": "mfma", "kernel": "backbone: 20 masked 3x3 convolutions (k_conv3x3_pc / _ldsx / _s2), sections_us backbone.*",
-            "achieved": round(tf, 1) if tf else None, "peak": 2500.0, "unit": "TFLOP/s (dense-equivalent bf16 FLOPs: row segments without an active site are skipped, "
-            "0.30 / 0.36 / 0.42 / 0.47 of them are computed in stages 0-3 on the sweep cloud)", "frac": round(tf / 2500.0, 4) if tf else None,
-            "kernel_us": round(us, 1), "algorithmic_flops_per_launch": flops,
-            "library_gemm_tflops": round(gemm_tf, 1), "library_gemm": "torch.matmul bf16 8192^3, random-normal operands, measured in this run: the practical MFMA ceiling under the power cap"}
+            "achieved": round(tf, 1) if tf else None, "peak": 2500.0, "unit": "TFLOP/s (real bf16 FLOPs: dense-equivalent FLOPs of a stage x the fraction of its 32-pixel row segments that hold an active site)",
+            "frac": round(tf / 2500.0, 4) if tf else None, "kernel_us": round(tot_us, 1), "algorithmic_flops_per_launch": real,
+            "active_row_segments_per_stage": [round(f, 3) for f in fr], "achieved_per_stage": per_stage,
+            "dense_equivalent_tflops": round(sum(dense) * frames / (tot_us * 1e-6) / 1e12, 1) if tot_us > 0 else None,
+            "library_gemm_tflops": round(gemm_tf, 1), "frac_of_library_gemm": round(tf / gemm_tf, 4) if tf else None,
+            "library_gemm": "torch.matmul bf16 8192^3, random-normal operands, measured in this run: the practical MFMA ceiling under the power cap"}
 
 
 def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAMES", "4")), steps=int(os.environ.get("PNX_BENCH_TRAIN_STEPS", "5")),
@@ -623,7 +640,7 @@ def main():
             if rank == 0 and not short:
                 extras["sections_us"] = sections(model, examples, a.batch)
                 extras["nms_us"] = nms_bench(dev)
-                extras["roofline_backbone"] = backbone_roofline(extras["sections_us"], a.batch, dev)
+                extras["roofline_backbone"] = backbone_roofline(extras["sections_us"], a.batch, dev, model, examples[0])
             for i in range(ROTATE):  # leave the persistent workspaces in the main distribution's state
                 model(examples[i])
 

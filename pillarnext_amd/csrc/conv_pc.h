@@ -131,6 +131,8 @@ __device__ __forceinline__ void pc_rows(const uint4* __restrict__ s_ring, int& g
         }
         uint4 pk[2];
         pack_tile(acc[j][0], act, relu, pk, HAS_RES ? rc : nullptr);
+        // (measured: storing each lane's own two 16-byte chunks instead -- 32 lines of 32 bytes per instruction, no transposition -- is 1 % slower end to end
+        // and the epilogue's share stays at 20 %: it is the stores' issue, not the transposition's VALU: profiles/r06_conv_pc_ab.txt)
         transpose_row32(pk, lane);
         store_row32<COUT>(pk, y_t + ((int64_t)rrow[j] * W) * COUT + mt * 32, n_valid, lane);
       }
@@ -151,8 +153,12 @@ __global__ __launch_bounds__(768, 3) void k_conv3x3_pc(const uint16_t* __restric
   constexpr int SLOT_N = (TH + 2) * LDS_HW * 8;
   static_assert(COUT % PASS_C == 0 && CIN % 64 == 0, "passes of NCG x 32 output channels over 64-channel input slabs");
   __shared__ uint4 s_ring[NSLOT * SLOT_N];
-  __shared__ int s_tile[4];                // tile id of this workgroup's n-th tile (n & 3), -1 = no more
+  __shared__ int4 s_tile[4];               // this workgroup's n-th tile (n & 3): {image b (-1 = no more tiles), y0, x0, rows with an active site}
   __shared__ uint32_t s_rowmask[4][TH];    // its active-site masks, one word per row
+  // the deal of the tile's active rows to the row groups, done ONCE by producer 0 (round 6: every consumer wave redoing it from the row masks was 11 % of the
+  // consumers' time): group rg takes the active rows number rg, rg + NRG, ...: row index (-1: none) and column mask of its j-th row
+  __shared__ int4 s_drow[4][NRG];
+  __shared__ uint4 s_dmask[4][NRG];
   __shared__ unsigned int s_tick[4];       // ticket that names tile n (n & 3), drawn three tiles earlier
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
@@ -208,8 +214,10 @@ __global__ __launch_bounds__(768, 3) void k_conv3x3_pc(const uint16_t* __restric
 
     auto advance = [&]() -> bool {
       const int64_t t = t_next;
-      if (pw == 0 && lane == 0) s_tile[n & 3] = (int)t;
-      if (t < 0) return false;
+      if (t < 0) {
+        if (pw == 0 && lane == 0) s_tile[n & 3] = make_int4(-1, 0, 0, 0);
+        return false;
+      }
       const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
       cb = (int)(t / ((int64_t)tiles_x * tiles_y));
       cx0 = tx * 32, cy0 = ty * TH;
@@ -225,7 +233,18 @@ __global__ __launch_bounds__(768, 3) void k_conv3x3_pc(const uint16_t* __restric
         am |= (lo != 0 ? 1u : 0u) << (2 * k) | (hi != 0 ? 1u : 0u) << (2 * k + 1);
       }
       const uint32_t was = (uint32_t)__ballot(dirty != 0) & ((1u << TH) - 1u);
-      if (pw == 0 && lane < TH) s_rowmask[n & 3][lane] = my_rm;
+      if (pw == 0) {
+        if (lane < TH) s_rowmask[n & 3][lane] = my_rm;
+        if (lane == 0) s_tile[n & 3] = make_int4(cb, cy0, cx0, (int)am);
+        if (lane < NRG * 4) {  // lane = position in the list of active rows = rg + j * NRG
+          uint32_t rest = am;
+          for (int k = 0; k < lane && rest; k++) rest &= rest - 1;
+          const int row = rest != 0 ? __builtin_ctz(rest) : -1;
+          const uint32_t m = row >= 0 ? s_rowmask[n & 3][row] : 0u;  // written above by this wave: LDS operations of a wave execute in order
+          reinterpret_cast<int*>(&s_drow[n & 3][lane % NRG])[lane / NRG] = row;
+          reinterpret_cast<uint32_t*>(&s_dmask[n & 3][lane % NRG])[lane / NRG] = m;
+        }
+      }
       if (slot >= 0 && pw == 0 && lane == 0) {  // the ticket that will name tile n + 3
         tick = atomicAdd(&g_tile_ctr[slot][0], 1u);
         have_tick = true;
@@ -314,36 +333,27 @@ __global__ __launch_bounds__(768, 3) void k_conv3x3_pc(const uint16_t* __restric
   int g = 0;
   PC_TOCK(7)
   for (int n = 0;; n++) {
-    const int t = __builtin_amdgcn_readfirstlane(s_tile[n & 3]);
-    if (t < 0) break;
-    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
-    const int x0 = tx * 32, y0 = ty * TH;
-    const uint32_t my_rm = s_rowmask[n & 3][lane & (TH - 1)];
-    const uint32_t am = (uint32_t)__ballot(my_rm != 0) & ((1u << TH) - 1u);
-    if (am == 0) {  // a tile of the list that only had stale rows: the producers zero-filled them
+    const int4 ti = s_tile[n & 3];
+    const int b = __builtin_amdgcn_readfirstlane(ti.x);
+    if (b < 0) break;
+    const int y0 = __builtin_amdgcn_readfirstlane(ti.y), x0 = __builtin_amdgcn_readfirstlane(ti.z);
+    if (__builtin_amdgcn_readfirstlane(ti.w) == 0) {  // a tile of the list that only had stale rows: the producers zero-filled them
       pc_barrier_lds();
       g++;
       PC_TOCK(2)
       continue;
     }
-    int nr = 0, rrow[4];
-    {  // the rows with an active site, dealt round-robin to the row groups
-      uint32_t rest = am;
-      for (int k = 0; k < rg && rest; k++) rest &= rest - 1;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const bool has = rest != 0;
-        rrow[j] = has ? __builtin_ctz(rest) : 0;
-        nr += has ? 1 : 0;
-        for (int k = 0; k < NRG && rest; k++) rest &= rest - 1;
-      }
-    }
-    nr = __builtin_amdgcn_readfirstlane(nr);
-    uint32_t rmask[4];
+    const int4 dr = s_drow[n & 3][rg];
+    const uint4 dm = s_dmask[n & 3][rg];
+    int rrow[4] = {__builtin_amdgcn_readfirstlane(dr.x), __builtin_amdgcn_readfirstlane(dr.y), __builtin_amdgcn_readfirstlane(dr.z),
+                   __builtin_amdgcn_readfirstlane(dr.w)};
+    const uint32_t rmask[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)dm.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)dm.y),
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)dm.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)dm.w)};
+    int nr = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      rrow[j] = __builtin_amdgcn_readfirstlane(rrow[j]);
-      rmask[j] = j < nr ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rowmask[n & 3][rrow[j]]) : 0u;
+      nr += rrow[j] >= 0 ? 1 : 0;
+      rrow[j] = rrow[j] >= 0 ? rrow[j] : 0;  // dummy rows point at row 0
     }
     const uint16_t* res_t = HAS_RES ? res + (((int64_t)b * H + y0) * W + x0) * COUT : nullptr;
     uint16_t* y_t = y + (((int64_t)b * H + y0) * W + x0) * COUT;
