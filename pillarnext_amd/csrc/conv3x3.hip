@@ -140,6 +140,34 @@ __device__ __forceinline__ void store_row64(const uint4 (&D)[4], uint16_t* __res
   }
 }
 
+// ---- the same for a wave that holds ONE 32-channel tile (the producer / consumer kernel, the 64 -> 128 stride-2 kernel): 64-byte half lines
+// R[t], t = 0, 1: chunk 2t + kb (8 channels = 16 bytes) of the wave's 32-channel group for pixel px = lane & 31 (what pack_tile leaves).
+// On return R[d] of lane L is chunk L & 3 of pixel 16 d + (L >> 2): one store instruction writes 16 complete 64-byte half lines.
+__device__ __forceinline__ void transpose_row32(uint4 (&R)[2], int lane) {
+  cswap((lane & 16) != 0, R[0], R[1]);  // rotate by the pixel half of the source: U[k] = R[k ^ (px >> 4)]
+  const int T = (lane >> 1) & 1;        // register (t) this lane wants as a destination
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int src = 16 * (k ^ T) + (lane >> 2) + 32 * (lane & 1);
+    R[k].x = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)R[k].x);
+    R[k].y = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)R[k].y);
+    R[k].z = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)R[k].z);
+    R[k].w = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)R[k].w);
+  }
+  cswap(T != 0, R[0], R[1]);  // round k delivered the piece of store k ^ T
+}
+
+// `row` (wave-uniform): channel 0 of the wave's 32-channel group at pixel 0 of the row segment
+template <int CSTRIDE>
+__device__ __forceinline__ void store_row32(const uint4 (&D)[2], uint16_t* __restrict__ row, int n_valid, int lane) {
+  const uint32_t voff = (uint32_t)((lane >> 2) * CSTRIDE + (lane & 3) * 8) * 2u;
+#pragma unroll
+  for (int d = 0; d < 2; d++) {
+    const int P = 16 * d + (lane >> 2);
+    if (P < n_valid) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(row) + voff + (uint32_t)(d * 16 * CSTRIDE * 2)) = D[d];
+  }
+}
+
 // The accumulators start from the (folded-BN) bias: register i of a lane's 32-channel tile is channel (i&3) + 8*(i>>2) + 4*kb.
 __device__ __forceinline__ v16f bias_tile(const float* __restrict__ bias, int cbase, int kb) {
   v16f r;
@@ -1088,16 +1116,16 @@ __device__ __forceinline__ void stage_tile64_s2(uint4* __restrict__ s_in, const 
   }
 }
 
-template <int NR, int CIN, int COUT>
+template <int NR, int CIN, int COUT, int MB>
 __device__ __forceinline__ void conv_rows_s2(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                              const float* __restrict__ bias, const int (&rbase)[4], const uint32_t (&rmask)[4],
                                              uint16_t* const (&yrow)[4], int b, int H, int W, int iy0, int ix0, int n_valid, uint32_t need, int mg,
                                              int relu, int px, int kb, int lane) {
   constexpr int NS = CIN / 64, NRA = NR > 0 ? NR : 1;
-  v16f acc[NRA][2];
+  v16f acc[NRA][MB];
   if (NR > 0) {
 #pragma unroll
-    for (int m = 0; m < 2; m++) {
+    for (int m = 0; m < MB; m++) {
       const v16f bq = bias_tile(bias, (mg + m) * 32, kb);
 #pragma unroll
       for (int j = 0; j < NR; j++) acc[j][m] = bq;
@@ -1110,21 +1138,28 @@ __device__ __forceinline__ void conv_rows_s2(uint4* __restrict__ s_in, const uin
       stage_tile64_s2<CIN>(s_in, x, b, H, W, 64 * sl, iy0, ix0, need);
       __syncthreads();
     }
-    if (NR > 0) conv_taps<NRA, COUT / 32, CIN / 16, 2>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 4 * sl);
+    if (NR > 0) conv_taps<NRA, COUT / 32, CIN / 16, 2, MB>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 4 * sl);
   }
   if (NR > 0) {
 #pragma unroll
     for (int j = 0; j < NR; j++) {
       const bool act = (rmask[j] >> px) & 1u;
-      uint4 D[4];
+      if constexpr (MB == 2) {
+        uint4 D[4];
 #pragma unroll
-      for (int m = 0; m < 2; m++) {
+        for (int m = 0; m < 2; m++) {
+          uint4 pk[2];
+          pack_tile(acc[j][m], act, relu, pk);
+          D[2 * m] = pk[0], D[2 * m + 1] = pk[1];
+        }
+        transpose_row64(D, lane);
+        store_row64<COUT>(D, yrow[j] + mg * 32, n_valid, lane);
+      } else {  // one 32-channel tile per wave: complete 64-byte half lines
         uint4 pk[2];
-        pack_tile(acc[j][m], act, relu, pk);
-        D[2 * m] = pk[0], D[2 * m + 1] = pk[1];
+        pack_tile(acc[j][0], act, relu, pk);
+        transpose_row32(pk, lane);
+        store_row32<COUT>(pk, yrow[j] + mg * 32, n_valid, lane);
       }
-      transpose_row64(D, lane);
-      store_row64<COUT>(D, yrow[j] + mg * 32, n_valid, lane);
     }
   }
 }
@@ -1134,14 +1169,18 @@ template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_s2(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
                                                     const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W, int Ho, int Wo,
                                                     int relu, uint8_t* __restrict__ row_dirty, int slot) {
-  static_assert(CIN % 64 == 0 && (COUT == 128 || COUT == 256), "64-channel input slabs; 2 or 4 groups of 64 output channels");
-  constexpr int TH = S2_TH, NCG = COUT / 64, NRG = 4 / NCG, NRMAX = TH / NRG;
+  static_assert(CIN % 64 == 0 && (COUT == 128 || COUT == 256), "64-channel input slabs; 4 groups of 32 or of 64 output channels");
+  // Round 6: with 128 output channels the waves were 2 row groups x 2 groups of 64 channels, i.e. at most TWO rows per wave -- one 1 KiB weight fragment from
+  // L1 per two MFMAs, which is all of the L1's bandwidth at full MFMA rate (the 759 us outlier of profiles/r06_bench_steady_trace.md).  Now every shape has one
+  // row group: four rows per wave, four channel groups of COUT / 4.
+  constexpr int TH = S2_TH, MB = COUT / 128, NCG = 4, NRG = 1, NRMAX = TH / NRG;
   extern __shared__ uint4 s_in[];  // S2_NSTAGE
   __shared__ uint32_t s_rowmask2[2 * TH];
   __shared__ unsigned int s_next[2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int px = lane & 31, kb = lane >> 5;
-  const int rg = wv % NRG, mg = 2 * (wv / NRG);
+  const int rg = wv % NRG, mg = MB * (wv / NRG);
+  static_assert(NCG * NRG == 4, "four waves");
   const int tiles_x = (Wo + 31) >> 5, tiles_y = (Ho + TH - 1) / TH;
   const int64_t n_tiles = (int64_t)B * tiles_y * tiles_x;
   int64_t next = 0;
@@ -1207,7 +1246,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_s2(const uint16_t* __restric
     const int iy0 = 2 * y0 - 1, ix0 = 2 * x0 - 1;
     stage_tile64_s2<CIN>(s_in, x, b, H, W, 0, iy0, ix0, need);
     __syncthreads();
-#define PNX_ROWS_S2(N_) conv_rows_s2<(N_ <= NRMAX ? N_ : NRMAX), CIN, COUT>(s_in, x, wfrag, bias, rbase, rmask, yrow, b, H, W, iy0, ix0, Wo - x0, need, mg, relu, px, kb, lane)
+#define PNX_ROWS_S2(N_) conv_rows_s2<(N_ <= NRMAX ? N_ : NRMAX), CIN, COUT, MB>(s_in, x, wfrag, bias, rbase, rmask, yrow, b, H, W, iy0, ix0, Wo - x0, need, mg, relu, px, kb, lane)
     switch (nr) {  // wave-uniform; every case runs the same barriers
       case 0: PNX_ROWS_S2(0); break;
       case 1: PNX_ROWS_S2(1); break;

@@ -15,37 +15,12 @@
 // landed); the consumers' barrier does not wait for their stores (s_waitcnt lgkmcnt(0) only).
 //   CIN = 64         : 16 x 32 tiles, 4 row groups x 2 channel groups, COUT / 64 passes over one fill, ring of 2 slots (2 x 76.5 KiB)
 //   CIN = 128 / 256  : 8 x 32 tiles, 2 row groups x 4 channel groups, fills = (pass of 128 output channels, 64-channel input slab), ring of 3
+// (A stride-2 form -- 4 x 32 output tiles, four consumer + four producer waves, two 73 KiB slots -- was built and measured in round 6: correct, and 5-18 %
+// slower than k_conv3x3_s2 on all three entry layers; removed.  profiles/r06_conv_pc_ab.txt (10).)
 #pragma once
 
 __device__ __forceinline__ void pc_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void pc_barrier_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// R[t], t = 0, 1: chunk 2t + kb (8 channels = 16 bytes) of the wave's 32-channel group for pixel px = lane & 31 (what pack_tile leaves).
-// On return R[d] of lane L is chunk L & 3 of pixel 16 d + (L >> 2): one store instruction writes 16 complete 64-byte half lines.
-__device__ __forceinline__ void transpose_row32(uint4 (&R)[2], int lane) {
-  cswap((lane & 16) != 0, R[0], R[1]);  // rotate by the pixel half of the source: U[k] = R[k ^ (px >> 4)]
-  const int T = (lane >> 1) & 1;        // register (t) this lane wants as a destination
-#pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const int src = 16 * (k ^ T) + (lane >> 2) + 32 * (lane & 1);
-    R[k].x = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)R[k].x);
-    R[k].y = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)R[k].y);
-    R[k].z = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)R[k].z);
-    R[k].w = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)R[k].w);
-  }
-  cswap(T != 0, R[0], R[1]);  // round k delivered the piece of store k ^ T
-}
-
-// `row` (wave-uniform): channel 0 of the wave's 32-channel group at pixel 0 of the row segment
-template <int CSTRIDE>
-__device__ __forceinline__ void store_row32(const uint4 (&D)[2], uint16_t* __restrict__ row, int n_valid, int lane) {
-  const uint32_t voff = (uint32_t)((lane >> 2) * CSTRIDE + (lane & 3) * 8) * 2u;
-#pragma unroll
-  for (int d = 0; d < 2; d++) {
-    const int P = 16 * d + (lane >> 2);
-    if (P < n_valid) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(row) + voff + (uint32_t)(d * 16 * CSTRIDE * 2)) = D[d];
-  }
-}
 
 #ifdef PNX_CONV_TIMERS
 #define PC_T_DECL unsigned long long pc_T[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pc_tk = __builtin_amdgcn_s_memtime();
