@@ -164,6 +164,55 @@ __global__ __launch_bounds__(256) void k_mask_pool4(const uint8_t* __restrict__ 
   *reinterpret_cast<uint32_t*>(out + ((int64_t)b * Ho + yo) * Wo + xo) = r & 0x01010101u;
 }
 
+// Sixteen output sites per thread from aligned 16-byte reads (round 6: the 4-byte form above ran the 1440 x 1440 x 12 dilation -- 25 MB in, 25 MB out -- in
+// 60 us): W, Wo multiples of 16 (and of 32 on the input side at stride 2), 16-byte aligned maps.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void k_mask_pool16(const uint8_t* __restrict__ in, int B, int H, int W, uint8_t* __restrict__ out, int Ho, int Wo) {
+  const int wq = Wo >> 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * Ho * wq) return;
+  const int xo = (int)(idx % wq) * 16, yo = (int)((idx / wq) % Ho), b = (int)(idx / ((int64_t)wq * Ho));
+  const int x0 = xo * STRIDE;
+  constexpr int ND = 4 * STRIDE;  // input dwords under the output's 16 columns
+  uint32_t D[ND + 2];             // D[0]: the dword in front (columns x0 - 4 .. x0 - 1), D[ND + 1]: the dword behind
+#pragma unroll
+  for (int k = 0; k < ND + 2; k++) D[k] = 0;
+#pragma unroll
+  for (int dy = -1; dy <= 1; dy++) {
+    const int y = yo * STRIDE + dy;
+    if (y < 0 || y >= H) continue;
+    const uint8_t* row = in + ((int64_t)b * H + y) * W;
+    if (x0 >= 4) D[0] |= *reinterpret_cast<const uint32_t*>(row + x0 - 4);
+#pragma unroll
+    for (int q = 0; q < STRIDE; q++) {
+      const uint4 v = *reinterpret_cast<const uint4*>(row + x0 + 16 * q);
+      D[1 + 4 * q] |= v.x, D[2 + 4 * q] |= v.y, D[3 + 4 * q] |= v.z, D[4 + 4 * q] |= v.w;
+    }
+    if (x0 + 16 * STRIDE < W) D[ND + 1] |= *reinterpret_cast<const uint32_t*>(row + x0 + 16 * STRIDE);
+  }
+  uint32_t R[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    uint32_t r;
+    if (STRIDE == 1) {
+      const uint32_t A = D[q], M = D[q + 1], C = D[q + 2];
+      r = M | ((M >> 8) | (C << 24)) | ((M << 8) | (A >> 24));
+    } else {
+      const uint32_t A = D[2 * q], M = D[2 * q + 1], C = D[2 * q + 2];
+      const uint32_t o0 = (A >> 24) | M | (M >> 8);          // byte 0: columns -1, 0, 1
+      const uint32_t o1 = (M >> 8) | (M >> 16) | (M >> 24);  // byte 0: columns 1, 2, 3
+      const uint32_t o2 = (M >> 24) | C | (C >> 8);          // byte 0: columns 3, 4, 5
+      const uint32_t o3 = (C >> 8) | (C >> 16) | (C >> 24);  // byte 0: columns 5, 6, 7
+      r = (o0 & 0xffu) | ((o1 & 0xffu) << 8) | ((o2 & 0xffu) << 16) | ((o3 & 0xffu) << 24);
+    }
+    r |= r >> 4;  // any bit of a byte -> its bit 0
+    r |= r >> 2;
+    r |= r >> 1;
+    R[q] = r & 0x01010101u;
+  }
+  *reinterpret_cast<uint4*>(out + ((int64_t)b * Ho + yo) * Wo + xo) = make_uint4(R[0], R[1], R[2], R[3]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -207,6 +256,13 @@ int pnx_mask_pool3(const uint8_t* mask_in, int32_t batch, int32_t h, int32_t w, 
   PNX_REQUIRE(mask_in && mask_out && batch > 0 && h > 0 && w > 0 && stride >= 1, PNX_ERR_INVALID, "bad arguments");
   const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
   const int64_t n = (int64_t)batch * ho * wo;
+  if ((stride == 1 || stride == 2) && (w & 15) == 0 && (wo & 15) == 0 && (((uintptr_t)mask_in | (uintptr_t)mask_out) & 15) == 0) {
+    const int64_t n16 = n / 16;
+    if (stride == 1) k_mask_pool16<1><<<(unsigned)((n16 + 255) / 256), 256, 0, (hipStream_t)stream>>>(mask_in, batch, h, w, mask_out, ho, wo);
+    else k_mask_pool16<2><<<(unsigned)((n16 + 255) / 256), 256, 0, (hipStream_t)stream>>>(mask_in, batch, h, w, mask_out, ho, wo);
+    PNX_LAUNCH_CHECK();
+    return PNX_OK;
+  }
   if ((stride == 1 || stride == 2) && (w & 3) == 0 && (wo & 3) == 0 && (((uintptr_t)mask_in | (uintptr_t)mask_out) & 3) == 0) {
     const int64_t n4 = n / 4;
     if (stride == 1) k_mask_pool4<1><<<(unsigned)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(mask_in, batch, h, w, mask_out, ho, wo);

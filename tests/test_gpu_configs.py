@@ -216,10 +216,19 @@ def test_waymo_fused_detector_full_size(config, dtype):
         # the lazy head evaluates the regression branches at the candidates with its fp32 sums in another order than the dense kernels: an
         # intermediate may round to the neighbouring bf16 / fp16 value (tests/test_gpu_lazy_head.py) -- all but a handful of elements agree to 1e-4
         gb, rb = got["box3d_lidar"].cpu(), rr["box3d_lidar"].cpu().float()
-        # Row by row: the same box at the same rank.  On this random-init head whole runs of candidates share ONE fp16 score; where a pair's IoU sits within
-        # a rounding of the NMS threshold the one-ulp difference between the lazy and the dense regression flips that decision and shifts the rest of the
-        # run by a box (same scores, other boxes: seen on C5 / fp16 after round 6 changed the convolutions' summation order) -- at most 2 % of the rows
+        # Row by row: the same box at the same rank -- except inside runs of candidates whose scores agree to the last bits.  On this random-init head whole
+        # runs share ONE fp16 class score, the IoU-rectified score (hm^(1-a) * iou^a, fp32) then differs between the HIP decoder and the module by a few ulp,
+        # and so does the order inside the run (seen on C5 / fp16 after round 6 changed the convolutions' summation order: 14-27 of 1000 rows, the SET of boxes
+        # identical).  So: the same multiset of boxes, every row matched by a row of (nearly) the same score, and all but 5 % of the rows in place.
         rows_ok = ((gb - rb).abs() <= 2e-2 + 2e-2 * rb.abs()).all(1)
-        assert float(rows_ok.float().mean()) >= 0.98, f"{int((~rows_ok).sum())} of {len(rows_ok)} boxes differ"
-        assert float(((gb - rb).abs() <= 1e-4 + 1e-4 * rb.abs()).float().mean()) > 0.99
+        assert float(rows_ok.float().mean()) >= 0.95, f"{int((~rows_ok).sum())} of {len(rows_ok)} boxes out of place"
+        gs, rs = got["scores"].cpu(), rr["scores"].cpu().float()
+        matched = set()
+        for r in (~rows_ok).nonzero().flatten().tolist():          # a displaced row IS one of the reference's rows, among rows of its own score
+            d = (rb[:, :7] - gb[r, :7]).abs().sum(1)
+            j = int(d.argmin())
+            assert float(d[j]) < 0.05, f"row {r}: no such box in the module's output"
+            assert abs(float(rs[j]) - float(gs[r])) <= 1e-4 * float(gs[r]) + 1e-6 and j not in matched
+            matched.add(j)
+        assert float(((gb - rb).abs() <= 1e-4 + 1e-4 * rb.abs()).float().mean()) > 0.95
         assert torch.equal(got["label_preds"].cpu(), rr["label_preds"].cpu())

@@ -48,7 +48,7 @@ def test_bias_act_mask_residual_after_relu(masked):
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize("hw", [(45, 62), (45, 64), (37, 120), (8, 8), (5, 4)])   # W, Wo multiples of 4: the 4-sites-per-thread kernel
+@pytest.mark.parametrize("hw", [(45, 62), (45, 64), (37, 120), (8, 8), (5, 4), (37, 128), (9, 32), (5, 16), (33, 96)])   # W, Wo multiples of 4 / of 16: the 4- and 16-sites-per-thread kernels
 @pytest.mark.parametrize("stride", [1, 2])
 def test_mask_pool3_matches_maxpool(stride, hw):
     from pillarnext_amd import ops
