@@ -856,11 +856,11 @@ template <int NR, int CIN, int COUT, bool HAS_RES>
 __device__ __forceinline__ void conv_rows_x(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                             const float* __restrict__ bias, const uint16_t* __restrict__ res, const int (&rrow)[4],
                                             const int (&rbase)[4], const uint32_t (&rmask)[4], uint16_t* const (&yrow)[4], int b, int H, int W,
-                                            int y0, int x0, uint32_t need, int mg0, int relu, int px, int kb, int lane) {
-  constexpr int NH = (COUT + 127) / 128, NS = CIN / 64, NRA = NR > 0 ? NR : 1;
+                                            int y0, int x0, uint32_t need, int mg0, int relu, int px, int kb, int lane, int hsel) {
+  constexpr int NS = CIN / 64, NRA = NR > 0 ? NR : 1;
   const int ox = x0 + px;
-#pragma unroll 1
-  for (int h = 0; h < NH; h++) {
+  {  // ONE pass of 128 output channels per call (round 6: a work unit is (tile, pass), see k_conv3x3_ldsx); slab 0 of the tile is already staged
+    const int h = hsel;
     const int mg = mg0 + 4 * h;
     v16f acc[NRA][2];
     if (NR > 0) {
@@ -892,7 +892,7 @@ __device__ __forceinline__ void conv_rows_x(uint4* __restrict__ s_in, const uint
     }
 #pragma unroll 1
     for (int sl = 0; sl < NS; sl++) {
-      if (h | sl) {
+      if (sl) {
         __syncthreads();  // previous slab consumed
         stage_tile64<CIN, L128_TH>(s_in, x, b, H, W, 64 * sl, y0, x0, need);
         __syncthreads();
@@ -952,6 +952,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
   const int rg = wv % NRG, mg0 = 2 * (wv / NRG);  // row group, first 32-channel output tile of this wave within a pass
   const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
   const int64_t n_tiles = tlist != nullptr ? (int64_t)__builtin_amdgcn_readfirstlane(*tcount) : (int64_t)B * tiles_y * tiles_x;
+  // Work unit = (tile, pass of 128 output channels) (round 6): every pass re-stages the tile's input slabs anyway, so handing the COUT / 128 passes of a tile to
+  // different workgroups costs nothing and doubles the number of units -- at 180 x 180 a 256 -> 256 layer has ~830 active 8 x 32 tiles for 512 workgroups.
+  // A unit is coded tile * NH + pass; pass 0 also does the tile's zero-fill / row_dirty bookkeeping.
+  constexpr int NH = (COUT + 127) / 128;
+  const int64_t n_units = n_tiles * NH;
+  auto unit_at = [&](int64_t idx) -> int64_t {
+    if (idx >= n_units) return -1;
+    const int64_t t = tlist != nullptr ? (int64_t)tlist[idx / NH] : idx / NH;
+    return t * NH + idx % NH;
+  };
   // requests the mask bytes / row_dirty flags of the rows this wave looks at in tile t (t < 0: none)
   auto load_mask = [&](int64_t t, bool (&a)[2], int (&wz)[2]) {
 #pragma unroll
@@ -969,15 +979,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
     }
   };
   int64_t idxB = (int64_t)blockIdx.x + gridDim.x, idxC = 0;
-  int64_t tileA = tile_at(tlist, blockIdx.x, n_tiles), tileB = tile_at(tlist, idxB, n_tiles), tileC = -1;
+  int64_t tileA = unit_at(blockIdx.x), tileB = unit_at(idxB), tileC = -1;
   bool aP[2], aN[2];
   int wasP[2], wasN[2];
-  load_mask(tileA, aP, wasP);
+  load_mask(tileA >= 0 ? tileA / NH : -1, aP, wasP);
 #pragma unroll
   for (int j = 0; j < 2; j++) aN[j] = false, wasN[j] = 1;
   int it = 0;
   for (; tileA >= 0; tileA = tileB, tileB = tileC, idxB = idxC, it++) {
-    const int64_t tile = (int64_t)__builtin_amdgcn_readfirstlane((int)tileA);  // uniform by construction: everything derived from it (origins, row pointers) lives in scalar registers
+    const int64_t unit = (int64_t)__builtin_amdgcn_readfirstlane((int)tileA);  // uniform by construction: everything derived from it (origins, row pointers) lives in scalar registers
+    const int64_t tile = unit / NH;
+    const int hsel = (int)(unit - tile * NH);
     sched_draw(s_next, it, slot);
     uint32_t* const s_rowmask = s_rowmask2 + (it & 1) * TH;
     const int tx = (int)(tile % tiles_x);
@@ -994,8 +1006,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
     }
     __syncthreads();  // row masks visible; everybody is done reading the previous tile's s_in
     idxC = sched_next2(s_next, it, slot, idxB);
-    tileC = tile_at(tlist, idxC, n_tiles);
-    load_mask(tileB, aN, wasN);  // consumed at the top of the next iteration
+    tileC = unit_at(idxC);
+    load_mask(tileB >= 0 ? tileB / NH : -1, aN, wasN);  // consumed at the top of the next iteration
 #pragma unroll
     for (int j = 0; j < 2; j++) aP[j] = aN[j], wasP[j] = wasN[j];
     const uint32_t my_rm = s_rowmask[lane & 7];
@@ -1004,6 +1016,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
     for (int j = 0; j < 2; j++) {  // rows without any active site: zero-fill where needed
       const int rr = wv * 2 + j, oy = y0 + rr;
       const bool active = (am >> rr) & 1u;
+      if (hsel != 0) continue;  // the tile's bookkeeping belongs to its pass-0 unit
       if (!active && was[j] && oy < H && ox < W) {
         uint4* dst = reinterpret_cast<uint4*>(y + (((int64_t)b * H + oy) * W + ox) * COUT);
 #pragma unroll 1
@@ -1038,7 +1051,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
     const uint32_t need = am | (am << 1) | (am << 2);  // halo rows some active row reads
     stage_tile64<CIN, TH>(s_in, x, b, H, W, 0, y0, x0, need);
     __syncthreads();
-#define PNX_ROWS_X(N_) conv_rows_x<(N_ <= NRMAX ? N_ : NRMAX), CIN, COUT, HAS_RES>(s_in, x, wfrag, bias, res, rrow, rbase, rmask, yrow, b, H, W, y0, x0, need, mg0, relu, px, kb, lane)
+#define PNX_ROWS_X(N_) conv_rows_x<(N_ <= NRMAX ? N_ : NRMAX), CIN, COUT, HAS_RES>(s_in, x, wfrag, bias, res, rrow, rbase, rmask, yrow, b, H, W, y0, x0, need, mg0, relu, px, kb, lane, hsel)
     switch (nr) {  // wave-uniform; every case runs the same barriers
       case 0: PNX_ROWS_X(0); break;
       case 1: PNX_ROWS_X(1); break;
@@ -1055,7 +1068,7 @@ template <int CIN, int COUT>
 int launch_ldsx(const void* x, const void* wfrag, const float* bias, const void* res, const uint8_t* mask, void* y, int B, int H, int W, int relu,
                 uint8_t* row_dirty, const int32_t* tlist, const int32_t* tcount, hipStream_t st) {
   const int slot = mask != nullptr ? next_sched_slot() : -1;
-  int64_t nb = (int64_t)B * ((H + L128_TH - 1) / L128_TH) * ((W + 31) / 32);
+  int64_t nb = (int64_t)B * ((H + L128_TH - 1) / L128_TH) * ((W + 31) / 32) * ((COUT + 127) / 128);  // work units = (tile, pass)
   if (nb > 512) nb = 512;  // resident workgroups: 2 per CU (registers)
   if (res != nullptr)
     k_conv3x3_ldsx<CIN, COUT, true><<<(unsigned)nb, 256, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y,
