@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--no-back-to-back", action="store_true", help="skip the 15 back-to-back reader calls behind the timed loop (PMC passes: every reader call is then an in-loop call)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="ranks beyond the visible GPUs share devices (rank r -> cuda:(r mod device_count)): runs the N-rank path with real kernels on a 1-GPU box (use --backend gloo)")
-    ap.add_argument("--leg", default="", choices=["", "train_fp32"],
+    ap.add_argument("--leg", default="", choices=["", "train_fp32", "train_bf16"],
                     help="internal: run ONE leg in this process and print its dict as a JSON line (the fp32 training leg runs in a child process with a clean MIOpen environment)")
     ap.add_argument("--all-legs", action="store_true", help="with --gpus > 1: also run the uniform / H2D-merge / Waymo legs (default: value, roofline, value_train only, so that an 8-rank run stays short)")
     return ap.parse_args()
@@ -411,30 +411,32 @@ def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAME
     return res
 
 
-def train_fp32_leg(dev):
-    """The training step at the reference's precision (fp32, channels_last, torch / MIOpen convolutions), in a CHILD process.  Why a child: this process pins
-    MIOpen's solver search for the inference legs (MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC=0, main()); MIOpen caches such switches per process,
-    and without the asm NHWC solver its fp32 forward convolutions fall back to solvers that transpose through workspaces -- 551 ms and 75 GiB per step instead of
-    375 ms and 50 GiB (rounds 4-5 reported the former; tools/train_step.py --nhwc always showed the latter: profiles/r06_train_fp32_env.txt)."""
+def train_child_leg(dev, leg):
+    """A single-GPU training leg ("train_bf16": bf16 autocast after MIOpen's find pass; "train_fp32": the reference's precision, torch / MIOpen convolutions) in a
+    CHILD process.  Why a child: this process pins MIOpen's solver search for the inference legs (MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC=0,
+    main()); MIOpen caches such switches per process, and without the asm NHWC solvers (a) the fp32 forward convolutions fall back to solvers that transpose
+    through workspaces -- 551 ms and 75 GiB per step instead of 375 ms and 50 GiB (rounds 4-5 reported the former; tools/train_step.py --nhwc always showed
+    the latter) -- and (b) the bf16 leg's find pass takes 127 s instead of 40 s for the same 92 ms step (profiles/r06_train_fp32_env.txt)."""
     import subprocess
 
     env = {k: v for k, v in os.environ.items() if not k.startswith("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM") and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     vis, idx = os.environ.get("HIP_VISIBLE_DEVICES"), dev.index or 0   # the child sees this rank's GPU as its device 0
     env["HIP_VISIBLE_DEVICES"] = vis.split(",")[idx] if vis else str(idx)
-    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", "train_fp32"], env=env, capture_output=True, text=True, timeout=1500)
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", leg], env=env, capture_output=True, text=True, timeout=1500)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     if p.returncode != 0 or not lines:
-        return {"train_fp32": {"error": (p.stderr or p.stdout)[-400:]}}
+        return {("train" if leg == "train_bf16" else leg): {"error": (p.stderr or p.stdout)[-400:]}}
     return json.loads(lines[-1])
 
 
 def main():
     a = parse()
-    if a.leg == "train_fp32":
+    if a.leg:
         import torch
 
         torch.cuda.set_device(0)
-        print(json.dumps(train_leg(torch.device("cuda", 0), 0, 1, steps=3, warmup=2, amp=False)))
+        d0 = torch.device("cuda", 0)
+        print(json.dumps(train_leg(d0, 0, 1, steps=3, warmup=2, amp=False) if a.leg == "train_fp32" else train_leg(d0, 0, 1)))
         return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn(a))
@@ -659,9 +661,10 @@ def main():
             # the training step (BASELINE configs[2]: 4 frames per GPU), timed by this run: value_train / roofline_train
         if not a.no_extras:
             if a.config == "C2" and not os.environ.get("PNX_BENCH_NO_TRAIN"):
-                extras.update(train_leg(dev, rank, world))
+                # N = 1: both training legs in child processes with MIOpen's default solver set (train_child_leg); N > 1: in process, under DDP
+                extras.update(train_child_leg(dev, "train_bf16") if world == 1 else train_leg(dev, rank, world))
                 if not short and not os.environ.get("PNX_BENCH_NO_TRAIN_FP32"):
-                    extras.update(train_fp32_leg(dev))
+                    extras.update(train_child_leg(dev, "train_fp32"))
             if rank == 0 and not short:
                 extras["sections_us"] = sections(model, examples, a.batch)
                 extras["nms_us"] = nms_bench(dev)
