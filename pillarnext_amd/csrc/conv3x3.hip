@@ -8,6 +8,8 @@
 // K = 9 taps x CIN.  The B fragment of a lane is 8 consecutive input channels of one pixel = ONE 16-byte NHWC read, the A
 // fragments (weights) are pre-arranged on the host in fragment order.  Kernels in this file:
 //   k_conv3x3          direct: B fragments straight from L1/L2 (strided layers; every input line is re-read 9 times)
+//   k_conv3x3_pc       (conv_pc.h, round 6; default for 64 -> 64) producer / consumer form: 4 producer waves stage the NEXT tile by LDS-DMA into a ring of
+//                      slots while 8 consumer waves (row groups x 32-channel groups) run the taps; one workgroup per CU
 //   k_conv3x3_lds      stride 1, 64 input channels: 18x34 halo tile staged once in LDS, 1..7 passes of 64 output channels
 //   k_conv3x3_ldsx     stride 1, 128 -> 128 and 256 -> 256: 10x34 tile, 64-channel input slabs through one LDS buffer under live
 //                      accumulators, 128 output channels per pass

@@ -6,11 +6,15 @@
 // workgroups per CU are all the latency hiding there is: the SQ counters show their waves parked 42 % of the time on the LiDAR masks and
 // the MFMA pipe 28 % busy (profiles/r02_conv_sq_counters.md).  A wave cannot prefetch the next tile behind its own weight stream because
 // LDS-DMA and the weight-fragment loads share one in-order vmcnt.  Here the roles are separate waves of ONE 12-wave workgroup per CU:
-//   waves 8..11  producers: tile schedule, mask bytes -> row masks, zero-fill of rows that went inactive, and the HBM -> LDS staging of the
-//                NEXT tile (global_load_lds) into a ring of halo-tile slots, one fill ahead of the consumers; their vmcnt holds nothing else;
+//   waves 8..11  producers: tile schedule (tickets three tiles ahead), mask bytes -> row masks, the deal of the tile's active rows to the row groups
+//                (producer 0), zero-fill of rows that went inactive, and the HBM -> LDS staging of the NEXT tile (global_load_lds) into a ring of
+//                halo-tile slots, one fill ahead of the consumers; their vmcnt holds nothing else;
 //   waves 0..7   consumers: NRG row groups x NCG groups of 32 output channels; a wave = up to 4 row segments x 32 channels (64 accumulator
-//                registers, <= 168 in all, so three waves fit a SIMD: two consumers + one producer), weights from L1/L2 one tap ahead,
-//                B fragments from the ring slot, epilogue = complete 64-byte half lines.
+//                registers, 140-167 in all and no scratch, so three waves fit a SIMD: two consumers + one producer), weights through a buffer
+//                resource four k-steps ahead (conv_taps), B fragments from the ring slot, epilogue = complete 64-byte half lines.
+// Measured (profiles/r06_conv_pc_ab.txt): the staging was not what bounded the row-split kernels -- with their rolled tap loop this form was 3 % slower;
+// with the unrolled loop it is 5 % faster at 64 channels (the default there: PNX_CONV_PC bit 0) and equal at 128 / 256 (bit 1), where every B fragment is
+// read by four consumer waves instead of two.
 // One s_barrier per fill hands a slot over in both directions (the consumers have finished reading slot g - NSLOT + 1 .. and fill g + 1 has
 // landed); the consumers' barrier does not wait for their stores (s_waitcnt lgkmcnt(0) only).
 //   CIN = 64         : 16 x 32 tiles, 4 row groups x 2 channel groups, COUT / 64 passes over one fill, ring of 2 slots (2 x 76.5 KiB)
