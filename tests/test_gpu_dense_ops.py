@@ -284,3 +284,17 @@ def test_conv3x3_tile_list_equals_full_walk(cin, cout, W):
         assert torch.equal(ws_a[1], ws_b[1])
         want = torch.relu(torch.nn.functional.conv2d(x.float(), w.float(), None, 1, 1) + bias.view(1, -1, 1, 1) + res.float()) * mask.unsqueeze(1)
         torch.testing.assert_close(got.float(), want, rtol=1.6e-2, atol=2e-2)
+
+
+def test_producer_consumer_kernel_on_every_shape_it_is_built_for():
+    """k_conv3x3_pc serves 64 -> 64 by default; its 128 / 256-channel and 64 -> 320 / 384 / 448 forms are selected by PNX_CONV_PC bits 1 and 2, which the library
+    reads once per process -- so they run in a child (tools/conv_pc_check.py: dense, half-dense and sparse masks, ragged sizes, residual, tile lists, stale
+    workspaces, against fp32 torch)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PNX_CONV_PC="7")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_pc_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), (p.stdout[-1500:], p.stderr[-500:])

@@ -3,7 +3,7 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("PNX_CONV_PC", "3")
+os.environ.setdefault("PNX_CONV_PC", "7")
 from pillarnext_amd import ops
 
 def one(cin, cout, B, H, W, density, res, tiles, ws):
