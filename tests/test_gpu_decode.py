@@ -287,14 +287,17 @@ def test_training_graph_on_the_fused_masked_bn_kernels(monkeypatch):
             rel = float((a - b).norm()) / float(a.norm())
             cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
             worst_rel, worst_cos = max(worst_rel, rel), min(worst_cos, cos)
-        print(f"[train-graph] {tag}: worst relative L2 error of a gradient tensor {worst_rel:.4f}, worst cosine {worst_cos:.5f}")
-        return worst_rel, worst_cos
+        va, vb = torch.cat([ga[n] for n in ga]), torch.cat([gb[n] for n in ga])   # all parameters as one vector: the stable statistic
+        g_rel = float((va - vb).norm() / va.norm())
+        g_cos = float(torch.dot(va, vb) / (va.norm() * vb.norm() + 1e-30))
+        print(f"[train-graph] {tag}: worst relative L2 error of a gradient tensor {worst_rel:.4f}, worst cosine {worst_cos:.5f}; whole gradient: rel {g_rel:.4f}, cosine {g_cos:.5f}")
+        return worst_rel, worst_cos, g_rel, g_cos
 
     l_ref, g_ref = run(ref, False)                                            # fp32, NCHW: torch node
     l_n, g_n = run(copy.deepcopy(ref).to(memory_format=torch.channels_last), False)   # fp32, channels_last: HIP kernels
     print(f"[train-graph] loss fp32 NCHW {l_ref:.6f}, fp32 channels_last/HIP {l_n:.6f}")
     assert abs(l_n - l_ref) <= 1e-5 * abs(l_ref)
-    r, c = compare("fp32 HIP vs fp32 torch", g_ref, g_n)
+    r, c, _, _ = compare("fp32 HIP vs fp32 torch", g_ref, g_n)
     assert r <= 0.04 and c >= 0.999
     l_a, g_a = run(copy.deepcopy(ref).to(memory_format=torch.channels_last), True)    # bf16 autocast: HIP kernels
     monkeypatch.setenv("PNX_MASKED_BN_HIP", "0")
@@ -302,12 +305,15 @@ def test_training_graph_on_the_fused_masked_bn_kernels(monkeypatch):
     monkeypatch.delenv("PNX_MASKED_BN_HIP")
     print(f"[train-graph] loss bf16 HIP {l_a:.5f}, bf16 torch node {l_t:.5f}")
     assert abs(l_a - l_t) <= 5e-3 * abs(l_t) and abs(l_a - l_ref) <= 2e-2 * abs(l_ref)
-    r, c = compare("bf16 HIP vs bf16 torch", g_t, g_a)
-    r2, c2 = compare("bf16 torch vs fp32", g_ref, g_t)
-    r3, c3 = compare("bf16 HIP vs fp32", g_ref, g_a)
-    # bf16 against fp32 is "for the record": the worst gradient tensor's cosine depends on which solvers MIOpen's find pass picked on this box and on the HIP
-    # convolutions' summation order (0.48-0.8 seen; the torch-node bf16 graph of the same run sits at the same place) -- the check that binds is the relative one
-    assert r <= max(1.25 * r2, 0.1) and c3 >= min(c2 - 0.1, 0.9) and c3 >= 0.3
+    # bf16: a freshly initialised 30-layer net with batch statistics over two frames amplifies rounding differences chaotically; which solvers MIOpen's find
+    # pass picked on this box and the HIP convolutions' summation order move the WORST gradient tensor's cosine anywhere between 0.45 and 0.8 (printed), for the
+    # torch-node graph as for the HIP one.  What is asserted is the whole gradient vector: the HIP graph is as close to fp32 as the torch-node graph is, and the
+    # two bf16 graphs are as close to each other as either is to fp32.
+    _, _, gr, gc = compare("bf16 HIP vs bf16 torch", g_t, g_a)
+    _, _, gr2, gc2 = compare("bf16 torch vs fp32", g_ref, g_t)
+    _, _, gr3, gc3 = compare("bf16 HIP vs fp32", g_ref, g_a)
+    assert gc3 >= gc2 - 0.05 and gr3 <= gr2 * 1.25 + 0.02, (gc3, gc2, gr3, gr2)
+    assert gc >= min(gc2, gc3) - 0.05, (gc, gc2, gc3)
 
 
 @pytest.mark.parametrize("layout,pre_max,n", [("mixed", 1000, 900_000), ("blocked", 1000, 900_000), ("blocked", 4096, 1_300_000), ("blocked", 83, 5_000),
