@@ -561,14 +561,14 @@ __device__ __forceinline__ void conv_taps_rolled(v16f (&acc)[NR][MB], const uint
 #ifndef TAPS_NOBUFW  // (-DTAPS_NOBUFW: per-lane global loads, the A/B reference: profiles/r06_conv_pc_ab.txt)
 #define TAPS_BUFW
 #endif
-template <int NR, int MTALL, int CB = 4, int STRIDE = 1, int MB = 2>
+template <int NR, int MTALL, int CB = 4, int STRIDE = 1, int MB = 2, int WD = TAPS_WD>
 __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][MB], const uint4* __restrict__ s_in, const uint4* __restrict__ wfrag, const int (&rbase)[4],
                                           int mg, int px, int kb, int lane, int kstep0 = 0) {
 #ifdef PNX_TAPS_ROLLED
   conv_taps_rolled<NR, MTALL, CB, STRIDE, MB>(acc, s_in, wfrag, rbase, mg, px, kb, lane, kstep0);
 #else
   constexpr int RS = STRIDE == 1 ? LDS_HW : S2_RS;
-  constexpr int KS = 36, PD = TAPS_PD, WD = TAPS_WD;
+  constexpr int KS = 36, PD = TAPS_PD;
   // weight fragment (k-step ks -> tap, chunk cbl; output tile m): a wave-uniform base + lane * 16
   const uint4* wu = wfrag + (int64_t)__builtin_amdgcn_readfirstlane(kstep0 * MTALL + mg) * 64;
 #ifdef TAPS_BUFW  // weights through a buffer resource: scalar base + scalar offset + lane * 16, one instruction per fragment and no per-lane 64-bit address
@@ -593,23 +593,17 @@ __device__ __forceinline__ void conv_taps(v16f (&acc)[NR][MB], const uint4* __re
 #endif
     }
   };
-  // per-lane slot of tap column dx, chunk cbl (before the row terms): c * 8 + ((2 cbl + kb) ^ swz(c)), c = tap_slot(px, dx), with
-  // (2 cbl + kb) ^ sw = (2 cbl ^ (sw & 6)) + (kb ^ (sw & 1))
-  int cdx[3], s6[3];
-#pragma unroll
-  for (int dx = 0; dx < 3; dx++) {
-    const int c = tap_slot<STRIDE>(px, dx), sw = lds_swz(c);
-    cdx[dx] = c * 8 + (kb ^ (sw & 1));
-    s6[dx] = sw & 6;
-  }
   // k-step order: ks = (dx * 4 + cbl) * 3 + dy.  The three dy taps of a (column dx, chunk cbl) group read the SAME per-lane slots one halo row apart, i.e.
-  // the same address registers with another immediate offset: NR address adds per three k-steps instead of per k-step.
+  // the same address registers with another immediate offset: NR address adds per three k-steps instead of per k-step.  The per-lane slot of a group --
+  // c * 8 + ((2 cbl + kb) ^ swz(c)), c = tap_slot(px, dx) -- is recomputed from an OPAQUE copy of px at every group (6 VALU per 3 k-steps): written as
+  // loop-invariant arrays hipcc kept them (and, before that, all 36 x NR slot addresses) live across the persistent tile loop and spilled.
   int addr[NR];
   auto group_addr = [&](int grp) {
     const int dx = grp >> 2, cbl = grp & 3;
-    int c0 = cdx[dx];
-    asm volatile("" : "+v"(c0));  // opaque: slot addresses are formed group by group, not hoisted out of the tile loop and spilled
-    const int a = c0 + ((2 * cbl) ^ s6[dx]);
+    int p = px;
+    asm volatile("" : "+v"(p));
+    const int c = tap_slot<STRIDE>(p, dx);
+    const int a = c * 8 + ((2 * cbl + kb) ^ lds_swz(c));
 #pragma unroll
     for (int j = 0; j < NR; j++) addr[j] = a + rbase[j];
   };
@@ -675,10 +669,7 @@ __device__ __forceinline__ void conv_rows(const uint4* __restrict__ s_in, const 
 #ifndef PNX_CONV_RES_EARLY
     if (HAS_RES) load_residual_u(rq, rrow_res[0], res_off, rmask[0] >> px & 1u);
 #endif
-    if constexpr (COUT == 64)  // the single-pass kernel (the cross-check of k_conv3x3_pc<64, 64>) keeps the rolled loop: unrolled, its depth-2 tile loop state spills 660 B / lane
-      conv_taps_rolled<NR, MTALL>(acc, s_in, wfrag, rbase, mg, px, kb, lane);
-    else
-      conv_taps<NR, MTALL>(acc, s_in, wfrag, rbase, mg, px, kb, lane);
+    conv_taps<NR, MTALL, 4, 1, 2, COUT == 64 ? 2 : TAPS_WD>(acc, s_in, wfrag, rbase, mg, px, kb, lane);  // 64 -> 64 (the cross-check of k_conv3x3_pc): a two-deep weight ring keeps it at 0 scratch
 #pragma unroll
     for (int j = 0; j < NR; j++) {
       const bool act = (rmask[j] >> px) & 1u;
@@ -902,7 +893,12 @@ __device__ __forceinline__ void conv_rows_x(uint4* __restrict__ s_in, const uint
 #ifndef PNX_CONV_RES_EARLY
       if (NR > 0 && HAS_RES && sl == NS - 1) load_residual_u(rq, rres[0], res_off, rmask[0] >> px & 1u);
 #endif
-      if (NR > 0) conv_taps<NRA, COUT / 32, CIN / 16>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 4 * sl);
+#ifndef LDSX_RES_WD
+#define LDSX_RES_WD 2
+#endif
+      // with a residual the row-0 lines are in flight under the last slab's taps (16 registers): one weight fragment pair less in the ring keeps the kernel at
+      // 256 registers without spilling the tile loop's state (profiles/r06_conv_pc_ab.txt (12))
+      if (NR > 0) conv_taps<NRA, COUT / 32, CIN / 16, 1, 2, HAS_RES ? LDSX_RES_WD : TAPS_WD>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 4 * sl);
     }
     if (NR > 0) {
       const int n_valid = W - x0;
@@ -953,19 +949,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
   const int px = lane & 31, kb = lane >> 5;
   const int rg = wv % NRG, mg0 = 2 * (wv / NRG);  // row group, first 32-channel output tile of this wave within a pass
   const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH;
-  const int64_t n_tiles = tlist != nullptr ? (int64_t)__builtin_amdgcn_readfirstlane(*tcount) : (int64_t)B * tiles_y * tiles_x;
+  const int n_tiles = tlist != nullptr ? __builtin_amdgcn_readfirstlane(*tcount) : B * tiles_y * tiles_x;  // < 2^31 / NH: 32-bit unit indices keep the tile loop's state in fewer registers
   // Work unit = (tile, pass of 128 output channels) (round 6): every pass re-stages the tile's input slabs anyway, so handing the COUT / 128 passes of a tile to
   // different workgroups costs nothing and doubles the number of units -- at 180 x 180 a 256 -> 256 layer has ~830 active 8 x 32 tiles for 512 workgroups.
   // A unit is coded tile * NH + pass; pass 0 also does the tile's zero-fill / row_dirty bookkeeping.
   constexpr int NH = (COUT + 127) / 128;
-  const int64_t n_units = n_tiles * NH;
-  auto unit_at = [&](int64_t idx) -> int64_t {
+  const int n_units = n_tiles * NH;
+  auto unit_at = [&](int64_t idx) -> int {
     if (idx >= n_units) return -1;
-    const int64_t t = tlist != nullptr ? (int64_t)tlist[idx / NH] : idx / NH;
-    return t * NH + idx % NH;
+    const int i = (int)idx;
+    const int t = tlist != nullptr ? tlist[i / NH] : i / NH;
+    return t * NH + i % NH;
   };
   // requests the mask bytes / row_dirty flags of the rows this wave looks at in tile t (t < 0: none)
-  auto load_mask = [&](int64_t t, bool (&a)[2], int (&wz)[2]) {
+  auto load_mask = [&](int t, bool (&a)[2], int (&wz)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; j++) a[j] = false, wz[j] = 1;
     if (t < 0) return;
@@ -981,7 +978,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
     }
   };
   int64_t idxB = (int64_t)blockIdx.x + gridDim.x, idxC = 0;
-  int64_t tileA = unit_at(blockIdx.x), tileB = unit_at(idxB), tileC = -1;
+  int tileA = unit_at(blockIdx.x), tileB = unit_at(idxB), tileC = -1;
   bool aP[2], aN[2];
   int wasP[2], wasN[2];
   load_mask(tileA >= 0 ? tileA / NH : -1, aP, wasP);
@@ -989,9 +986,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ldsx(const uint16_t* __restr
   for (int j = 0; j < 2; j++) aN[j] = false, wasN[j] = 1;
   int it = 0;
   for (; tileA >= 0; tileA = tileB, tileB = tileC, idxB = idxC, it++) {
-    const int64_t unit = (int64_t)__builtin_amdgcn_readfirstlane((int)tileA);  // uniform by construction: everything derived from it (origins, row pointers) lives in scalar registers
-    const int64_t tile = unit / NH;
-    const int hsel = (int)(unit - tile * NH);
+    const int unit = __builtin_amdgcn_readfirstlane(tileA);  // uniform by construction: everything derived from it (origins, row pointers) lives in scalar registers
+    const int tile = unit / NH;
+    const int hsel = unit - tile * NH;
     sched_draw(s_next, it, slot);
     uint32_t* const s_rowmask = s_rowmask2 + (it & 1) * TH;
     const int tx = (int)(tile % tiles_x);
