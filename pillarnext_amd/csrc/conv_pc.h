@@ -188,8 +188,6 @@ __global__ __launch_bounds__(768, 3) void k_conv3x3_pc(const uint16_t* __restric
     // current tile
     int cb = 0, cy0 = 0, cx0 = 0;
     uint32_t am = 0;
-    bool have_tick = false;
-    unsigned int tick = 0;
 
     auto advance = [&]() -> bool {
       const int64_t t = t_next;
@@ -224,10 +222,11 @@ __global__ __launch_bounds__(768, 3) void k_conv3x3_pc(const uint16_t* __restric
           reinterpret_cast<uint32_t*>(&s_dmask[n & 3][lane % NRG])[lane / NRG] = m;
         }
       }
-      if (slot >= 0 && pw == 0 && lane == 0) {  // the ticket that will name tile n + 3
-        tick = atomicAdd(&g_tile_ctr[slot][0], 1u);
-        have_tick = true;
-      }
+      // The ticket that will name tile n + 3, published at once (the producers have the slack for the atomic's round trip).  Slot (n + 3) & 3 was last read at
+      // advance(n - 2) and is next read at advance(n + 2): at most two advances run without a barrier between them (the ring's prologue fill and the first
+      // fill of the loop), so a barrier separates the write from both.  (A deferred publish in the main loop lost the first ticket when tile 0 of a
+      // three-slot ring had no active row: two advances, one publish.)
+      if (slot >= 0 && pw == 0 && lane == 0) s_tick[(n + 3) & 3] = atomicAdd(&g_tile_ctr[slot][0], 1u);
       // next tile's meta data: requested now, consumed at the next advance
       t_next = tile_index(n + 1);
       load_meta(t_next);
@@ -293,10 +292,6 @@ __global__ __launch_bounds__(768, 3) void k_conv3x3_pc(const uint16_t* __restric
         if (!alive) nbar_total = g + 1;
       }
       PC_TOCK(5)
-      if (have_tick) {  // only producer 0 / lane 0
-        s_tick[(n + 2) & 3] = tick;  // n was already incremented by the advance that drew it: the ticket names tile (n - 1) + 3
-        have_tick = false;
-      }
       pc_barrier_all();
       PC_TOCK(6)
       if (++nbar == nbar_total) break;

@@ -43,5 +43,37 @@ for cin, cout in ((64, 64), (128, 128), (256, 256), (64, 384)):
             if res and cout != cin:
                 res = False
             ok &= one(cin, cout, B, H, W, density, res, tiles, ws)
+
+
+def moving(cin, cout, B, H, W):
+    """A workspace that goes stale: frame 0 is active in the left half, frame 1 in the right half -- the tile list of frame 1 then holds the left half's tiles with
+    NO active row (zero-fill only) in front of the active ones, more than 3 tiles per workgroup, so the ticketed schedule and the null-tile path of the ring
+    are both exercised (a lost first ticket showed here)."""
+    g = torch.Generator(device="cuda").manual_seed(99 + cin)
+    w = (torch.randn((cout, cin, 3, 3), device="cuda", generator=g) / 24).to(torch.bfloat16)
+    wf = ops.conv3x3_pack_weights(w)
+    bias = torch.randn((cout,), device="cuda", generator=g)
+    out = ops.conv3x3_workspace(B, cout, H, W, "cuda")
+    good = True
+    for frame in range(3):
+        mask = (torch.rand((B, H, W), device="cuda", generator=g) < 0.15).to(torch.uint8)
+        if frame % 2 == 0:
+            mask[:, :, W // 2:] = 0
+        else:
+            mask[:, :, :W // 2] = 0
+        x = (torch.randn((B, cin, H, W), device="cuda", generator=g) * mask.unsqueeze(1)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        tl = ops.conv_tile_list(mask, [out[1]], ops.conv_tile_rows(cin, cout, 1))
+        y = ops.conv3x3_masked(x, wf, bias, cout, 1, mask, None, True, out=out, tiles=tl)
+        ref = torch.relu(torch.nn.functional.conv2d(x.float(), w.float(), bias, 1, 1)) * mask.unsqueeze(1)
+        err = (y.float() - ref).abs().max().item()
+        stale = int(tl[1].item())
+        print(f"moving mask {cin}->{cout} B{B} {H}x{W} frame {frame}: listed tiles {stale}, max err {err:.4f}", flush=True)
+        good &= err <= 0.02 * max(1.0, ref.abs().max().item())
+    return good
+
+
+ok &= moving(64, 64, 4, 384, 384)
+ok &= moving(128, 128, 2, 384, 384)
+ok &= moving(256, 256, 2, 384, 384)
 print("OK" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)
