@@ -171,6 +171,20 @@ __device__ __forceinline__ void store_row32(const uint4 (&D)[2], uint16_t* __res
 }
 
 // The accumulators start from the (folded-BN) bias: register i of a lane's 32-channel tile is channel (i&3) + 8*(i>>2) + 4*kb.
+// fp32 epilogue of the three-product kernels: the accumulator tile as it is, lane (px, kb) writing channels 8g + 4kb + 0..3 of its pixel (the two half-waves
+// complete 32 bytes per pixel and g); inactive sites get zeros.  `row`: channel 0 of the tile at pixel 0 of the row segment.
+template <int COUT>
+__device__ __forceinline__ void store_tile_f32(const v16f& a, bool act, float* __restrict__ row, int n_valid, int px, int kb) {
+  if (px >= n_valid) return;
+  float* p = row + (int64_t)px * COUT + 4 * kb;
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    float4 v = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+    if (!act) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(p + 8 * g) = v;
+  }
+}
+
 __device__ __forceinline__ v16f bias_tile(const float* __restrict__ bias, int cbase, int kb) {
   v16f r;
 #pragma unroll
@@ -1128,9 +1142,9 @@ __device__ __forceinline__ void stage_tile64_s2(uint4* __restrict__ s_in, const 
   }
 }
 
-template <int NR, int CIN, int COUT, int MB>
-__device__ __forceinline__ void conv_rows_s2(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
-                                             const float* __restrict__ bias, const int (&rbase)[4], const uint32_t (&rmask)[4],
+template <int NR, int CIN, int COUT, int MB, bool X3 = false>
+__device__ __forceinline__ void conv_rows_s2(uint4* __restrict__ s_in, const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2,
+                                             const uint4* __restrict__ wfrag, const uint4* __restrict__ wfrag2, const float* __restrict__ bias, const int (&rbase)[4], const uint32_t (&rmask)[4],
                                              uint16_t* const (&yrow)[4], int b, int H, int W, int iy0, int ix0, int n_valid, uint32_t need, int mg,
                                              int relu, int px, int kb, int lane) {
   constexpr int NS = CIN / 64, NRA = NR > 0 ? NR : 1;
@@ -1138,25 +1152,41 @@ __device__ __forceinline__ void conv_rows_s2(uint4* __restrict__ s_in, const uin
   if (NR > 0) {
 #pragma unroll
     for (int m = 0; m < MB; m++) {
-      const v16f bq = bias_tile(bias, (mg + m) * 32, kb);
+      v16f bq;
+      if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) bq[i] = 0.f;
+      } else {
+        bq = bias_tile(bias, (mg + m) * 32, kb);
+      }
 #pragma unroll
       for (int j = 0; j < NR; j++) acc[j][m] = bq;
     }
   }
+  // X3 (fp32 product of bf16 pairs, see conv_pc.h): the NS slabs of the high halves (taps with W_hi and with W_lo), then those of the low halves (W_hi)
 #pragma unroll 1
-  for (int sl = 0; sl < NS; sl++) {
-    if (sl) {
+  for (int sq = 0; sq < NS * (X3 ? 2 : 1); sq++) {
+    const int sl = X3 ? sq % NS : sq;
+    if (sq) {
       __syncthreads();  // previous slab consumed
-      stage_tile64_s2<CIN>(s_in, x, b, H, W, 64 * sl, iy0, ix0, need);
+      stage_tile64_s2<CIN>(s_in, X3 && sq >= NS ? x2 : x, b, H, W, 64 * sl, iy0, ix0, need);
       __syncthreads();
     }
-    if (NR > 0) conv_taps<NRA, COUT / 32, CIN / 16, 2, MB>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 4 * sl);
+    if (NR > 0) {
+      conv_taps<NRA, COUT / 32, CIN / 16, 2, MB>(acc, s_in, wfrag, rbase, mg, px, kb, lane, 4 * sl);
+      if constexpr (X3) {
+        if (sq < NS) conv_taps<NRA, COUT / 32, CIN / 16, 2, MB>(acc, s_in, wfrag2, rbase, mg, px, kb, lane, 4 * sl);
+      }
+    }
   }
   if (NR > 0) {
 #pragma unroll
     for (int j = 0; j < NR; j++) {
       const bool act = (rmask[j] >> px) & 1u;
-      if constexpr (MB == 2) {
+      if constexpr (X3) {
+#pragma unroll
+        for (int m = 0; m < MB; m++) store_tile_f32<COUT>(acc[j][m], act, reinterpret_cast<float*>(yrow[j]) + (mg + m) * 32, n_valid, px, kb);
+      } else if constexpr (MB == 2) {
         uint4 D[4];
 #pragma unroll
         for (int m = 0; m < 2; m++) {
@@ -1177,8 +1207,9 @@ __device__ __forceinline__ void conv_rows_s2(uint4* __restrict__ s_in, const uin
 }
 
 // H, W: input; Ho, Wo: output.  The 4 waves are COUT/64 groups of 64 output channels x 4/(COUT/64) row groups.
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_s2(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+template <int CIN, int COUT, bool X3 = false>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_s2(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, const uint4* __restrict__ wfrag,
+                                                    const uint4* __restrict__ wfrag2, const float* __restrict__ bias,
                                                     const uint8_t* __restrict__ mask, uint16_t* __restrict__ y, int B, int H, int W, int Ho, int Wo,
                                                     int relu, uint8_t* __restrict__ row_dirty, int slot) {
   static_assert(CIN % 64 == 0 && (COUT == 128 || COUT == 256), "64-channel input slabs; 4 groups of 32 or of 64 output channels");
@@ -1186,6 +1217,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_s2(const uint16_t* __restric
   // L1 per two MFMAs, which is all of the L1's bandwidth at full MFMA rate (the 759 us outlier of profiles/r06_bench_steady_trace.md).  Now every shape has one
   // row group: four rows per wave, four channel groups of COUT / 4.
   constexpr int TH = S2_TH, MB = COUT / 128, NCG = 4, NRG = 1, NRMAX = TH / NRG;
+  constexpr int YS = X3 ? 2 : 1;  // output element in units of uint16_t (X3: fp32)
   extern __shared__ uint4 s_in[];  // S2_NSTAGE
   __shared__ uint32_t s_rowmask2[2 * TH];
   __shared__ unsigned int s_next[2];
@@ -1221,9 +1253,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_s2(const uint16_t* __restric
       const int oy = y0 + wv;
       const bool active = (am >> wv) & 1u;
       if (!active && was && oy < Ho && ox < Wo) {
-        uint4* dst = reinterpret_cast<uint4*>(y + (((int64_t)b * Ho + oy) * Wo + ox) * COUT);
+        uint4* dst = reinterpret_cast<uint4*>(y + (((int64_t)b * Ho + oy) * Wo + ox) * COUT * YS);
 #pragma unroll 1
-        for (int ch = kb; ch < COUT / 8; ch += 2) dst[ch] = make_uint4(0, 0, 0, 0);
+        for (int ch = kb; ch < COUT * YS / 8; ch += 2) dst[ch] = make_uint4(0, 0, 0, 0);
       }
       if (row_dirty != nullptr && oy < Ho && lane == 0 && was != active) row_dirty[((int64_t)b * Ho + oy) * tiles_x + tx] = active ? 1 : 0;
     }
@@ -1249,7 +1281,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_s2(const uint16_t* __restric
       rrow[j] = __builtin_amdgcn_readfirstlane(rrow[j]);
       rbase[j] = 2 * rrow[j] * S2_RS * 8;
       rmask[j] = j < nr ? __builtin_amdgcn_readfirstlane(s_rowmask[rrow[j]]) : 0u;
-      yrow[j] = y + (((int64_t)b * Ho + (y0 + rrow[j])) * Wo + x0) * COUT;
+      yrow[j] = y + (((int64_t)b * Ho + (y0 + rrow[j])) * Wo + x0) * COUT * YS;
     }
     uint32_t need = 0;  // halo rows some active output row reads: rows 2r, 2r+1, 2r+2
 #pragma unroll
@@ -1258,7 +1290,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_s2(const uint16_t* __restric
     const int iy0 = 2 * y0 - 1, ix0 = 2 * x0 - 1;
     stage_tile64_s2<CIN>(s_in, x, b, H, W, 0, iy0, ix0, need);
     __syncthreads();
-#define PNX_ROWS_S2(N_) conv_rows_s2<(N_ <= NRMAX ? N_ : NRMAX), CIN, COUT, MB>(s_in, x, wfrag, bias, rbase, rmask, yrow, b, H, W, iy0, ix0, Wo - x0, need, mg, relu, px, kb, lane)
+#define PNX_ROWS_S2(N_) conv_rows_s2<(N_ <= NRMAX ? N_ : NRMAX), CIN, COUT, MB, X3>(s_in, x, x2, wfrag, wfrag2, bias, rbase, rmask, yrow, b, H, W, iy0, ix0, Wo - x0, need, mg, relu, px, kb, lane)
     switch (nr) {  // wave-uniform; every case runs the same barriers
       case 0: PNX_ROWS_S2(0); break;
       case 1: PNX_ROWS_S2(1); break;
@@ -1271,20 +1303,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_s2(const uint16_t* __restric
   sched_done(slot);
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool X3 = false>
 int launch_s2(const void* x, const void* wfrag, const float* bias, const uint8_t* mask, void* y, int B, int H, int W, int Ho, int Wo, int relu,
-              uint8_t* row_dirty, hipStream_t st) {
+              uint8_t* row_dirty, hipStream_t st, const void* x2 = nullptr, const void* wfrag2 = nullptr) {
   const int slot = mask != nullptr ? next_sched_slot() : -1;
   int64_t nb = (int64_t)B * ((Ho + S2_TH - 1) / S2_TH) * ((Wo + 31) / 32);
   if (nb > 512) nb = 512;  // resident workgroups: 2 per CU (LDS and registers)
-  auto kern = k_conv3x3_s2<CIN, COUT>;
+  auto kern = k_conv3x3_s2<CIN, COUT, X3>;
   constexpr int lds = S2_NSTAGE * 16;
   static bool attr_done = false;
   if (!attr_done) {
     PNX_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  kern<<<(unsigned)nb, 256, lds, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, mask, (uint16_t*)y, B, H, W, Ho, Wo, relu, row_dirty, slot);
+  kern<<<(unsigned)nb, 256, lds, st>>>((const uint16_t*)x, (const uint16_t*)x2, (const uint4*)wfrag, (const uint4*)wfrag2, bias, mask, (uint16_t*)y, B, H, W, Ho,
+                                       Wo, relu, row_dirty, slot);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
@@ -1669,6 +1702,34 @@ int PNX_CONV_FN(pnx_conv3x3)(const void* x, const void* wfrag, const float* bias
   pnx_set_error("pnx_conv3x3: no kernel for %d -> %d channels", cin, cout);
   return PNX_ERR_UNSUPPORTED;
 }
+
+#ifndef PNX_CONV_F16  // the fp32 training convolution exists once, on the bf16 instructions
+// fp32 convolution out of three bf16 products: x = x_hi + x_lo and W = W_hi + W_lo (bf16 halves of fp32 values, pnx_split_f32; both weight halves in
+// pnx_conv3x3_pack_weights order), y = x_hi W_hi + x_hi W_lo + x_lo W_hi accumulated in fp32 inside ONE launch (the low x low term is below the
+// halves' own rounding, 2^-17 relative) and written as fp32 NHWC; zeros at inactive sites, every site written.  No bias, no activation: this is the
+// convolution of the fp32 training graph (forward, and the stride-1 data gradient with transposed weights).
+int pnx_conv3x3_x3(const void* x_hi, const void* x_lo, const void* wfrag_hi, const void* wfrag_lo, const uint8_t* mask, float* y, int32_t batch, int32_t h,
+                   int32_t w, int32_t cin, int32_t cout, int32_t stride, pnx_stream_t stream) {
+  PNX_REQUIRE(x_hi && x_lo && wfrag_hi && wfrag_lo && y, PNX_ERR_INVALID, "null pointer");
+  PNX_REQUIRE(batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "bad shape");
+  PNX_REQUIRE(stride == 1 || stride == 2, PNX_ERR_UNSUPPORTED, "stride %d", stride);
+  PNX_REQUIRE((((uintptr_t)x_hi | (uintptr_t)x_lo | (uintptr_t)y | (uintptr_t)wfrag_hi | (uintptr_t)wfrag_lo) & 15) == 0, PNX_ERR_INVALID,
+              "16-byte alignment required");
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1) {
+    if (cin == 64 && cout == 64) return launch_pc_x3<64, 64>(x_hi, x_lo, wfrag_hi, wfrag_lo, mask, y, batch, h, w, st);
+    if (cin == 128 && cout == 128) return launch_pc_x3<128, 128>(x_hi, x_lo, wfrag_hi, wfrag_lo, mask, y, batch, h, w, st);
+    if (cin == 256 && cout == 256) return launch_pc_x3<256, 256>(x_hi, x_lo, wfrag_hi, wfrag_lo, mask, y, batch, h, w, st);
+  } else {
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+    if (cin == 64 && cout == 128) return launch_s2<64, 128, true>(x_hi, wfrag_hi, nullptr, mask, y, batch, h, w, ho, wo, 0, nullptr, st, x_lo, wfrag_lo);
+    if (cin == 128 && cout == 256) return launch_s2<128, 256, true>(x_hi, wfrag_hi, nullptr, mask, y, batch, h, w, ho, wo, 0, nullptr, st, x_lo, wfrag_lo);
+    if (cin == 256 && cout == 256) return launch_s2<256, 256, true>(x_hi, wfrag_hi, nullptr, mask, y, batch, h, w, ho, wo, 0, nullptr, st, x_lo, wfrag_lo);
+  }
+  pnx_set_error("pnx_conv3x3_x3: no kernel for %d -> %d channels, stride %d", cin, cout, stride);
+  return PNX_ERR_UNSUPPORTED;
+}
+#endif
 
 }  // extern "C"
 

@@ -46,8 +46,11 @@ __device__ __forceinline__ void pc_barrier_all() { asm volatile("s_waitcnt vmcnt
 
 // Everything a consumer wave does for one tile: NPASS passes (CIN = 64: over the one fill; otherwise over NSLAB fills each), every fill closed
 // by pc_barrier_lds().  NR = 0: the wave has no row in this tile and only keeps the barrier count.
-template <int NR, int CIN, int COUT, bool HAS_RES, int NRG, int NSLOT, int SLOT_N>
-__device__ __forceinline__ void pc_rows(const uint4* __restrict__ s_ring, int& g, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+// X3: the fp32 product from bf16 pairs (pnx_conv3x3_x3): the fills alternate between the tensor of high halves (taps with W_hi, then with W_lo) and the
+// tensor of low halves (taps with W_hi); no bias, no ReLU, and the accumulators go out as fp32.
+template <int NR, int CIN, int COUT, bool HAS_RES, int NRG, int NSLOT, int SLOT_N, bool X3 = false>
+__device__ __forceinline__ void pc_rows(const uint4* __restrict__ s_ring, int& g, const uint4* __restrict__ wfrag, const uint4* __restrict__ wfrag2,
+                                        const float* __restrict__ bias,
                                         const uint16_t* __restrict__ res_t, uint16_t* __restrict__ y_t, const int (&rrow)[4], const uint32_t (&rmask)[4],
                                         int W, int n_valid, int cg, int relu, int px, int kb, int lane
 #ifdef PNX_CONV_TIMERS
@@ -65,13 +68,20 @@ __device__ __forceinline__ void pc_rows(const uint4* __restrict__ s_ring, int& g
     const int mt = pass * NCG + cg;  // 32-channel output tile of this wave
     v16f acc[NRA][1];
     if (NR > 0) {
-      const v16f bq = bias_tile(bias, mt * 32, kb);
+      v16f bq;
+      if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) bq[i] = 0.f;
+      } else {
+        bq = bias_tile(bias, mt * 32, kb);
+      }
 #pragma unroll
       for (int j = 0; j < NR; j++) acc[j][0] = bq;
     }
     uint4 rq[2];
 #pragma unroll 1
-    for (int sl = 0; sl < NSLAB; sl++) {
+    for (int sq = 0; sq < NSLAB * (X3 ? 2 : 1); sq++) {
+      const int sl = X3 ? sq % NSLAB : sq;
       if (NR > 0) {
         if (HAS_RES && sl == NSLAB - 1) {  // residual lines of row 0: requested before the last slab's taps, arrive under them
           const bool a0 = (rmask[0] >> px) & 1u;
@@ -83,9 +93,12 @@ __device__ __forceinline__ void pc_rows(const uint4* __restrict__ s_ring, int& g
           }
         }
         conv_taps<NRA, MTALL, CB, 1, 1>(acc, s_ring + (g % NSLOT) * SLOT_N, wfrag, rbase, mt, px, kb, lane, 4 * sl);
+        if constexpr (X3) {
+          if (sq < NSLAB) conv_taps<NRA, MTALL, CB, 1, 1>(acc, s_ring + (g % NSLOT) * SLOT_N, wfrag2, rbase, mt, px, kb, lane, 4 * sl);
+        }
       }
       PC_TOCK(1)
-      if (NSLAB > 1 || pass == NPASS - 1) {
+      if (X3 || NSLAB > 1 || pass == NPASS - 1) {
         pc_barrier_lds();
         g++;
       }
@@ -95,6 +108,10 @@ __device__ __forceinline__ void pc_rows(const uint4* __restrict__ s_ring, int& g
 #pragma unroll
       for (int j = 0; j < NR; j++) {
         const bool act = (rmask[j] >> px) & 1u;
+        if constexpr (X3) {
+          store_tile_f32<COUT>(acc[j][0], act, reinterpret_cast<float*>(y_t) + ((int64_t)rrow[j] * W) * COUT + mt * 32, n_valid, px, kb);
+          continue;
+        }
         uint4 rc[2];
         if (HAS_RES) {
           rc[0] = rq[0], rc[1] = rq[1];
@@ -120,15 +137,18 @@ __device__ __forceinline__ void pc_rows(const uint4* __restrict__ s_ring, int& g
   }
 }
 
-template <int CIN, int COUT, bool HAS_RES>
-__global__ __launch_bounds__(768, 3) void k_conv3x3_pc(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+template <int CIN, int COUT, bool HAS_RES, bool X3 = false>
+__global__ __launch_bounds__(768, 3) void k_conv3x3_pc(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, const uint4* __restrict__ wfrag,
+                                                       const uint4* __restrict__ wfrag2, const float* __restrict__ bias,
                                                        const uint16_t* __restrict__ res, const uint8_t* __restrict__ mask, uint16_t* __restrict__ y,
                                                        int B, int H, int W, int relu, uint8_t* __restrict__ row_dirty, int slot,
                                                        const int32_t* __restrict__ tlist, const int32_t* __restrict__ tcount) {
   constexpr int TH = CIN == 64 ? 16 : 8;
   constexpr int NRG = TH / 4, NCG = 8 / NRG, PASS_C = NCG * 32, NPASS = COUT / PASS_C, NSLAB = CIN / 64;
   constexpr int NSLOT = CIN == 64 ? 2 : 3, DEPTH = NSLOT - 1;
-  constexpr int NFILL = CIN == 64 ? 1 : NPASS * NSLAB;  // fills per tile with an active site
+  constexpr int NFILL = X3 ? NPASS * NSLAB * 2 : CIN == 64 ? 1 : NPASS * NSLAB;  // fills per tile with an active site
+  constexpr int YS = X3 ? 2 : 1;                                                 // output element in units of uint16_t
+  static_assert(!X3 || (!HAS_RES && (CIN > 64 || NPASS == 1)), "fp32 product: no residual; one pass when the tile is filled once per source");
   constexpr int SLOT_N = (TH + 2) * LDS_HW * 8;
   static_assert(COUT % PASS_C == 0 && CIN % 64 == 0, "passes of NCG x 32 output channels over 64-channel input slabs");
   __shared__ uint4 s_ring[NSLOT * SLOT_N];
@@ -237,8 +257,8 @@ __global__ __launch_bounds__(768, 3) void k_conv3x3_pc(const uint16_t* __restric
         if (oy >= H) break;
         const bool active = (am >> r) & 1u, w = (was >> r) & 1u;
         if (!active && w) {
-          char* dst = reinterpret_cast<char*>(y + (((int64_t)cb * H + oy) * W + cx0) * COUT);
-          const int nbytes = (W - cx0 < 32 ? W - cx0 : 32) * COUT * 2;
+          char* dst = reinterpret_cast<char*>(y + (((int64_t)cb * H + oy) * W + cx0) * COUT * YS);
+          const int nbytes = (W - cx0 < 32 ? W - cx0 : 32) * COUT * 2 * YS;
 #pragma unroll 1
           for (int o = lane * 16; o < nbytes; o += 1024) *reinterpret_cast<uint4*>(dst + o) = make_uint4(0, 0, 0, 0);
         }
@@ -255,7 +275,8 @@ __global__ __launch_bounds__(768, 3) void k_conv3x3_pc(const uint16_t* __restric
       if (am != 0) {
         const int sl = f % NSLAB;
         uint4* dstslot = s_ring + (g % NSLOT) * SLOT_N;
-        const uint16_t* xt = x + (((int64_t)cb * H + (cy0 - 1)) * W + (cx0 - 1)) * CIN + 64 * sl;  // element (0, 0) of the halo tile
+        const uint16_t* xs = X3 && (f / NSLAB) % 2 == 1 ? x2 : x;  // fp32 product: per pass the NSLAB slabs of the high halves, then those of the low halves
+        const uint16_t* xt = xs + (((int64_t)cb * H + (cy0 - 1)) * W + (cx0 - 1)) * CIN + 64 * sl;  // element (0, 0) of the halo tile
         bool col_ok[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) col_ok[i] = (unsigned)(cx0 - 1 + colv[i]) < (unsigned)W && (i < 4 || lane < 16);
@@ -330,13 +351,13 @@ __global__ __launch_bounds__(768, 3) void k_conv3x3_pc(const uint16_t* __restric
       rrow[j] = rrow[j] >= 0 ? rrow[j] : 0;  // dummy rows point at row 0
     }
     const uint16_t* res_t = HAS_RES ? res + (((int64_t)b * H + y0) * W + x0) * COUT : nullptr;
-    uint16_t* y_t = y + (((int64_t)b * H + y0) * W + x0) * COUT;
+    uint16_t* y_t = y + (((int64_t)b * H + y0) * W + x0) * COUT * YS;
     const int n_valid = W - x0;
     PC_TOCK(0)
 #ifdef PNX_CONV_TIMERS
-#define PC_ROWS(N_) pc_rows<N_, CIN, COUT, HAS_RES, NRG, NSLOT, SLOT_N>(s_ring, g, wfrag, bias, res_t, y_t, rrow, rmask, W, n_valid, cg, relu, px, kb, lane, pc_T, pc_tk)
+#define PC_ROWS(N_) pc_rows<N_, CIN, COUT, HAS_RES, NRG, NSLOT, SLOT_N, X3>(s_ring, g, wfrag, wfrag2, bias, res_t, y_t, rrow, rmask, W, n_valid, cg, relu, px, kb, lane, pc_T, pc_tk)
 #else
-#define PC_ROWS(N_) pc_rows<N_, CIN, COUT, HAS_RES, NRG, NSLOT, SLOT_N>(s_ring, g, wfrag, bias, res_t, y_t, rrow, rmask, W, n_valid, cg, relu, px, kb, lane)
+#define PC_ROWS(N_) pc_rows<N_, CIN, COUT, HAS_RES, NRG, NSLOT, SLOT_N, X3>(s_ring, g, wfrag, wfrag2, bias, res_t, y_t, rrow, rmask, W, n_valid, cg, relu, px, kb, lane)
 #endif
     switch (nr) {  // wave-uniform; every case runs the same barriers
       case 0: PC_ROWS(0); break;
@@ -359,11 +380,24 @@ int launch_pc(const void* x, const void* wfrag, const float* bias, const void* r
   if (nb > 256) nb = 256;  // one 12-wave workgroup per CU (LDS: the ring takes 128-153 KiB)
   const int slot = mask != nullptr ? next_sched_slot() : -1;
   if (res != nullptr)
-    k_conv3x3_pc<CIN, COUT, true><<<(unsigned)nb, 768, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, (const uint16_t*)res, mask, (uint16_t*)y, B, H,
+    k_conv3x3_pc<CIN, COUT, true><<<(unsigned)nb, 768, 0, st>>>((const uint16_t*)x, nullptr, (const uint4*)wfrag, nullptr, bias, (const uint16_t*)res, mask, (uint16_t*)y, B, H,
                                                               W, relu, row_dirty, slot, tlist, tcount);
   else
-    k_conv3x3_pc<CIN, COUT, false><<<(unsigned)nb, 768, 0, st>>>((const uint16_t*)x, (const uint4*)wfrag, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu,
+    k_conv3x3_pc<CIN, COUT, false><<<(unsigned)nb, 768, 0, st>>>((const uint16_t*)x, nullptr, (const uint4*)wfrag, nullptr, bias, nullptr, mask, (uint16_t*)y, B, H, W, relu,
                                                                row_dirty, slot, tlist, tcount);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+// fp32 product of bf16 pairs (pnx_conv3x3_x3): x = x_hi + x_lo, W = W_hi + W_lo, y = x_hi W_hi + x_hi W_lo + x_lo W_hi in one launch, fp32 out.
+template <int CIN, int COUT>
+int launch_pc_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const uint8_t* mask, float* y, int B, int H, int W, hipStream_t st) {
+  constexpr int TH = CIN == 64 ? 16 : 8;
+  int64_t nb = (int64_t)B * ((H + TH - 1) / TH) * ((W + 31) / 32);
+  if (nb > 256) nb = 256;
+  const int slot = mask != nullptr ? next_sched_slot() : -1;
+  k_conv3x3_pc<CIN, COUT, false, true><<<(unsigned)nb, 768, 0, st>>>((const uint16_t*)x_hi, (const uint16_t*)x_lo, (const uint4*)w_hi, (const uint4*)w_lo,
+                                                                     nullptr, nullptr, mask, (uint16_t*)y, B, H, W, 0, nullptr, slot, nullptr, nullptr);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

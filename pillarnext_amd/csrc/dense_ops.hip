@@ -213,9 +213,43 @@ __global__ __launch_bounds__(256) void k_mask_pool16(const uint8_t* __restrict__
   *reinterpret_cast<uint4*>(out + ((int64_t)b * Ho + yo) * Wo + xo) = make_uint4(R[0], R[1], R[2], R[3]);
 }
 
+// fp32 -> two bf16 halves: hi = RNE(x), lo = RNE(x - hi); x - hi is exact in fp32, so hi + lo carries 16 mantissa bits of x (2^-17 relative).
+// 8 values per thread: two 16-byte loads, two 16-byte stores.
+__device__ __forceinline__ uint32_t bf16_rne(float v) {
+  const uint32_t u = __float_as_uint(v);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (u >> 16) | ((u & 0xffffu) != 0 ? 0x40u : 0u);  // inf / nan stay what they are
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ __launch_bounds__(256) void k_split_f32(const float4* __restrict__ x, uint4* __restrict__ hi, uint4* __restrict__ lo, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const float4 a = x[2 * i], b = x[2 * i + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      h[k] = bf16_rne(v[k]);
+      l[k] = bf16_rne(v[k] - __uint_as_float(h[k] << 16));
+    }
+    hi[i] = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
+    lo[i] = make_uint4(l[0] | l[1] << 16, l[2] | l[3] << 16, l[4] | l[5] << 16, l[6] | l[7] << 16);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pnx_split_f32(const float* x, void* hi, void* lo, int64_t n, pnx_stream_t stream) {
+  PNX_REQUIRE(x && hi && lo && n >= 0 && n % 8 == 0, PNX_ERR_INVALID, "pnx_split_f32: null pointer or a count that is not a multiple of 8");
+  PNX_REQUIRE((((uintptr_t)x | (uintptr_t)hi | (uintptr_t)lo) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
+  if (n == 0) return PNX_OK;
+  const int64_t n8 = n / 8;
+  int64_t nb = (n8 + 255) / 256;
+  if (nb > 256 * 16) nb = 256 * 16;
+  k_split_f32<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>((const float4*)x, (uint4*)hi, (uint4*)lo, n8);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
 
 int pnx_bias_act_mask(const void* x, const void* residual, const float* bias, const uint8_t* mask, void* out, int64_t sites,
                       int32_t channels, int32_t dtype, int32_t relu, pnx_stream_t stream) {

@@ -286,7 +286,7 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
                 site would be thrown away by that site's own mask; stride 2: MIOpen's dense dgrad
       wgrad     stride 1: pnx_conv3x3_wgrad_bf16 (csrc/conv_wgrad.hip) over the 16-pixel row pieces that hold an active output, fp32 accumulation,
                 deterministic, stride 1 and 2 (PNX_TRAIN_HIPWGRAD=0: MIOpen's dense wrw on (x, g), exact because g is zero outside the active outputs)
-    The fp32 training path (the reference's precision) stays on MIOpen: the kernels are bf16."""
+    The fp32 training graph (the reference's precision) has its own node, _MaskedConv3x3F32Fn."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
@@ -326,18 +326,70 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
+def _split_pack(weight, transposed=False):
+    """fp32 (Cout,Cin,3,3) -> the packed bf16 halves (W_hi, W_lo) pnx_conv3x3_x3 takes."""
+    hi, lo = ops.split_f32(weight.detach().contiguous())
+    return ops.conv3x3_pack_weights(hi, transposed=transposed), ops.conv3x3_pack_weights(lo, transposed=transposed)
+
+
+class _MaskedConv3x3F32Fn(torch.autograd.Function):
+    """_MaskedConv3x3Fn for the fp32 training graph (the reference's training precision: tools/train.py runs without autocast): every fp32 operand
+    is split into two bf16 halves (16 mantissa bits together) and the three significant products run on the bf16 matrix cores with fp32 accumulation.
+      forward   pnx_conv3x3_x3 on (x_hi, x_lo) x (W_hi, W_lo): one launch, fp32 out
+      dgrad     stride 1: the same kernel on the halves of g and of W^T flipped, masked by the INPUT's active set; stride 2: MIOpen's fp32 dgrad
+      wgrad     pnx_conv3x3_wgrad_bf16 three times (x_hi g_hi + x_lo g_hi + x_hi g_lo), each accumulated in fp32
+    Relative error of every product ~ 2^-16 (the dropped low x low term and the halves' own rounding), against MIOpen's fp32 kernels' ~ 2^-22:
+    tests/test_gpu_masked_conv_train.py holds both against an fp64 convolution.  PNX_TRAIN_F32_HIP=0 keeps the fp32 graph on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight, mask_out, mask_in, stride):
+        x = x.contiguous(memory_format=torch.channels_last)
+        xh, xl = ops.split_f32(x)
+        wh, wl = _split_pack(weight)
+        y = ops.conv3x3_x3(xh, xl, wh, wl, weight.shape[0], stride, mask_out)
+        ctx.save_for_backward(xh, xl, weight, mask_in, mask_out)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xh, xl, weight, mask_in, mask_out = ctx.saved_tensors
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g = g.contiguous(memory_format=torch.channels_last)
+        s = ctx.stride
+        dx = dw = None
+        if need_w or (need_x and s == 1):
+            gh, gl = ops.split_f32(g)
+        if need_x:
+            if s == 1:
+                wth, wtl = _split_pack(weight, transposed=True)
+                dx = ops.conv3x3_x3(gh, gl, wth, wtl, weight.shape[1], 1, mask_in)
+            else:
+                dx = torch.nn.grad.conv2d_input(xh.shape, weight, g, stride=s, padding=1)
+        if need_w:
+            dw = ops.conv3x3_wgrad(xh, gh, mask_out, stride=s)
+            dw += ops.conv3x3_wgrad(xl, gh, mask_out, stride=s)
+            dw += ops.conv3x3_wgrad(xh, gl, mask_out, stride=s)
+        return dx, dw, None, None, None
+
+
 # (Cin, Cout, stride) served by the LDS-staged kernels of csrc/conv3x3.hip (every 3x3 layer of the PillarNeXt-B backbone)
 _HIP_TRAIN_CONVS = {(64, 64, 1), (128, 128, 1), (256, 256, 1), (64, 128, 2), (128, 256, 2), (256, 256, 2)}
 
 
 def masked_conv(conv, x, mask_out, mask_in):
-    """conv(x) of a backbone block; in bf16-autocast training the 3x3 layers run on the product's masked kernels (_MaskedConv3x3Fn).
-    PNX_TRAIN_HIPCONV=0 keeps every layer on MIOpen."""
+    """conv(x) of a backbone block; in training the 3x3 layers run on the product's masked kernels: _MaskedConv3x3Fn under bf16 autocast
+    (PNX_TRAIN_HIPCONV=0 keeps every layer on MIOpen), _MaskedConv3x3F32Fn in the fp32 graph (PNX_TRAIN_F32_HIP=0: MIOpen)."""
     if (conv.training and torch.is_grad_enabled() and x.is_cuda and conv.kernel_size == (3, 3) and conv.bias is None
             and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
             and os.environ.get("PNX_TRAIN_HIPCONV", "1") != "0"
             and (conv.in_channels, conv.out_channels, conv.stride[0]) in _HIP_TRAIN_CONVS):
         return _MaskedConv3x3Fn.apply(x, conv.weight, _mask_u8(mask_out), _mask_u8(mask_in), conv.stride[0])
+    if (conv.training and torch.is_grad_enabled() and x.is_cuda and conv.kernel_size == (3, 3) and conv.bias is None
+            and not torch.is_autocast_enabled() and x.dtype == torch.float32 and conv.weight.dtype == torch.float32
+            and os.environ.get("PNX_TRAIN_F32_HIP", "1") != "0"
+            and (conv.in_channels, conv.out_channels, conv.stride[0]) in _HIP_TRAIN_CONVS):
+        return _MaskedConv3x3F32Fn.apply(x, conv.weight, _mask_u8(mask_out), _mask_u8(mask_in), conv.stride[0])
     return conv(x)
 
 

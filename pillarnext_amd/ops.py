@@ -451,6 +451,37 @@ def conv3x3_wgrad(x, dy, mask, stride=1):
     return dw
 
 
+def split_f32(x):
+    """fp32 tensor -> (hi, lo) bf16 tensors of the same shape and memory layout: hi = RNE(x), lo = RNE(x - hi) (pnx_split_f32)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.numel() % 8 == 0):
+        raise PnxError("split_f32 needs an fp32 CUDA tensor with a multiple of 8 elements")
+    if not (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))):
+        raise PnxError("split_f32 needs a dense tensor (contiguous or channels_last)")
+    hi, lo = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
+    check(lib().pnx_split_f32(ptr(x), ptr(hi), ptr(lo), x.numel(), stream_ptr()), "pnx_split_f32")
+    return hi, lo
+
+
+CONV3X3_X3_SHAPES = {1: {(64, 64), (128, 128), (256, 256)}, 2: {(64, 128), (128, 256), (256, 256)}}   # stride -> (Cin, Cout) of pnx_conv3x3_x3
+
+
+def conv3x3_x3(x_hi, x_lo, wfrag_hi, wfrag_lo, cout, stride, mask):
+    """fp32 (B,Cout,Ho,Wo) channels_last = masked 3x3 convolution of x_hi + x_lo with W_hi + W_lo (three bf16 products accumulated in fp32 in one
+    launch, pnx_conv3x3_x3); mask uint8 (B,Ho,Wo) of the OUTPUT sites or None; zeros at inactive sites."""
+    for tns in (x_hi, x_lo):
+        if not (tns.is_cuda and tns.dtype == torch.bfloat16 and tns.dim() == 4 and tns.is_contiguous(memory_format=torch.channels_last)):
+            raise PnxError("conv3x3_x3 needs channels_last bf16 CUDA halves")
+    if x_hi.shape != x_lo.shape or wfrag_hi.dtype != torch.bfloat16 or wfrag_lo.dtype != torch.bfloat16:
+        raise PnxError("conv3x3_x3: the two halves must have one shape, the weights must be packed bf16")
+    B, ci, H, W = x_hi.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if mask is not None and (tuple(mask.shape) != (B, Ho, Wo) or mask.dtype != torch.uint8):
+        raise PnxError("conv3x3_x3: mask must be uint8 (B,Ho,Wo)")
+    y = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x_hi.device, memory_format=torch.channels_last)
+    check(lib().pnx_conv3x3_x3(ptr(x_hi), ptr(x_lo), ptr(wfrag_hi), ptr(wfrag_lo), ptr(mask), ptr(y), B, H, W, ci, cout, stride, stream_ptr()), "pnx_conv3x3_x3")
+    return y
+
+
 def conv3x3_workspace(batch, cout, ho, wo, device, dtype=torch.bfloat16):
     """A persistent (output buffer, row_dirty flags) pair for conv3x3_masked(out=...): both start zeroed (pnx.h: row_dirty)."""
     y = torch.zeros((batch, cout, ho, wo), dtype=dtype, device=device).contiguous(memory_format=torch.channels_last)
