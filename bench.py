@@ -363,7 +363,8 @@ def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAME
     bench_mode = torch.backends.cudnn.benchmark
     # Round 6: the SAME mode at every N (find, each rank with its own find-db -- main()), so that value_train(N) / (N x value_train(1)) compares like with like;
     # PNX_BENCH_TRAIN_FIND=0 switches every N to immediate mode.
-    find = os.environ.get("PNX_BENCH_TRAIN_FIND", "1") == "1" and amp   # the fp32 leg: immediate mode (its find pass over fp32 wrw problems takes minutes)
+    # The fp32 leg: PNX_BENCH_TRAIN_F32_FIND (its backbone is on the product's kernels since round 6, what MIOpen still has to search is the neck / head).
+    find = os.environ.get("PNX_BENCH_TRAIN_FIND", "1") == "1" if amp else os.environ.get("PNX_BENCH_TRAIN_F32_FIND", "0") == "1"
     torch.backends.cudnn.benchmark = find
     t_leg = time.perf_counter()
     for _ in range(warmup):
@@ -390,9 +391,11 @@ def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAME
         torch.backends.cudnn.benchmark = bench_mode
         res = {"value_train_fp32": round(frames * world * steps / dt, 2),
                "train_fp32": {"frames_per_gpu_per_step": frames, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
-                              "dtype": "fp32, channels_last -- the reference's training precision; convolutions on MIOpen (the masked HIP convolution kernels are bf16 / fp16); run in a child process with MIOpen's default solver set",
+                              "dtype": "fp32, channels_last -- the reference's training precision; backbone 3x3 layers: three bf16 products of the operands' bf16 halves "
+                                       "accumulated in fp32 on the masked HIP kernels (pnx_conv3x3_x3, relative error 4e-6; PNX_TRAIN_F32_HIP=0: MIOpen fp32), "
+                                       "stride-2 dgrad and the dense neck / head on MIOpen fp32; run in a child process with MIOpen's default solver set",
                               "loss_finite": finite, "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
-                              "miopen": "immediate mode", "leg_seconds": round(time.perf_counter() - t_leg, 1)}}
+                              "miopen": "find (cudnn.benchmark)" if find else "immediate mode", "leg_seconds": round(time.perf_counter() - t_leg, 1)}}
         del model, opt, ex
         torch.cuda.empty_cache()
         return res

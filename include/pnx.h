@@ -319,11 +319,12 @@ int pnx_sephead_lazy_f16(const PnxLazyTask* tasks, int32_t n_tasks, const int32_
  * training precision, tools/train.py) on the bf16 matrix cores: every fp32 operand is split into two bf16 halves (pnx_split_f32: hi = RNE(x),
  * lo = RNE(x - hi), 16 mantissa bits together) and pnx_conv3x3_x3 accumulates x_hi W_hi + x_hi W_lo + x_lo W_hi in fp32 inside one launch.  x_hi, x_lo:
  * NHWC bf16; wfrag_hi, wfrag_lo: pnx_conv3x3_pack_weights of the two weight halves; y: fp32 NHWC (batch, ho, wo, cout), zeros at inactive sites, every
- * site written; no bias and no activation (the training graph's BatchNorm follows).  Shapes: stride 1 64->64, 128->128, 256->256; stride 2 64->128,
+ * site written; bias: cout fp32 values added at the active sites, or NULL; no activation (the training graph's BatchNorm follows).  mask NULL: every site
+ * is active (the dense head / neck layers: det3d/models/heads/centerhead.py:24-41, det3d/models/utils/conv.py).  Shapes: stride 1 64->64, 128->128, 256->256; stride 2 64->128,
  * 128->256, 256->256.  n of pnx_split_f32: a multiple of 8. */
 int pnx_split_f32(const float* x, void* hi, void* lo, int64_t n, pnx_stream_t stream);
-int pnx_conv3x3_x3(const void* x_hi, const void* x_lo, const void* wfrag_hi, const void* wfrag_lo, const uint8_t* mask, float* y, int32_t batch,
-                   int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, pnx_stream_t stream);
+int pnx_conv3x3_x3(const void* x_hi, const void* x_lo, const void* wfrag_hi, const void* wfrag_lo, const float* bias, const uint8_t* mask, float* y,
+                   int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, pnx_stream_t stream);
 /* Active-site rule of SparseConv2d(k=3, stride, pad=1): mask_out = maxpool3x3(mask_in, stride, 1); uint8 (B,h,w) -> (B,ho,wo). */
 int pnx_mask_pool3(const uint8_t* mask_in, int32_t batch, int32_t h, int32_t w, int32_t stride, uint8_t* mask_out, pnx_stream_t stream);
 

@@ -1153,7 +1153,7 @@ __device__ __forceinline__ void conv_rows_s2(uint4* __restrict__ s_in, const uin
 #pragma unroll
     for (int m = 0; m < MB; m++) {
       v16f bq;
-      if constexpr (X3) {
+      if (X3 && bias == nullptr) {
 #pragma unroll
         for (int i = 0; i < 16; i++) bq[i] = 0.f;
       } else {
@@ -1706,25 +1706,25 @@ int PNX_CONV_FN(pnx_conv3x3)(const void* x, const void* wfrag, const float* bias
 #ifndef PNX_CONV_F16  // the fp32 training convolution exists once, on the bf16 instructions
 // fp32 convolution out of three bf16 products: x = x_hi + x_lo and W = W_hi + W_lo (bf16 halves of fp32 values, pnx_split_f32; both weight halves in
 // pnx_conv3x3_pack_weights order), y = x_hi W_hi + x_hi W_lo + x_lo W_hi accumulated in fp32 inside ONE launch (the low x low term is below the
-// halves' own rounding, 2^-17 relative) and written as fp32 NHWC; zeros at inactive sites, every site written.  No bias, no activation: this is the
-// convolution of the fp32 training graph (forward, and the stride-1 data gradient with transposed weights).
-int pnx_conv3x3_x3(const void* x_hi, const void* x_lo, const void* wfrag_hi, const void* wfrag_lo, const uint8_t* mask, float* y, int32_t batch, int32_t h,
-                   int32_t w, int32_t cin, int32_t cout, int32_t stride, pnx_stream_t stream) {
+// halves' own rounding, 2^-17 relative) and written as fp32 NHWC; zeros at inactive sites, every site written.  bias (fp32, may be null) starts the
+// accumulators; no activation: this is the convolution of the fp32 training graph (forward, and the stride-1 data gradient with transposed weights).
+int pnx_conv3x3_x3(const void* x_hi, const void* x_lo, const void* wfrag_hi, const void* wfrag_lo, const float* bias, const uint8_t* mask, float* y,
+                   int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, pnx_stream_t stream) {
   PNX_REQUIRE(x_hi && x_lo && wfrag_hi && wfrag_lo && y, PNX_ERR_INVALID, "null pointer");
   PNX_REQUIRE(batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "bad shape");
   PNX_REQUIRE(stride == 1 || stride == 2, PNX_ERR_UNSUPPORTED, "stride %d", stride);
-  PNX_REQUIRE((((uintptr_t)x_hi | (uintptr_t)x_lo | (uintptr_t)y | (uintptr_t)wfrag_hi | (uintptr_t)wfrag_lo) & 15) == 0, PNX_ERR_INVALID,
+  PNX_REQUIRE((((uintptr_t)x_hi | (uintptr_t)x_lo | (uintptr_t)y | (uintptr_t)wfrag_hi | (uintptr_t)wfrag_lo | (uintptr_t)bias) & 15) == 0, PNX_ERR_INVALID,
               "16-byte alignment required");
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1) {
-    if (cin == 64 && cout == 64) return launch_pc_x3<64, 64>(x_hi, x_lo, wfrag_hi, wfrag_lo, mask, y, batch, h, w, st);
-    if (cin == 128 && cout == 128) return launch_pc_x3<128, 128>(x_hi, x_lo, wfrag_hi, wfrag_lo, mask, y, batch, h, w, st);
-    if (cin == 256 && cout == 256) return launch_pc_x3<256, 256>(x_hi, x_lo, wfrag_hi, wfrag_lo, mask, y, batch, h, w, st);
+    if (cin == 64 && cout == 64) return launch_pc_x3<64, 64>(x_hi, x_lo, wfrag_hi, wfrag_lo, bias, mask, y, batch, h, w, st);
+    if (cin == 128 && cout == 128) return launch_pc_x3<128, 128>(x_hi, x_lo, wfrag_hi, wfrag_lo, bias, mask, y, batch, h, w, st);
+    if (cin == 256 && cout == 256) return launch_pc_x3<256, 256>(x_hi, x_lo, wfrag_hi, wfrag_lo, bias, mask, y, batch, h, w, st);
   } else {
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
-    if (cin == 64 && cout == 128) return launch_s2<64, 128, true>(x_hi, wfrag_hi, nullptr, mask, y, batch, h, w, ho, wo, 0, nullptr, st, x_lo, wfrag_lo);
-    if (cin == 128 && cout == 256) return launch_s2<128, 256, true>(x_hi, wfrag_hi, nullptr, mask, y, batch, h, w, ho, wo, 0, nullptr, st, x_lo, wfrag_lo);
-    if (cin == 256 && cout == 256) return launch_s2<256, 256, true>(x_hi, wfrag_hi, nullptr, mask, y, batch, h, w, ho, wo, 0, nullptr, st, x_lo, wfrag_lo);
+    if (cin == 64 && cout == 128) return launch_s2<64, 128, true>(x_hi, wfrag_hi, bias, mask, y, batch, h, w, ho, wo, 0, nullptr, st, x_lo, wfrag_lo);
+    if (cin == 128 && cout == 256) return launch_s2<128, 256, true>(x_hi, wfrag_hi, bias, mask, y, batch, h, w, ho, wo, 0, nullptr, st, x_lo, wfrag_lo);
+    if (cin == 256 && cout == 256) return launch_s2<256, 256, true>(x_hi, wfrag_hi, bias, mask, y, batch, h, w, ho, wo, 0, nullptr, st, x_lo, wfrag_lo);
   }
   pnx_set_error("pnx_conv3x3_x3: no kernel for %d -> %d channels, stride %d", cin, cout, stride);
   return PNX_ERR_UNSUPPORTED;

@@ -69,7 +69,7 @@ __device__ __forceinline__ void pc_rows(const uint4* __restrict__ s_ring, int& g
     v16f acc[NRA][1];
     if (NR > 0) {
       v16f bq;
-      if constexpr (X3) {
+      if (X3 && bias == nullptr) {
 #pragma unroll
         for (int i = 0; i < 16; i++) bq[i] = 0.f;
       } else {
@@ -391,13 +391,14 @@ int launch_pc(const void* x, const void* wfrag, const float* bias, const void* r
 
 // fp32 product of bf16 pairs (pnx_conv3x3_x3): x = x_hi + x_lo, W = W_hi + W_lo, y = x_hi W_hi + x_hi W_lo + x_lo W_hi in one launch, fp32 out.
 template <int CIN, int COUT>
-int launch_pc_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const uint8_t* mask, float* y, int B, int H, int W, hipStream_t st) {
+int launch_pc_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, const uint8_t* mask, float* y, int B, int H, int W,
+                 hipStream_t st) {
   constexpr int TH = CIN == 64 ? 16 : 8;
   int64_t nb = (int64_t)B * ((H + TH - 1) / TH) * ((W + 31) / 32);
   if (nb > 256) nb = 256;
   const int slot = mask != nullptr ? next_sched_slot() : -1;
   k_conv3x3_pc<CIN, COUT, false, true><<<(unsigned)nb, 768, 0, st>>>((const uint16_t*)x_hi, (const uint16_t*)x_lo, (const uint4*)w_hi, (const uint4*)w_lo,
-                                                                     nullptr, nullptr, mask, (uint16_t*)y, B, H, W, 0, nullptr, slot, nullptr, nullptr);
+                                                                     bias, nullptr, mask, (uint16_t*)y, B, H, W, 0, nullptr, slot, nullptr, nullptr);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

@@ -332,21 +332,34 @@ def _split_pack(weight, transposed=False):
     return ops.conv3x3_pack_weights(hi, transposed=transposed), ops.conv3x3_pack_weights(lo, transposed=transposed)
 
 
+_ONES_MASK = {}
+
+
+def _ones_mask(b, h, w, device):
+    key = (b, h, w, device)
+    if key not in _ONES_MASK:
+        _ONES_MASK[key] = torch.ones((b, h, w), dtype=torch.uint8, device=device)
+    return _ONES_MASK[key]
+
+
 class _MaskedConv3x3F32Fn(torch.autograd.Function):
     """_MaskedConv3x3Fn for the fp32 training graph (the reference's training precision: tools/train.py runs without autocast): every fp32 operand
     is split into two bf16 halves (16 mantissa bits together) and the three significant products run on the bf16 matrix cores with fp32 accumulation.
-      forward   pnx_conv3x3_x3 on (x_hi, x_lo) x (W_hi, W_lo): one launch, fp32 out
+      forward   pnx_conv3x3_x3 on (x_hi, x_lo) x (W_hi, W_lo) [+ bias]: one launch, fp32 out
       dgrad     stride 1: the same kernel on the halves of g and of W^T flipped, masked by the INPUT's active set; stride 2: MIOpen's fp32 dgrad
       wgrad     pnx_conv3x3_wgrad_bf16 three times (x_hi g_hi + x_lo g_hi + x_hi g_lo), each accumulated in fp32
-    Relative error of every product ~ 2^-16 (the dropped low x low term and the halves' own rounding), against MIOpen's fp32 kernels' ~ 2^-22:
-    tests/test_gpu_masked_conv_train.py holds both against an fp64 convolution.  PNX_TRAIN_F32_HIP=0 keeps the fp32 graph on MIOpen."""
+    mask_out = mask_in = None: a dense layer (the neck's and the head's 3x3 convolutions, x3_conv below).  halves: (x_hi, x_lo) when the caller
+    already split x (the six branches of a SepHead share their input).
+    Relative error of every product ~ 4e-6 (the dropped low x low term and the halves' rounding, 2^-17 each), against MIOpen's fp32 kernels' ~ 2e-7:
+    tests/test_gpu_masked_conv_train.py holds the node against an fp64 convolution.  PNX_TRAIN_F32_HIP=0 keeps the fp32 graph on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, mask_out, mask_in, stride):
-        x = x.contiguous(memory_format=torch.channels_last)
-        xh, xl = ops.split_f32(x)
+    def forward(ctx, x, weight, bias, mask_out, mask_in, stride, halves):
+        if halves is None:
+            halves = ops.split_f32(x.contiguous(memory_format=torch.channels_last))
+        xh, xl = halves
         wh, wl = _split_pack(weight)
-        y = ops.conv3x3_x3(xh, xl, wh, wl, weight.shape[0], stride, mask_out)
+        y = ops.conv3x3_x3(xh, xl, wh, wl, weight.shape[0], stride, mask_out, bias=None if bias is None else bias.detach().contiguous())
         ctx.save_for_backward(xh, xl, weight, mask_in, mask_out)
         ctx.stride = stride
         return y
@@ -354,10 +367,10 @@ class _MaskedConv3x3F32Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         xh, xl, weight, mask_in, mask_out = ctx.saved_tensors
-        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
         g = g.contiguous(memory_format=torch.channels_last)
         s = ctx.stride
-        dx = dw = None
+        dx = dw = db = None
         if need_w or (need_x and s == 1):
             gh, gl = ops.split_f32(g)
         if need_x:
@@ -367,10 +380,31 @@ class _MaskedConv3x3F32Fn(torch.autograd.Function):
             else:
                 dx = torch.nn.grad.conv2d_input(xh.shape, weight, g, stride=s, padding=1)
         if need_w:
-            dw = ops.conv3x3_wgrad(xh, gh, mask_out, stride=s)
-            dw += ops.conv3x3_wgrad(xl, gh, mask_out, stride=s)
-            dw += ops.conv3x3_wgrad(xh, gl, mask_out, stride=s)
-        return dx, dw, None, None, None
+            m = mask_out if mask_out is not None else _ones_mask(g.shape[0], g.shape[2], g.shape[3], g.device)
+            dw = ops.conv3x3_wgrad(xh, gh, m, stride=s)
+            dw += ops.conv3x3_wgrad(xl, gh, m, stride=s)
+            dw += ops.conv3x3_wgrad(xh, gl, m, stride=s)
+        if need_b:
+            db = g.sum(dim=(0, 2, 3))
+        return dx, dw, db, None, None, None, None
+
+
+_X3_DENSE = {(64, 64), (128, 128), (256, 256)}   # stride-1 shapes of pnx_conv3x3_x3
+
+
+def x3_ok(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1, training=True):
+    """Does a DENSE 3x3 convolution of the fp32 training graph (neck / head: det3d/models/utils/conv.py, centerhead.py:24-41) run on the three-product node?"""
+    return (training and torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and not torch.is_autocast_enabled() and tuple(weight.shape[2:]) == (3, 3) and (weight.shape[1], weight.shape[0]) in _X3_DENSE
+            and x.shape[1] == weight.shape[1] and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and groups == 1
+            and os.environ.get("PNX_TRAIN_F32_HIP", "1") != "0")
+
+
+def x3_conv(conv, x, halves=None):
+    """conv(x) of a dense nn.Conv2d: on _MaskedConv3x3F32Fn where x3_ok says so, the module itself (MIOpen) otherwise."""
+    if type(conv) is nn.Conv2d and conv.padding_mode == "zeros" and x3_ok(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups, conv.training):
+        return _MaskedConv3x3F32Fn.apply(x, conv.weight, conv.bias, None, None, 1, halves)
+    return conv(x)
 
 
 # (Cin, Cout, stride) served by the LDS-staged kernels of csrc/conv3x3.hip (every 3x3 layer of the PillarNeXt-B backbone)
@@ -389,7 +423,7 @@ def masked_conv(conv, x, mask_out, mask_in):
             and not torch.is_autocast_enabled() and x.dtype == torch.float32 and conv.weight.dtype == torch.float32
             and os.environ.get("PNX_TRAIN_F32_HIP", "1") != "0"
             and (conv.in_channels, conv.out_channels, conv.stride[0]) in _HIP_TRAIN_CONVS):
-        return _MaskedConv3x3F32Fn.apply(x, conv.weight, _mask_u8(mask_out), _mask_u8(mask_in), conv.stride[0])
+        return _MaskedConv3x3F32Fn.apply(x, conv.weight, None, _mask_u8(mask_out), _mask_u8(mask_in), conv.stride[0], None)
     return conv(x)
 
 
@@ -523,7 +557,7 @@ class Conv(nn.Module):
         self.conv = conv_layer(inplanes, planes, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias)
 
     def forward(self, x):
-        return self.conv(x)
+        return x3_conv(self.conv, x)
 
 
 class ConvBlock(nn.Module):
@@ -562,7 +596,8 @@ class ASPPNeck(nn.Module):
     def _forward(self, x):
         x = self.pre_conv(x)
         w = self.weight.to(x.dtype)
-        outs = [x, self.conv1x1(x)] + [F.conv2d(x, w, stride=1, bias=None, padding=d, dilation=d) for d in (1, 6, 12, 18)]
+        d1 = _MaskedConv3x3F32Fn.apply(x, w, None, None, None, 1, None) if x3_ok(x, w, training=self.training) else F.conv2d(x, w, stride=1, bias=None, padding=1)
+        outs = [x, self.conv1x1(x), d1] + [F.conv2d(x, w, stride=1, bias=None, padding=d, dilation=d) for d in (6, 12, 18)]
         return self.post_conv(torch.cat(outs, dim=1))
 
     def forward(self, x):
@@ -595,7 +630,19 @@ class SepHead(nn.Module):
 
     def forward(self, x):
         x = self.deblock(x)
-        return {head: getattr(self, head)(x) for head in self.heads}
+        first = [getattr(self, head)[0] for head in self.heads]
+        if not (x.is_cuda and any(type(c) is nn.Conv2d and x3_ok(x, c.weight, c.stride, c.padding, c.dilation, c.groups, c.training) for c in first)):
+            return {head: getattr(self, head)(x) for head in self.heads}
+        # fp32 training: the branches' first 3x3 convolutions on the three-product node, their shared input split into its bf16 halves once
+        halves = ops.split_f32(x.contiguous(memory_format=torch.channels_last))
+        out = {}
+        for head in self.heads:
+            fc = getattr(self, head)
+            h = x3_conv(fc[0], x, halves)
+            for layer in list(fc)[1:]:
+                h = layer(h)
+            out[head] = h
+        return out
 
 
 def _cfg_get(cfg, name):

@@ -465,9 +465,11 @@ def split_f32(x):
 CONV3X3_X3_SHAPES = {1: {(64, 64), (128, 128), (256, 256)}, 2: {(64, 128), (128, 256), (256, 256)}}   # stride -> (Cin, Cout) of pnx_conv3x3_x3
 
 
-def conv3x3_x3(x_hi, x_lo, wfrag_hi, wfrag_lo, cout, stride, mask):
+def conv3x3_x3(x_hi, x_lo, wfrag_hi, wfrag_lo, cout, stride, mask, bias=None):
     """fp32 (B,Cout,Ho,Wo) channels_last = masked 3x3 convolution of x_hi + x_lo with W_hi + W_lo (three bf16 products accumulated in fp32 in one
-    launch, pnx_conv3x3_x3); mask uint8 (B,Ho,Wo) of the OUTPUT sites or None; zeros at inactive sites."""
+    launch, pnx_conv3x3_x3) [+ bias, fp32 (Cout,)]; mask uint8 (B,Ho,Wo) of the OUTPUT sites or None (dense); zeros at inactive sites."""
+    if bias is not None and not (bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == cout and bias.is_contiguous()):
+        raise PnxError("conv3x3_x3: bias must be a contiguous fp32 CUDA vector of Cout values")
     for tns in (x_hi, x_lo):
         if not (tns.is_cuda and tns.dtype == torch.bfloat16 and tns.dim() == 4 and tns.is_contiguous(memory_format=torch.channels_last)):
             raise PnxError("conv3x3_x3 needs channels_last bf16 CUDA halves")
@@ -478,7 +480,7 @@ def conv3x3_x3(x_hi, x_lo, wfrag_hi, wfrag_lo, cout, stride, mask):
     if mask is not None and (tuple(mask.shape) != (B, Ho, Wo) or mask.dtype != torch.uint8):
         raise PnxError("conv3x3_x3: mask must be uint8 (B,Ho,Wo)")
     y = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x_hi.device, memory_format=torch.channels_last)
-    check(lib().pnx_conv3x3_x3(ptr(x_hi), ptr(x_lo), ptr(wfrag_hi), ptr(wfrag_lo), ptr(mask), ptr(y), B, H, W, ci, cout, stride, stream_ptr()), "pnx_conv3x3_x3")
+    check(lib().pnx_conv3x3_x3(ptr(x_hi), ptr(x_lo), ptr(wfrag_hi), ptr(wfrag_lo), ptr(bias), ptr(mask), ptr(y), B, H, W, ci, cout, stride, stream_ptr()), "pnx_conv3x3_x3")
     return y
 
 

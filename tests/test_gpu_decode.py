@@ -239,8 +239,9 @@ def test_training_step_end_to_end():
 def test_training_graph_on_the_fused_masked_bn_kernels(monkeypatch):
     """The training graph with the masked BatchNorm + residual + ReLU node on the HIP kernels (csrc/masked_bn.hip; channels_last maps) against
     the same detector with the node in its torch statement:
-      fp32:  channels_last + HIP kernels  vs  NCHW + torch node -- same loss to 1e-5, every parameter gradient within 4 % norm-wise (what is left
-             is MIOpen running other fp32 solvers for NHWC than for NCHW; measured 0.5-2 %)
+      fp32:  channels_last + HIP kernels (masked BN node; 3x3 convolutions on the three-bf16-product node, models._MaskedConv3x3F32Fn)  vs  NCHW + torch node +
+             MIOpen fp32 convolutions -- same loss to 1e-5, every parameter gradient within 8 % norm-wise (this freshly initialised net amplifies ANY rounding difference ~1e4-1e5 x: what is left
+             is MIOpen running other fp32 solvers for NHWC than for NCHW, measured 0.5-2 %, and the three-product node's 4e-6 per layer, measured 2.5-3.9 %)
       bf16:  autocast + channels_last, HIP kernels  vs  the torch node in the same graph -- loss within 0.5 %, gradients within the run-to-run
              spread of two bf16 graphs that round differently (measured values are printed with -s)
     and, for the record, bf16 against fp32 (a freshly initialised 30-layer net with batch statistics over two frames amplifies bf16 rounding:
@@ -293,12 +294,14 @@ def test_training_graph_on_the_fused_masked_bn_kernels(monkeypatch):
         print(f"[train-graph] {tag}: worst relative L2 error of a gradient tensor {worst_rel:.4f}, worst cosine {worst_cos:.5f}; whole gradient: rel {g_rel:.4f}, cosine {g_cos:.5f}")
         return worst_rel, worst_cos, g_rel, g_cos
 
-    l_ref, g_ref = run(ref, False)                                            # fp32, NCHW: torch node
-    l_n, g_n = run(copy.deepcopy(ref).to(memory_format=torch.channels_last), False)   # fp32, channels_last: HIP kernels
+    monkeypatch.setenv("PNX_TRAIN_F32_HIP", "0")
+    l_ref, g_ref = run(ref, False)                                            # fp32, NCHW: torch node, every convolution on MIOpen's fp32 kernels
+    monkeypatch.delenv("PNX_TRAIN_F32_HIP")
+    l_n, g_n = run(copy.deepcopy(ref).to(memory_format=torch.channels_last), False)   # fp32, channels_last: HIP kernels, 3x3 layers on the three-product node
     print(f"[train-graph] loss fp32 NCHW {l_ref:.6f}, fp32 channels_last/HIP {l_n:.6f}")
     assert abs(l_n - l_ref) <= 1e-5 * abs(l_ref)
     r, c, _, _ = compare("fp32 HIP vs fp32 torch", g_ref, g_n)
-    assert r <= 0.04 and c >= 0.999
+    assert r <= 0.08 and c >= 0.997
     l_a, g_a = run(copy.deepcopy(ref).to(memory_format=torch.channels_last), True)    # bf16 autocast: HIP kernels
     monkeypatch.setenv("PNX_MASKED_BN_HIP", "0")
     l_t, g_t = run(copy.deepcopy(ref).to(memory_format=torch.channels_last), True)    # bf16 autocast: torch node

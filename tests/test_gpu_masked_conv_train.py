@@ -119,6 +119,38 @@ def test_fp32_node_on_three_bf16_products_against_fp64(cin, cout, stride, subm, 
         assert e < 3e-5, (name, e)
 
 
+@pytest.mark.parametrize("c,shape,shared", [(64, (2, 40, 72), True), (256, (1, 20, 33), False), (128, (1, 9, 31), False)])
+def test_dense_fp32_layers_on_the_three_product_node(c, shape, shared):
+    """models.x3_conv: the head's / neck's dense 3x3 nn.Conv2d (bias, every site active) on the same node, against fp64; `shared`: halves split once
+    by the caller (SepHead.forward)."""
+    import torch.nn.functional as F
+
+    from pillarnext_amd import ops
+    from pillarnext_amd.models import x3_conv
+
+    B, H, W = shape
+    gen = torch.Generator(device="cuda").manual_seed(c + H)
+    conv = torch.nn.Conv2d(c, c, 3, padding=1, bias=True).cuda().train()
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(c, device="cuda", generator=gen))
+    x0 = torch.randn((B, c, H, W), device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+    g0 = torch.randn((B, c, H, W), device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+    x = x0.clone().requires_grad_(True)
+    y = x3_conv(conv, x, ops.split_f32(x.detach()) if shared else None)
+    assert type(y.grad_fn).__name__.startswith("_MaskedConv3x3F32Fn")
+    y.backward(g0)
+    xr, wr, br = x0.double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, 1, 1)
+    yr.backward(g0.double())
+    for name, a, r in (("y", y, yr.detach()), ("dx", x.grad, xr.grad), ("dw", conv.weight.grad, wr.grad), ("db", conv.bias.grad, br.grad)):
+        e = float((a.double() - r).norm() / r.norm())
+        assert e < 3e-5, (name, e)
+    with torch.autocast("cuda", dtype=torch.bfloat16):     # not the fp32 graph: the module itself
+        assert not type(x3_conv(conv, x).grad_fn).__name__.startswith("_MaskedConv3x3F32Fn")
+    conv.eval()
+    assert not type(x3_conv(conv, x).grad_fn).__name__.startswith("_MaskedConv3x3F32Fn")
+
+
 def test_split_f32_halves():
     from pillarnext_amd import ops
 
