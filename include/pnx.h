@@ -273,6 +273,10 @@ int pnx_conv3x3_f16(const void* x, const void* wfrag, const float* bias, const v
 size_t pnx_conv3x3_wgrad_workspace_bytes(int32_t cin, int32_t cout);
 int pnx_conv3x3_wgrad_bf16(const void* x, const void* dy, const uint8_t* mask, float* dw, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
                            int32_t stride, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
+/* The fp32 graph's weight gradient from the bf16 halves of both operands (pnx_split_f32): x_hi dY_hi + x_lo dY_hi + x_hi dY_lo in one pass, four operand
+ * tiles staged for the three products, fp32 accumulation, deterministic; shapes, mask and workspace as pnx_conv3x3_wgrad_bf16. */
+int pnx_conv3x3_wgrad_x3(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, const uint8_t* mask, float* dw, int32_t batch, int32_t h,
+                         int32_t w, int32_t cin, int32_t cout, int32_t stride, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
 /* (cout, cin, 3, 3) fp32 / bf16 weights -> wfrag of pnx_conv3x3_bf16 (9*cout*cin bf16) in one launch; transposed != 0: the weights of the data
  * gradient of a stride-1 layer, wt[ci][co][ky][kx] = w[co][ci][2-ky][2-kx], i.e. the wfrag of a cout -> cin convolution. */
 int pnx_conv3x3_pack_weights(const void* w, int32_t dtype, int32_t cout, int32_t cin, int32_t transposed, void* wfrag, pnx_stream_t stream);
@@ -321,8 +325,9 @@ int pnx_sephead_lazy_f16(const PnxLazyTask* tasks, int32_t n_tasks, const int32_
  * NHWC bf16; wfrag_hi, wfrag_lo: pnx_conv3x3_pack_weights of the two weight halves; y: fp32 NHWC (batch, ho, wo, cout), zeros at inactive sites, every
  * site written; bias: cout fp32 values added at the active sites, or NULL; no activation (the training graph's BatchNorm follows).  mask NULL: every site
  * is active (the dense head / neck layers: det3d/models/heads/centerhead.py:24-41, det3d/models/utils/conv.py).  Shapes: stride 1 64->64, 128->128, 256->256; stride 2 64->128,
- * 128->256, 256->256.  n of pnx_split_f32: a multiple of 8. */
-int pnx_split_f32(const float* x, void* hi, void* lo, int64_t n, pnx_stream_t stream);
+ * 128->256, 256->256.  n of pnx_split_f32: a multiple of 8; mask (may be NULL): x is an NHWC map of n / channels sites that is zero at the sites where
+ * mask is 0 -- those sites are not read, zeros are written (the maps of the sparse backbone: x at its active set, the gradient at the output's). */
+int pnx_split_f32(const float* x, void* hi, void* lo, int64_t n, const uint8_t* mask, int32_t channels, pnx_stream_t stream);
 int pnx_conv3x3_x3(const void* x_hi, const void* x_lo, const void* wfrag_hi, const void* wfrag_lo, const float* bias, const uint8_t* mask, float* y,
                    int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, pnx_stream_t stream);
 /* Active-site rule of SparseConv2d(k=3, stride, pad=1): mask_out = maxpool3x3(mask_in, stride, 1); uint8 (B,h,w) -> (B,ho,wo). */

@@ -61,13 +61,14 @@ struct TileRegs {
 // H, W: the INPUT map; Ho, Wo: the output map (= H, W at stride 1)
 template <int S>
 __device__ __forceinline__ void tile_load(TileRegs<S>& R, const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, const uint8_t* __restrict__ mask, int tile,
-                                          int tiles_x, int tiles_y, int H, int W, int Ho, int Wo, int cin, int cout, int cb, int ib, int t) {
+                                          int tiles_x, int tiles_y, int H, int W, int Ho, int Wo, int cin, int cout, int cb, int ib, int t, bool ld_x = true,
+                                          bool ld_y = true) {
   using G = WgGeo<S>;
   const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
   const int x0 = tx << 5, y0 = ty * G::TH;
   R.on = 0u;
 #pragma unroll
-  for (int j = 0; j < G::NY; j++) {  // dY: chunk c = t + 256 j -> row j, pixel (t >> 3), chunk t & 7; zero at inactive outputs
+  for (int j = 0; j < G::NY && ld_y; j++) {  // dY: chunk c = t + 256 j -> row j, pixel (t >> 3), chunk t & 7; zero at inactive outputs
     const int q = t & 7, px = t >> 3, oy = y0 + j, ox = x0 + px;
     R.y[j] = make_uint4(0, 0, 0, 0);
     if (oy < Ho && ox < Wo) {
@@ -79,7 +80,7 @@ __device__ __forceinline__ void tile_load(TileRegs<S>& R, const uint16_t* __rest
     }
   }
 #pragma unroll
-  for (int j = 0; j < G::NX; j++) {  // X halo: chunk c = t + 256 j of XH x XW x 8; zero outside the image
+  for (int j = 0; j < G::NX && ld_x; j++) {  // X halo: chunk c = t + 256 j of XH x XW x 8; zero outside the image
     const int c = t + 256 * j, q = c & 7, p = c >> 3, r = p / G::XW, px = p - r * G::XW;
     const int iy = S * y0 - 1 + r, ix = S * x0 - 1 + px;
     R.x[j] = make_uint4(0, 0, 0, 0);
@@ -89,23 +90,26 @@ __device__ __forceinline__ void tile_load(TileRegs<S>& R, const uint16_t* __rest
 }
 
 template <int S>
-__device__ __forceinline__ void tile_store(const TileRegs<S>& R, uint8_t* sx, uint8_t* sy, uint32_t* rowmask, int t) {
+__device__ __forceinline__ void tile_store(const TileRegs<S>& R, uint8_t* sx, uint8_t* sy, uint32_t* rowmask, int t, bool st_x = true, bool st_y = true) {
   using G = WgGeo<S>;
 #pragma unroll
-  for (int j = 0; j < G::NY; j++) {
+  for (int j = 0; j < G::NY && st_y; j++) {
     *reinterpret_cast<uint4*>(sy + (j * 32 + (t >> 3)) * WG_PS + 16 * (t & 7)) = R.y[j];
     if ((t & 7) == 0 && ((R.on >> j) & 1u)) atomicOr(&rowmask[j], 1u << (t >> 3));  // row masks of the tile: which 16-pixel pieces hold an active output
   }
 #pragma unroll
-  for (int j = 0; j < G::NX; j++) {
+  for (int j = 0; j < G::NX && st_x; j++) {
     const int c = t + 256 * j;
     if (c < G::XH * G::XW * 8) *reinterpret_cast<uint4*>(sx + (c >> 3) * WG_PS + 16 * (c & 7)) = R.x[j];
   }
 }
 
-template <int S>
+// X3 (pnx_conv3x3_wgrad_x3: the fp32 weight gradient from the operands' bf16 halves): every listed tile is visited three times, the accumulators running
+// through -- X = x_lo, Y = dy_hi;  then X = x_hi (Y stays in LDS);  then Y = dy_lo (X stays) -- four operand tiles from HBM for the three products.
+template <int S, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void k_wgrad64(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, const uint8_t* __restrict__ mask,
-                                                    float* __restrict__ part, int B, int H, int W, int Ho, int Wo, int cin, int cout, int G) {
+                                                    float* __restrict__ part, int B, int H, int W, int Ho, int Wo, int cin, int cout, int G,
+                                                    const uint16_t* __restrict__ x_lo = nullptr, const uint16_t* __restrict__ dy_lo = nullptr) {
   using Geo = WgGeo<S>;
   constexpr int TH = Geo::TH, XW = Geo::XW;
   extern __shared__ __align__(16) uint8_t s_tile[];  // X halo tile, the dY tile, the workgroup's list of non-empty tiles (no static LDS in front: the base stays 16-byte aligned)
@@ -171,13 +175,20 @@ __global__ __launch_bounds__(256, 2) void k_wgrad64(const uint16_t* __restrict__
   const int n_mine = min(s_list[0], WG_LIST_MAX);
   // ---- software pipeline over the non-empty tiles: the operands of tile k + 1 travel HBM -> registers while the K steps of tile k run
   TileRegs<S> R;
-  if (n_mine > 0) tile_load<S>(R, x, dy, mask, s_list[1], tiles_x, tiles_y, H, W, Ho, Wo, cin, cout, cb, ib, t);
-  for (int k = 0; k < n_mine; k++) {
-    uint32_t* rm = s_rm + 4 * (k & 1);
-    tile_store<S>(R, sx, sy, rm, t);
+  constexpr int NV = X3 ? 3 : 1;  // visits per tile
+  auto visit_load = [&](int v) {
+    const int ph = X3 ? v % 3 : 0;
+    tile_load<S>(R, X3 && ph == 0 ? x_lo : x, X3 && ph == 2 ? dy_lo : dy, mask, s_list[1 + v / NV], tiles_x, tiles_y, H, W, Ho, Wo, cin, cout, cb, ib, t,
+                 !X3 || ph != 2, !X3 || ph != 1);
+  };
+  if (n_mine > 0) visit_load(0);
+  for (int v = 0; v < NV * n_mine; v++) {
+    const int k = v / NV, ph = X3 ? v % 3 : 0;
+    uint32_t* rm = s_rm + 4 * (k & 1);  // the tile's row masks: set by the visits that stage dY (the same bits each time)
+    tile_store<S>(R, sx, sy, rm, t, !X3 || ph != 2, !X3 || ph != 1);
     __syncthreads();
-    if (t < 4) s_rm[4 * ((k + 1) & 1) + t] = 0u;  // the next tile's set: its writers come behind this iteration's last barrier
-    if (k + 1 < n_mine) tile_load<S>(R, x, dy, mask, s_list[2 + k], tiles_x, tiles_y, H, W, Ho, Wo, cin, cout, cb, ib, t);
+    if (t < 4 && ph == NV - 1) s_rm[4 * ((k + 1) & 1) + t] = 0u;  // the next tile's set: its writers come behind this iteration's last barrier
+    if (v + 1 < NV * n_mine) visit_load(v + 1);
 #pragma unroll 1
     for (int ks = 0; ks < 2 * TH; ks++) {  // rolled: unrolled, the steps' reads are hoisted and the accumulators spill
       const int r = ks >> 1, hs = ks & 1;
@@ -264,8 +275,9 @@ extern "C" size_t pnx_conv3x3_wgrad_workspace_bytes(int32_t cin, int32_t cout) {
   return (size_t)(cin >> 6) * (cout >> 6) * groups_per_pair(cin, cout) * 9 * 4096 * sizeof(float) + 256;
 }
 
-template <int S>
-int launch_wgrad(const void* x, const void* dy, const uint8_t* mask, float* dw, int batch, int h, int w, int cin, int cout, void* workspace, hipStream_t st) {
+template <int S, bool X3 = false>
+int launch_wgrad(const void* x, const void* dy, const uint8_t* mask, float* dw, int batch, int h, int w, int cin, int cout, void* workspace, hipStream_t st,
+                 const void* x_lo = nullptr, const void* dy_lo = nullptr) {
   using Geo = WgGeo<S>;
   const int ho = (h - 1) / S + 1, wo = (w - 1) / S + 1;
   const int G = groups_per_pair(cin, cout), n_pairs = (cin >> 6) * (cout >> 6);
@@ -274,11 +286,11 @@ int launch_wgrad(const void* x, const void* dy, const uint8_t* mask, float* dw, 
               (long long)n_tiles, G, WG_LIST_MAX);
   static bool attr_done = false;
   if (!attr_done) {
-    PNX_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad64<S>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS));
+    PNX_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad64<S, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS));
     attr_done = true;
   }
-  k_wgrad64<S><<<dim3((unsigned)G, (unsigned)n_pairs), 256, Geo::LDS, st>>>((const uint16_t*)x, (const uint16_t*)dy, mask, (float*)workspace, batch, h, w, ho, wo,
-                                                                             cin, cout, G);
+  k_wgrad64<S, X3><<<dim3((unsigned)G, (unsigned)n_pairs), 256, Geo::LDS, st>>>((const uint16_t*)x, (const uint16_t*)dy, mask, (float*)workspace, batch, h, w, ho,
+                                                                                 wo, cin, cout, G, (const uint16_t*)x_lo, (const uint16_t*)dy_lo);
   PNX_LAUNCH_CHECK();
   k_wgrad_reduce<<<(unsigned)((n_pairs * 9 * 4096 + 31) / 32), 256, 0, st>>>((const float*)workspace, dw, cin, cout, G);
   PNX_LAUNCH_CHECK();
@@ -308,4 +320,21 @@ extern "C" int pnx_conv3x3_pack_weights(const void* w, int32_t dtype, int32_t co
   else k_pack_w3x3<__bf16><<<(n + 255) / 256, 256, 0, st>>>((const __bf16*)w, cout, cin, transposed, (uint16_t*)wfrag);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
+}
+
+// fp32 weight gradient from the bf16 halves of x and of the upstream gradient (pnx_split_f32): dW = x_hi dY_hi + x_lo dY_hi + x_hi dY_lo in ONE pass over
+// the tiles (k_wgrad64<S, true>), fp32 accumulation throughout, deterministic.  Same shapes, mask and workspace as pnx_conv3x3_wgrad_bf16.
+extern "C" int pnx_conv3x3_wgrad_x3(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, const uint8_t* mask, float* dw, int32_t batch,
+                                    int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, void* workspace, size_t workspace_bytes,
+                                    pnx_stream_t stream) {
+  PNX_REQUIRE(x_hi && x_lo && dy_hi && dy_lo && mask && dw && workspace && batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "pnx_conv3x3_wgrad_x3: bad arguments");
+  PNX_REQUIRE(stride == 1 || stride == 2, PNX_ERR_UNSUPPORTED, "stride %d", stride);
+  PNX_REQUIRE(cin >= 64 && cout >= 64 && (cin & 63) == 0 && (cout & 63) == 0 && cin <= 512 && cout <= 512, PNX_ERR_UNSUPPORTED,
+              "weight gradient for %d -> %d channels (multiples of 64 up to 512)", cin, cout);
+  PNX_REQUIRE((((uintptr_t)x_hi | (uintptr_t)x_lo | (uintptr_t)dy_hi | (uintptr_t)dy_lo | (uintptr_t)workspace) & 15) == 0, PNX_ERR_INVALID,
+              "16-byte alignment required");
+  PNX_REQUIRE(workspace_bytes >= pnx_conv3x3_wgrad_workspace_bytes(cin, cout), PNX_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1) return launch_wgrad<1, true>(x_hi, dy_hi, mask, dw, batch, h, w, cin, cout, workspace, st, x_lo, dy_lo);
+  return launch_wgrad<2, true>(x_hi, dy_hi, mask, dw, batch, h, w, cin, cout, workspace, st, x_lo, dy_lo);
 }

@@ -220,8 +220,16 @@ __device__ __forceinline__ uint32_t bf16_rne(float v) {
   if ((u & 0x7f800000u) == 0x7f800000u) return (u >> 16) | ((u & 0xffffu) != 0 ? 0x40u : 0u);  // inf / nan stay what they are
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-__global__ __launch_bounds__(256) void k_split_f32(const float4* __restrict__ x, uint4* __restrict__ hi, uint4* __restrict__ lo, int64_t n8) {
+// MASKED: x is an NHWC map that is zero at the inactive sites of `mask` (c8 = channels / 8 threads per site): those sites are not read, zeros are written.
+template <bool MASKED>
+__global__ __launch_bounds__(256) void k_split_f32(const float4* __restrict__ x, uint4* __restrict__ hi, uint4* __restrict__ lo, int64_t n8,
+                                                   const uint8_t* __restrict__ mask, int c8) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    if (MASKED && mask[i / c8] == 0) {
+      hi[i] = make_uint4(0, 0, 0, 0);
+      lo[i] = make_uint4(0, 0, 0, 0);
+      continue;
+    }
     const float4 a = x[2 * i], b = x[2 * i + 1];
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     uint32_t h[8], l[8];
@@ -239,14 +247,17 @@ __global__ __launch_bounds__(256) void k_split_f32(const float4* __restrict__ x,
 
 extern "C" {
 
-int pnx_split_f32(const float* x, void* hi, void* lo, int64_t n, pnx_stream_t stream) {
+int pnx_split_f32(const float* x, void* hi, void* lo, int64_t n, const uint8_t* mask, int32_t channels, pnx_stream_t stream) {
   PNX_REQUIRE(x && hi && lo && n >= 0 && n % 8 == 0, PNX_ERR_INVALID, "pnx_split_f32: null pointer or a count that is not a multiple of 8");
+  PNX_REQUIRE(mask == nullptr || (channels > 0 && channels % 8 == 0 && n % channels == 0), PNX_ERR_INVALID,
+              "pnx_split_f32: with a mask, channels must be a multiple of 8 that divides n");
   PNX_REQUIRE((((uintptr_t)x | (uintptr_t)hi | (uintptr_t)lo) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
   if (n == 0) return PNX_OK;
   const int64_t n8 = n / 8;
   int64_t nb = (n8 + 255) / 256;
   if (nb > 256 * 16) nb = 256 * 16;
-  k_split_f32<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>((const float4*)x, (uint4*)hi, (uint4*)lo, n8);
+  if (mask != nullptr) k_split_f32<true><<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>((const float4*)x, (uint4*)hi, (uint4*)lo, n8, mask, channels / 8);
+  else k_split_f32<false><<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>((const float4*)x, (uint4*)hi, (uint4*)lo, n8, nullptr, 1);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }

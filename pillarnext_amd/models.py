@@ -347,7 +347,7 @@ class _MaskedConv3x3F32Fn(torch.autograd.Function):
     is split into two bf16 halves (16 mantissa bits together) and the three significant products run on the bf16 matrix cores with fp32 accumulation.
       forward   pnx_conv3x3_x3 on (x_hi, x_lo) x (W_hi, W_lo) [+ bias]: one launch, fp32 out
       dgrad     stride 1: the same kernel on the halves of g and of W^T flipped, masked by the INPUT's active set; stride 2: MIOpen's fp32 dgrad
-      wgrad     pnx_conv3x3_wgrad_bf16 three times (x_hi g_hi + x_lo g_hi + x_hi g_lo), each accumulated in fp32
+      wgrad     pnx_conv3x3_wgrad_x3: x_hi g_hi + x_lo g_hi + x_hi g_lo in one pass, accumulated in fp32
     mask_out = mask_in = None: a dense layer (the neck's and the head's 3x3 convolutions, x3_conv below).  halves: (x_hi, x_lo) when the caller
     already split x (the six branches of a SepHead share their input).
     Relative error of every product ~ 4e-6 (the dropped low x low term and the halves' rounding, 2^-17 each), against MIOpen's fp32 kernels' ~ 2e-7:
@@ -356,7 +356,7 @@ class _MaskedConv3x3F32Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, mask_out, mask_in, stride, halves):
         if halves is None:
-            halves = ops.split_f32(x.contiguous(memory_format=torch.channels_last))
+            halves = ops.split_f32(x.contiguous(memory_format=torch.channels_last), mask_in)   # x is zero outside its active set (masked_bn_act, the scatter)
         xh, xl = halves
         wh, wl = _split_pack(weight)
         y = ops.conv3x3_x3(xh, xl, wh, wl, weight.shape[0], stride, mask_out, bias=None if bias is None else bias.detach().contiguous())
@@ -372,7 +372,7 @@ class _MaskedConv3x3F32Fn(torch.autograd.Function):
         s = ctx.stride
         dx = dw = db = None
         if need_w or (need_x and s == 1):
-            gh, gl = ops.split_f32(g)
+            gh, gl = ops.split_f32(g, mask_out)   # the upstream gradient is zero outside mask_out (the BatchNorm node's backward writes zeros there)
         if need_x:
             if s == 1:
                 wth, wtl = _split_pack(weight, transposed=True)
@@ -381,9 +381,7 @@ class _MaskedConv3x3F32Fn(torch.autograd.Function):
                 dx = torch.nn.grad.conv2d_input(xh.shape, weight, g, stride=s, padding=1)
         if need_w:
             m = mask_out if mask_out is not None else _ones_mask(g.shape[0], g.shape[2], g.shape[3], g.device)
-            dw = ops.conv3x3_wgrad(xh, gh, m, stride=s)
-            dw += ops.conv3x3_wgrad(xl, gh, m, stride=s)
-            dw += ops.conv3x3_wgrad(xh, gl, m, stride=s)
+            dw = ops.conv3x3_wgrad_x3(xh, xl, gh, gl, m, stride=s)
         if need_b:
             db = g.sum(dim=(0, 2, 3))
         return dx, dw, db, None, None, None, None

@@ -451,14 +451,21 @@ def conv3x3_wgrad(x, dy, mask, stride=1):
     return dw
 
 
-def split_f32(x):
-    """fp32 tensor -> (hi, lo) bf16 tensors of the same shape and memory layout: hi = RNE(x), lo = RNE(x - hi) (pnx_split_f32)."""
+def split_f32(x, mask=None):
+    """fp32 tensor -> (hi, lo) bf16 tensors of the same shape and memory layout: hi = RNE(x), lo = RNE(x - hi) (pnx_split_f32).
+    mask: uint8 (B,H,W) for a channels_last (B,C,H,W) x that is zero where mask is 0 -- those sites are not read."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.numel() % 8 == 0):
         raise PnxError("split_f32 needs an fp32 CUDA tensor with a multiple of 8 elements")
     if not (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))):
         raise PnxError("split_f32 needs a dense tensor (contiguous or channels_last)")
+    c = 0
+    if mask is not None:
+        if not (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and mask.dtype == torch.uint8 and mask.is_contiguous()
+                and tuple(mask.shape) == (x.shape[0], x.shape[2], x.shape[3]) and x.shape[1] % 8 == 0):
+            raise PnxError("split_f32: mask needs a channels_last (B,C,H,W) tensor with C % 8 == 0 and a contiguous uint8 (B,H,W) mask")
+        c = x.shape[1]
     hi, lo = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
-    check(lib().pnx_split_f32(ptr(x), ptr(hi), ptr(lo), x.numel(), stream_ptr()), "pnx_split_f32")
+    check(lib().pnx_split_f32(ptr(x), ptr(hi), ptr(lo), x.numel(), ptr(mask), c, stream_ptr()), "pnx_split_f32")
     return hi, lo
 
 
@@ -482,6 +489,30 @@ def conv3x3_x3(x_hi, x_lo, wfrag_hi, wfrag_lo, cout, stride, mask, bias=None):
     y = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x_hi.device, memory_format=torch.channels_last)
     check(lib().pnx_conv3x3_x3(ptr(x_hi), ptr(x_lo), ptr(wfrag_hi), ptr(wfrag_lo), ptr(bias), ptr(mask), ptr(y), B, H, W, ci, cout, stride, stream_ptr()), "pnx_conv3x3_x3")
     return y
+
+
+def conv3x3_wgrad_x3(x_hi, x_lo, dy_hi, dy_lo, mask, stride=1):
+    """conv3x3_wgrad of x_hi + x_lo with dy_hi + dy_lo (three products, one pass: pnx_conv3x3_wgrad_x3): (Cout, Cin, 3, 3) fp32."""
+    for tns in (x_hi, x_lo, dy_hi, dy_lo):
+        if not (tns.is_cuda and tns.dtype == torch.bfloat16 and tns.dim() == 4 and tns.is_contiguous(memory_format=torch.channels_last)):
+            raise PnxError("conv3x3_wgrad_x3 needs channels_last bf16 CUDA halves")
+    B, ci, H, W = x_hi.shape
+    co = dy_hi.shape[1]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if (stride not in (1, 2) or x_lo.shape != x_hi.shape or dy_lo.shape != dy_hi.shape or tuple(dy_hi.shape) != (B, co, Ho, Wo)
+            or tuple(mask.shape) != (B, Ho, Wo) or mask.dtype != torch.uint8):
+        raise PnxError("conv3x3_wgrad_x3: stride 1 or 2, halves of one shape, dy (B,Cout,Ho,Wo) and a uint8 (B,Ho,Wo) mask of the output sites")
+    nbytes = int(lib().pnx_conv3x3_wgrad_workspace_bytes(ci, co))
+    if nbytes == 0:
+        raise PnxError(f"conv3x3_wgrad_x3: no kernel for {ci} -> {co} channels")
+    key = (nbytes, x_hi.device, torch.cuda.current_stream().cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=x_hi.device)
+    dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=x_hi.device)
+    check(lib().pnx_conv3x3_wgrad_x3(ptr(x_hi), ptr(x_lo), ptr(dy_hi), ptr(dy_lo), ptr(mask), ptr(dw), B, H, W, ci, co, stride, ptr(ws), ws.numel(), stream_ptr()),
+          "pnx_conv3x3_wgrad_x3")
+    return dw
 
 
 def conv3x3_workspace(batch, cout, ho, wo, device, dtype=torch.bfloat16):

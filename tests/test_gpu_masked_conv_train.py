@@ -165,6 +165,15 @@ def test_split_f32_halves():
     assert torch.equal(lo[fin], (x - hi.float()).to(torch.bfloat16)[fin])
     err = ((hi.float() + lo.float()) - x)[fin].abs()
     assert bool((err <= x[fin].abs() * 2.0 ** -16 + 1e-38).all())
+    # with a mask: inactive sites are not read (their content does not matter), zeros are written
+    m = (torch.rand((3, 17, 8), device="cuda", generator=gen) < 0.4).to(torch.uint8)
+    xm = torch.where(m[:, None].bool(), x, torch.full_like(x, float("nan")))
+    hm, lm = ops.split_f32(xm, m)
+    keep = m[:, None].bool().expand_as(x)
+    assert torch.equal(hm[keep], hi[keep]) and torch.equal(lm[keep & fin], lo[keep & fin])
+    assert bool((hm[~keep] == 0).all()) and bool((lm[~keep] == 0).all())
+    with pytest.raises(Exception):
+        ops.split_f32(x.contiguous(), m)           # the mask form is for channels_last maps
 
 
 def test_masked_conv_falls_back_outside_training_shapes():
