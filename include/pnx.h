@@ -330,6 +330,18 @@ int pnx_sephead_lazy_f16(const PnxLazyTask* tasks, int32_t n_tasks, const int32_
 int pnx_split_f32(const float* x, void* hi, void* lo, int64_t n, const uint8_t* mask, int32_t channels, pnx_stream_t stream);
 int pnx_conv3x3_x3(const void* x_hi, const void* x_lo, const void* wfrag_hi, const void* wfrag_lo, const float* bias, const uint8_t* mask, float* y,
                    int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, pnx_stream_t stream);
+/* The SepHead's output convolutions in training (csrc/head_train.hip; reference: det3d/models/heads/centerhead.py:31-41, nn.Conv2d(64, k, 3, padding 1,
+ * bias=True) with k = classes / 2 / 1 / 3 / 2 / 2, under autograd): bandwidth-bound layers MIOpen runs at 1/7 of the HBM rate.
+ *   pnx_conv3x3_smallk        y = conv3x3(x, weight) + bias: x NHWC (batch, h, w, 64), y NHWC (batch, h, w, k), both `dtype` (PNX_F32 or PNX_BF16);
+ *                             weight fp32 (k, 64, 3, 3) as the module holds it, bias fp32 (k) or NULL; fp32 accumulation
+ *   pnx_conv3x3_smallk_wgrad  dw (k, 64, 3, 3) and dbias (k; may be NULL) fp32 from x and the upstream gradient dy (NHWC, k channels), deterministic;
+ *                             workspace: pnx_conv3x3_smallk_wgrad_workspace_bytes(k)
+ * cin must be 64, 1 <= k <= 4. */
+int pnx_conv3x3_smallk(const void* x, const float* weight, const float* bias, void* y, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t k,
+                       int32_t dtype, pnx_stream_t stream);
+size_t pnx_conv3x3_smallk_wgrad_workspace_bytes(int32_t k);
+int pnx_conv3x3_smallk_wgrad(const void* x, const void* dy, float* dw, float* dbias, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t k,
+                             int32_t dtype, void* workspace, size_t workspace_bytes, pnx_stream_t stream);
 /* Active-site rule of SparseConv2d(k=3, stride, pad=1): mask_out = maxpool3x3(mask_in, stride, 1); uint8 (B,h,w) -> (B,ho,wo). */
 int pnx_mask_pool3(const uint8_t* mask_in, int32_t batch, int32_t h, int32_t w, int32_t stride, uint8_t* mask_out, pnx_stream_t stream);
 

@@ -387,6 +387,52 @@ class _MaskedConv3x3F32Fn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class _SmallKConv3x3Fn(torch.autograd.Function):
+    """nn.Conv2d(64, k <= 4, 3, padding 1, bias) of a SepHead branch in training (centerhead.py:31-41) on csrc/head_train.hip: forward and the weight / bias
+    gradient at the map's HBM rate (fp32 FMAs, fp32 accumulation, fp32 master weights also under autocast); the data gradient on MIOpen."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous(memory_format=torch.channels_last)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.conv3x3_smallk(x, weight.detach().contiguous(), None if bias is None else bias.detach().contiguous())
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad
+        dx = dw = db = None
+        g = g.to(x.dtype)
+        if need_x:
+            dx = torch.nn.grad.conv2d_input(x.shape, weight.to(x.dtype), g, stride=1, padding=1)
+        if need_w or (need_b and ctx.has_bias):
+            dw, db = ops.conv3x3_smallk_wgrad(x, g, want_bias=ctx.has_bias)
+        return dx, dw, db
+
+
+def smallk_ok(conv, x):
+    """Does the output convolution of a SepHead branch run on _SmallKConv3x3Fn?  (training, a CUDA fp32 graph or bf16 autocast; PNX_TRAIN_HEAD_HIP=0: MIOpen)"""
+    if not (type(conv) is nn.Conv2d and conv.training and torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and conv.in_channels == 64
+            and 1 <= conv.out_channels <= 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and conv.weight.dtype == torch.float32
+            and os.environ.get("PNX_TRAIN_HEAD_HIP", "1") != "0"):
+        return False
+    if torch.is_autocast_enabled():
+        return torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.dtype in (torch.bfloat16, torch.float32)
+    return x.dtype == torch.float32
+
+
+def smallk_conv(conv, x):
+    if smallk_ok(conv, x):
+        if torch.is_autocast_enabled() and x.dtype == torch.float32:
+            x = x.to(torch.bfloat16)     # what autocast does to a convolution's input
+        return _SmallKConv3x3Fn.apply(x, conv.weight, conv.bias)
+    return conv(x)
+
+
 _X3_DENSE = {(64, 64), (128, 128), (256, 256)}   # stride-1 shapes of pnx_conv3x3_x3
 
 
@@ -628,17 +674,26 @@ class SepHead(nn.Module):
 
     def forward(self, x):
         x = self.deblock(x)
-        first = [getattr(self, head)[0] for head in self.heads]
-        if not (x.is_cuda and any(type(c) is nn.Conv2d and x3_ok(x, c.weight, c.stride, c.padding, c.dilation, c.groups, c.training) for c in first)):
+        if not (self.training and x.is_cuda and torch.is_grad_enabled()):
             return {head: getattr(self, head)(x) for head in self.heads}
-        # fp32 training: the branches' first 3x3 convolutions on the three-product node, their shared input split into its bf16 halves once
-        halves = ops.split_f32(x.contiguous(memory_format=torch.channels_last))
+        # training: the branches' first 3x3 convolutions of the fp32 graph on the three-product node (their shared input split into its bf16 halves
+        # once), the output convolutions (64 -> k <= 4) on csrc/head_train.hip; anything else is the module itself
+        first = [getattr(self, head)[0] for head in self.heads]
+        halves = None
+        if any(type(c) is nn.Conv2d and len(getattr(self, h)) > 1 and x3_ok(x, c.weight, c.stride, c.padding, c.dilation, c.groups, c.training)
+               for h, c in zip(self.heads, first)):
+            halves = ops.split_f32(x.contiguous(memory_format=torch.channels_last))
         out = {}
         for head in self.heads:
-            fc = getattr(self, head)
-            h = x3_conv(fc[0], x, halves)
-            for layer in list(fc)[1:]:
-                h = layer(h)
+            layers = list(getattr(self, head))
+            h = x
+            for i, layer in enumerate(layers):
+                if i == len(layers) - 1:
+                    h = smallk_conv(layer, h)
+                elif i == 0 and halves is not None:
+                    h = x3_conv(layer, h, halves)
+                else:
+                    h = layer(h)
             out[head] = h
         return out
 

@@ -515,6 +515,47 @@ def conv3x3_wgrad_x3(x_hi, x_lo, dy_hi, dy_lo, mask, stride=1):
     return dw
 
 
+def _smallk_check(x, what):
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous(memory_format=torch.channels_last)):
+        raise PnxError(f"{what} must be a channels_last fp32 / bf16 CUDA tensor")
+
+
+def conv3x3_smallk(x, weight, bias=None):
+    """nn.Conv2d(64, k, 3, padding=1) with k <= 4 on a channels_last fp32 / bf16 map (pnx_conv3x3_smallk): (B,k,H,W) channels_last of x's dtype;
+    weight (k,64,3,3) and bias (k) fp32."""
+    _smallk_check(x, "conv3x3_smallk: x")
+    k = weight.shape[0]
+    if not (weight.is_cuda and weight.dtype == torch.float32 and tuple(weight.shape[1:]) == (64, 3, 3) and weight.is_contiguous() and 1 <= k <= 4
+            and x.shape[1] == 64 and (bias is None or (bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == k and bias.is_contiguous()))):
+        raise PnxError("conv3x3_smallk: weight must be a contiguous fp32 (k,64,3,3) with k <= 4, bias fp32 (k)")
+    B, _, H, W = x.shape
+    y = torch.empty((B, k, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if k == 1:   # (B,1,H,W): channels_last and contiguous coincide, torch may report either stride set
+        y = torch.empty((B, H, W, 1), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+    check(lib().pnx_conv3x3_smallk(ptr(x), ptr(weight), ptr(bias), ptr(y), B, H, W, 64, k, 0 if x.dtype == torch.float32 else 1, stream_ptr()), "pnx_conv3x3_smallk")
+    return y
+
+
+def conv3x3_smallk_wgrad(x, dy, want_bias=True):
+    """(dw (k,64,3,3), dbias (k) or None), fp32, of conv3x3_smallk from x and the upstream gradient dy (B,k,H,W) (pnx_conv3x3_smallk_wgrad)."""
+    _smallk_check(x, "conv3x3_smallk_wgrad: x")
+    B, c, H, W = x.shape
+    k = dy.shape[1]
+    if not (c == 64 and 1 <= k <= 4 and dy.is_cuda and dy.dtype == x.dtype and tuple(dy.shape) == (B, k, H, W)):
+        raise PnxError("conv3x3_smallk_wgrad: x (B,64,H,W), dy (B,k,H,W) of the same dtype, k <= 4")
+    dyc = dy.permute(0, 2, 3, 1).contiguous()    # NHWC with k channels (a no-op for a channels_last gradient)
+    nbytes = int(lib().pnx_conv3x3_smallk_wgrad_workspace_bytes(k))
+    key = (nbytes, x.device, torch.cuda.current_stream().cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dw = torch.empty((k, 64, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((k,), dtype=torch.float32, device=x.device) if want_bias else None
+    check(lib().pnx_conv3x3_smallk_wgrad(ptr(x), ptr(dyc), ptr(dw), ptr(db), B, H, W, 64, k, 0 if x.dtype == torch.float32 else 1, ptr(ws), ws.numel(), stream_ptr()),
+          "pnx_conv3x3_smallk_wgrad")
+    return dw, db
+
+
 def conv3x3_workspace(batch, cout, ho, wo, device, dtype=torch.bfloat16):
     """A persistent (output buffer, row_dirty flags) pair for conv3x3_masked(out=...): both start zeroed (pnx.h: row_dirty)."""
     y = torch.zeros((batch, cout, ho, wo), dtype=dtype, device=device).contiguous(memory_format=torch.channels_last)

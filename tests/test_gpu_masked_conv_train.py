@@ -151,6 +151,45 @@ def test_dense_fp32_layers_on_the_three_product_node(c, shape, shared):
     assert not type(x3_conv(conv, x).grad_fn).__name__.startswith("_MaskedConv3x3F32Fn")
 
 
+@pytest.mark.parametrize("k,shape,dtype", [(1, (2, 37, 50), torch.float32), (2, (1, 64, 64), torch.float32), (3, (2, 21, 19), torch.float32),
+                                           (4, (1, 8, 16), torch.float32), (2, (2, 40, 33), torch.bfloat16), (3, (1, 30, 47), torch.bfloat16),
+                                           (1, (1, 5, 3), torch.bfloat16)])
+def test_sephead_output_convolution_kernels(k, shape, dtype):
+    """csrc/head_train.hip (models._SmallKConv3x3Fn) against the fp64 autograd of F.conv2d on the same operands: fp32 maps to 1e-5 of the sum of |terms|,
+    bf16 maps (fp32 accumulation of bf16 inputs, output rounded once) to one bf16 ulp on top."""
+    import torch.nn.functional as F
+
+    from pillarnext_amd.models import smallk_conv
+
+    B, H, W = shape
+    gen = torch.Generator(device="cuda").manual_seed(11 * k + H)
+    conv = torch.nn.Conv2d(64, k, 3, padding=1, bias=True).cuda().train()
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(k, device="cuda", generator=gen))
+    x0 = torch.randn((B, 64, H, W), device="cuda", generator=gen).to(dtype).contiguous(memory_format=torch.channels_last)
+    g0 = torch.randn((B, k, H, W), device="cuda", generator=gen).to(dtype)
+    x = x0.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        y = smallk_conv(conv, x)
+    assert y.dtype == dtype and type(y.grad_fn).__name__.startswith("_SmallKConv3x3Fn") and tuple(y.shape) == (B, k, H, W)
+    y.backward(g0)
+    xr, wr, br = x0.double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, 1, 1)
+    yr.backward(g0.double())
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 0.0
+    ya = F.conv2d(x0.double().abs(), wr.detach().abs(), br.detach().abs(), 1, 1)
+    assert bool(((y.double() - yr.detach()).abs() <= 1e-5 * ya + ulp * yr.detach().abs()).all())
+    dwa = torch.nn.grad.conv2d_weight(x0.double().abs(), wr.shape, g0.double().abs(), stride=1, padding=1)
+    assert bool(((conv.weight.grad.double() - wr.grad).abs() <= 1e-5 * dwa).all())
+    assert bool(((conv.bias.grad.double() - br.grad).abs() <= 1e-5 * g0.double().abs().sum(dim=(0, 2, 3))).all())
+    # the data gradient is MIOpen's (fp32: its fp32 kernels; bf16: weights rounded to bf16 like any autocast convolution)
+    e = float((x.grad.double() - xr.grad).norm() / xr.grad.norm())
+    assert e < (2e-2 if dtype == torch.bfloat16 else 1e-5), e
+    conv.eval()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        assert not type(smallk_conv(conv, x).grad_fn).__name__.startswith("_SmallKConv3x3Fn")
+
+
 def test_split_f32_halves():
     from pillarnext_amd import ops
 
