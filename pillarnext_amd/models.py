@@ -290,10 +290,11 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
-    def forward(ctx, x, weight, mask_out, mask_in, stride):
+    def forward(ctx, x, weight, mask_out, mask_in, stride, bias=None):
         x = x.contiguous(memory_format=torch.channels_last)
         co = weight.shape[0]
-        y = ops.conv3x3_masked(x, ops.conv3x3_pack_weights(weight), _zero_bias(co, x.device), co, stride=stride, mask=mask_out, relu=False)
+        b = _zero_bias(co, x.device) if bias is None else bias.detach().float().contiguous()   # the kernel's bias is fp32 (autocast handed in a bf16 copy)
+        y = ops.conv3x3_masked(x, ops.conv3x3_pack_weights(weight), b, co, stride=stride, mask=mask_out, relu=False)
         ctx.save_for_backward(x, weight, mask_in, mask_out)
         ctx.stride = stride
         return y
@@ -305,6 +306,9 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
         g = g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = None
+        db = g.sum(dim=(0, 2, 3), dtype=torch.float32) if len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5] else None
+        if mask_out is None:   # a dense layer (dense_conv below): the weight-gradient kernel wants the output's active set
+            mask_out = _ones_mask(g.shape[0], g.shape[2], g.shape[3], g.device)
         if ctx.stride == 1:
             if need_x:
                 ci = weight.shape[1]
@@ -323,7 +327,7 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
             if need_x or (need_w and not hip_w):
                 dx, dw2, _ = torch.ops.aten.convolution_backward(g, x, weight, None, (s, s), (1, 1), (1, 1), False, (0, 0), 1, (need_x, need_w and not hip_w, False))
                 dw = dw if hip_w else dw2
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, db
 
 
 def _split_pack(weight, transposed=False):
@@ -444,10 +448,23 @@ def x3_ok(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1, t
             and os.environ.get("PNX_TRAIN_F32_HIP", "1") != "0")
 
 
+def bf16_dense_ok(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1, training=True):
+    """x3_ok's twin under bf16 autocast: the same dense layers on the bf16 masked kernels with every site active (_MaskedConv3x3Fn)."""
+    return (training and torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and tuple(weight.shape[2:]) == (3, 3) and (weight.shape[1], weight.shape[0]) in _X3_DENSE
+            and x.shape[1] == weight.shape[1] and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and groups == 1
+            and os.environ.get("PNX_TRAIN_HIPCONV", "1") != "0" and os.environ.get("PNX_TRAIN_DENSE_HIP", "1") != "0")
+
+
 def x3_conv(conv, x, halves=None):
-    """conv(x) of a dense nn.Conv2d: on _MaskedConv3x3F32Fn where x3_ok says so, the module itself (MIOpen) otherwise."""
-    if type(conv) is nn.Conv2d and conv.padding_mode == "zeros" and x3_ok(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups, conv.training):
-        return _MaskedConv3x3F32Fn.apply(x, conv.weight, conv.bias, None, None, 1, halves)
+    """conv(x) of a dense nn.Conv2d in training: the fp32 graph on _MaskedConv3x3F32Fn where x3_ok says so, bf16 autocast on _MaskedConv3x3Fn where
+    bf16_dense_ok does, the module itself (MIOpen) otherwise."""
+    if type(conv) is nn.Conv2d and conv.padding_mode == "zeros":
+        if x3_ok(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups, conv.training):
+            return _MaskedConv3x3F32Fn.apply(x, conv.weight, conv.bias, None, None, 1, halves)
+        if bf16_dense_ok(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups, conv.training):
+            return _MaskedConv3x3Fn.apply(x, conv.weight, None, None, 1, conv.bias)
     return conv(x)
 
 
@@ -640,7 +657,12 @@ class ASPPNeck(nn.Module):
     def _forward(self, x):
         x = self.pre_conv(x)
         w = self.weight.to(x.dtype)
-        d1 = _MaskedConv3x3F32Fn.apply(x, w, None, None, None, 1, None) if x3_ok(x, w, training=self.training) else F.conv2d(x, w, stride=1, bias=None, padding=1)
+        if x3_ok(x, w, training=self.training):
+            d1 = _MaskedConv3x3F32Fn.apply(x, w, None, None, None, 1, None)
+        elif bf16_dense_ok(x, w, training=self.training):
+            d1 = _MaskedConv3x3Fn.apply(x, w, None, None, 1, None)
+        else:
+            d1 = F.conv2d(x, w, stride=1, bias=None, padding=1)
         outs = [x, self.conv1x1(x), d1] + [F.conv2d(x, w, stride=1, bias=None, padding=d, dilation=d) for d in (6, 12, 18)]
         return self.post_conv(torch.cat(outs, dim=1))
 
@@ -676,8 +698,9 @@ class SepHead(nn.Module):
         x = self.deblock(x)
         if not (self.training and x.is_cuda and torch.is_grad_enabled()):
             return {head: getattr(self, head)(x) for head in self.heads}
-        # training: the branches' first 3x3 convolutions of the fp32 graph on the three-product node (their shared input split into its bf16 halves
-        # once), the output convolutions (64 -> k <= 4) on csrc/head_train.hip; anything else is the module itself
+        # training: the branches' first 3x3 convolutions on the product's kernels (x3_conv: the fp32 graph on the three-product node, their shared input
+        # split into its bf16 halves once; bf16 autocast on the bf16 kernels), the output convolutions (64 -> k <= 4) on csrc/head_train.hip; anything
+        # else is the module itself
         first = [getattr(self, head)[0] for head in self.heads]
         halves = None
         if any(type(c) is nn.Conv2d and len(getattr(self, h)) > 1 and x3_ok(x, c.weight, c.stride, c.padding, c.dilation, c.groups, c.training)
@@ -690,7 +713,7 @@ class SepHead(nn.Module):
             for i, layer in enumerate(layers):
                 if i == len(layers) - 1:
                     h = smallk_conv(layer, h)
-                elif i == 0 and halves is not None:
+                elif i == 0:
                     h = x3_conv(layer, h, halves)
                 else:
                     h = layer(h)

@@ -145,8 +145,15 @@ def test_dense_fp32_layers_on_the_three_product_node(c, shape, shared):
     for name, a, r in (("y", y, yr.detach()), ("dx", x.grad, xr.grad), ("dw", conv.weight.grad, wr.grad), ("db", conv.bias.grad, br.grad)):
         e = float((a.double() - r).norm() / r.norm())
         assert e < 3e-5, (name, e)
-    with torch.autocast("cuda", dtype=torch.bfloat16):     # not the fp32 graph: the module itself
-        assert not type(x3_conv(conv, x).grad_fn).__name__.startswith("_MaskedConv3x3F32Fn")
+    conv.weight.grad = conv.bias.grad = None
+    x2 = x0.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):     # bf16 autocast: the same layer on the bf16 kernels, every site active
+        yb = x3_conv(conv, x2)
+    assert yb.dtype == torch.bfloat16 and type(yb.grad_fn).__name__.startswith("_MaskedConv3x3Fn")
+    yb.backward(g0.to(torch.bfloat16))
+    for name, a, r in (("y", yb, yr.detach()), ("dx", x2.grad, xr.grad), ("dw", conv.weight.grad, wr.grad), ("db", conv.bias.grad, br.grad)):
+        e = float((a.double() - r).norm() / r.norm())
+        assert e < 1.5e-2, (name, e)     # bf16 operands, fp32 accumulation
     conv.eval()
     assert not type(x3_conv(conv, x).grad_fn).__name__.startswith("_MaskedConv3x3F32Fn")
 
