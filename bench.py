@@ -21,7 +21,7 @@ under a launcher (RANK/LOCAL_RANK/WORLD_SIZE set) it is one rank.  Frames are sh
   value_with_h2d_merge   the same loop fed the way the reference's loader feeds it (collate.py:15-22, trainer.py:111, nusc.py:101-121):
                   every step the frames' RAW sweeps are copied into pinned memory, uploaded on a side stream (double-buffered) and merged
                   on the device (pnx_merge_sweeps: per-sweep transform, time lag, batch index) before the reader sees them
-  value_train_fp32 / train_fp32   the same step at the reference's precision (fp32 channels_last, torch / MIOpen convolutions, immediate mode); N = 1 only;
+  value_train_fp32 / train_fp32   the same step at the reference's precision (fp32 channels_last; 3x3 layers as three bf16 products accumulated in fp32 on the HIP kernels, the rest on MIOpen fp32, immediate mode); N = 1 only;
                   PNX_BENCH_NO_TRAIN_FP32=1 skips it (MIOpen compiles its fp32 kernels for ~3.5 minutes on a fresh box)
   value_uniform / roofline_uniform   frames/s on the worst-case uniform cloud (~1.2 points per pillar) and the reader's in-loop roofline on it
   ranks           per-rank ms/step (min / max) and the world size the backend reports; N > 1 runs the short form (value, roofline, value_train)
@@ -393,7 +393,7 @@ def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAME
                "train_fp32": {"frames_per_gpu_per_step": frames, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
                               "dtype": "fp32, channels_last -- the reference's training precision; backbone 3x3 layers: three bf16 products of the operands' bf16 halves "
                                        "accumulated in fp32 on the masked HIP kernels (pnx_conv3x3_x3, relative error 4e-6; PNX_TRAIN_F32_HIP=0: MIOpen fp32), "
-                                       "stride-2 dgrad and the dense neck / head on MIOpen fp32; run in a child process with MIOpen's default solver set",
+                                       "the head's 64 -> 64 and output convolutions and the neck's BasicBlock likewise; stride-2 dgrad, dilated / 1x1 / 256 -> 64 layers on MIOpen fp32; run in a child process with MIOpen's default solver set",
                               "loss_finite": finite, "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                               "miopen": "find (cudnn.benchmark)" if find else "immediate mode", "leg_seconds": round(time.perf_counter() - t_leg, 1)}}
         del model, opt, ex
@@ -405,7 +405,7 @@ def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAME
                      "step": "forward + CenterHead losses + backward + clip 35 + AdamW + OneCycle, DDP + SyncBN when n_gpus > 1",
                      "loss_finite": finite, "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                      "miopen": "find (cudnn.benchmark)" if find else "immediate mode", "leg_seconds": round(time.perf_counter() - t_leg, 1)},
-           "roofline_train": {"bound": "mfma", "kernel": "whole training step (backbone 3x3 layers: forward, stride-1 dgrad and every weight gradient on the masked HIP kernels; stride-2 dgrad and the dense neck / head layers on MIOpen)",
+           "roofline_train": {"bound": "mfma", "kernel": "whole training step (backbone 3x3 layers, the head's 64 -> 64 and output convolutions, the neck's BasicBlock: forward, stride-1 dgrad and weight gradients on the HIP kernels; stride-2 dgrad, dilated / 1x1 / 256 -> 64 layers and dense BatchNorm on MIOpen)",
                               "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s (dense-equivalent bf16 FLOPs, 3 x forward)",
                               "frac": round(tf / 2500.0, 4), "algorithmic_flops_per_step": flops}}
     torch.backends.cudnn.benchmark = bench_mode
