@@ -449,8 +449,20 @@ int pnx_gather_kept(const float* boxes9, const float* scores, const int32_t* kee
  *              scale = gamma * invstd, shift = beta - mean * scale
  *   apply      y = [relu](x * scale + shift [+ residual]) at the active sites
  *   bwd_stats  partials fp32 [blocks][2*channels]: sum g | sum g * xhat with g = gy * [pre-activation > 0], xhat = (x - mean) * invstd
- *   bwd_apply  dx = scale * (g - mean_g - xhat * mean_gx), dresidual (optional) = g; mean_g = sum g / count, mean_gx = sum g*xhat / count */
+ *   bwd_apply  dx = scale * (g - mean_g - xhat * mean_gx), dresidual (optional) = g; mean_g = sum g / count, mean_gx = sum g*xhat / count
+ * The per-channel arithmetic between those passes, as three small launches instead of ~30 host tensor statements per layer:
+ *   reduce        sums fp64[cols] = the rows of a partials array added in a fixed order (all-reduce `sums` under SyncBatchNorm before the next call)
+ *   finalize      from sums = [sum d | sum d^2 | count]: mean, invstd, scale, shift, count (fp32 vectors for apply / the backward) and torch's running-statistics
+ *                 update in place (running_mean / running_var fp32, both or neither; unbiased variance; num_batches_tracked += 1 when not NULL); center may
+ *                 alias running_mean
+ *   bwd_finalize  dgamma / dbeta from the LOCAL sums [sum g | sum g xhat], mean_g / mean_gx from the global ones (NULL: the local ones) */
 int32_t pnx_masked_bn_blocks(void);
+int pnx_masked_bn_reduce(const float* partials, int32_t rows, int32_t cols, double* sums, pnx_stream_t stream);
+int pnx_masked_bn_finalize(const double* sums, int32_t channels, const float* center, const float* weight, const float* bias, double eps, double momentum,
+                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                           float* count, pnx_stream_t stream);
+int pnx_masked_bn_bwd_finalize(const double* sums_local, const double* sums_global, int32_t channels, const float* count, float* dgamma, float* dbeta,
+                               float* mean_g, float* mean_gx, pnx_stream_t stream);
 int pnx_masked_bn_stats(const void* x, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels, const float* center, float* partials,
                         pnx_stream_t stream);
 int pnx_masked_bn_apply(const void* x, const void* residual, int32_t dtype, const float* mask, int64_t n_sites, int32_t channels, const float* scale,

@@ -70,6 +70,9 @@ PROTOTYPES = {
     "pnx_sephead_out_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pnx_sephead_out_f16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pnx_masked_bn_blocks": (_i32, []),
+    "pnx_masked_bn_reduce": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "pnx_masked_bn_finalize": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pnx_masked_bn_bwd_finalize": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pnx_masked_bn_stats": (ctypes.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     "pnx_masked_bn_apply": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp]),
     "pnx_masked_bn_bwd_stats": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),

@@ -191,9 +191,105 @@ bool mbn_shape_ok(int C) {
 
 }  // namespace
 
+namespace {
+
+// sums[j] = sum over the rows of partials[r][j], in fp64 and a fixed order: 32 slices of the rows by 32 threads per column, then slice 0..31
+__global__ __launch_bounds__(256) void k_mbn_reduce(const float* __restrict__ part, int rows, int cols, double* __restrict__ sums) {
+  __shared__ double s_sum[32][8];
+  const int t = threadIdx.x, el = t & 7, sl = t >> 3;
+  const int j = blockIdx.x * 8 + el;
+  double s = 0.0;
+  if (j < cols)
+    for (int r = sl; r < rows; r += 32) s += (double)part[(int64_t)r * cols + j];
+  s_sum[sl][el] = s;
+  __syncthreads();
+  if (sl == 0 && j < cols) {
+    double r = s_sum[0][el];
+#pragma unroll
+    for (int k = 1; k < 32; k++) r += s_sum[k][el];
+    sums[j] = r;
+  }
+}
+
+// what the host did with ~20 small tensor statements per layer: batch statistics from [sum d | sum d^2 | count], the running statistics' update
+// (torch's BatchNorm rule: unbiased variance, fp32 buffers), scale / shift for the apply kernel, and the vectors the backward needs
+__global__ __launch_bounds__(256) void k_mbn_finalize(const double* __restrict__ sums, int C, const float* __restrict__ center, const float* __restrict__ weight,
+                                                      const float* __restrict__ bias, double eps, double momentum, float* __restrict__ running_mean,
+                                                      float* __restrict__ running_var, int64_t* __restrict__ nbt, float* __restrict__ mean_o,
+                                                      float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o,
+                                                      float* __restrict__ cnt_o) {
+  const int c = threadIdx.x;
+  const double cnt = sums[2 * C] < 1.0 ? 1.0 : sums[2 * C];
+  if (c == 0) {
+    cnt_o[0] = (float)cnt;
+    if (nbt != nullptr) nbt[0] += 1;
+  }
+  if (c >= C) return;
+  const double dmean = sums[c] / cnt;
+  double var = sums[C + c] / cnt - dmean * dmean;
+  var = var < 0.0 ? 0.0 : var;
+  const double mean = (center != nullptr ? (double)center[c] : 0.0) + dmean;
+  const double invstd = 1.0 / sqrt(var + eps);
+  if (running_mean != nullptr) {
+    const float keep = (float)(1.0 - momentum), mom = (float)momentum;
+    const double unb = var * cnt / (cnt - 1.0 < 1.0 ? 1.0 : cnt - 1.0);
+    running_mean[c] = running_mean[c] * keep + mom * (float)mean;   // center aliases running_mean: read above, written here by the same thread
+    running_var[c] = running_var[c] * keep + mom * (float)unb;
+  }
+  const double w = (double)weight[c], b = (double)bias[c];
+  mean_o[c] = (float)mean;
+  invstd_o[c] = (float)invstd;
+  scale_o[c] = (float)(invstd * w);
+  shift_o[c] = (float)(b - mean * invstd * w);
+}
+
+// backward: parameter gradients from the LOCAL sums [sum g | sum g xhat], the two means the apply kernel subtracts from the (all-reduced) ones
+__global__ __launch_bounds__(256) void k_mbn_bwd_finalize(const double* __restrict__ s_local, const double* __restrict__ s_global, int C,
+                                                          const float* __restrict__ cnt, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ mean_g, float* __restrict__ mean_gx) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const double n = (double)cnt[0];
+  dbeta[c] = (float)s_local[c];
+  dgamma[c] = (float)s_local[C + c];
+  mean_g[c] = (float)(s_global[c] / n);
+  mean_gx[c] = (float)(s_global[C + c] / n);
+}
+
+}  // namespace
+
 extern "C" {
 
 int32_t pnx_masked_bn_blocks(void) { return kMbnBlocks; }
+
+int pnx_masked_bn_reduce(const float* partials, int32_t rows, int32_t cols, double* sums, pnx_stream_t stream) {
+  PNX_REQUIRE(partials && sums && rows > 0 && cols > 0, PNX_ERR_INVALID, "pnx_masked_bn_reduce: bad arguments");
+  k_mbn_reduce<<<(unsigned)((cols + 7) / 8), 256, 0, (hipStream_t)stream>>>(partials, rows, cols, sums);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+int pnx_masked_bn_finalize(const double* sums, int32_t channels, const float* center, const float* weight, const float* bias, double eps, double momentum,
+                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                           float* count, pnx_stream_t stream) {
+  PNX_REQUIRE(sums && weight && bias && mean && invstd && scale && shift && count && channels > 0 && channels <= 256, PNX_ERR_INVALID,
+              "pnx_masked_bn_finalize: bad arguments (channels <= 256)");
+  PNX_REQUIRE((running_mean == nullptr) == (running_var == nullptr), PNX_ERR_INVALID, "running_mean and running_var come together");
+  k_mbn_finalize<<<1, 256, 0, (hipStream_t)stream>>>(sums, channels, center, weight, bias, eps, momentum, running_mean, running_var, num_batches_tracked, mean,
+                                                     invstd, scale, shift, count);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
+
+int pnx_masked_bn_bwd_finalize(const double* sums_local, const double* sums_global, int32_t channels, const float* count, float* dgamma, float* dbeta,
+                               float* mean_g, float* mean_gx, pnx_stream_t stream) {
+  PNX_REQUIRE(sums_local && count && dgamma && dbeta && mean_g && mean_gx && channels > 0 && channels <= 256, PNX_ERR_INVALID,
+              "pnx_masked_bn_bwd_finalize: bad arguments (channels <= 256)");
+  k_mbn_bwd_finalize<<<1, 256, 0, (hipStream_t)stream>>>(sums_local, sums_global != nullptr ? sums_global : sums_local, channels, count, dgamma, dbeta, mean_g,
+                                                         mean_gx);
+  PNX_LAUNCH_CHECK();
+  return PNX_OK;
+}
 
 #define MBN_COMMON_CHECKS                                                                                                        \
   PNX_REQUIRE(x && mask && n_sites > 0 && mbn_shape_ok(channels), PNX_ERR_INVALID, "bad arguments (channels %d: 8, 16, 32, 64, 128 or 256)", channels); \

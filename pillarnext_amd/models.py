@@ -114,16 +114,22 @@ class _MaskedBNActFn(torch.autograd.Function):
     forward and [sum g, sum g*xhat] backward over the ACTIVE sites of the global batch (dist_utils.all_reduce_sum)."""
 
     @staticmethod
-    def _hip_ok(x, residual):
-        """The fused HIP kernels (csrc/masked_bn.hip) take channels_last bf16 / fp32 CUDA maps with 8..256 channels."""
+    def _hip_ok(x, residual, weight=None, bias=None, norm=None):
+        """The fused HIP kernels (csrc/masked_bn.hip) take channels_last bf16 / fp32 CUDA maps with 8..256 channels (fp32 parameters and buffers)."""
         C = x.shape[1]
-        return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and C in (8, 16, 32, 64, 128, 256)
+        f32 = all(t is None or (t.dtype == torch.float32 and t.is_contiguous()) for t in (weight, bias))
+        if norm is not None:
+            f32 = f32 and norm.momentum is not None and norm.running_mean is not None and norm.running_mean.dtype == torch.float32 \
+                and norm.running_var.dtype == torch.float32
+        return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and C in (8, 16, 32, 64, 128, 256) and f32
                 and x.is_contiguous(memory_format=torch.channels_last) and os.environ.get("PNX_MASKED_BN_HIP", "1") != "0"
                 and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
                                           and residual.is_contiguous(memory_format=torch.channels_last))))
 
     @staticmethod
     def _forward_hip(ctx, x, m, weight, bias, residual, norm, relu):
+        """stats -> reduce -> [all-reduce] -> finalize -> apply: five launches (round 6: the per-channel arithmetic between the passes was ~20 host tensor
+        statements per layer, 800 tiny launches per training step)."""
         from ._lib import check, lib, ptr, stream_ptr
 
         L = lib()
@@ -131,30 +137,24 @@ class _MaskedBNActFn(torch.autograd.Function):
         n = B * H * W
         dt = ops._DT[x.dtype]
         nblk = int(L.pnx_masked_bn_blocks())
-        part = torch.empty((nblk, 2 * C + 1), dtype=torch.float32, device=x.device)
+        dev = x.device
+        part = torch.empty((nblk, 2 * C + 1), dtype=torch.float32, device=dev)
         mflat = m.reshape(-1)
         # statistics around the running mean (identical on every rank: DDP broadcasts the buffers): sum d, sum d^2 with d = x - centre
-        center = norm.running_mean.detach().float().contiguous().clone()
-        check(L.pnx_masked_bn_stats(ptr(x), dt, ptr(mflat), n, C, ptr(center), ptr(part), stream_ptr()), "pnx_masked_bn_stats")
-        s = part.double().sum(0)                                            # [sum d | sum d^2 | count]
+        rm, rv = norm.running_mean, norm.running_var
+        check(L.pnx_masked_bn_stats(ptr(x), dt, ptr(mflat), n, C, ptr(rm), ptr(part), stream_ptr()), "pnx_masked_bn_stats")
+        s = torch.empty((2 * C + 1,), dtype=torch.float64, device=dev)       # [sum d | sum d^2 | count]
+        check(L.pnx_masked_bn_reduce(ptr(part), nblk, 2 * C + 1, ptr(s), stream_ptr()), "pnx_masked_bn_reduce")
         group = norm.sync_group if norm.sync else False
         if group is not False:
             from .dist_utils import all_reduce_sum
 
             all_reduce_sum(s, group)
-        cnt = s[-1].clamp(min=1.0)
-        dmean = s[:C] / cnt
-        var = (s[C:2 * C] / cnt - dmean * dmean).clamp(min=0.0)
-        mean = center.double() + dmean
-        invstd = torch.rsqrt(var + norm.eps)
-        with torch.no_grad():
-            mom = norm.momentum
-            norm.running_mean.mul_(1 - mom).add_(mean.to(norm.running_mean.dtype), alpha=mom)
-            norm.running_var.mul_(1 - mom).add_((var * cnt / (cnt - 1).clamp(min=1.0)).to(norm.running_var.dtype), alpha=mom)
-            norm.num_batches_tracked += 1
-        scale = (invstd * weight.double()).float().contiguous()
-        shift = (bias.double() - mean * invstd * weight.double()).float().contiguous()
-        mean32, invstd32, cnt32 = mean.float().contiguous(), invstd.float().contiguous(), cnt.float()
+        vec = torch.empty((4 * C + 1,), dtype=torch.float32, device=dev)
+        mean32, invstd32, scale, shift, cnt32 = vec[:C], vec[C:2 * C], vec[2 * C:3 * C], vec[3 * C:4 * C], vec[4 * C:]
+        check(L.pnx_masked_bn_finalize(ptr(s), C, ptr(rm), ptr(weight), ptr(bias), float(norm.eps), float(norm.momentum), ptr(rm), ptr(rv),
+                                       ptr(norm.num_batches_tracked), ptr(mean32), ptr(invstd32), ptr(scale), ptr(shift), ptr(cnt32), stream_ptr()),
+              "pnx_masked_bn_finalize")
         y = torch.empty_like(x)
         check(L.pnx_masked_bn_apply(ptr(x), ptr(residual), dt, ptr(mflat), n, C, ptr(scale), ptr(shift), 1 if relu else 0, ptr(y), stream_ptr()),
               "pnx_masked_bn_apply")
@@ -180,13 +180,17 @@ class _MaskedBNActFn(torch.autograd.Function):
         relu = 1 if ctx.relu else 0
         check(L.pnx_masked_bn_bwd_stats(ptr(gy), ptr(x), ptr(residual), dt, ptr(mflat), n, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), relu, ptr(part),
                                         stream_ptr()), "pnx_masked_bn_bwd_stats")
-        sg = part.double().sum(0)
-        dbeta, dgamma = sg[:C].clone(), sg[C:].clone()                      # parameter gradients: local sums (DDP averages them)
+        sg = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+        check(L.pnx_masked_bn_reduce(ptr(part), nblk, 2 * C, ptr(sg), stream_ptr()), "pnx_masked_bn_reduce")
+        sg_all = None                                                       # parameter gradients: local sums (DDP averages them)
         if ctx.group is not False:
             from .dist_utils import all_reduce_sum
 
-            all_reduce_sum(sg, ctx.group)
-        mg, mgx = (sg[:C] / cnt.double()).float().contiguous(), (sg[C:] / cnt.double()).float().contiguous()
+            sg_all = sg.clone()
+            all_reduce_sum(sg_all, ctx.group)
+        vec = torch.empty((4 * C,), dtype=torch.float32, device=x.device)
+        dgamma, dbeta, mg, mgx = vec[:C], vec[C:2 * C], vec[2 * C:3 * C], vec[3 * C:]
+        check(L.pnx_masked_bn_bwd_finalize(ptr(sg), ptr(sg_all), C, ptr(cnt), ptr(dgamma), ptr(dbeta), ptr(mg), ptr(mgx), stream_ptr()), "pnx_masked_bn_bwd_finalize")
         dx = torch.empty_like(x)
         gres = torch.empty_like(residual) if residual is not None and ctx.needs_input_grad[4] else None
         check(L.pnx_masked_bn_bwd_apply(ptr(gy), ptr(x), ptr(residual), dt, ptr(mflat), n, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), relu, ptr(mg),
@@ -196,7 +200,7 @@ class _MaskedBNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mask, weight, bias, residual, norm, relu):
         m = mask if mask.dtype == torch.float32 else mask.float()
-        if _MaskedBNActFn._hip_ok(x, residual):
+        if _MaskedBNActFn._hip_ok(x, residual, weight, bias, norm):
             return _MaskedBNActFn._forward_hip(ctx, x, m.contiguous(), weight, bias, residual, norm, relu)
         ctx.hip = False
         xf = x.float()
