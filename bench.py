@@ -357,14 +357,15 @@ def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAME
         sched.step()
         return loss
 
-    # MIOpen's find pass over the forward / dgrad / wgrad shapes of a 1440^2 training graph (~50 problems: the dense neck / head layers and
-    # every weight gradient) takes ~2 minutes and buys a 2.2 x faster step (102 vs 227 ms) over MIOpen's immediate-mode choices.
+    # Rounds 3-5: MIOpen's find pass over the forward / dgrad / wgrad shapes of a 1440^2 training graph (~50 problems) took ~2 minutes and bought a 2.2 x faster
+    # step over MIOpen's immediate-mode choices.  Round 6 moved the backbone's, the head's and the neck's 3x3 layers onto the product's kernels: what MIOpen
+    # still runs (dilated / 1x1 / 256 -> 64 layers, stride-2 dgrad) is as fast in immediate mode (84.4 vs 84.9 ms per step measured in one run), so immediate
+    # mode is the default at every N and the leg takes seconds; PNX_BENCH_TRAIN_FIND=1 turns the find pass back on.
     # `train.miopen` / `ranks.miopen` say which mode a line was measured with.
     bench_mode = torch.backends.cudnn.benchmark
-    # Round 6: the SAME mode at every N (find, each rank with its own find-db -- main()), so that value_train(N) / (N x value_train(1)) compares like with like;
-    # PNX_BENCH_TRAIN_FIND=0 switches every N to immediate mode.
+    # The SAME mode at every N, so that value_train(N) / (N x value_train(1)) compares like with like.
     # The fp32 leg: PNX_BENCH_TRAIN_F32_FIND (its backbone is on the product's kernels since round 6, what MIOpen still has to search is the neck / head).
-    find = os.environ.get("PNX_BENCH_TRAIN_FIND", "1") == "1" if amp else os.environ.get("PNX_BENCH_TRAIN_F32_FIND", "0") == "1"
+    find = os.environ.get("PNX_BENCH_TRAIN_FIND", "0") == "1" if amp else os.environ.get("PNX_BENCH_TRAIN_F32_FIND", "0") == "1"
     torch.backends.cudnn.benchmark = find
     t_leg = time.perf_counter()
     for _ in range(warmup):
@@ -415,7 +416,7 @@ def train_leg(dev, rank, world, frames=int(os.environ.get("PNX_BENCH_TRAIN_FRAME
 
 
 def train_child_leg(dev, leg):
-    """A single-GPU training leg ("train_bf16": bf16 autocast after MIOpen's find pass; "train_fp32": the reference's precision, torch / MIOpen convolutions) in a
+    """A single-GPU training leg ("train_bf16": bf16 autocast; "train_fp32": the reference's precision, torch / MIOpen convolutions) in a
     CHILD process.  Why a child: this process pins MIOpen's solver search for the inference legs (MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC=0,
     main()); MIOpen caches such switches per process, and without the asm NHWC solvers (a) the fp32 forward convolutions fall back to solvers that transpose
     through workspaces -- 551 ms and 75 GiB per step instead of 375 ms and 50 GiB (rounds 4-5 reported the former; tools/train_step.py --nhwc always showed
@@ -710,7 +711,7 @@ def main():
         "ranks": {"world_size_seen_by_backend": dist.get_world_size() if world > 1 else 1, "backend": a.backend if world > 1 else None,
                   "ms_per_step_min": min(rank_ms), "ms_per_step_max": max(rank_ms),
                   "miopen": {"inference": "find (cudnn.benchmark), one find-db per rank" if torch.backends.cudnn.benchmark else "immediate mode",
-                             "train": "find (cudnn.benchmark), one find-db per rank" if os.environ.get("PNX_BENCH_TRAIN_FIND", "1") == "1" else "immediate mode"}},
+                             "train": "find (cudnn.benchmark), one find-db per rank" if os.environ.get("PNX_BENCH_TRAIN_FIND", "0") == "1" else "immediate mode"}},
         # which two numbers a scaling efficiency is computed from: the same leg, the same MIOpen mode, the same frames per GPU at N and at 1
         "efficiency_basis": {"inference": "value(N) / (N x value(1))", "train": "value_train(N) / (N x value_train(1))",
                              "frames_per_gpu_per_step": {"inference": a.batch, "train": int(os.environ.get("PNX_BENCH_TRAIN_FRAMES", "4"))},

@@ -49,7 +49,7 @@ def test_gpus_2_with_real_kernels_on_one_gpu():
     assert "value_uniform" not in r and "value_c4" not in r                           # short form
     assert r["value_train"] > 0 and r["train"]["loss_finite"] and "DDP" in r["train"]["step"]
     # one MIOpen mode per line, the same at every N: the N = 2 line says which, and what an efficiency is computed from
-    assert r["ranks"]["miopen"]["train"].startswith("find") and r["train"]["miopen"].startswith("find") and r["ranks"]["miopen"]["inference"].startswith("find")
+    assert r["ranks"]["miopen"]["train"].startswith("immediate") and r["train"]["miopen"].startswith("immediate") and r["ranks"]["miopen"]["inference"].startswith("find")
     assert r["efficiency_basis"]["train"] == "value_train(N) / (N x value_train(1))" and r["efficiency_basis"]["frames_per_gpu_per_step"] == {"inference": 2, "train": 1}
 
 
@@ -64,4 +64,4 @@ def test_gpus_2_over_rccl_when_two_devices_are_visible():
             {"PNX_BENCH_TRAIN_FRAMES": "1", "PNX_BENCH_TRAIN_STEPS": "1", "PNX_BENCH_TRAIN_WARMUP": "1", "MIOPEN_FIND_MODE": "2", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=1200)
     assert r["n_gpus"] == 2 and r["ranks"]["backend"] == "nccl" and r["ranks"]["world_size_seen_by_backend"] == 2
     assert r["value"] > 0 and r["value_train"] > 0 and r["train"]["loss_finite"]
-    assert r["ranks"]["miopen"]["train"].startswith("find")
+    assert r["ranks"]["miopen"]["train"].startswith("immediate")
