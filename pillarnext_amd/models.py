@@ -145,7 +145,7 @@ class _MaskedBNActFn(torch.autograd.Function):
         check(L.pnx_masked_bn_stats(ptr(x), dt, ptr(mflat), n, C, ptr(rm), ptr(part), stream_ptr()), "pnx_masked_bn_stats")
         s = torch.empty((2 * C + 1,), dtype=torch.float64, device=dev)       # [sum d | sum d^2 | count]
         check(L.pnx_masked_bn_reduce(ptr(part), nblk, 2 * C + 1, ptr(s), stream_ptr()), "pnx_masked_bn_reduce")
-        group = norm.sync_group if norm.sync else False
+        group = norm.sync_group if getattr(norm, "sync", False) else False
         if group is not False:
             from .dist_utils import all_reduce_sum
 
@@ -205,7 +205,7 @@ class _MaskedBNActFn(torch.autograd.Function):
         ctx.hip = False
         xf = x.float()
         s1 = torch.cat([(xf * m).sum(dim=(0, 2, 3)), m.sum().view(1)])
-        group = norm.sync_group if norm.sync else False
+        group = norm.sync_group if getattr(norm, "sync", False) else False
         if group is not False:
             from .dist_utils import all_reduce_sum
 
@@ -502,6 +502,25 @@ def masked_bn_act(x, mask, norm, residual=None, relu=True):
     return (F.relu(out) if relu else out) * mask
 
 
+_ONES_F32 = {}
+
+
+def dense_bn_act(norm, x, relu=True):
+    """[relu](norm(x)) of a DENSE nn.BatchNorm2d in training (the head's and the neck's layers: det3d/models/utils/conv.py:21-34, centerhead.py:24-30): the
+    masked node with every site active -- statistics, apply + ReLU, and the backward in four passes over the map on csrc/masked_bn.hip instead of MIOpen's
+    three + three kernels and a separate ReLU forward and backward.  Anything else (eval, SyncBatchNorm, CPU, other shapes, PNX_TRAIN_DENSE_BN_HIP=0): the modules."""
+    if (type(norm) is nn.BatchNorm2d and norm.training and torch.is_grad_enabled() and norm.affine and norm.track_running_stats and x.is_cuda and x.dim() == 4
+            and os.environ.get("PNX_TRAIN_DENSE_BN_HIP", "1") != "0"):
+        xc = x if x.is_contiguous(memory_format=torch.channels_last) else None
+        if xc is not None and _MaskedBNActFn._hip_ok(xc, None, norm.weight, norm.bias, norm):
+            key = (x.shape[0], x.shape[2], x.shape[3], x.device)
+            if key not in _ONES_F32:
+                _ONES_F32[key] = torch.ones((x.shape[0], 1, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+            return _MaskedBNActFn.apply(xc, _ONES_F32[key], norm.weight, norm.bias, None, norm, relu)
+    y = norm(x)
+    return F.relu(y) if relu else y
+
+
 def convert_sync_batchnorm(module, process_group=None, cpu_ok=False):
     """tools/train.py:56 for this model, callable BEFORE or after .cuda() like torch's own converter (the reference converts first,
     train.py:56 then :59): MaskedBatchNorm layers switch to global active-site statistics in place; the reader's fused training
@@ -634,6 +653,8 @@ class ConvBlock(nn.Module):
         self.act = act_layer()
 
     def forward(self, x):
+        if type(self.act) is nn.ReLU:
+            return dense_bn_act(self.norm, self.conv(x))
         return self.act(self.norm(self.conv(x)))
 
 
@@ -713,14 +734,19 @@ class SepHead(nn.Module):
         out = {}
         for head in self.heads:
             layers = list(getattr(self, head))
-            h = x
-            for i, layer in enumerate(layers):
+            h, i = x, 0
+            while i < len(layers):
+                layer = layers[i]
                 if i == len(layers) - 1:
                     h = smallk_conv(layer, h)
                 elif i == 0:
                     h = x3_conv(layer, h, halves)
+                elif type(layer) is nn.BatchNorm2d and type(layers[i + 1]) is nn.ReLU:
+                    h = dense_bn_act(layer, h)
+                    i += 1
                 else:
                     h = layer(h)
+                i += 1
             out[head] = h
         return out
 
@@ -753,7 +779,11 @@ class CenterHead(nn.Module):
             self.tasks.append(SepHead(share_conv_channel, heads, stride=stride, bn=True, init_bias=init_bias, final_kernel=3))
 
     def forward(self, x, *kwargs):
-        x = self.shared_conv(x)
+        sc = self.shared_conv
+        if self.training and len(sc) == 3 and type(sc[1]) is nn.BatchNorm2d and type(sc[2]) is nn.ReLU:
+            x = dense_bn_act(sc[1], sc[0](x))
+        else:
+            x = sc(x)
         return [task(x) for task in self.tasks]
 
     # ---- training loss (centerhead.py:142-229)

@@ -56,3 +56,41 @@ def test_fused_masked_bn_matches_the_torch_node(monkeypatch, C, shape, dtype, wi
     torch.testing.assert_close(a[5], b[5], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(a[6], b[6], rtol=1e-4, atol=1e-5)
     assert a[7] == b[7] == 1
+
+
+@pytest.mark.parametrize("dtype,c,shape", [(torch.float32, 64, (2, 33, 41)), (torch.bfloat16, 64, (2, 40, 24)), (torch.float32, 256, (1, 9, 17))])
+def test_dense_batchnorm_relu_on_the_masked_node(dtype, c, shape):
+    """models.dense_bn_act: nn.BatchNorm2d + ReLU of the head / neck in training on the masked node with every site active, against the modules themselves
+    (output, input / weight / bias gradients, running statistics, num_batches_tracked)."""
+    import copy
+
+    import torch.nn.functional as F
+
+    from pillarnext_amd.models import dense_bn_act
+
+    B, H, W = shape
+    gen = torch.Generator(device="cuda").manual_seed(c + H)
+    bn = torch.nn.BatchNorm2d(c).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, device="cuda", generator=gen) + 0.5)
+        bn.bias.copy_(torch.randn(c, device="cuda", generator=gen) * 0.3)
+        bn.running_mean.copy_(torch.randn(c, device="cuda", generator=gen) * 0.1)
+    ref = copy.deepcopy(bn).double()     # the modules in fp64 (MIOpen's fp32 BatchNorm backward is itself 2e-4 off on these shapes, and segfaults on channels_last fp32 input)
+    x0 = (torch.randn((B, c, H, W), device="cuda", generator=gen) * 2 + 0.5).to(dtype).contiguous(memory_format=torch.channels_last)
+    g0 = torch.randn((B, c, H, W), device="cuda", generator=gen).to(dtype).contiguous(memory_format=torch.channels_last)
+    x = x0.clone().requires_grad_(True)
+    y = dense_bn_act(bn, x)
+    assert type(y.grad_fn).__name__.startswith("_MaskedBNActFn") and y.dtype == dtype
+    y.backward(g0)
+    xr = x0.double().contiguous().requires_grad_(True)
+    yr = F.relu(ref(xr))
+    yr.backward(g0.double().contiguous())
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    assert float((y.double() - yr.detach()).abs().max()) <= tol * max(1.0, float(yr.detach().abs().max()))
+    assert float((x.grad.double() - xr.grad).abs().max()) <= tol * max(1.0, float(xr.grad.abs().max()))
+    for a, r in ((bn.weight.grad, ref.weight.grad), (bn.bias.grad, ref.bias.grad)):
+        assert float((a.double() - r).abs().max()) <= (3e-2 if dtype == torch.bfloat16 else 1e-4) * max(1.0, float(r.abs().max()))
+    assert torch.allclose(bn.running_mean.double(), ref.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(bn.running_var.double(), ref.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    bn.eval()
+    assert not type(dense_bn_act(bn, x).grad_fn).__name__.startswith("_MaskedBNActFn")
