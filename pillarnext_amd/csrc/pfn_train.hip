@@ -57,9 +57,21 @@ __global__ __launch_bounds__(256) void k_pfn_train(const uint32_t* __restrict__ 
   float* sd = su + 64;
   const int P = counters[0];
   const int nw = gridDim.x * 4, w = blockIdx.x * 4 + wv;
-  const int per = (P + nw - 1) / nw;
-  const int r0 = __builtin_amdgcn_readfirstlane(w * per);
-  const int r1 = __builtin_amdgcn_readfirstlane(min(P, r0 + per));
+  // a wave's pillars: a contiguous range of ranks holding ~1/nw of the POINTS (round 6: equal pillar counts gave the waves of the dense near range 3-5 x the
+  // work of the others, and the pass lasts as long as its slowest wave).  pfirst is ascending: the range starts at the first pillar whose first record is at
+  // or behind the wave's share of the records -- the same split for the same cloud, whatever the timing.
+  const int64_t n_rec = counters[1];
+  auto first_at = [&](int64_t target) -> int {
+    int lo = 0, hi = P;  // first r in [0, P] with pfirst[r] >= target
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)pfirst[mid] >= target) hi = mid;
+      else lo = mid + 1;
+    }
+    return lo;
+  };
+  const int r0 = __builtin_amdgcn_readfirstlane(w == 0 ? 0 : first_at(n_rec * w / nw));
+  const int r1 = __builtin_amdgcn_readfirstlane(w + 1 == nw ? P : first_at(n_rec * (w + 1) / nw));
 
   float w0[C0];
 #pragma unroll
