@@ -90,16 +90,26 @@ __global__ __launch_bounds__(256) void k_mbn_stats(const T* __restrict__ x, cons
 #pragma unroll
     for (int k = 0; k < 8; k++) ctr[k] = center[chunk * 8 + k];
   }
-  for (int64_t site = (int64_t)blockIdx.x * rows + t / cvec; site < n; site += (int64_t)gridDim.x * rows) {
-    if (mask[site] == 0.f) continue;
-    float v[8];
-    Ld8<T>::load(x + site * C + chunk * 8, v);
+  // four sites of the thread's walk per iteration, their mask words and then their lines requested together (round 6: one site at a time was a chain of two
+  // dependent loads per iteration -- 36 us for a 66 MB map); the additions keep the walk's order
+  const int64_t stride = (int64_t)gridDim.x * rows;
+  for (int64_t s0 = (int64_t)blockIdx.x * rows + t / cvec; s0 < n; s0 += 4 * stride) {
+    float m[4], v[4][8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const float d = v[k] - ctr[k];
-      acc[0][k] += d, acc[1][k] += d * d;
+    for (int u = 0; u < 4; u++) m[u] = s0 + u * stride < n ? mask[s0 + u * stride] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (m[u] != 0.f) Ld8<T>::load(x + (s0 + u * stride) * C + chunk * 8, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (m[u] == 0.f) continue;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const float d = v[u][k] - ctr[k];
+        acc[0][k] += d, acc[1][k] += d * d;
+      }
+      if (chunk == 0) cnt += 1.f;
     }
-    if (chunk == 0) cnt += 1.f;
   }
   block_reduce<2>(acc, cnt, true, cvec, C, partials + (size_t)blockIdx.x * (2 * C + 1));
 }
@@ -107,11 +117,11 @@ __global__ __launch_bounds__(256) void k_mbn_stats(const T* __restrict__ x, cons
 template <typename T, bool HAS_RES>
 __global__ __launch_bounds__(256) void k_mbn_apply(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ mask, int64_t n, int C,
                                                    const float* __restrict__ scale, const float* __restrict__ shift, int relu, T* __restrict__ y) {
-  const int cvec = C >> 3;
+  const int cvec = C >> 3, csh = __builtin_ctz(cvec);
   const int64_t nvec = n * cvec;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const int64_t site = i / cvec;
-    const int c0 = (int)(i - site * cvec) * 8;
+    const int64_t site = i >> csh;  // cvec is a power of two (mbn_shape_ok): no 64-bit division per vector
+    const int c0 = (int)(i & (cvec - 1)) * 8;
     float o[8] = {};
     if (mask[site] != 0.f) {
       float v[8], r[8] = {};
@@ -151,12 +161,20 @@ __global__ __launch_bounds__(256) void k_mbn_bwd_stats(const T* __restrict__ gy,
                                                        int relu, float* __restrict__ partials) {
   const int cvec = C >> 3, t = threadIdx.x, chunk = t % cvec, rows = 256 / cvec;
   float acc[2][8] = {};
-  for (int64_t site = (int64_t)blockIdx.x * rows + t / cvec; site < n; site += (int64_t)gridDim.x * rows) {
-    if (mask[site] == 0.f) continue;
-    float g[8], xh[8];
-    bwd_terms<T, HAS_RES>(gy, x, res, site * C + chunk * 8, chunk * 8, scale, shift, mean, invstd, relu, g, xh);
+  const int64_t stride = (int64_t)gridDim.x * rows;  // two sites per iteration, their loads requested together (see k_mbn_stats)
+  for (int64_t s0 = (int64_t)blockIdx.x * rows + t / cvec; s0 < n; s0 += 2 * stride) {
+    float m[2], g[2][8], xh[2][8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) acc[0][k] += g[k], acc[1][k] += g[k] * xh[k];
+    for (int u = 0; u < 2; u++) m[u] = s0 + u * stride < n ? mask[s0 + u * stride] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+      if (m[u] != 0.f) bwd_terms<T, HAS_RES>(gy, x, res, (s0 + u * stride) * C + chunk * 8, chunk * 8, scale, shift, mean, invstd, relu, g[u], xh[u]);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (m[u] == 0.f) continue;
+#pragma unroll
+      for (int k = 0; k < 8; k++) acc[0][k] += g[u][k], acc[1][k] += g[u][k] * xh[u][k];
+    }
   }
   block_reduce<2>(acc, 0.f, false, cvec, C, partials + (size_t)blockIdx.x * (2 * C));
 }
@@ -167,11 +185,11 @@ __global__ __launch_bounds__(256) void k_mbn_bwd_apply(const T* __restrict__ gy,
                                                        const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        int relu, const float* __restrict__ mg, const float* __restrict__ mgx, T* __restrict__ dx,
                                                        T* __restrict__ gres) {
-  const int cvec = C >> 3;
+  const int cvec = C >> 3, csh = __builtin_ctz(cvec);
   const int64_t nvec = n * cvec;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const int64_t site = i / cvec;
-    const int c0 = (int)(i - site * cvec) * 8;
+    const int64_t site = i >> csh;  // cvec is a power of two (mbn_shape_ok): no 64-bit division per vector
+    const int c0 = (int)(i & (cvec - 1)) * 8;
     float d[8] = {}, g[8] = {};
     if (mask[site] != 0.f) {
       float xh[8];
@@ -186,27 +204,34 @@ __global__ __launch_bounds__(256) void k_mbn_bwd_apply(const T* __restrict__ gy,
 
 bool mbn_shape_ok(int C) {
   const int cvec = C >> 3;
-  return C % 8 == 0 && cvec >= 1 && cvec <= 32 && 256 % cvec == 0;
+  return C % 8 == 0 && cvec >= 1 && cvec <= 32 && (cvec & (cvec - 1)) == 0;
 }
 
 }  // namespace
 
 namespace {
 
-// sums[j] = sum over the rows of partials[r][j], in fp64 and a fixed order: 32 slices of the rows by 32 threads per column, then slice 0..31
+// sums[j] = sum over the rows of partials[r][j], in fp64 and a fixed order: 64 slices of the rows by 64 threads per column, then slice 0..63
 __global__ __launch_bounds__(256) void k_mbn_reduce(const float* __restrict__ part, int rows, int cols, double* __restrict__ sums) {
-  __shared__ double s_sum[32][8];
-  const int t = threadIdx.x, el = t & 7, sl = t >> 3;
-  const int j = blockIdx.x * 8 + el;
+  __shared__ double s_sum[64][4];
+  const int t = threadIdx.x, el = t & 3, sl = t >> 2;
+  const int j = blockIdx.x * 4 + el;
   double s = 0.0;
-  if (j < cols)
-    for (int r = sl; r < rows; r += 32) s += (double)part[(int64_t)r * cols + j];
+  if (j < cols) {
+    int r = sl;
+    for (; r + 192 < rows; r += 256) {  // four independent loads per step
+      const float a = part[(int64_t)r * cols + j], b = part[(int64_t)(r + 64) * cols + j], c = part[(int64_t)(r + 128) * cols + j],
+                  d = part[(int64_t)(r + 192) * cols + j];
+      s += (double)a, s += (double)b, s += (double)c, s += (double)d;
+    }
+    for (; r < rows; r += 64) s += (double)part[(int64_t)r * cols + j];
+  }
   s_sum[sl][el] = s;
   __syncthreads();
   if (sl == 0 && j < cols) {
     double r = s_sum[0][el];
 #pragma unroll
-    for (int k = 1; k < 32; k++) r += s_sum[k][el];
+    for (int k = 1; k < 64; k++) r += s_sum[k][el];
     sums[j] = r;
   }
 }
@@ -264,7 +289,7 @@ int32_t pnx_masked_bn_blocks(void) { return kMbnBlocks; }
 
 int pnx_masked_bn_reduce(const float* partials, int32_t rows, int32_t cols, double* sums, pnx_stream_t stream) {
   PNX_REQUIRE(partials && sums && rows > 0 && cols > 0, PNX_ERR_INVALID, "pnx_masked_bn_reduce: bad arguments");
-  k_mbn_reduce<<<(unsigned)((cols + 7) / 8), 256, 0, (hipStream_t)stream>>>(partials, rows, cols, sums);
+  k_mbn_reduce<<<(unsigned)((cols + 3) / 4), 256, 0, (hipStream_t)stream>>>(partials, rows, cols, sums);
   PNX_LAUNCH_CHECK();
   return PNX_OK;
 }
