@@ -330,6 +330,15 @@ int pnx_sephead_lazy_f16(const PnxLazyTask* tasks, int32_t n_tasks, const int32_
 int pnx_split_f32(const float* x, void* hi, void* lo, int64_t n, const uint8_t* mask, int32_t channels, pnx_stream_t stream);
 int pnx_conv3x3_x3(const void* x_hi, const void* x_lo, const void* wfrag_hi, const void* wfrag_lo, const float* bias, const uint8_t* mask, float* y,
                    int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t stride, pnx_stream_t stream);
+/* Data gradient of the backbone's stride-2 SparseConv2d layers in training (csrc/conv_dgrad_s2.h; reference: det3d/models/utils/sparse_conv.py:16-39 under
+ * autograd): the four parity planes of dx as four small convolutions of the upstream gradient (1, 2, 2, 4 taps).  g: NHWC (batch, ho, wo, cout) bf16 with
+ * ho = (h - 1) / 2 + 1; wfrag_t: pnx_conv3x3_pack_weights(transposed = 1) of the (cout, cin, 3, 3) weights; mask_in: uint8 (batch, h, w), the layer's INPUT active
+ * set; dx: NHWC (batch, h, w, cin), zeros at inactive sites, every site written.  (cin, cout): (64, 128), (128, 256), (256, 256).  _x3: the fp32 graph's form
+ * (bf16 halves of g and of the weights, three products, fp32 dx). */
+int pnx_conv3x3_dgrad_s2_bf16(const void* g, const void* wfrag_t, const uint8_t* mask_in, void* dx, int32_t batch, int32_t h, int32_t w, int32_t cin,
+                              int32_t cout, pnx_stream_t stream);
+int pnx_conv3x3_dgrad_s2_x3(const void* g_hi, const void* g_lo, const void* wfrag_t_hi, const void* wfrag_t_lo, const uint8_t* mask_in, float* dx, int32_t batch,
+                            int32_t h, int32_t w, int32_t cin, int32_t cout, pnx_stream_t stream);
 /* The SepHead's output convolutions in training (csrc/head_train.hip; reference: det3d/models/heads/centerhead.py:31-41, nn.Conv2d(64, k, 3, padding 1,
  * bias=True) with k = classes / 2 / 1 / 3 / 2 / 2, under autograd): bandwidth-bound layers MIOpen runs at 1/7 of the HBM rate.
  *   pnx_conv3x3_smallk        y = conv3x3(x, weight) + bias: x NHWC (batch, h, w, 64), y NHWC (batch, h, w, k), both `dtype` (PNX_F32 or PNX_BF16);

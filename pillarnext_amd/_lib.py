@@ -86,6 +86,8 @@ PROTOTYPES = {
     "pnx_conv3x3_wgrad_workspace_bytes": (_sz, [_i32, _i32]),
     "pnx_conv3x3_wgrad_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "pnx_conv3x3_wgrad_x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "pnx_conv3x3_dgrad_s2_bf16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pnx_conv3x3_dgrad_s2_x3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pnx_conv3x3_smallk": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pnx_conv3x3_smallk_wgrad_workspace_bytes": (_sz, [_i32]),
     "pnx_conv3x3_smallk_wgrad": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),

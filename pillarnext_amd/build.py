@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("PNX_LIB_OUT") or os.path.join(HERE, "libpnx_hip.so")  # PNX_LIB_OUT: where an instrumented build goes
 SOURCES = ["reader.hip", "pfn_v3.hip", "chunk_sort.hip", "pfn_spans.hip", "pfn_train.hip", "scatter.hip", "group.hip", "merge.hip", "iou3d.hip", "dense_ops.hip", "masked_bn.hip", "conv3x3.hip", "conv_wgrad.hip", "head_train.hip", "decode.hip", "center_loss.hip", "enqueue.hip", "iou3d_host.cpp", "capi.cpp"]
-HEADERS = ["pnx_common.h", "pnx_scan.h", "pnx_detmath.h", "pnx_fill.h", "pnx_dppscan.h", "pfn_common.h", "reader_bins.h", "spans.h", "iou3d_geom.h", "conv_pc.h", os.path.join("..", "..", "include", "pnx.h")]
+HEADERS = ["pnx_common.h", "pnx_scan.h", "pnx_detmath.h", "pnx_fill.h", "pnx_dppscan.h", "pfn_common.h", "reader_bins.h", "spans.h", "iou3d_geom.h", "conv_pc.h", "conv_dgrad_s2.h", os.path.join("..", "..", "include", "pnx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
 

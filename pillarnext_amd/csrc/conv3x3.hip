@@ -1703,7 +1703,41 @@ int PNX_CONV_FN(pnx_conv3x3)(const void* x, const void* wfrag, const float* bias
   return PNX_ERR_UNSUPPORTED;
 }
 
-#ifndef PNX_CONV_F16  // the fp32 training convolution exists once, on the bf16 instructions
+#ifndef PNX_CONV_F16  // the training-only entries exist once, on the bf16 instructions
+}  // extern "C"
+namespace {
+#include "conv_dgrad_s2.h"
+}
+extern "C" {
+
+// Data gradient of a stride-2 SparseConv2d layer (conv_dgrad_s2.h): g (batch, ho, wo, cout) NHWC bf16, wfrag_t = pnx_conv3x3_pack_weights(transposed = 1) of the
+// layer's (cout, cin, 3, 3) weights, mask_in = active sites of the layer's INPUT (batch, h, w); dx (batch, h, w, cin) bf16, zeros at inactive sites, every site written.
+int pnx_conv3x3_dgrad_s2_bf16(const void* g, const void* wfrag_t, const uint8_t* mask_in, void* dx, int32_t batch, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                              pnx_stream_t stream) {
+  PNX_REQUIRE(g && wfrag_t && mask_in && dx && batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "pnx_conv3x3_dgrad_s2_bf16: bad arguments");
+  PNX_REQUIRE((((uintptr_t)g | (uintptr_t)wfrag_t | (uintptr_t)dx) & 15) == 0, PNX_ERR_INVALID, "16-byte alignment required");
+  hipStream_t st = (hipStream_t)stream;
+  if (cin == 64 && cout == 128) return launch_dgrad_s2<128, 64, false>(g, nullptr, wfrag_t, nullptr, mask_in, dx, batch, h, w, st);
+  if (cin == 128 && cout == 256) return launch_dgrad_s2<256, 128, false>(g, nullptr, wfrag_t, nullptr, mask_in, dx, batch, h, w, st);
+  if (cin == 256 && cout == 256) return launch_dgrad_s2<256, 256, false>(g, nullptr, wfrag_t, nullptr, mask_in, dx, batch, h, w, st);
+  pnx_set_error("pnx_conv3x3_dgrad_s2_bf16: no kernel for %d -> %d channels", cin, cout);
+  return PNX_ERR_UNSUPPORTED;
+}
+
+// The same from the bf16 halves of an fp32 gradient and of the fp32 weights (pnx_split_f32), fp32 out: the stride-2 companion of pnx_conv3x3_x3.
+int pnx_conv3x3_dgrad_s2_x3(const void* g_hi, const void* g_lo, const void* wfrag_t_hi, const void* wfrag_t_lo, const uint8_t* mask_in, float* dx, int32_t batch,
+                            int32_t h, int32_t w, int32_t cin, int32_t cout, pnx_stream_t stream) {
+  PNX_REQUIRE(g_hi && g_lo && wfrag_t_hi && wfrag_t_lo && mask_in && dx && batch > 0 && h > 0 && w > 0, PNX_ERR_INVALID, "pnx_conv3x3_dgrad_s2_x3: bad arguments");
+  PNX_REQUIRE((((uintptr_t)g_hi | (uintptr_t)g_lo | (uintptr_t)wfrag_t_hi | (uintptr_t)wfrag_t_lo | (uintptr_t)dx) & 15) == 0, PNX_ERR_INVALID,
+              "16-byte alignment required");
+  hipStream_t st = (hipStream_t)stream;
+  if (cin == 64 && cout == 128) return launch_dgrad_s2<128, 64, true>(g_hi, g_lo, wfrag_t_hi, wfrag_t_lo, mask_in, dx, batch, h, w, st);
+  if (cin == 128 && cout == 256) return launch_dgrad_s2<256, 128, true>(g_hi, g_lo, wfrag_t_hi, wfrag_t_lo, mask_in, dx, batch, h, w, st);
+  if (cin == 256 && cout == 256) return launch_dgrad_s2<256, 256, true>(g_hi, g_lo, wfrag_t_hi, wfrag_t_lo, mask_in, dx, batch, h, w, st);
+  pnx_set_error("pnx_conv3x3_dgrad_s2_x3: no kernel for %d -> %d channels", cin, cout);
+  return PNX_ERR_UNSUPPORTED;
+}
+
 // fp32 convolution out of three bf16 products: x = x_hi + x_lo and W = W_hi + W_lo (bf16 halves of fp32 values, pnx_split_f32; both weight halves in
 // pnx_conv3x3_pack_weights order), y = x_hi W_hi + x_hi W_lo + x_lo W_hi accumulated in fp32 inside ONE launch (the low x low term is below the
 // halves' own rounding, 2^-17 relative) and written as fp32 NHWC; zeros at inactive sites, every site written.  bias (fp32, may be null) starts the

@@ -281,13 +281,18 @@ def _zero_bias(c, device):
     return _ZERO_BIAS[key]
 
 
+def _hip_dgrad_s2(weight):
+    """(cin, cout) of the stride-2 data-gradient kernels; PNX_TRAIN_HIP_DGRAD_S2=0: MIOpen / CK."""
+    return (weight.shape[1], weight.shape[0]) in {(64, 128), (128, 256), (256, 256)} and os.environ.get("PNX_TRAIN_HIP_DGRAD_S2", "1") != "0"
+
+
 class _MaskedConv3x3Fn(torch.autograd.Function):
     """y = mask_out * conv3x3(x, W) on the product's masked-convolution kernels (csrc/conv3x3.hip) in TRAINING, bf16 autocast
     (sparse_conv.py:16-63: SubMConv2d / SparseConv2d compute only at the active sites, forward and backward).
       forward   pnx_conv3x3_bf16 (no bias, no ReLU), row segments without an active site are skipped
       dgrad     stride 1: the SAME kernel on the flipped, transposed weights with the INPUT's active set as its mask -- the upstream
                 gradient is zero outside mask_out (the BatchNorm node's backward writes zeros there), and what reaches an inactive input
-                site would be thrown away by that site's own mask; stride 2: MIOpen's dense dgrad
+                site would be thrown away by that site's own mask; stride 2: pnx_conv3x3_dgrad_s2_bf16 (four parity planes; csrc/conv_dgrad_s2.h)
       wgrad     stride 1: pnx_conv3x3_wgrad_bf16 (csrc/conv_wgrad.hip) over the 16-pixel row pieces that hold an active output, fp32 accumulation,
                 deterministic, stride 1 and 2 (PNX_TRAIN_HIPWGRAD=0: MIOpen's dense wrw on (x, g), exact because g is zero outside the active outputs)
     The fp32 training graph (the reference's precision) has its own node, _MaskedConv3x3F32Fn."""
@@ -328,6 +333,9 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
             hip_w = need_w and os.environ.get("PNX_TRAIN_HIPWGRAD", "1") != "0"
             if hip_w:
                 dw = ops.conv3x3_wgrad(x, g, mask_out, stride=s).to(weight.dtype)
+            if need_x and s == 2 and mask_in is not None and _hip_dgrad_s2(weight):   # round 6: the four parity planes on csrc/conv_dgrad_s2.h
+                dx = ops.conv3x3_dgrad_s2(g, ops.conv3x3_pack_weights(weight, transposed=True), weight.shape[1], x.shape[2:], mask_in)
+                need_x = False
             if need_x or (need_w and not hip_w):
                 dx, dw2, _ = torch.ops.aten.convolution_backward(g, x, weight, None, (s, s), (1, 1), (1, 1), False, (0, 0), 1, (need_x, need_w and not hip_w, False))
                 dw = dw if hip_w else dw2
@@ -354,7 +362,7 @@ class _MaskedConv3x3F32Fn(torch.autograd.Function):
     """_MaskedConv3x3Fn for the fp32 training graph (the reference's training precision: tools/train.py runs without autocast): every fp32 operand
     is split into two bf16 halves (16 mantissa bits together) and the three significant products run on the bf16 matrix cores with fp32 accumulation.
       forward   pnx_conv3x3_x3 on (x_hi, x_lo) x (W_hi, W_lo) [+ bias]: one launch, fp32 out
-      dgrad     stride 1: the same kernel on the halves of g and of W^T flipped, masked by the INPUT's active set; stride 2: MIOpen's fp32 dgrad
+      dgrad     stride 1: the same kernel on the halves of g and of W^T flipped, masked by the INPUT's active set; stride 2: pnx_conv3x3_dgrad_s2_x3
       wgrad     pnx_conv3x3_wgrad_x3: x_hi g_hi + x_lo g_hi + x_hi g_lo in one pass, accumulated in fp32
     mask_out = mask_in = None: a dense layer (the neck's and the head's 3x3 convolutions, x3_conv below).  halves: (x_hi, x_lo) when the caller
     already split x (the six branches of a SepHead share their input).
@@ -379,12 +387,15 @@ class _MaskedConv3x3F32Fn(torch.autograd.Function):
         g = g.contiguous(memory_format=torch.channels_last)
         s = ctx.stride
         dx = dw = db = None
-        if need_w or (need_x and s == 1):
+        if need_w or need_x:
             gh, gl = ops.split_f32(g, mask_out)   # the upstream gradient is zero outside mask_out (the BatchNorm node's backward writes zeros there)
         if need_x:
             if s == 1:
                 wth, wtl = _split_pack(weight, transposed=True)
                 dx = ops.conv3x3_x3(gh, gl, wth, wtl, weight.shape[1], 1, mask_in)
+            elif mask_in is not None and _hip_dgrad_s2(weight):
+                wth, wtl = _split_pack(weight, transposed=True)
+                dx = ops.conv3x3_dgrad_s2(gh, wth, weight.shape[1], xh.shape[2:], mask_in, g_lo=gl, wfrag_t_lo=wtl)
             else:
                 dx = torch.nn.grad.conv2d_input(xh.shape, weight, g, stride=s, padding=1)
         if need_w:

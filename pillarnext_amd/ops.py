@@ -515,6 +515,26 @@ def conv3x3_wgrad_x3(x_hi, x_lo, dy_hi, dy_lo, mask, stride=1):
     return dw
 
 
+def conv3x3_dgrad_s2(g, wfrag_t, cin, in_hw, mask_in, g_lo=None, wfrag_t_lo=None):
+    """Data gradient (B,cin,H,W) channels_last of a stride-2 masked 3x3 convolution from the upstream gradient g (B,cout,Ho,Wo) channels_last bf16 and the
+    TRANSPOSED weight pack (conv3x3_pack_weights(w, transposed=True)); mask_in uint8 (B,H,W): the layer's input active set.  With g_lo / wfrag_t_lo (the
+    bf16 low halves, split_f32) the three-product fp32 form: fp32 out."""
+    H, W = in_hw
+    B, co, Ho, Wo = g.shape
+    x3 = g_lo is not None
+    for tns in (g,) + ((g_lo,) if x3 else ()):
+        if not (tns.is_cuda and tns.dtype == torch.bfloat16 and tns.dim() == 4 and tns.is_contiguous(memory_format=torch.channels_last) and tns.shape == g.shape):
+            raise PnxError("conv3x3_dgrad_s2 needs channels_last bf16 CUDA gradients")
+    if (Ho, Wo) != ((H - 1) // 2 + 1, (W - 1) // 2 + 1) or tuple(mask_in.shape) != (B, H, W) or mask_in.dtype != torch.uint8 or not mask_in.is_contiguous():
+        raise PnxError("conv3x3_dgrad_s2: g (B,cout,Ho,Wo) with Ho = (H - 1) // 2 + 1 and a contiguous uint8 (B,H,W) mask of the input sites")
+    dx = torch.empty((B, cin, H, W), dtype=torch.float32 if x3 else torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+    if x3:
+        check(lib().pnx_conv3x3_dgrad_s2_x3(ptr(g), ptr(g_lo), ptr(wfrag_t), ptr(wfrag_t_lo), ptr(mask_in), ptr(dx), B, H, W, cin, co, stream_ptr()), "pnx_conv3x3_dgrad_s2_x3")
+    else:
+        check(lib().pnx_conv3x3_dgrad_s2_bf16(ptr(g), ptr(wfrag_t), ptr(mask_in), ptr(dx), B, H, W, cin, co, stream_ptr()), "pnx_conv3x3_dgrad_s2_bf16")
+    return dx
+
+
 def _smallk_check(x, what):
     if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous(memory_format=torch.channels_last)):
         raise PnxError(f"{what} must be a channels_last fp32 / bf16 CUDA tensor")
