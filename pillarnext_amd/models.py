@@ -298,11 +298,14 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
     The fp32 training graph (the reference's precision) has its own node, _MaskedConv3x3F32Fn."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, weight, mask_out, mask_in, stride, bias=None):
-        x = x.contiguous(memory_format=torch.channels_last)
+        # No cast_inputs (round 6): the fp32 master weight goes straight into the packing kernel (which rounds to bf16 exactly like the cast), the bias
+        # stays fp32 for the kernel, and the weight gradient comes back in fp32 -- autocast's casts of both and the bf16 round trip of dW were ~240
+        # tiny launches per step.
+        x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         co = weight.shape[0]
-        b = _zero_bias(co, x.device) if bias is None else bias.detach().float().contiguous()   # the kernel's bias is fp32 (autocast handed in a bf16 copy)
+        b = _zero_bias(co, x.device) if bias is None else bias.detach().float().contiguous()
         y = ops.conv3x3_masked(x, ops.conv3x3_pack_weights(weight), b, co, stride=stride, mask=mask_out, relu=False)
         ctx.save_for_backward(x, weight, mask_in, mask_out)
         ctx.stride = stride
@@ -327,7 +330,7 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
                 if os.environ.get("PNX_TRAIN_HIPWGRAD", "1") != "0":
                     dw = ops.conv3x3_wgrad(x, g, mask_out).to(weight.dtype)
                 else:
-                    dw = torch.nn.grad.conv2d_weight(x, weight.shape, g, stride=1, padding=1)
+                    dw = torch.nn.grad.conv2d_weight(x, weight.shape, g, stride=1, padding=1).to(weight.dtype)
         else:
             s = ctx.stride
             hip_w = need_w and os.environ.get("PNX_TRAIN_HIPWGRAD", "1") != "0"
@@ -337,8 +340,9 @@ class _MaskedConv3x3Fn(torch.autograd.Function):
                 dx = ops.conv3x3_dgrad_s2(g, ops.conv3x3_pack_weights(weight, transposed=True), weight.shape[1], x.shape[2:], mask_in)
                 need_x = False
             if need_x or (need_w and not hip_w):
-                dx, dw2, _ = torch.ops.aten.convolution_backward(g, x, weight, None, (s, s), (1, 1), (1, 1), False, (0, 0), 1, (need_x, need_w and not hip_w, False))
-                dw = dw if hip_w else dw2
+                dx, dw2, _ = torch.ops.aten.convolution_backward(g, x, weight.to(g.dtype), None, (s, s), (1, 1), (1, 1), False, (0, 0), 1,
+                                                                 (need_x, need_w and not hip_w, False))
+                dw = dw if hip_w else dw2.to(weight.dtype)
         return dx, dw, None, None, None, db
 
 
