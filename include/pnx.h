@@ -450,7 +450,7 @@ int pnx_gather_kept(const float* boxes9, const float* scores, const int32_t* kee
  * Train-mode BatchNorm over the ACTIVE sites of a dense NHWC map (the reference: BatchNorm1d on the features of a SparseConvTensor,
  * det3d/models/utils/sparse_conv.py:31-37,57-60) fused with the residual add, ReLU and the active-site mask, forward and backward.
  * x, residual, y, gy, dx, dresidual: (n_sites, channels) bf16 or fp32 (channels_last maps); mask fp32[n_sites], 0 = inactive (never read,
- * written as zeros); channels in {8,16,32,64,128,256}.
+ * written as zeros), or NULL = every site active (a dense BatchNorm2d: no mask word in front of a site's loads); channels in {8,16,32,64,128,256}.
  *   stats      partials fp32 [pnx_masked_bn_blocks()][2*channels + 1]: per workgroup sum d | sum d^2 | active sites with d = x - center[c]
  *              (center: fp32[channels] or NULL = 0; the running mean keeps the one-pass variance sum d^2 / n - (sum d / n)^2 from
  *              cancelling when |mean| >> std; every rank of a SyncBatchNorm group must pass the same values) -- the caller adds the rows

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_mbn_stats(const T* __restrict__ x, cons
   for (int64_t s0 = (int64_t)blockIdx.x * rows + t / cvec; s0 < n; s0 += 4 * stride) {
     float m[4], v[4][8];
 #pragma unroll
-    for (int u = 0; u < 4; u++) m[u] = s0 + u * stride < n ? mask[s0 + u * stride] : 0.f;
+    for (int u = 0; u < 4; u++) m[u] = s0 + u * stride < n ? (mask != nullptr ? mask[s0 + u * stride] : 1.f) : 0.f;
 #pragma unroll
     for (int u = 0; u < 4; u++)
       if (m[u] != 0.f) Ld8<T>::load(x + (s0 + u * stride) * C + chunk * 8, v[u]);
@@ -114,43 +114,70 @@ __global__ __launch_bounds__(256) void k_mbn_stats(const T* __restrict__ x, cons
   block_reduce<2>(acc, cnt, true, cvec, C, partials + (size_t)blockIdx.x * (2 * C + 1));
 }
 
+// 8 per-channel values of a thread's channel chunk, read once: in the apply passes a thread's chunk never changes (the grid stride is a multiple of the
+// chunks per site), and fetching scale / shift / mean / ... per vector was 4-12 extra load instructions for every 16 or 32 bytes of map
+__device__ __forceinline__ void ld_par(const float* __restrict__ p, int c0, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p + c0), b = *reinterpret_cast<const float4*>(p + c0 + 4);
+  v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+}
+
 template <typename T, bool HAS_RES>
 __global__ __launch_bounds__(256) void k_mbn_apply(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ mask, int64_t n, int C,
                                                    const float* __restrict__ scale, const float* __restrict__ shift, int relu, T* __restrict__ y) {
   const int cvec = C >> 3, csh = __builtin_ctz(cvec);
-  const int64_t nvec = n * cvec;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const int64_t site = i >> csh;  // cvec is a power of two (mbn_shape_ok): no 64-bit division per vector
-    const int c0 = (int)(i & (cvec - 1)) * 8;
-    float o[8] = {};
-    if (mask[site] != 0.f) {
-      float v[8], r[8] = {};
-      Ld8<T>::load(x + site * C + c0, v);
-      if (HAS_RES) Ld8<T>::load(res + site * C + c0, r);
+  const int64_t nvec = n * cvec, stride = (int64_t)gridDim.x * 256;
+  const int c0 = (int)(threadIdx.x & (cvec - 1)) * 8;  // 256 and the grid stride are multiples of cvec (a power of two <= 32)
+  float sc[8], sh[8];
+  ld_par(scale, c0, sc), ld_par(shift, c0, sh);
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < nvec; i0 += 2 * stride) {  // two vectors per iteration, their loads requested together
+    float m[2], v[2][8], r[2][8] = {};
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        float p = v[k] * scale[c0 + k] + shift[c0 + k] + r[k];
-        o[k] = relu ? fmaxf(p, 0.f) : p;
+    for (int u = 0; u < 2; u++) m[u] = i0 + u * stride < nvec ? (mask != nullptr ? mask[(i0 + u * stride) >> csh] : 1.f) : 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+      if (m[u] != 0.f) {
+        const int64_t off = ((i0 + u * stride) >> csh) * C + c0;
+        Ld8<T>::load(x + off, v[u]);
+        if (HAS_RES) Ld8<T>::load(res + off, r[u]);
       }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (i0 + u * stride >= nvec) continue;
+      float o[8] = {};
+      if (m[u] != 0.f) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const float p = v[u][k] * sc[k] + sh[k] + r[u][k];
+          o[k] = relu ? fmaxf(p, 0.f) : p;
+        }
+      }
+      Ld8<T>::store(y + ((i0 + u * stride) >> csh) * C + c0, o);
     }
-    Ld8<T>::store(y + site * C + c0, o);
   }
+}
+
+// the per-channel vectors of the backward passes for one channel chunk
+struct BwdPar {
+  float sc[8], sh[8], mu[8], is[8];
+};
+__device__ __forceinline__ void ld_bwd_par(BwdPar& P, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                                           const float* __restrict__ invstd, int c0) {
+  ld_par(scale, c0, P.sc), ld_par(shift, c0, P.sh), ld_par(mean, c0, P.mu), ld_par(invstd, c0, P.is);
 }
 
 // g of one (site, chunk): gy gated by the recomputed pre-activation; xh = (x - mean) * invstd
 template <typename T, bool HAS_RES>
-__device__ __forceinline__ void bwd_terms(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ res, int64_t off, int c0,
-                                          const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-                                          const float* __restrict__ invstd, int relu, float (&g)[8], float (&xh)[8]) {
+__device__ __forceinline__ void bwd_terms(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ res, int64_t off, const BwdPar& P, int relu,
+                                          float (&g)[8], float (&xh)[8]) {
   float v[8], r[8] = {};
   Ld8<T>::load(gy + off, g);
   Ld8<T>::load(x + off, v);
   if (HAS_RES) Ld8<T>::load(res + off, r);
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    const float pre = v[k] * scale[c0 + k] + shift[c0 + k] + r[k];
+    const float pre = v[k] * P.sc[k] + P.sh[k] + r[k];
     if (relu && !(pre > 0.f)) g[k] = 0.f;
-    xh[k] = (v[k] - mean[c0 + k]) * invstd[c0 + k];
+    xh[k] = (v[k] - P.mu[k]) * P.is[k];
   }
 }
 
@@ -160,15 +187,17 @@ __global__ __launch_bounds__(256) void k_mbn_bwd_stats(const T* __restrict__ gy,
                                                        const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        int relu, float* __restrict__ partials) {
   const int cvec = C >> 3, t = threadIdx.x, chunk = t % cvec, rows = 256 / cvec;
+  BwdPar P;
+  ld_bwd_par(P, scale, shift, mean, invstd, chunk * 8);
   float acc[2][8] = {};
   const int64_t stride = (int64_t)gridDim.x * rows;  // two sites per iteration, their loads requested together (see k_mbn_stats)
   for (int64_t s0 = (int64_t)blockIdx.x * rows + t / cvec; s0 < n; s0 += 2 * stride) {
     float m[2], g[2][8], xh[2][8];
 #pragma unroll
-    for (int u = 0; u < 2; u++) m[u] = s0 + u * stride < n ? mask[s0 + u * stride] : 0.f;
+    for (int u = 0; u < 2; u++) m[u] = s0 + u * stride < n ? (mask != nullptr ? mask[s0 + u * stride] : 1.f) : 0.f;
 #pragma unroll
     for (int u = 0; u < 2; u++)
-      if (m[u] != 0.f) bwd_terms<T, HAS_RES>(gy, x, res, (s0 + u * stride) * C + chunk * 8, chunk * 8, scale, shift, mean, invstd, relu, g[u], xh[u]);
+      if (m[u] != 0.f) bwd_terms<T, HAS_RES>(gy, x, res, (s0 + u * stride) * C + chunk * 8, P, relu, g[u], xh[u]);
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       if (m[u] == 0.f) continue;
@@ -186,19 +215,31 @@ __global__ __launch_bounds__(256) void k_mbn_bwd_apply(const T* __restrict__ gy,
                                                        int relu, const float* __restrict__ mg, const float* __restrict__ mgx, T* __restrict__ dx,
                                                        T* __restrict__ gres) {
   const int cvec = C >> 3, csh = __builtin_ctz(cvec);
-  const int64_t nvec = n * cvec;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const int64_t site = i >> csh;  // cvec is a power of two (mbn_shape_ok): no 64-bit division per vector
-    const int c0 = (int)(i & (cvec - 1)) * 8;
-    float d[8] = {}, g[8] = {};
-    if (mask[site] != 0.f) {
-      float xh[8];
-      bwd_terms<T, HAS_RES>(gy, x, res, site * C + c0, c0, scale, shift, mean, invstd, relu, g, xh);
+  const int64_t nvec = n * cvec, stride = (int64_t)gridDim.x * 256;
+  const int c0 = (int)(threadIdx.x & (cvec - 1)) * 8;
+  BwdPar P;
+  ld_bwd_par(P, scale, shift, mean, invstd, c0);
+  float pmg[8], pmgx[8];
+  ld_par(mg, c0, pmg), ld_par(mgx, c0, pmgx);
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < nvec; i0 += 2 * stride) {
+    float m[2], g[2][8] = {}, xh[2][8] = {};
 #pragma unroll
-      for (int k = 0; k < 8; k++) d[k] = scale[c0 + k] * (g[k] - mg[c0 + k] - xh[k] * mgx[c0 + k]);
+    for (int u = 0; u < 2; u++) m[u] = i0 + u * stride < nvec ? (mask != nullptr ? mask[(i0 + u * stride) >> csh] : 1.f) : 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+      if (m[u] != 0.f) bwd_terms<T, HAS_RES>(gy, x, res, ((i0 + u * stride) >> csh) * C + c0, P, relu, g[u], xh[u]);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (i0 + u * stride >= nvec) continue;
+      float d[8] = {};
+      if (m[u] != 0.f) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = P.sc[k] * (g[u][k] - pmg[k] - xh[u][k] * pmgx[k]);
+      }
+      const int64_t off = ((i0 + u * stride) >> csh) * C + c0;
+      Ld8<T>::store(dx + off, d);
+      if (gres != nullptr) Ld8<T>::store(gres + off, g[u]);
     }
-    Ld8<T>::store(dx + site * C + c0, d);
-    if (gres != nullptr) Ld8<T>::store(gres + site * C + c0, g);
   }
 }
 
@@ -317,7 +358,7 @@ int pnx_masked_bn_bwd_finalize(const double* sums_local, const double* sums_glob
 }
 
 #define MBN_COMMON_CHECKS                                                                                                        \
-  PNX_REQUIRE(x && mask && n_sites > 0 && mbn_shape_ok(channels), PNX_ERR_INVALID, "bad arguments (channels %d: 8, 16, 32, 64, 128 or 256)", channels); \
+  PNX_REQUIRE(x && n_sites > 0 && mbn_shape_ok(channels), PNX_ERR_INVALID, "bad arguments (channels %d: 8, 16, 32, 64, 128 or 256)", channels); \
   PNX_REQUIRE(dtype == PNX_BF16 || dtype == PNX_F32, PNX_ERR_INVALID, "dtype %d: bf16 or fp32", dtype);                          \
   PNX_REQUIRE(n_sites < ((int64_t)1 << 40), PNX_ERR_INVALID, "too many sites");                                                  \
   hipStream_t st = (hipStream_t)stream;

@@ -139,7 +139,7 @@ class _MaskedBNActFn(torch.autograd.Function):
         nblk = int(L.pnx_masked_bn_blocks())
         dev = x.device
         part = torch.empty((nblk, 2 * C + 1), dtype=torch.float32, device=dev)
-        mflat = m.reshape(-1)
+        mflat = None if m is None else m.reshape(-1)
         # statistics around the running mean (identical on every rank: DDP broadcasts the buffers): sum d, sum d^2 with d = x - centre
         rm, rv = norm.running_mean, norm.running_var
         check(L.pnx_masked_bn_stats(ptr(x), dt, ptr(mflat), n, C, ptr(rm), ptr(part), stream_ptr()), "pnx_masked_bn_stats")
@@ -174,7 +174,7 @@ class _MaskedBNActFn(torch.autograd.Function):
         gy = gy.to(x.dtype)
         if not gy.is_contiguous(memory_format=torch.channels_last):
             gy = gy.contiguous(memory_format=torch.channels_last)
-        mflat = m.reshape(-1)
+        mflat = None if m is None else m.reshape(-1)
         nblk = int(L.pnx_masked_bn_blocks())
         part = torch.empty((nblk, 2 * C), dtype=torch.float32, device=x.device)
         relu = 1 if ctx.relu else 0
@@ -199,6 +199,8 @@ class _MaskedBNActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mask, weight, bias, residual, norm, relu):
+        if mask is None:   # every site active (dense_bn_act): the HIP kernels only -- no mask word in front of a site's loads
+            return _MaskedBNActFn._forward_hip(ctx, x, None, weight, bias, residual, norm, relu)
         m = mask if mask.dtype == torch.float32 else mask.float()
         if _MaskedBNActFn._hip_ok(x, residual, weight, bias, norm):
             return _MaskedBNActFn._forward_hip(ctx, x, m.contiguous(), weight, bias, residual, norm, relu)
@@ -517,9 +519,6 @@ def masked_bn_act(x, mask, norm, residual=None, relu=True):
     return (F.relu(out) if relu else out) * mask
 
 
-_ONES_F32 = {}
-
-
 def dense_bn_act(norm, x, relu=True):
     """[relu](norm(x)) of a DENSE nn.BatchNorm2d in training (the head's and the neck's layers: det3d/models/utils/conv.py:21-34, centerhead.py:24-30): the
     masked node with every site active -- statistics, apply + ReLU, and the backward in four passes over the map on csrc/masked_bn.hip instead of MIOpen's
@@ -528,10 +527,7 @@ def dense_bn_act(norm, x, relu=True):
             and os.environ.get("PNX_TRAIN_DENSE_BN_HIP", "1") != "0"):
         xc = x if x.is_contiguous(memory_format=torch.channels_last) else None
         if xc is not None and _MaskedBNActFn._hip_ok(xc, None, norm.weight, norm.bias, norm):
-            key = (x.shape[0], x.shape[2], x.shape[3], x.device)
-            if key not in _ONES_F32:
-                _ONES_F32[key] = torch.ones((x.shape[0], 1, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
-            return _MaskedBNActFn.apply(xc, _ONES_F32[key], norm.weight, norm.bias, None, norm, relu)
+            return _MaskedBNActFn.apply(xc, None, norm.weight, norm.bias, None, norm, relu)
     y = norm(x)
     return F.relu(y) if relu else y
 
