@@ -196,6 +196,60 @@ def test_sephead_output_convolution_kernels(k, shape, dtype):
         assert not type(smallk_conv(conv, x).grad_fn).__name__.startswith("_SmallKConv3x3Fn")
 
 
+@pytest.mark.parametrize("amp", [False, True])
+def test_sephead_training_path_against_its_modules(amp, monkeypatch):
+    """models.SepHead.forward in training on a CUDA channels_last map (first convolutions on the three-product / bf16 nodes, BatchNorm + ReLU on the masked node,
+    output convolutions on csrc/head_train.hip) against the same head with every switch off (the nn.Sequential statement of centerhead.py:12-59 on MIOpen):
+    outputs, input gradient, every parameter gradient, running statistics."""
+    import copy
+
+    from pillarnext_amd.models import SepHead
+
+    torch.manual_seed(4)
+    heads = {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2), "hm": (2, 2)}
+    head = SepHead(64, heads, stride=1, head_conv=64, final_kernel=3, bn=True).cuda().train().to(memory_format=torch.channels_last)
+    ref = copy.deepcopy(head)
+    x0 = torch.randn((2, 64, 40, 56), device="cuda").contiguous(memory_format=torch.channels_last)
+    gs = {h: torch.randn((2, heads[h][0], 40, 56), device="cuda") for h in heads}
+
+    def run(m, x):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            out = m(x)
+        sum((out[h].float() * gs[h]).sum() for h in heads).backward()
+        return out
+
+    xa = x0.clone().requires_grad_(True)
+    out = run(head, xa)
+    kinds = {type(out[h].grad_fn).__name__ for h in heads}
+    assert kinds == {"_SmallKConv3x3FnBackward"}, kinds                       # the HIP path ran
+    # the reference: the modules themselves in fp64 (MIOpen's fp32 BatchNorm backward is itself ~2e-4 off, tests/test_gpu_masked_bn.py)
+    for k in ("PNX_TRAIN_F32_HIP", "PNX_TRAIN_DENSE_HIP", "PNX_TRAIN_HEAD_HIP", "PNX_TRAIN_DENSE_BN_HIP"):
+        monkeypatch.setenv(k, "0")
+    ref = ref.double().to(memory_format=torch.contiguous_format)
+    xb = x0.double().contiguous().requires_grad_(True)
+    want = ref(xb)
+    assert not any(type(want[h].grad_fn).__name__.startswith("_SmallK") for h in heads)
+    sum((want[h] * gs[h].double()).sum() for h in heads).backward()
+    # Outputs: bf16 operands | the three-product node's 4e-6 per layer, two layers and a BatchNorm deep.  Gradients pass a ReLU gate: a pre-activation within
+    # the forward error of zero flips its gate, a discrete change of one term of a sum -- measured 7e-4 (dx) and 3e-3 (a BatchNorm bias) for the fp32 graph
+    # on the three-product node, 2.5e-7 / 3.6e-7 for MIOpen's fp32 kernels (whose forward error is 20 x smaller), a few percent for bf16.
+    tol_out, tol_grad = (4e-2, 8e-2) if amp else (5e-5, 1e-2)
+
+    def close(a, b, what, tol):
+        e = float((a.detach().double() - b.detach()).norm() / b.detach().norm().clamp(min=1e-12))
+        assert e <= tol, (what, e)
+
+    for h in heads:
+        close(out[h], want[h], h, tol_out)
+    close(xa.grad, xb.grad, "dx", tol_grad)
+    big = max(float(r.grad.norm()) for r in ref.parameters())
+    for (n, p), (_, q) in zip(head.named_parameters(), ref.named_parameters()):
+        if float(q.grad.norm()) > 1e-3 * big:                                  # biases in front of a BatchNorm: zero in exact arithmetic
+            close(p.grad, q.grad, n, tol_grad)
+    for (n, p), (_, q) in zip(head.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(p.double(), q.double(), rtol=1e-2 if amp else 1e-4, atol=1e-3 if amp else 1e-5), n
+
+
 def test_split_f32_halves():
     from pillarnext_amd import ops
 
